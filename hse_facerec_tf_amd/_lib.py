@@ -1,0 +1,95 @@
+"""ctypes binding of libhsefr.so (include/hsefr.h).  No fallback: if the library is missing the
+import of anything that needs it raises, and every non-zero status becomes a Python exception
+in the reference's error style (ValueError for shape errors, NotImplementedError for unsupported
+graphs, RuntimeError otherwise)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhsefr.so")
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_SHAPE = 0, -1, -2, -3, -4, -5
+
+_lib = None
+
+# name -> (restype, argtypes); one row per declaration in include/hsefr.h
+_fp = c_void_p   # device pointers travel as integers (tensor.data_ptr())
+SIGNATURES = {
+    "hsefr_version": (c_int, []),
+    "hsefr_last_error_string": (c_char_p, []),
+    "hsefr_engine_create": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
+    "hsefr_engine_workspace_bytes": (c_size_t, [c_void_p]),
+    "hsefr_engine_max_batch": (c_int, [c_void_p]),
+    "hsefr_engine_forward": (c_int, [c_void_p, _fp, c_int, _fp, _fp, _fp, c_void_p]),
+    "hsefr_engine_buffer": (c_void_p, [c_void_p, c_int]),
+    "hsefr_engine_copy_buffer": (c_int, [c_void_p, c_int, _fp, c_size_t, c_void_p]),
+    "hsefr_engine_set_profiling": (c_int, [c_void_p, c_int]),
+    "hsefr_engine_op_times_ms": (c_int, [c_void_p, POINTER(c_float), c_int]),
+    "hsefr_engine_destroy": (c_int, [c_void_p]),
+    "hsefr_conv_c3_bias_act": (c_int, [_fp, _fp, _fp, _fp] + [c_int] * 12 + [c_void_p]),
+    "hsefr_dwconv3x3_bn_relu6": (c_int, [_fp, _fp, _fp, _fp, _fp] + [c_int] * 10 + [c_void_p]),
+    "hsefr_pwconv1x1_bias_relu6": (c_int, [_fp, _fp, _fp, _fp, c_longlong, c_int, c_int, c_int, c_void_p]),
+    "hsefr_gap": (c_int, [_fp, _fp, c_int, c_int, c_int, c_void_p]),
+    "hsefr_dense": (c_int, [_fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, c_void_p]),
+    "hsefr_softmax": (c_int, [_fp, _fp, c_int, c_int, c_void_p]),
+    "hsefr_l2_normalize": (c_int, [_fp, _fp, c_int, c_int, c_void_p]),
+    "hsefr_nn1": (c_int, [_fp, _fp, c_int, c_int, c_int, _fp, _fp, c_void_p]),
+}
+
+
+class HsefrError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load libhsefr.so once.  torch is imported first on purpose: the library's DT_NEEDED
+    libamdhip64.so.7 must resolve to the HIP runtime PyTorch already mapped, so that torch
+    streams and ``data_ptr()`` addresses belong to the same runtime instance."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (side effect: maps torch's libamdhip64)
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    s = lib().hsefr_last_error_string()
+    return s.decode("utf-8", "replace") if s else ""
+
+
+def check(status: int, what: str = "") -> None:
+    if status == OK:
+        return
+    msg = "%s%s (hsefr status %d)" % (what + ": " if what else "", last_error(), status)
+    if status == ERR_SHAPE or status == ERR_INVALID:
+        raise ValueError(msg)
+    if status == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if status == ERR_NOMEM:
+        raise MemoryError(msg)
+    raise HsefrError(msg)
+
+
+def require_gpu():
+    """The product path runs on an MI355X or not at all."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("hse_facerec_tf_amd needs a ROCm GPU (gfx950); torch.cuda.is_available() is False "
+                           "and there is no CPU fallback")
+    return torch
+
+
+def current_stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds libhsefr.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libhsefr.so
+SRCS="engine.hip conv_first.hip dwconv.hip pwconv_f32.hip pool_dense.hip nn1.hip"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
+OBJS=""
+for s in $SRCS; do
+  o="build/${s%.hip}.o"
+  mkdir -p build
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/hsefr.h -nt "$o" ]; then
+    hipcc $FLAGS ${HSEFR_EXTRA_FLAGS:-} -c "$s" -o "$o" &
+  fi
+  OBJS="$OBJS $o"
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS
+echo "built $(realpath $OUT)"

@@ -1,0 +1,88 @@
+// Shared helpers for libhsefr (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/hsefr.h"
+
+namespace hsefr {
+
+void set_error(const char* fmt, ...);
+
+#define HSEFR_HIP_CHECK(expr)                                                          \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            ::hsefr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
+                               __FILE__, __LINE__);                                    \
+            return HSEFR_ERR_HIP;                                                      \
+        }                                                                              \
+    } while (0)
+
+#define HSEFR_REQUIRE(cond, code, ...)     \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::hsefr::set_error(__VA_ARGS__); \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return HSEFR_ERR_HIP;
+    }
+    return HSEFR_OK;
+}
+
+// Epilogue activation.  RELU6 restates the graph's Relu -> Minimum(.,6) -> Maximum(.,0)
+// chain (nodes #32-34): max(min(max(x,0),6),0) == min(max(x,0),6).
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v) {
+    if (ACT == HSEFR_ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == HSEFR_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    if (ACT == HSEFR_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+__device__ __forceinline__ float apply_act_rt(float v, int act) {
+    switch (act) {
+        case HSEFR_ACT_RELU: return fmaxf(v, 0.f);
+        case HSEFR_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
+        case HSEFR_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+// XCD-aware, bijective remap of a linear workgroup id: the hardware deals consecutive
+// workgroup ids round-robin over the 8 XCDs (each with a private 4 MiB L2), so workgroups
+// that share operand rows (GEMM N-tiles of one M-tile, vertically adjacent depthwise
+// row-tiles) are given ids that land on ONE XCD.  Speed only -- never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned NX = 8;
+    const unsigned q = nwg / NX, r = nwg % NX;
+    const unsigned xcd = bid % NX, idx = bid / NX;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// --- launchers implemented in the .hip files (same ones the engine calls) -------------
+int launch_conv_c3(const float* x, const float* wgt, const float* shift, float* y, int n, int h, int w,
+                   int kh, int kw, int stride, int pad_t, int pad_l, int oh, int ow, int cout, int act,
+                   hipStream_t s);
+int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const float* shift, float* y,
+                     int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
+                     hipStream_t s);
+int launch_pwconv_f32(const float* x, const float* wgt_t, const float* shift, float* y, long long m, int k,
+                      int cout, int act, hipStream_t s);
+int launch_gap(const float* x, float* y, int n, int hw, int c, hipStream_t s);
+int launch_dense(const float* x, const float* wgt, const float* bias, float* y, int n, int k, int cout,
+                 int act, hipStream_t s);
+int launch_softmax(const float* x, float* y, int n, int c, hipStream_t s);
+int launch_l2_normalize(const float* x, float* y, int n, int d, hipStream_t s);
+int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2,
+               hipStream_t s);
+
+}  // namespace hsefr

@@ -1,0 +1,333 @@
+// libhsefr C ABI: plan loader + static-graph executor (include/hsefr.h).
+//
+// The engine is the replacement for tf.import_graph_def + tf.Session + Session.run
+// (facerec_test.py:41-58,117-120; facial_analysis.py:55-58,109): a frozen graph that the host
+// side has lowered to a linear op list ("plan") runs as a fixed sequence of kernel launches on
+// ONE stream over pre-allocated NHWC activation buffers.  No allocation, no synchronisation and
+// no host<->device copy happens inside hsefr_engine_forward, so a forward can be captured into
+// a hipGraph by the caller.
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace hsefr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace hsefr
+
+using namespace hsefr;
+
+static_assert(sizeof(hsefr_plan_header) == 64, "plan header layout is part of the ABI");
+static_assert(sizeof(hsefr_plan_buffer) == 16, "plan buffer layout is part of the ABI");
+static_assert(sizeof(hsefr_plan_op) == 96, "plan op layout is part of the ABI");
+
+struct hsefr_engine {
+    hsefr_plan_header hdr;
+    std::vector<hsefr_plan_buffer> bufs;
+    std::vector<hsefr_plan_op> ops;
+    std::vector<void*> d_bufs;
+    char* d_blob = nullptr;
+    size_t device_bytes = 0;
+    int max_batch = 0;
+    int device = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> events;  // n_ops + 1
+    bool have_times = false;
+};
+
+static const void* blob_ptr(const hsefr_engine* e, uint64_t off) {
+    return off == HSEFR_NO_OFFSET ? nullptr : (const void*)(e->d_blob + off);
+}
+
+static void* buf_ptr(hsefr_engine* e, int id, const void* d_input) {
+    if (id == HSEFR_BUF_INPUT) return const_cast<void*>(d_input);
+    if (id < 0 || id >= (int)e->d_bufs.size()) return nullptr;
+    return e->d_bufs[id];
+}
+
+static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bufs, const hsefr_plan_op* ops) {
+    for (uint32_t i = 0; i < h.n_ops; ++i) {
+        const hsefr_plan_op& o = ops[i];
+        auto okbuf = [&](int b, bool allow_input) {
+            return (b >= 0 && b < (int)h.n_buffers) || (allow_input && b == HSEFR_BUF_INPUT);
+        };
+        HSEFR_REQUIRE(okbuf(o.in_buf, true) && okbuf(o.out_buf, false), HSEFR_ERR_INVALID,
+                      "plan op %u: bad buffer ids (%d -> %d)", i, o.in_buf, o.out_buf);
+        HSEFR_REQUIRE(o.res_buf == HSEFR_BUF_NONE || okbuf(o.res_buf, false), HSEFR_ERR_INVALID,
+                      "plan op %u: bad residual buffer %d", i, o.res_buf);
+        for (uint64_t off : {o.w_off, o.scale_off, o.shift_off})
+            HSEFR_REQUIRE(off == HSEFR_NO_OFFSET || (off < h.blob_bytes && off % 16 == 0), HSEFR_ERR_INVALID,
+                          "plan op %u: blob offset %llu out of range / unaligned", i, (unsigned long long)off);
+        const uint64_t out_elems = (uint64_t)o.oh * o.ow * o.cout;
+        HSEFR_REQUIRE(out_elems <= bufs[o.out_buf].elems_per_image, HSEFR_ERR_INVALID,
+                      "plan op %u: output %llu elems/image exceeds buffer %d (%llu)", i,
+                      (unsigned long long)out_elems, o.out_buf,
+                      (unsigned long long)bufs[o.out_buf].elems_per_image);
+        if (o.in_buf >= 0) {
+            const uint64_t in_elems = (uint64_t)o.h * o.w * o.cin;
+            HSEFR_REQUIRE(in_elems <= bufs[o.in_buf].elems_per_image, HSEFR_ERR_INVALID,
+                          "plan op %u: input exceeds buffer %d", i, o.in_buf);
+        }
+        switch (o.kind) {
+            case HSEFR_OP_CONV_C3: case HSEFR_OP_DWCONV3X3: case HSEFR_OP_PWCONV_F32: case HSEFR_OP_GAP:
+            case HSEFR_OP_DENSE: case HSEFR_OP_SOFTMAX:
+                break;
+            default:
+                set_error("plan op %u: unknown kind %u", i, o.kind);
+                return HSEFR_ERR_UNSUPPORTED;
+        }
+    }
+    for (int s = 0; s < HSEFR_N_OUTPUT_SLOTS; ++s)
+        HSEFR_REQUIRE(h.out_buffer[s] == HSEFR_BUF_NONE || (h.out_buffer[s] >= 0 && h.out_buffer[s] < (int)h.n_buffers),
+                      HSEFR_ERR_INVALID, "plan: output slot %d names buffer %d", s, h.out_buffer[s]);
+    return HSEFR_OK;
+}
+
+extern "C" {
+
+int hsefr_version(void) { return HSEFR_VERSION; }
+
+const char* hsefr_last_error_string(void) { return g_err; }
+
+int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsefr_engine** out) {
+    HSEFR_REQUIRE(plan && out, HSEFR_ERR_INVALID, "engine_create: null argument");
+    *out = nullptr;
+    HSEFR_REQUIRE(max_batch > 0, HSEFR_ERR_INVALID, "engine_create: max_batch=%d", max_batch);
+    HSEFR_REQUIRE(plan_bytes >= sizeof(hsefr_plan_header), HSEFR_ERR_INVALID, "engine_create: plan too short");
+    hsefr_plan_header h;
+    memcpy(&h, plan, sizeof(h));
+    HSEFR_REQUIRE(h.magic == HSEFR_PLAN_MAGIC && h.version == 1, HSEFR_ERR_INVALID,
+                  "engine_create: bad plan magic/version");
+    const size_t need = sizeof(h) + (size_t)h.n_buffers * sizeof(hsefr_plan_buffer) +
+                        (size_t)h.n_ops * sizeof(hsefr_plan_op) + h.blob_bytes;
+    HSEFR_REQUIRE(plan_bytes == need, HSEFR_ERR_INVALID, "engine_create: plan is %zu bytes, header implies %zu",
+                  plan_bytes, need);
+    const char* p = (const char*)plan + sizeof(h);
+    hsefr_engine* e = new (std::nothrow) hsefr_engine();
+    HSEFR_REQUIRE(e, HSEFR_ERR_NOMEM, "engine_create: out of host memory");
+    e->hdr = h;
+    e->bufs.resize(h.n_buffers);
+    memcpy(e->bufs.data(), p, h.n_buffers * sizeof(hsefr_plan_buffer));
+    p += h.n_buffers * sizeof(hsefr_plan_buffer);
+    e->ops.resize(h.n_ops);
+    memcpy(e->ops.data(), p, h.n_ops * sizeof(hsefr_plan_op));
+    p += h.n_ops * sizeof(hsefr_plan_op);
+    int rc = validate_plan(h, e->bufs.data(), e->ops.data());
+    if (rc != HSEFR_OK) { delete e; return rc; }
+    e->max_batch = max_batch;
+
+    auto fail = [&](int code) { hsefr_engine_destroy(e); return code; };
+    if (hipGetDevice(&e->device) != hipSuccess) { set_error("engine_create: hipGetDevice failed"); return fail(HSEFR_ERR_HIP); }
+    if (h.blob_bytes) {
+        if (hipMalloc((void**)&e->d_blob, h.blob_bytes) != hipSuccess) {
+            set_error("engine_create: hipMalloc(%llu) for weights failed", (unsigned long long)h.blob_bytes);
+            return fail(HSEFR_ERR_NOMEM);
+        }
+        if (hipMemcpy(e->d_blob, p, h.blob_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("engine_create: weight upload failed");
+            return fail(HSEFR_ERR_HIP);
+        }
+        e->device_bytes += h.blob_bytes;
+    }
+    e->d_bufs.assign(h.n_buffers, nullptr);
+    for (uint32_t i = 0; i < h.n_buffers; ++i) {
+        const size_t bytes = (size_t)e->bufs[i].elems_per_image * e->bufs[i].elem_bytes * max_batch;
+        if (hipMalloc(&e->d_bufs[i], bytes ? bytes : 16) != hipSuccess) {
+            set_error("engine_create: hipMalloc(%zu) for activation buffer %u failed", bytes, i);
+            return fail(HSEFR_ERR_NOMEM);
+        }
+        e->device_bytes += bytes;
+    }
+    *out = e;
+    return HSEFR_OK;
+}
+
+size_t hsefr_engine_workspace_bytes(const hsefr_engine* e) { return e ? e->device_bytes : 0; }
+int hsefr_engine_max_batch(const hsefr_engine* e) { return e ? e->max_batch : 0; }
+
+void* hsefr_engine_buffer(hsefr_engine* e, int buffer) {
+    if (!e || buffer < 0 || buffer >= (int)e->d_bufs.size()) return nullptr;
+    return e->d_bufs[buffer];
+}
+
+int hsefr_engine_copy_buffer(hsefr_engine* e, int buffer, void* d_dst, size_t bytes, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(e && d_dst, HSEFR_ERR_INVALID, "copy_buffer: null argument");
+    HSEFR_REQUIRE(buffer >= 0 && buffer < (int)e->d_bufs.size(), HSEFR_ERR_INVALID, "copy_buffer: buffer %d", buffer);
+    const size_t cap = (size_t)e->bufs[buffer].elems_per_image * e->bufs[buffer].elem_bytes * e->max_batch;
+    HSEFR_REQUIRE(bytes <= cap, HSEFR_ERR_SHAPE, "copy_buffer: %zu bytes exceed buffer %d (%zu)", bytes, buffer, cap);
+    HSEFR_HIP_CHECK(hipMemcpyAsync(d_dst, e->d_bufs[buffer], bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return HSEFR_OK;
+}
+
+int hsefr_engine_set_profiling(hsefr_engine* e, int on) {
+    HSEFR_REQUIRE(e, HSEFR_ERR_INVALID, "set_profiling: null engine");
+    if (on && e->events.empty()) {
+        e->events.resize(e->ops.size() + 1);
+        for (auto& ev : e->events) HSEFR_HIP_CHECK(hipEventCreate(&ev));
+    }
+    e->profiling = on != 0;
+    e->have_times = false;
+    return HSEFR_OK;
+}
+
+int hsefr_engine_op_times_ms(hsefr_engine* e, float* ms, int n_ops) {
+    HSEFR_REQUIRE(e && ms, HSEFR_ERR_INVALID, "op_times: null argument");
+    HSEFR_REQUIRE(e->have_times, HSEFR_ERR_INVALID, "op_times: no profiled forward has run");
+    HSEFR_REQUIRE(n_ops == (int)e->ops.size(), HSEFR_ERR_INVALID, "op_times: expected %zu ops", e->ops.size());
+    HSEFR_HIP_CHECK(hipEventSynchronize(e->events.back()));
+    for (int i = 0; i < n_ops; ++i) HSEFR_HIP_CHECK(hipEventElapsedTime(&ms[i], e->events[i], e->events[i + 1]));
+    return HSEFR_OK;
+}
+
+int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_features, void* d_age_probs,
+                         void* d_gender, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(e, HSEFR_ERR_INVALID, "forward: null engine");
+    HSEFR_REQUIRE(d_input || n == 0, HSEFR_ERR_INVALID, "forward: null input");
+    HSEFR_REQUIRE(n >= 0 && n <= e->max_batch, HSEFR_ERR_SHAPE, "forward: batch %d outside [0, %d]", n, e->max_batch);
+    void* outs[HSEFR_N_OUTPUT_SLOTS] = {d_features, d_age_probs, d_gender};
+    for (int s = 0; s < HSEFR_N_OUTPUT_SLOTS; ++s)
+        HSEFR_REQUIRE(!outs[s] || e->hdr.out_buffer[s] != HSEFR_BUF_NONE, HSEFR_ERR_INVALID,
+                      "forward: the plan does not produce output slot %d", s);
+    if (n == 0) return HSEFR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool prof = e->profiling;
+    // Like sess.run, evaluate only what the requested fetches need: walk the op list backwards
+    // from the requested output buffers (buffers are reused, so liveness is positional).
+    // With no output pointer at all, every op runs (per-layer parity tests read the buffers).
+    std::vector<char> needed(e->ops.size(), 1);
+    if (d_features || d_age_probs || d_gender) {
+        std::vector<char> live(e->d_bufs.size(), 0);
+        for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl)
+            if (outs[sl]) live[e->hdr.out_buffer[sl]] = 1;
+        for (size_t i = e->ops.size(); i-- > 0;) {
+            const hsefr_plan_op& o = e->ops[i];
+            needed[i] = live[o.out_buf];
+            if (!needed[i]) continue;
+            live[o.out_buf] = 0;
+            if (o.in_buf >= 0) live[o.in_buf] = 1;
+            if (o.res_buf >= 0) live[o.res_buf] = 1;
+        }
+    }
+    if (prof) HSEFR_HIP_CHECK(hipEventRecord(e->events[0], s));
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        const hsefr_plan_op& o = e->ops[i];
+        if (!needed[i]) {
+            if (prof) HSEFR_HIP_CHECK(hipEventRecord(e->events[i + 1], s));
+            continue;
+        }
+        const void* in = buf_ptr(e, o.in_buf, d_input);
+        void* out = buf_ptr(e, o.out_buf, d_input);
+        int rc = HSEFR_OK;
+        switch (o.kind) {
+            case HSEFR_OP_CONV_C3:
+                rc = launch_conv_c3((const float*)in, (const float*)blob_ptr(e, o.w_off),
+                                    (const float*)blob_ptr(e, o.shift_off), (float*)out, n, o.h, o.w, o.kh, o.kw,
+                                    o.stride, o.pad_t, o.pad_l, o.oh, o.ow, o.cout, o.act, s);
+                break;
+            case HSEFR_OP_DWCONV3X3:
+                rc = launch_dwconv3x3((const float*)in, (const float*)blob_ptr(e, o.w_off),
+                                      (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
+                                      (float*)out, n, o.h, o.w, o.cin, o.stride, o.pad_t, o.pad_l, o.oh, o.ow, o.act, s);
+                break;
+            case HSEFR_OP_PWCONV_F32:
+                rc = launch_pwconv_f32((const float*)in, (const float*)blob_ptr(e, o.w_off),
+                                       (const float*)blob_ptr(e, o.shift_off), (float*)out,
+                                       (long long)n * o.h * o.w, o.cin, o.cout, o.act, s);
+                break;
+            case HSEFR_OP_GAP:
+                rc = launch_gap((const float*)in, (float*)out, n, o.h * o.w, o.cin, s);
+                break;
+            case HSEFR_OP_DENSE:
+                rc = launch_dense((const float*)in, (const float*)blob_ptr(e, o.w_off),
+                                  (const float*)blob_ptr(e, o.shift_off), (float*)out, n, o.cin, o.cout, o.act, s);
+                break;
+            case HSEFR_OP_SOFTMAX:
+                rc = launch_softmax((const float*)in, (float*)out, n, o.cout, s);
+                break;
+            default:
+                set_error("forward: op %zu has unknown kind %u", i, o.kind);
+                rc = HSEFR_ERR_UNSUPPORTED;
+        }
+        if (rc != HSEFR_OK) return rc;
+        if (prof) HSEFR_HIP_CHECK(hipEventRecord(e->events[i + 1], s));
+    }
+    for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl) {
+        if (!outs[sl]) continue;
+        const int b = e->hdr.out_buffer[sl];
+        const size_t bytes = (size_t)e->hdr.out_elems[sl] * sizeof(float) * n;
+        HSEFR_HIP_CHECK(hipMemcpyAsync(outs[sl], e->d_bufs[b], bytes, hipMemcpyDeviceToDevice, s));
+    }
+    if (prof) e->have_times = true;
+    return HSEFR_OK;
+}
+
+int hsefr_engine_destroy(hsefr_engine* e) {
+    if (!e) return HSEFR_OK;
+    for (void* b : e->d_bufs)
+        if (b) (void)hipFree(b);
+    if (e->d_blob) (void)hipFree(e->d_blob);
+    for (auto ev : e->events) (void)hipEventDestroy(ev);
+    delete e;
+    return HSEFR_OK;
+}
+
+// ---- per-kernel entry points ---------------------------------------------------------------
+int hsefr_conv_c3_bias_act(const float* x, const float* wgt, const float* shift, float* y, int n, int h, int w,
+                           int kh, int kw, int stride, int pad_t, int pad_l, int oh, int ow, int cout, int act,
+                           hsefr_stream_t stream) {
+    HSEFR_REQUIRE(x && wgt && shift && y, HSEFR_ERR_INVALID, "conv_c3: null pointer");
+    return launch_conv_c3(x, wgt, shift, y, n, h, w, kh, kw, stride, pad_t, pad_l, oh, ow, cout, act, (hipStream_t)stream);
+}
+
+int hsefr_dwconv3x3_bn_relu6(const float* x, const float* wgt, const float* scale, const float* shift, float* y,
+                             int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
+                             hsefr_stream_t stream) {
+    HSEFR_REQUIRE(x && wgt && scale && shift && y, HSEFR_ERR_INVALID, "dwconv3x3: null pointer");
+    return launch_dwconv3x3(x, wgt, scale, shift, y, n, h, w, c, stride, pad_t, pad_l, oh, ow, act, (hipStream_t)stream);
+}
+
+int hsefr_pwconv1x1_bias_relu6(const float* x, const float* wgt_t, const float* shift, float* y, long long m, int k,
+                               int cout, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(x && wgt_t && shift && y, HSEFR_ERR_INVALID, "pwconv: null pointer");
+    return launch_pwconv_f32(x, wgt_t, shift, y, m, k, cout, act, (hipStream_t)stream);
+}
+
+int hsefr_gap(const float* x, float* y, int n, int hw, int c, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(x && y, HSEFR_ERR_INVALID, "gap: null pointer");
+    return launch_gap(x, y, n, hw, c, (hipStream_t)stream);
+}
+
+int hsefr_dense(const float* x, const float* wgt, const float* bias, float* y, int n, int k, int cout, int act,
+                hsefr_stream_t stream) {
+    HSEFR_REQUIRE(x && wgt && y, HSEFR_ERR_INVALID, "dense: null pointer");
+    return launch_dense(x, wgt, bias, y, n, k, cout, act, (hipStream_t)stream);
+}
+
+int hsefr_softmax(const float* x, float* y, int n, int c, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(x && y, HSEFR_ERR_INVALID, "softmax: null pointer");
+    return launch_softmax(x, y, n, c, (hipStream_t)stream);
+}
+
+int hsefr_l2_normalize(const float* x, float* y, int n, int d, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(x && y, HSEFR_ERR_INVALID, "l2_normalize: null pointer");
+    return launch_l2_normalize(x, y, n, d, (hipStream_t)stream);
+}
+
+int hsefr_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2,
+              hsefr_stream_t stream) {
+    HSEFR_REQUIRE(q && g && nn_index, HSEFR_ERR_INVALID, "nn1: null pointer");
+    return launch_nn1(q, g, nq, ng, d, nn_index, nn_dist2, (hipStream_t)stream);
+}
+
+}  // extern "C"

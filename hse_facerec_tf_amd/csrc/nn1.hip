@@ -1,0 +1,139 @@
+// Post-extract identification on device: L2 row normalisation and brute-force 1-NN, gfx950.
+//
+// Replaces preprocessing.normalize(X, 'l2') (facerec_test.py:401) and
+// KNeighborsClassifier(n_neighbors=1, p=2).fit(gallery).kneighbors(probe)
+// (facerec_test.py:422 scored through classifier_tester :200-207).
+//
+// 1-NN = a [nq x ng x d] contraction (4582 x 4582 x 1024 for LFW, 43 GFLOP) -> fp32 MFMA:
+//   dist2[q, g] = |q|^2 + |g|^2 - 2 q.g ,  arg-min over g, ties to the lowest gallery index.
+// One workgroup = 32 probe rows x the whole gallery; its 4 waves take gallery tiles of 32 rows
+// round-robin, each keeps a per-lane running (min, index) for its 16 accumulator rows, and the
+// candidates meet once at the end (wavefront shuffles, then LDS across the 4 waves).  Row norms
+// are accumulated from the very fragments that feed the MFMAs.
+#include "common.h"
+
+namespace hsefr {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* xr = x + (size_t)row * d;
+    float ss = 0.f;
+    for (int j = lane; j < d; j += 64) ss = fmaf(xr[j], xr[j], ss);
+    ss = wave_sum64(ss);
+    float nrm = sqrtf(ss);
+    if (nrm == 0.f) nrm = 1.f;  // sklearn: zero rows are left as they are
+    for (int j = lane; j < d; j += 64) y[(size_t)row * d + j] = xr[j] / nrm;
+}
+
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v < bv || (v == bv && i < bi); }
+
+__global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ q, const float* __restrict__ g, int nq,
+                                                  int ng, int d, int* __restrict__ nn_index,
+                                                  float* __restrict__ nn_dist2) {
+    __shared__ float s_val[4][32];
+    __shared__ int s_idx[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * 32;
+    const int qrow = min(q0 + li, nq - 1);
+    const float* qp = q + (size_t)qrow * d + 4 * lh;
+
+    float best_v[16];
+    int best_i[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { best_v[r] = INFINITY; best_i[r] = 0x7fffffff; }
+
+    float qq = 0.f;  // |q_row|^2, accumulated on the first gallery tile only
+    bool qq_done = false;
+    const int gtiles = (ng + 31) / 32;
+    for (int gt = wave; gt < gtiles; gt += 4) {
+        const int gcol = gt * 32 + li;
+        const int grow = min(gcol, ng - 1);
+        const float* gp = g + (size_t)grow * d + 4 * lh;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float gg = 0.f, qs = 0.f;
+        for (int k = 0; k < d; k += 8) {
+            const f32x4 a = *(const f32x4*)(qp + k);
+            const f32x4 b = *(const f32x4*)(gp + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+                gg = fmaf(b[j], b[j], gg);
+                qs = fmaf(a[j], a[j], qs);
+            }
+        }
+        gg += __shfl_xor(gg, 32);
+        if (!qq_done) { qq = qs + __shfl_xor(qs, 32); qq_done = true; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;  // probe row of this accumulator register
+            const float qr = __shfl(qq, rr);
+            const float v = fmaxf(qr + gg - 2.f * acc[r], 0.f);
+            if (gcol < ng && better(v, gcol, best_v[r], best_i[r])) { best_v[r] = v; best_i[r] = gcol; }
+        }
+    }
+    // arg-min across the 32 gallery columns held by the lanes of each half-wave
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(best_v[r], m);
+            const int oi = __shfl_xor(best_i[r], m);
+            if (better(ov, oi, best_v[r], best_i[r])) { best_v[r] = ov; best_i[r] = oi; }
+        }
+    }
+    if (li == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            s_val[wave][rr] = best_v[r];
+            s_idx[wave][rr] = best_i[r];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && q0 + threadIdx.x < nq) {
+        float bv = s_val[0][threadIdx.x];
+        int bi = s_idx[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (better(s_val[w][threadIdx.x], s_idx[w][threadIdx.x], bv, bi)) { bv = s_val[w][threadIdx.x]; bi = s_idx[w][threadIdx.x]; }
+        nn_index[q0 + threadIdx.x] = bi;
+        if (nn_dist2) nn_dist2[q0 + threadIdx.x] = bv;
+    }
+}
+
+}  // namespace
+
+int launch_l2_normalize(const float* x, float* y, int n, int d, hipStream_t s) {
+    HSEFR_REQUIRE(n >= 0 && d > 0, HSEFR_ERR_INVALID, "l2_normalize: bad shape");
+    if (n == 0) return HSEFR_OK;
+    dim3 grid((n + 3) / 4), block(256);
+    hipLaunchKernelGGL(l2_normalize_kernel, grid, block, 0, s, x, y, n, d);
+    return launch_status("l2_normalize");
+}
+
+int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2, hipStream_t s) {
+    HSEFR_REQUIRE(d > 0 && d % 8 == 0, HSEFR_ERR_UNSUPPORTED, "nn1: d=%d must be a multiple of 8", d);
+    HSEFR_REQUIRE(nq >= 0 && ng > 0, HSEFR_ERR_INVALID, "nn1: nq=%d ng=%d", nq, ng);
+    if (nq == 0) return HSEFR_OK;
+    dim3 grid((nq + 31) / 32), block(256);
+    hipLaunchKernelGGL(nn1_kernel, grid, block, 0, s, q, g, nq, ng, d, nn_index, nn_dist2);
+    return launch_status("nn1");
+}
+
+}  // namespace hsefr

@@ -1,0 +1,100 @@
+"""Python handle on an hsefr engine (the object that stands where ``tf.Session`` stood:
+facerec_test.py:58, facial_analysis.py:58).  torch is used for device memory and streams
+only: tensors are containers whose ``data_ptr()`` is handed to the C ABI."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .lowering import OUT_AGE, OUT_FEATURES, OUT_GENDER, Plan
+
+_SLOT_NAMES = {OUT_FEATURES: "features", OUT_AGE: "age_probs", OUT_GENDER: "gender"}
+
+
+class Engine:
+    def __init__(self, plan: Plan, max_batch: int = 256, device: Optional[int] = None):
+        torch = _lib.require_gpu()
+        self._torch = torch
+        self.plan = plan
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.max_batch = int(max_batch)
+        blob = plan.serialize()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            buf = ctypes.create_string_buffer(blob, len(blob))
+            _lib.check(_lib.lib().hsefr_engine_create(ctypes.cast(buf, ctypes.c_void_p), len(blob), self.max_batch,
+                                                      ctypes.byref(handle)), "hsefr_engine_create")
+        self._h = handle
+        self.in_hwc = plan.in_hwc
+        self.out_elems = {slot: elems for slot, (_, elems) in plan.outputs.items()}
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _lib.lib().hsefr_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        return int(_lib.lib().hsefr_engine_workspace_bytes(self._h))
+
+    # -- forward -----------------------------------------------------------------------------
+    def forward(self, x, want: Sequence[int] = (OUT_FEATURES,)) -> Dict[str, "object"]:
+        """x: CUDA float32 tensor [n, h, w, c] NHWC contiguous (already preprocessed).  Returns
+        {'features'|'age_probs'|'gender': CUDA tensor}.  Asynchronous on the current stream."""
+        torch = self._torch
+        if self._h is None:
+            raise RuntimeError("Attempted to use a closed Session.")   # TF's message for a closed session
+        h, w, c = self.in_hwc
+        if x.dim() != 4 or tuple(x.shape[1:]) != (h, w, c):
+            raise ValueError("Cannot feed value of shape %r for Tensor which has shape '(?, %d, %d, %d)'"
+                             % (tuple(x.shape), h, w, c))
+        if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
+            raise ValueError("engine input must be a contiguous float32 CUDA tensor")
+        n = int(x.shape[0])
+        outs = {}
+        ptrs = [None, None, None]
+        for slot in want:
+            if slot not in self.out_elems:
+                raise KeyError("the plan has no output %r" % _SLOT_NAMES[slot])
+            t = torch.empty((n, self.out_elems[slot]), dtype=torch.float32, device=x.device)
+            outs[_SLOT_NAMES[slot]] = t
+            ptrs[slot] = t.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hsefr_engine_forward(self._h, x.data_ptr(), n, ptrs[0], ptrs[1], ptrs[2],
+                                                       _lib.current_stream_ptr()), "hsefr_engine_forward")
+        return outs
+
+    def forward_all_layers(self, x) -> None:
+        """Run every op (no fetch pruning); intermediate buffers can then be read with layer_output."""
+        _lib.check(_lib.lib().hsefr_engine_forward(self._h, x.data_ptr(), int(x.shape[0]), None, None, None,
+                                                   _lib.current_stream_ptr()), "hsefr_engine_forward")
+
+    def layer_output(self, layer_index: int, n: int):
+        """Copy of a layer's activation buffer as a CUDA tensor [n, oh, ow, c].  Only meaningful
+        right after the op ran and before a later op recycled the buffer."""
+        torch = self._torch
+        L = self.plan.layers[layer_index]
+        out = torch.empty((n,) + tuple(L.out_shape), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().hsefr_engine_copy_buffer(self._h, L.out_buf, out.data_ptr(), out.numel() * 4,
+                                                       _lib.current_stream_ptr()), "hsefr_engine_copy_buffer")
+        return out
+
+    # -- profiling -----------------------------------------------------------------------------
+    def set_profiling(self, on: bool) -> None:
+        _lib.check(_lib.lib().hsefr_engine_set_profiling(self._h, 1 if on else 0))
+
+    def op_times_ms(self) -> List[float]:
+        n = len(self.plan.layers)
+        arr = (ctypes.c_float * n)()
+        _lib.check(_lib.lib().hsefr_engine_op_times_ms(self._h, arr, n))
+        return list(arr)

@@ -1,0 +1,150 @@
+"""Drop-in for the age/gender/identity part of the reference's ``FacialImageProcessing``
+(age_gender_identity/facial_analysis.py:36-130,225-294): ``age_gender_fun(img)``,
+``process_image(draw)``, ``close()``, ``is_male()`` -- on libhsefr instead of ``tf.Session``.
+
+Face *detection* (MTCNN / LBP cascade, facial_analysis.py:210-223,334-604) is the step before
+the hot path: a detector is injected as a callable
+``detector(img_rgb) -> (bounding_boxes, points)``.
+
+Added for throughput: ``age_gender_batch`` -- all faces of a frame/album in ONE forward (the
+reference runs one ``sess.run`` per face, facial_analysis.py:266-271).
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib, preprocess
+from .engine import Engine
+from .graphdef import read_graph
+from .lowering import OUT_AGE, OUT_FEATURES, OUT_GENDER, lower_graph
+from .tf_inference import AGE_GENDER_PB
+
+
+def decode_age(age_preds: np.ndarray, min_age: int = 1):
+    """facial_analysis.py:112-124: renormalised expectation over the two most probable age bins."""
+    indices = age_preds.argsort()[::-1][:2]
+    norm_preds = age_preds[indices] / np.sum(age_preds[indices])
+    res_age = min_age
+    for age, probab in zip(indices, norm_preds):
+        res_age += age * probab
+    return res_age, indices, norm_preds
+
+
+class FacialImageProcessing:
+    # minsize: minimum of faces' size
+    def __init__(self, print_stat=False, mtcnn_detector=True, minsize=32, model_file: Optional[str] = None,
+                 detector: Optional[Callable] = None, max_batch: int = 64, device: Optional[int] = None):
+        self.mtcnn_detector = mtcnn_detector
+        self.print_stat = print_stat
+        self.minsize = minsize
+        self.detector = detector
+        # facial_analysis.py:45 loads a sibling .pb; the one that ships with the reference checkout is
+        # the quantised age_gender_tf2_new-01-0.14-0.92 model.
+        self.model_file = model_file or AGE_GENDER_PB
+        self.age_gender_fun = self.load_age_gender(self.model_file, max_batch, device)
+
+    def close(self):                          # facial_analysis.py:73-74
+        self.sess.close()
+
+    @staticmethod
+    def is_male(gender_preds):                # facial_analysis.py:76-81, use_sota=False
+        return (gender_preds >= 0.6)
+
+    # ---- facial_analysis.py:83-130 -------------------------------------------------------------
+    def load_age_gender(self, model_file, max_batch, device):
+        graph = read_graph(model_file)
+        outs = {OUT_AGE: 'age_pred/Softmax:0', OUT_GENDER: 'gender_pred/Sigmoid:0',
+                OUT_FEATURES: 'global_pooling/Mean:0'}
+        for t in outs.values():
+            graph.get_tensor_by_name(t)       # KeyError like graph.get_tensor_by_name (:84-86)
+        in_node, _ = graph.get_tensor_by_name('input_1:0')
+        _, w, h, _ = graph.placeholder_shape(in_node.name)
+        self.w, self.h = int(w), int(h)
+        self.plan = lower_graph(graph, 'input_1:0', outs, (self.w, self.h))
+        self.sess = Engine(self.plan, max_batch=max_batch, device=device)
+
+        def age_gender_fun(img):
+            ages, genders, feats = self.age_gender_batch([img])
+            if self.print_stat:
+                print('gender', genders[0])
+                print('age', ages[0])
+            return ages[0], genders[0], feats[0]
+        return age_gender_fun
+
+    def preprocess_face(self, img_rgb_u8: np.ndarray) -> np.ndarray:
+        """facial_analysis.py:95-107: cv2.resize -> float32 -> BGR -> ImageNet-Caffe mean."""
+        resized = preprocess.resize_linear_u8(img_rgb_u8, self.w, self.h)
+        return preprocess.to_model_input(resized, True, True, dtype=np.float32)
+
+    def age_gender_batch(self, faces_rgb_u8: Sequence[np.ndarray]):
+        """-> (ages [float], genders [ndarray[1]], features [ndarray[1024]]) for a list of face crops."""
+        torch = _lib.require_gpu()
+        ages, genders, feats = [], [], []
+        mb = self.sess.max_batch
+        for i in range(0, len(faces_rgb_u8), mb):
+            x = np.stack([self.preprocess_face(f) for f in faces_rgb_u8[i:i + mb]])
+            xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.sess.device)
+            r = self.sess.forward(xd, (OUT_FEATURES, OUT_AGE, OUT_GENDER))
+            age_p = r["age_probs"].cpu().numpy()
+            gen = r["gender"].cpu().numpy()
+            fea = r["features"].cpu().numpy()
+            for j in range(x.shape[0]):
+                ages.append(decode_age(age_p[j])[0])
+                genders.append(gen[j])
+                feats.append(fea[j])
+        return ages, genders, feats
+
+    # ---- facial_analysis.py:210-223 ---------------------------------------------------------------
+    def detect_faces(self, img):
+        if self.detector is None:
+            raise NotImplementedError("no face detector configured: pass detector=callable(img_rgb) -> "
+                                      "(bounding_boxes, points); the MTCNN cascade is the step before this path")
+        return self.detector(img)
+
+    # ---- facial_analysis.py:225-294 -----------------------------------------------------------------
+    @staticmethod
+    def face_boxes(bounding_boxes, img_w: int, img_h: int) -> List[List[int]]:
+        """The per-bbox geometry of process_image: int cast, keep x2>x1 and y2>y1, pad 10 px,
+        clip to the frame (:233-263)."""
+        out = []
+        for b in bounding_boxes:
+            b = [int(bi) for bi in b]
+            x1, y1, x2, y2 = b[0:4]
+            if x2 > x1 and y2 > y1:
+                dw, dh = 10, 10
+                x1, x2 = x1 - dw, x2 + dw
+                y1, y2 = y1 - dh, y2 + dh
+                box = [x1, y1, x2, y2]
+                if box[0] < 0:
+                    box[0] = 0
+                if box[2] > img_w:
+                    box[2] = img_w
+                if box[1] < 0:
+                    box[1] = 0
+                if box[3] > img_h:
+                    box[3] = img_h
+                out.append(box)
+        return out
+
+    def process_image(self, draw, bounding_boxes=None, points=None):
+        """draw: BGR uint8 frame, as cv2.imread returns it (:225-226).  Detection runs unless
+        ``bounding_boxes`` is supplied.  Returns (bboxes, points, ages, genders, facial_features)."""
+        img = np.ascontiguousarray(np.asarray(draw)[..., ::-1])      # cv2.cvtColor(draw, COLOR_BGR2RGB)
+        t = time.time()
+        if bounding_boxes is None:
+            bounding_boxes, points = self.detect_faces(img)
+        elapsed = time.time() - t
+        if self.print_stat:
+            print('detection elapsed', elapsed)
+        img_h, img_w, _ = img.shape
+        bboxes = self.face_boxes(bounding_boxes, img_w, img_h)
+        crops = [img[y1:y2, x1:x2, :] for (x1, y1, x2, y2) in bboxes]
+        t = time.time()
+        ages, genders, facial_features = self.age_gender_batch(crops) if crops else ([], [], [])
+        if self.print_stat:
+            print('age gender elapsed', time.time() - t)
+        return bboxes, points if points is not None else [], ages, genders, facial_features

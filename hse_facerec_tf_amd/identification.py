@@ -1,0 +1,54 @@
+"""Post-extract identification (facerec_test.py:401-432, 200-207) with the distance work on the GPU.
+
+Host steps stay what the reference does on the host -- including its own scikit-learn calls
+for the label encoding and the stratified split (scikit-learn is a dependency of the
+reference's callers, not of the engine); the O(N_test x N_train x D) nearest-neighbour search
+(KNeighborsClassifier(1).fit/predict, :422,:203) and the L2 normalisation (:401) run through
+libhsefr (ops.l2_normalize / ops.nn1).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+
+def filter_classes(y: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """facerec_test.py:407-412: keep samples whose label occurs more than once, re-encode the
+    labels to 0..C-1 in sorted order (LabelEncoder).  Returns (indices, y_encoded)."""
+    y = np.asarray(y)
+    classes, inverse, counts = np.unique(y, return_inverse=True, return_counts=True)
+    indices = np.nonzero(counts[inverse] > 1)[0]
+    _, y_enc = np.unique(y[indices], return_inverse=True)
+    return indices, y_enc
+
+
+def stratified_half_split(y: np.ndarray, random_state: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """StratifiedShuffleSplit(n_splits=1, test_size=0.5, random_state=0) (facerec_test.py:202)."""
+    from sklearn import model_selection
+    sss = model_selection.StratifiedShuffleSplit(n_splits=1, test_size=0.5, random_state=random_state)
+    (train, test), = sss.split(np.zeros((len(y), 1)), y)
+    return train, test
+
+
+def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np.ndarray]] = None) -> Dict:
+    """The protocol of facerec_test.py:401-432 for the plain 1-NN classifier.
+
+    X: [N, D] float32 embeddings, CUDA tensor or NumPy array (uploaded); y: [N] labels.
+    Returns accuracy, the split, predictions and nearest-gallery indices."""
+    from . import _lib, ops
+    torch = _lib.require_gpu()
+    if isinstance(X, np.ndarray):
+        X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).cuda()
+    Xn = ops.l2_normalize(X.contiguous())                       # :401
+    indices, y_enc = filter_classes(y)                          # :407-412
+    Xn = Xn[torch.from_numpy(indices).to(Xn.device)].contiguous()   # :413
+    train, test = split if split is not None else stratified_half_split(y_enc)
+    gal = Xn[torch.from_numpy(train).to(Xn.device)].contiguous()
+    qry = Xn[torch.from_numpy(test).to(Xn.device)].contiguous()
+    nn_idx, nn_d2 = ops.nn1(qry, gal)
+    nn_idx_h = nn_idx.cpu().numpy()
+    y_pred = y_enc[train][nn_idx_h]
+    acc = float((y_pred == y_enc[test]).mean()) if len(test) else float("nan")
+    return {"accuracy": acc, "indices": indices, "y": y_enc, "train": train, "test": test, "y_pred": y_pred,
+            "nn_index": nn_idx_h, "nn_dist": np.sqrt(nn_d2.cpu().numpy()), "num_classes": int(y_enc.max() + 1) if len(y_enc) else 0}

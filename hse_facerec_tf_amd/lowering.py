@@ -1,0 +1,527 @@
+"""Lower a frozen TensorFlow graph to an hsefr *plan* (the op list libhsefr executes).
+
+This is the host half of what ``tf.import_graph_def`` + ``tf.Session`` did for the reference
+(facerec_test.py:41-58; facial_analysis.py:55-58): instead of interpreting ~160 graph nodes
+per image, the graph is pattern-matched ONCE into fused layers
+
+    Conv2D(3x3x3)  + Add                 + Relu/Minimum/Maximum  -> CONV_C3   (+shift +ReLU6)
+    DepthwiseConv  + Mul + Add           + Relu/Minimum/Maximum  -> DWCONV3X3 (+scale +shift +ReLU6)
+    Conv2D(1x1)    + Add                 + Relu/Minimum/Maximum  -> PWCONV    (+shift +ReLU6)
+    Mean[1,2] (+Reshape)                                           -> GAP
+    MatMul + BiasAdd (+Relu | Sigmoid)                             -> DENSE
+    Softmax                                                        -> SOFTMAX
+
+Constant sub-graphs (``Dequantize(MIN_FIRST)`` weight decode, un-folded BatchNorm
+arithmetic, learning-phase ``Switch``/``Merge``) are folded on the host at load time.
+Topology and constants come from the graph itself; nothing here knows "MobileNet".
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .graphdef import Graph, GraphNode
+
+# mirrors include/hsefr.h
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
+OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_GAP, OP_DENSE, OP_SOFTMAX = 1, 2, 3, 4, 5, 6
+OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
+BUF_INPUT, BUF_NONE = -1, -2
+PLAN_MAGIC = 0x314C505246455348
+NO_OFFSET = 0xFFFFFFFFFFFFFFFF
+
+_HEADER = struct.Struct("<QIIIIII3i3IQ")          # hsefr_plan_header
+_BUFFER = struct.Struct("<QII")                   # hsefr_plan_buffer
+_OP = struct.Struct("<II3i3i3i3i2ii4x3Q")        # hsefr_plan_op (96 bytes, 8-aligned tail)
+
+
+class LoweringError(NotImplementedError):
+    """The graph uses a construct the engine has no kernel for (analogue of TF's
+    'No OpKernel was registered' error)."""
+
+
+# --------------------------------------------------------------------------------------
+# weight decode: tf.dequantize(mode='MIN_FIRST') as graph_transforms quantize_weights emits it
+# --------------------------------------------------------------------------------------
+def dequantize_min_first_u8(q: np.ndarray, range_min, range_max) -> np.ndarray:
+    """TensorFlow's QuantizedToFloatStruct<quint8>: step = (max-min)/255 held as float32,
+    the range minimum is first snapped to a multiple of the step, value = q*step + min_snapped.
+    (Using the raw minimum instead shifts every weight by up to half a step.)"""
+    lo = np.float32(range_min)
+    hi = np.float32(range_max)
+    if lo == hi:
+        return np.full(q.shape, lo, dtype=np.float32)
+    step = np.float32(np.float64(hi - lo) / 255.0)
+    lo_snapped = np.float32(np.round(lo / step) * step)
+    return q.astype(np.float32) * step + lo_snapped
+
+
+def tf_same_padding(size: int, k: int, stride: int) -> Tuple[int, int]:
+    """(output size, pad before) of TensorFlow 'SAME': the odd pixel goes bottom/right."""
+    out = (size + stride - 1) // stride
+    total = max((out - 1) * stride + k - size, 0)
+    return out, total // 2
+
+
+# --------------------------------------------------------------------------------------
+# IR
+# --------------------------------------------------------------------------------------
+@dataclass
+class Layer:
+    kind: int
+    name: str                      # graph node that started the layer
+    src: int                       # producing layer index, -1 = graph input
+    in_shape: Tuple[int, int, int]
+    out_shape: Tuple[int, int, int]
+    w: Optional[np.ndarray] = None       # TF layout until packing
+    scale: Optional[np.ndarray] = None
+    shift: Optional[np.ndarray] = None
+    act: int = ACT_NONE
+    kh: int = 1
+    kw: int = 1
+    stride: int = 1
+    pad_t: int = 0
+    pad_l: int = 0
+    tensors: List[str] = field(default_factory=list)   # graph tensors this layer's OUTPUT stands for
+    sealed: bool = False                               # output materialised; no more epilogue folding
+    version: int = 0                                   # bumped by every op folded into the epilogue
+    out_buf: int = BUF_NONE
+
+
+@dataclass
+class Plan:
+    layers: List[Layer]
+    in_hwc: Tuple[int, int, int]
+    buffers: List[int]                     # elems per image
+    outputs: Dict[int, Tuple[int, int]]    # slot -> (layer index, elems per image)
+    tensor_layer: Dict[str, int]           # graph tensor name (no ':0') -> layer whose output it is
+
+    def serialize(self) -> bytes:
+        blob = bytearray()
+
+        def put(a: Optional[np.ndarray]) -> int:
+            if a is None:
+                return NO_OFFSET
+            while len(blob) % 16:
+                blob.append(0)
+            off = len(blob)
+            blob.extend(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+            return off
+
+        ops = []
+        for L in self.layers:
+            w = L.w
+            if L.kind == OP_PWCONV_F32:
+                w = np.ascontiguousarray(w.reshape(w.shape[-2], w.shape[-1]).T)      # [1,1,K,Cout] -> [Cout,K]
+            elif L.kind == OP_DWCONV3X3:
+                w = w.reshape(3, 3, -1)
+            in_buf = BUF_INPUT if L.src < 0 else self.layers[L.src].out_buf
+            h, wd, cin = L.in_shape
+            oh, ow, cout = L.out_shape
+            ops.append(_OP.pack(L.kind, L.act, in_buf, L.out_buf, BUF_NONE, h, wd, cin, oh, ow, cout,
+                                L.kh, L.kw, L.stride, L.pad_t, L.pad_l, 0, put(w), put(L.scale), put(L.shift)))
+        while len(blob) % 16:
+            blob.append(0)
+        out_buf = [BUF_NONE] * 3
+        out_elems = [0] * 3
+        for slot, (li, elems) in self.outputs.items():
+            out_buf[slot] = self.layers[li].out_buf
+            out_elems[slot] = elems
+        head = _HEADER.pack(PLAN_MAGIC, 1, len(self.buffers), len(ops), self.in_hwc[0], self.in_hwc[1],
+                            self.in_hwc[2], *out_buf, *out_elems, len(blob))
+        bufs = b"".join(_BUFFER.pack(e, 4, 0) for e in self.buffers)
+        return head + bufs + b"".join(ops) + bytes(blob)
+
+    # algorithmic cost model: every layer reads its input once, writes its output once
+    def bytes_per_image(self, kinds: Optional[Sequence[int]] = None) -> int:
+        tot = 0
+        for L in self.layers:
+            if kinds is None or L.kind in kinds:
+                tot += 4 * (int(np.prod(L.in_shape)) + int(np.prod(L.out_shape)))
+        return tot
+
+    def weight_bytes(self, kinds: Optional[Sequence[int]] = None) -> int:
+        tot = 0
+        for L in self.layers:
+            if kinds is None or L.kind in kinds:
+                for a in (L.w, L.scale, L.shift):
+                    if a is not None:
+                        tot += 4 * a.size
+        return tot
+
+    def flops_per_image(self, kinds: Optional[Sequence[int]] = None) -> int:
+        tot = 0
+        for L in self.layers:
+            if kinds is not None and L.kind not in kinds:
+                continue
+            oh, ow, cout = L.out_shape
+            if L.kind in (OP_CONV_C3, OP_PWCONV_F32, OP_DENSE):
+                tot += 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
+            elif L.kind == OP_DWCONV3X3:
+                tot += 2 * oh * ow * cout * 9
+        return tot
+
+
+# --------------------------------------------------------------------------------------
+# lowering
+# --------------------------------------------------------------------------------------
+class _Lowerer:
+    def __init__(self, g: Graph, input_name: str, in_hw: Tuple[int, int], feeds: Dict[str, object]):
+        self.g = g
+        self.input_name = input_name
+        self.in_hw = in_hw
+        self.feeds = feeds
+        self.layers: List[Layer] = []
+        self.const: Dict[str, np.ndarray] = {}
+        self.where: Dict[str, int] = {}      # node name -> layer index whose (possibly open) output it is
+        self.ver: Dict[str, int] = {}        # node name -> layer version at which it was that output
+        self.in_c = 3
+
+    # ---- constant folding ---------------------------------------------------------------
+    def const_of(self, node: GraphNode) -> Optional[np.ndarray]:
+        if node.name in self.const:
+            return self.const[node.name]
+        v = self._const_eval(node)
+        if v is not None:
+            self.const[node.name] = v
+        return v
+
+    def _const_eval(self, node: GraphNode) -> Optional[np.ndarray]:
+        g = self.g
+        if node.name in self.feeds:
+            return np.asarray(self.feeds[node.name])
+        if node.op == "Const":
+            return g.const_value(node)
+        if node.op in ("Placeholder",):
+            return None
+        if node.op == "PlaceholderWithDefault":
+            return self.const_of(g.data_inputs(node)[0][0])
+        if node.op == "Switch":
+            return None  # resolved through Merge
+        if node.op == "Merge":
+            return None
+        ins = [self.const_of(n) for n, _ in g.data_inputs(node)]
+        if any(v is None for v in ins) or not ins:
+            return None
+        f32 = lambda a: np.asarray(a, dtype=np.float32) if np.asarray(a).dtype.kind == "f" else np.asarray(a)
+        op = node.op
+        if op in ("Identity", "StopGradient"):
+            return ins[0]
+        if op == "Dequantize":
+            if node.attr_s("mode", "MIN_COMBINED") != "MIN_FIRST" or node.attr_type("T") != 12:
+                raise LoweringError("Dequantize mode %r / T=%r is not supported (node %s)" %
+                                    (node.attr_s("mode"), node.attr_type("T"), node.name))
+            return dequantize_min_first_u8(ins[0], ins[1].reshape(()), ins[2].reshape(()))
+        if op in ("Add", "AddV2", "BiasAdd"):
+            return f32(ins[0]) + f32(ins[1])
+        if op == "Sub":
+            return f32(ins[0]) - f32(ins[1])
+        if op == "Mul":
+            return f32(ins[0]) * f32(ins[1])
+        if op == "RealDiv":
+            return f32(ins[0]) / f32(ins[1])
+        if op == "Rsqrt":
+            return (np.float32(1.0) / np.sqrt(f32(ins[0]))).astype(np.float32)
+        if op == "Sqrt":
+            return np.sqrt(f32(ins[0]))
+        if op == "Neg":
+            return -ins[0]
+        if op == "Reshape":
+            return ins[0].reshape([int(d) for d in ins[1].reshape(-1)])
+        if op in ("Cast",):
+            return ins[0]
+        return None
+
+    # ---- activation-tensor walk -----------------------------------------------------------
+    def resolve_merge(self, node: GraphNode) -> GraphNode:
+        """Keras learning-phase graphs: cond/Merge picks between a training and an inference
+        branch hanging off Switch(pred).  With the predicate fed (facerec_test.py:118-119 feeds
+        0) only one branch is live; return its node."""
+        live = []
+        for n, idx in self.g.data_inputs(node):
+            port = self._switch_port(n, idx)
+            if port is None:
+                live.append(n)
+                continue
+            sw, p = port
+            pred = self.const_of(self.g.data_inputs(sw)[1][0])
+            if pred is None:
+                raise LoweringError("Switch %s: predicate is not constant; feed the learning-phase tensor" % sw.name)
+            if bool(np.asarray(pred).reshape(-1)[0]) == bool(p):
+                live.append(n)
+        if len(live) != 1:
+            raise LoweringError("Merge %s: %d live inputs" % (node.name, len(live)))
+        return live[0]
+
+    def _switch_port(self, n: GraphNode, idx: int):
+        for _ in range(64):
+            if n.op == "Switch":
+                return n, idx
+            nxt = None
+            for m, i in self.g.data_inputs(n):
+                if self.const_of(m) is None:
+                    nxt = (m, i)
+                    break
+            if nxt is None:
+                return None
+            n, idx = nxt
+        return None
+
+    def mark_live(self, roots: Sequence[GraphNode]) -> None:
+        """Nodes the requested outputs actually depend on (dead Switch branches excluded), and
+        how many live consumers each tensor has -- fusion into a producer's epilogue is only
+        legal when nothing else alive reads the un-fused tensor."""
+        self.live: Dict[str, int] = {}
+        seen = set()
+        stack = list(roots)
+        while stack:
+            n = stack.pop()
+            if n.name in seen:
+                continue
+            seen.add(n.name)
+            ins = [self.resolve_merge(n)] if n.op == "Merge" else [m for m, _ in self.g.data_inputs(n)]
+            for m in ins:
+                self.live[m.name] = self.live.get(m.name, 0) + 1
+                stack.append(m)
+
+    def live_consumers(self, name: str) -> int:
+        return self.live.get(name, 0)
+
+    def new_layer(self, L: Layer, node: GraphNode) -> int:
+        self.layers.append(L)
+        idx = len(self.layers) - 1
+        self.where[node.name] = idx
+        return idx
+
+    def finished(self, idx: int) -> int:
+        """Mark layer idx's current output as a materialised tensor (used as a conv input)."""
+        if idx >= 0:
+            self.layers[idx].sealed = True
+        return idx
+
+    def shape_of(self, idx: int) -> Tuple[int, int, int]:
+        return (self.in_hw[0], self.in_hw[1], self.in_c) if idx < 0 else self.layers[idx].out_shape
+
+    def lower_node(self, node: GraphNode) -> int:
+        """Returns the layer index whose output equals this node's output (-1 = graph input)."""
+        if node.name in self.where:
+            return self.where[node.name]
+        idx = self._lower_node(node)
+        self.ver[node.name] = self.layers[idx].version if idx >= 0 else 0
+        return idx
+
+    def _lower_node(self, node: GraphNode) -> int:
+        g = self.g
+        op = node.op
+        if node.name == self.input_name:
+            self.where[node.name] = -1
+            return -1
+        if op == "Merge":
+            r = self.lower_node(self.resolve_merge(node))
+            self.where[node.name] = r
+            return r
+        ins = g.data_inputs(node)
+        acts = [(n, i) for n, i in ins if self.const_of(n) is None]
+        consts = [self.const_of(n) for n, _ in ins if self.const_of(n) is not None]
+        if op in ("Identity", "StopGradient", "Switch"):
+            r = self.lower_node(acts[0][0])
+            self.where[node.name] = r
+            return r
+        if op in ("Conv2D", "DepthwiseConv2dNative"):
+            if node.attr_s("data_format", "NHWC") != "NHWC":
+                raise LoweringError("%s: only NHWC graphs are supported" % node.name)
+            src = self.finished(self.lower_node(acts[0][0]))
+            w = consts[0].astype(np.float32)
+            h, wd, c = self.shape_of(src)
+            s = node.attr_ints("strides")
+            if s[1] != s[2] or s[0] != 1 or s[3] != 1:
+                raise LoweringError("%s: strides %r" % (node.name, s))
+            if any(d != 1 for d in node.attr_ints("dilations") or [1]):
+                raise LoweringError("%s: dilated convolution" % node.name)
+            kh, kw = int(w.shape[0]), int(w.shape[1])
+            pad = node.attr_s("padding")
+            if pad == "SAME":
+                oh, pt = tf_same_padding(h, kh, s[1])
+                ow, pl = tf_same_padding(wd, kw, s[1])
+            elif pad == "VALID":
+                oh, ow, pt, pl = (h - kh) // s[1] + 1, (wd - kw) // s[1] + 1, 0, 0
+            else:
+                raise LoweringError("%s: padding %r" % (node.name, pad))
+            if op == "DepthwiseConv2dNative":
+                if w.shape[3] != 1 or (kh, kw) != (3, 3) or w.shape[2] != c or c % 4:
+                    raise LoweringError("%s: depthwise kernel %r over %d channels" % (node.name, w.shape, c))
+                L = Layer(OP_DWCONV3X3, node.name, src, (h, wd, c), (oh, ow, c), w=w, kh=3, kw=3, stride=s[1],
+                          pad_t=pt, pad_l=pl)
+            else:
+                cout = int(w.shape[3])
+                if w.shape[2] != c:
+                    raise LoweringError("%s: kernel %r does not match %d input channels" % (node.name, w.shape, c))
+                if (kh, kw) == (1, 1) and s[1] == 1 and c % 32 == 0 and cout % 64 == 0:
+                    kind = OP_PWCONV_F32
+                elif c == 3 and (kh, kw) == (3, 3) and cout % 4 == 0:
+                    kind = OP_CONV_C3
+                else:
+                    raise LoweringError("%s: no fp32 kernel for Conv2D k=%r stride %d" % (node.name, w.shape, s[1]))
+                L = Layer(kind, node.name, src, (h, wd, c), (oh, ow, cout), w=w, kh=kh, kw=kw, stride=s[1],
+                          pad_t=pt, pad_l=pl)
+            return self.new_layer(L, node)
+        if op == "MatMul":
+            if node.attr_b("transpose_a") or node.attr_b("transpose_b"):
+                raise LoweringError("%s: transposed MatMul" % node.name)
+            src = self.finished(self.lower_node(acts[0][0]))
+            w = consts[0].astype(np.float32)
+            h, wd, c = self.shape_of(src)
+            if h * wd * c != w.shape[0]:
+                raise LoweringError("%s: MatMul %r on a tensor of %d features" % (node.name, w.shape, h * wd * c))
+            L = Layer(OP_DENSE, node.name, src, (1, 1, int(w.shape[0])), (1, 1, int(w.shape[1])), w=w)
+            return self.new_layer(L, node)
+        if op == "Mean":
+            axes = sorted(int(a) for a in consts[0].reshape(-1))
+            if axes != [1, 2]:
+                raise LoweringError("%s: Mean over axes %r" % (node.name, axes))
+            src = self.finished(self.lower_node(acts[0][0]))
+            h, wd, c = self.shape_of(src)
+            L = Layer(OP_GAP, node.name, src, (h, wd, c), (1, 1, c), sealed=True)
+            return self.new_layer(L, node)
+        if op == "Softmax":
+            src = self.finished(self.lower_node(acts[0][0]))
+            shp = self.shape_of(src)
+            L = Layer(OP_SOFTMAX, node.name, src, shp, shp, sealed=True)
+            return self.new_layer(L, node)
+        if op in ("Reshape", "Squeeze"):
+            r = self.lower_node(acts[0][0])
+            if self.shape_of(r)[0] * self.shape_of(r)[1] != 1:
+                raise LoweringError("%s: reshape of a spatial tensor" % node.name)
+            self.where[node.name] = r
+            return r
+
+        # ---- elementwise ops folded into the producing layer's epilogue ---------------------
+        if len(acts) != 1:
+            raise LoweringError("%s: op %s with %d non-constant inputs" % (node.name, op, len(acts)))
+        idx = self.lower_node(acts[0][0])
+        if idx < 0:
+            raise LoweringError("%s: elementwise op directly on the graph input" % node.name)
+        L = self.layers[idx]
+        nconsumers = self.live_consumers(acts[0][0].name)
+        if nconsumers != 1:
+            raise LoweringError("%s: cannot fuse, input %s has %d consumers" % (node.name, acts[0][0].name, nconsumers))
+        cout = L.out_shape[2]
+
+        def vec(v):
+            v = np.asarray(v, dtype=np.float32).reshape(-1)
+            if v.size == 1:
+                v = np.full(cout, v[0], np.float32)
+            if v.size != cout:
+                raise LoweringError("%s: operand of %d elements against %d channels" % (node.name, v.size, cout))
+            return v
+
+        if op in ("Mul",) and not L.sealed and L.act == ACT_NONE and L.kind in (OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_DENSE):
+            v = vec(consts[0])
+            L.scale = v if L.scale is None else L.scale * v
+            if L.shift is not None:
+                L.shift = L.shift * v
+        elif op in ("Add", "AddV2", "BiasAdd") and not L.sealed and L.act == ACT_NONE and L.kind in (OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_DENSE):
+            v = vec(consts[0])
+            L.shift = v if L.shift is None else L.shift + v
+        elif op == "Sub" and not L.sealed and L.act == ACT_NONE and ins[0][0] is acts[0][0]:
+            v = vec(consts[0])
+            L.shift = -v if L.shift is None else L.shift - v
+        elif op in ("FusedBatchNorm", "FusedBatchNormV3") and not L.sealed and L.act == ACT_NONE:
+            if node.attr_b("is_training", True):
+                raise LoweringError("%s: training-mode FusedBatchNorm in a frozen graph" % node.name)
+            gamma, beta, mean, var = [vec(c) for c in consts[:4]]
+            k = gamma / np.sqrt(var + np.float32(node.attr_f("epsilon", 1e-3)))
+            L.scale = k if L.scale is None else L.scale * k
+            L.shift = (beta - mean * k) if L.shift is None else (L.shift * k + beta - mean * k)
+        elif op == "Relu" and not L.sealed and L.act == ACT_NONE:
+            L.act = ACT_RELU
+        elif op == "Relu6" and not L.sealed and L.act == ACT_NONE:
+            L.act = ACT_RELU6
+        elif op == "Minimum" and not L.sealed and L.act == ACT_RELU and float(np.asarray(consts[0]).reshape(-1)[0]) == 6.0:
+            L.act = ACT_RELU6                      # conv*_relu/clip_by_value/Minimum (node #33)
+        elif op == "Maximum" and L.act in (ACT_RELU, ACT_RELU6) and float(np.asarray(consts[0]).reshape(-1)[0]) == 0.0:
+            pass                                   # conv*_relu/clip_by_value (node #34): already >= 0
+        elif op == "Sigmoid" and not L.sealed and L.act == ACT_NONE and L.kind == OP_DENSE:
+            L.act = ACT_SIGMOID
+        else:
+            raise LoweringError("%s: cannot fuse op %s into layer %s (act=%d sealed=%s)" %
+                                (node.name, op, L.name, L.act, L.sealed))
+        L.version += 1
+        self.where[node.name] = idx
+        return idx
+
+    def is_final(self, name: str) -> bool:
+        li = self.where[name]
+        return li >= 0 and self.ver.get(name, 0) == self.layers[li].version
+
+
+def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
+                feeds: Optional[Dict[str, object]] = None) -> Plan:
+    """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase."""
+    in_node, _ = g.get_tensor_by_name(input_tensor)
+    shape = g.placeholder_shape(in_node.name)
+    if input_hw is None:
+        if shape is None or len(shape) != 4 or shape[1] <= 0 or shape[2] <= 0:
+            raise ValueError("input tensor %s has no static HxW; pass input_hw" % input_tensor)
+        input_hw = (int(shape[1]), int(shape[2]))
+    feeds_n = {}
+    for k, v in (feeds or {}).items():
+        feeds_n[g.get_tensor_by_name(k)[0].name] = v
+    low = _Lowerer(g, in_node.name, input_hw, feeds_n)
+    if shape is not None and len(shape) == 4 and shape[3] > 0:
+        low.in_c = int(shape[3])
+    out_layers: Dict[int, Tuple[int, int]] = {}
+    low.mark_live([g.get_tensor_by_name(t)[0] for t in outputs.values()])
+    for slot, tname in outputs.items():
+        node, _ = g.get_tensor_by_name(tname)
+        li = low.lower_node(node)
+        if li < 0:
+            raise LoweringError("output %s is the graph input" % tname)
+        out_layers[slot] = (li, int(np.prod(low.layers[li].out_shape)))
+    layers = low.layers
+
+    # post-conditions every kernel relies on
+    for L in layers:
+        if L.kind in (OP_CONV_C3, OP_PWCONV_F32, OP_DENSE) and L.scale is not None:
+            L.w = (L.w * L.scale.reshape((1,) * (L.w.ndim - 1) + (-1,))).astype(np.float32)   # fold scale into kernel
+            L.scale = None
+        if L.kind in (OP_CONV_C3, OP_PWCONV_F32, OP_DWCONV3X3, OP_DENSE) and L.shift is None:
+            L.shift = np.zeros(L.out_shape[2], np.float32)
+        if L.kind == OP_DWCONV3X3 and L.scale is None:
+            L.scale = np.ones(L.out_shape[2], np.float32)
+
+    for slot, tname in outputs.items():
+        nm = g.get_tensor_by_name(tname)[0].name
+        if not low.is_final(nm):
+            raise LoweringError("output %s is an intermediate of fused layer %s; fetch the layer's final tensor"
+                                % (tname, layers[low.where[nm]].name))
+    tensor_layer = {name: li for name, li in low.where.items() if li >= 0 and low.is_final(name)}
+
+    # Buffer assignment by liveness.  A layer's output is allocated BEFORE its input is released,
+    # so no kernel ever writes the buffer it reads; requested outputs are pinned to the end.
+    last_use = list(range(len(layers)))
+    for i, L in enumerate(layers):
+        if L.src >= 0:
+            last_use[L.src] = i
+    pinned = {li for li, _ in out_layers.values()}
+    buffers: List[int] = []
+    free: List[int] = []
+    for i, L in enumerate(layers):
+        need = int(np.prod(L.out_shape))
+        pick = None
+        if i not in pinned and free:
+            fits = [b for b in free if buffers[b] >= need]
+            pick = min(fits, key=lambda b: buffers[b]) if fits else max(free, key=lambda b: buffers[b])
+            free.remove(pick)
+            buffers[pick] = max(buffers[pick], need)
+        if pick is None:
+            buffers.append(need)
+            pick = len(buffers) - 1
+        L.out_buf = pick
+        for j in range(i + 1):
+            if last_use[j] == i and j not in pinned and layers[j].out_buf not in free:
+                free.append(layers[j].out_buf)
+    return Plan(layers, (input_hw[0], input_hw[1], low.in_c), buffers, out_layers, tensor_layer)

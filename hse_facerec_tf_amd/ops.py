@@ -1,0 +1,120 @@
+"""Per-kernel Python entry points: torch CUDA tensors in, torch CUDA tensors out, through the
+C ABI of libhsefr (include/hsefr.h "Per-kernel entry points").  Used by the unit parity tests
+and by the identification stage; the engine calls the same launchers internally."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+from . import _lib
+from .lowering import ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID, tf_same_padding  # noqa: F401
+
+
+def _f32c(t, name):
+    torch = _lib.require_gpu()
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous float32 CUDA tensor" % name)
+    return t
+
+
+def _same(h: int, w: int, k: int, stride: int) -> Tuple[int, int, int, int]:
+    oh, pt = tf_same_padding(h, k, stride)
+    ow, pl = tf_same_padding(w, k, stride)
+    return oh, ow, pt, pl
+
+
+def conv3x3_c3(x, w_hwio, shift, stride: int = 2, act: int = ACT_RELU6):
+    """Conv2D 3x3 SAME over a 3-channel NHWC image + shift + act (graph nodes #30-34)."""
+    torch = _lib.require_gpu()
+    _f32c(x, "x"), _f32c(w_hwio, "w"), _f32c(shift, "shift")
+    n, h, w, c = x.shape
+    if c != 3 or tuple(w_hwio.shape[:3]) != (3, 3, 3):
+        raise ValueError("conv3x3_c3 wants x [n,h,w,3] and w [3,3,3,cout]")
+    cout = w_hwio.shape[3]
+    oh, ow, pt, pl = _same(h, w, 3, stride)
+    y = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_conv_c3_bias_act(x.data_ptr(), w_hwio.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                                 n, h, w, 3, 3, stride, pt, pl, oh, ow, cout, act,
+                                                 _lib.current_stream_ptr()), "hsefr_conv_c3_bias_act")
+    return y
+
+
+def dwconv3x3(x, w_hwc, scale, shift, stride: int = 1, act: int = ACT_RELU6):
+    """DepthwiseConv2dNative 3x3 SAME + scale + shift + act (graph nodes #35-39,#44)."""
+    torch = _lib.require_gpu()
+    _f32c(x, "x"), _f32c(w_hwc, "w"), _f32c(scale, "scale"), _f32c(shift, "shift")
+    n, h, w, c = x.shape
+    oh, ow, pt, pl = _same(h, w, 3, stride)
+    y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_dwconv3x3_bn_relu6(x.data_ptr(), w_hwc.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                   y.data_ptr(), n, h, w, c, stride, pt, pl, oh, ow, act,
+                                                   _lib.current_stream_ptr()), "hsefr_dwconv3x3_bn_relu6")
+    return y
+
+
+def pwconv1x1(x, w_t, shift, act: int = ACT_RELU6):
+    """1x1 conv + shift + act on NHWC x [..., k]; w_t is the TF kernel transposed: [cout, k]."""
+    torch = _lib.require_gpu()
+    _f32c(x, "x"), _f32c(w_t, "w_t"), _f32c(shift, "shift")
+    k = x.shape[-1]
+    cout = w_t.shape[0]
+    m = x.numel() // k
+    y = torch.empty(tuple(x.shape[:-1]) + (cout,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_pwconv1x1_bias_relu6(x.data_ptr(), w_t.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                                     m, k, cout, act, _lib.current_stream_ptr()),
+               "hsefr_pwconv1x1_bias_relu6")
+    return y
+
+
+def gap(x):
+    torch = _lib.require_gpu()
+    _f32c(x, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_gap(x.data_ptr(), y.data_ptr(), n, h * w, c, _lib.current_stream_ptr()), "hsefr_gap")
+    return y
+
+
+def dense(x, w, bias=None, act: int = ACT_NONE):
+    torch = _lib.require_gpu()
+    _f32c(x, "x"), _f32c(w, "w")
+    n, k = x.shape
+    cout = w.shape[1]
+    y = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_dense(x.data_ptr(), w.data_ptr(), None if bias is None else _f32c(bias, "bias").data_ptr(),
+                                      y.data_ptr(), n, k, cout, act, _lib.current_stream_ptr()), "hsefr_dense")
+    return y
+
+
+def softmax(x):
+    torch = _lib.require_gpu()
+    _f32c(x, "x")
+    n, c = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().hsefr_softmax(x.data_ptr(), y.data_ptr(), n, c, _lib.current_stream_ptr()), "hsefr_softmax")
+    return y
+
+
+def l2_normalize(x):
+    """preprocessing.normalize(X, norm='l2') (facerec_test.py:401)."""
+    torch = _lib.require_gpu()
+    _f32c(x, "x")
+    n, d = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().hsefr_l2_normalize(x.data_ptr(), y.data_ptr(), n, d, _lib.current_stream_ptr()),
+               "hsefr_l2_normalize")
+    return y
+
+
+def nn1(queries, gallery):
+    """Index (int32) and squared L2 distance of each query's nearest gallery row."""
+    torch = _lib.require_gpu()
+    _f32c(queries, "queries"), _f32c(gallery, "gallery")
+    nq, d = queries.shape
+    ng = gallery.shape[0]
+    if gallery.shape[1] != d:
+        raise ValueError("queries are %d-D, gallery is %d-D" % (d, gallery.shape[1]))
+    idx = torch.empty((nq,), dtype=torch.int32, device=queries.device)
+    dist = torch.empty((nq,), dtype=torch.float32, device=queries.device)
+    _lib.check(_lib.lib().hsefr_nn1(queries.data_ptr(), gallery.data_ptr(), nq, ng, d, idx.data_ptr(), dist.data_ptr(),
+                                    _lib.current_stream_ptr()), "hsefr_nn1")
+    return idx, dist

@@ -1,0 +1,139 @@
+"""Drop-in for the reference's ``TensorFlowInference`` (facerec_test.py:50-125) and its model
+registry ``get_tf_face_recognizer`` (facerec_test.py:209-218), running on libhsefr instead of
+``tf.Session``.  Same constructor signature, attributes (``w``, ``h``), methods and error
+behaviour; ``facial_clustering_test.py:16,291`` imports and constructs it by these names.
+
+Added for the metric (the reference only has the batch-1 loop, facerec_test.py:394):
+``extract_batch`` (device tensor in, device tensor out) and ``extract_files``.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib, preprocess
+from .engine import Engine
+from .graphdef import Graph, read_graph
+from .lowering import OUT_AGE, OUT_FEATURES, OUT_GENDER, Plan, lower_graph
+
+img_extensions = ['.jpg', '.jpeg', '.png']   # facerec_test.py:33
+
+
+def is_image(path):                          # facerec_test.py:34-36
+    _, file_extension = os.path.splitext(path)
+    return file_extension.lower() in img_extensions
+
+
+def get_files(db_dir):                       # facerec_test.py:38-39 (os.walk order made deterministic)
+    return [[d, os.path.join(d, f)] for d in sorted(next(os.walk(db_dir))[1])
+            for f in sorted(next(os.walk(os.path.join(db_dir, d)))[2]) if not f.startswith(".") and is_image(f)]
+
+
+def load_graph(frozen_graph_filename, prefix='') -> Graph:   # facerec_test.py:41-48
+    g = read_graph(frozen_graph_filename)
+    if prefix:
+        raise NotImplementedError("name prefixes are not needed by any caller of the hot path")
+    return g
+
+
+class TensorFlowInference:
+    def __init__(self, frozen_graph_filename, input_tensor, output_tensor, learning_phase_tensor=None,
+                 convert2BGR=True, imageNetUtilsMean=True, additional_input_value=0,
+                 input_size: Optional[Tuple[int, int]] = None, max_batch: int = 256, device: Optional[int] = None):
+        graph = load_graph(frozen_graph_filename, '')
+        self.graph = graph
+        # graph.get_tensor_by_name semantics: KeyError for unknown names (facerec_test.py:60-64)
+        in_node, _ = graph.get_tensor_by_name(input_tensor)
+        graph.get_tensor_by_name(output_tensor)
+        feeds = {}
+        if learning_phase_tensor:
+            graph.get_tensor_by_name(learning_phase_tensor)
+            feeds[learning_phase_tensor] = additional_input_value   # fed on every run at facerec_test.py:118-119
+        shape = graph.placeholder_shape(in_node.name)
+        if shape is None or len(shape) != 4:           # facerec_test.py:66-70
+            w = h = 160
+        else:
+            _, w, h, _ = shape
+        if input_size is not None:                     # extension: the trunk is fully convolutional
+            w, h = input_size
+        self.w, self.h = int(w), int(h)
+        if self.w <= 0 or self.h <= 0:
+            raise ValueError("input placeholder has no static size; pass input_size=(w, h)")
+        self.convert2BGR = convert2BGR
+        self.imageNetUtilsMean = imageNetUtilsMean
+        self.additional_input_value = additional_input_value
+        self.tf_input_image, self.tf_output_features = input_tensor, output_tensor
+        self.tf_learning_phase = learning_phase_tensor
+        # NB the reference unpacks the NHWC placeholder shape as (_, w, h, _) and feeds [h?, w?]:
+        # rows = self.w.  All models in scope are square.
+        self.plan: Plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds)
+        self.engine = Engine(self.plan, max_batch=max_batch, device=device)
+        self.tf_sess = self.engine           # attribute name kept for callers that poke at it
+        self.feature_dim = self.engine.out_elems[OUT_FEATURES]
+
+    # ---- facerec_test.py:80-112 ---------------------------------------------------------------
+    def preprocess_image(self, img_filepath, crop_center):
+        img = preprocess.imread_rgb(img_filepath)
+        if crop_center:
+            img = preprocess.center_crop_250_128(img)
+        x = preprocess.imresize_bilinear(img, (self.w, self.h))
+        return preprocess.to_model_input(x, self.convert2BGR, self.imageNetUtilsMean, dtype=float)
+
+    # ---- facerec_test.py:114-122 ----------------------------------------------------------------
+    def extract_features(self, img_filepath, crop_center=False):
+        torch = _lib.require_gpu()
+        x = self.preprocess_image(img_filepath, crop_center)
+        x = np.expand_dims(x, axis=0)
+        xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.engine.device)
+        preds = self.engine.forward(xd, (OUT_FEATURES,))["features"]
+        return preds.cpu().numpy().reshape(-1)
+
+    def close_session(self):                 # facerec_test.py:124-125
+        self.engine.close()
+
+    # ---- batched entries (new) ------------------------------------------------------------------
+    def extract_batch(self, x):
+        """x: float32 [n, h, w, 3] NHWC, preprocessed as preprocess_image leaves it; a CUDA tensor
+        (returned: CUDA tensor [n, D], asynchronous) or a NumPy array (returned: NumPy array)."""
+        torch = _lib.require_gpu()
+        if isinstance(x, np.ndarray):
+            out = []
+            for i in range(0, x.shape[0], self.engine.max_batch):
+                xd = torch.from_numpy(np.ascontiguousarray(x[i:i + self.engine.max_batch], dtype=np.float32))
+                out.append(self.engine.forward(xd.to(self.engine.device), (OUT_FEATURES,))["features"].cpu().numpy())
+            return np.concatenate(out) if out else np.zeros((0, self.feature_dim), np.float32)
+        return self.engine.forward(x, (OUT_FEATURES,))["features"]
+
+    def extract_files(self, paths: Sequence[str], batch: int = 256, crop_center: bool = False) -> np.ndarray:
+        """The loop of facerec_test.py:394 with the per-image sess.run replaced by batched forwards."""
+        batch = min(batch, self.engine.max_batch)
+        feats: List[np.ndarray] = []
+        for i in range(0, len(paths), batch):
+            xs = np.stack([self.preprocess_image(p, crop_center) for p in paths[i:i + batch]]).astype(np.float32)
+            feats.append(self.extract_batch(xs))
+        return np.concatenate(feats) if feats else np.zeros((0, self.feature_dim), np.float32)
+
+
+_MODELS_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models")
+AGE_GENDER_PB = os.path.join(_MODELS_DIR, "age_gender_tf2_new-01-0.14-0.92_quantized.pb")
+
+
+def get_tf_face_recognizer(model: str = "age_gender", models_dir: Optional[str] = None, **kw) -> TensorFlowInference:
+    """The registry of facerec_test.py:209-218 as a function of a name instead of (un)commenting.
+    Only 'age_gender' ships with the repository; the VGGFace2 MobileNet/ResNet files are the
+    reference's missing blobs (.MISSING_LARGE_BLOBS) and load when a user supplies them."""
+    d = models_dir or _MODELS_DIR
+    if model == "age_gender":            # facerec_test.py:210
+        return TensorFlowInference(os.path.join(d, os.path.basename(AGE_GENDER_PB)), input_tensor='input_1:0',
+                                   output_tensor='global_pooling/Mean:0', convert2BGR=True, imageNetUtilsMean=True, **kw)
+    if model == "vgg2_mobilenet":        # facerec_test.py:212
+        return TensorFlowInference(os.path.join(d, 'vgg2_mobilenet.pb'), input_tensor='input_1:0',
+                                   output_tensor='reshape_1/Reshape:0',
+                                   learning_phase_tensor='conv1_bn/keras_learning_phase:0', convert2BGR=True,
+                                   imageNetUtilsMean=True, **kw)
+    if model == "vgg2_resnet":           # facerec_test.py:213
+        return TensorFlowInference(os.path.join(d, 'vgg2_resnet.pb'), input_tensor='input:0',
+                                   output_tensor='pool5_7x7_s1:0', convert2BGR=True, imageNetUtilsMean=False, **kw)
+    raise KeyError(model)

@@ -1,0 +1,205 @@
+/*
+ * hsefr.h -- C ABI of libhsefr.so, the MI355X (gfx950) forward-pass engine that replaces
+ * the TensorFlow `Session.run` call of av-savchenko/HSE_FaceRec_tf's feature-extract path.
+ *
+ * What it replaces in the reference (the reference has a Python-object boundary, no FFI;
+ * this is the thin layer a binding puts under those objects -- see INTEGRATION.md):
+ *   - tf.import_graph_def + tf.Session(graph)   facerec_test.py:41-48,58 ; facial_analysis.py:55-58
+ *       -> hsefr_engine_create()  (the caller lowers the frozen GraphDef to a "plan" first)
+ *   - tf_sess.run(out, {in: x})                 facerec_test.py:117-120 (features)
+ *     sess.run([age, gender, feats], {in: x})   facial_analysis.py:109   (three fetches)
+ *       -> hsefr_engine_forward()
+ *   - tf_sess.close() / sess.close()            facerec_test.py:124-125 ; facial_analysis.py:73-74
+ *       -> hsefr_engine_destroy()
+ *   - sklearn normalize + KNeighborsClassifier(1).kneighbors   facerec_test.py:401,200-207,422
+ *       -> hsefr_l2_normalize() + hsefr_nn1()
+ *   - misc.imresize/cv2.resize + BGR + mean      facerec_test.py:93-106 ; facial_analysis.py:95-108
+ *       -> hsefr_preprocess_u8()
+ *
+ * Conventions: extern "C", plain C types; every function returns 0 on success or a negative
+ * hsefr_status (never throws); hsefr_last_error_string() describes the last failure on the
+ * calling thread.  ALL data pointers are DEVICE pointers owned by the caller (e.g. torch
+ * `tensor.data_ptr()`); launches are asynchronous on the `stream` argument (a hipStream_t
+ * passed as void*; NULL = the default stream).  An engine owns only its weights and its
+ * activation workspace; it is re-entrant per engine (one forward at a time per engine),
+ * starts no threads and never synchronises the device.  Activations are NHWC, fp32 unless
+ * stated.  Built for gfx950 only.
+ */
+#ifndef HSEFR_H
+#define HSEFR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSEFR_VERSION 100 /* 0.1.0 */
+
+typedef enum hsefr_status {
+    HSEFR_OK = 0,
+    HSEFR_ERR_INVALID = -1,     /* bad argument / malformed plan            */
+    HSEFR_ERR_UNSUPPORTED = -2, /* shape the kernels do not cover            */
+    HSEFR_ERR_HIP = -3,         /* a HIP runtime call failed                 */
+    HSEFR_ERR_NOMEM = -4,       /* device or host allocation failed          */
+    HSEFR_ERR_SHAPE = -5        /* n > max_batch, etc. (ValueError in Python) */
+} hsefr_status;
+
+/* fused activation applied in a kernel's epilogue (graph pattern Relu -> Minimum(.,6) ->
+ * Maximum(.,0), nodes #32-34 of the reference's frozen MobileNet, == RELU6) */
+typedef enum hsefr_act {
+    HSEFR_ACT_NONE = 0,
+    HSEFR_ACT_RELU = 1,
+    HSEFR_ACT_RELU6 = 2,
+    HSEFR_ACT_SIGMOID = 3
+} hsefr_act;
+
+typedef void* hsefr_stream_t; /* hipStream_t */
+
+int hsefr_version(void);
+const char* hsefr_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* Plan: the lowered frozen graph handed to hsefr_engine_create (host memory).           */
+/* Layout: hsefr_plan_header | hsefr_plan_buffer[n_buffers] | hsefr_plan_op[n_ops] | blob */
+/* All offsets in ops are BYTE offsets into the blob; HSEFR_NO_OFFSET = absent.          */
+/* ------------------------------------------------------------------------------------ */
+#define HSEFR_PLAN_MAGIC 0x314c505246455348ull /* "HSEFRPL1" little-endian */
+#define HSEFR_NO_OFFSET 0xffffffffffffffffull
+#define HSEFR_BUF_INPUT (-1) /* op reads the caller's d_input */
+#define HSEFR_BUF_NONE (-2)
+
+typedef enum hsefr_op_kind {
+    HSEFR_OP_CONV_C3 = 1,      /* dense KxK conv, Cin==3 (MobileNet conv1 3x3/2, ResNet stem 7x7/2), fp32 in */
+    HSEFR_OP_DWCONV3X3 = 2,    /* depthwise 3x3 stride 1|2 + scale + shift + act                          */
+    HSEFR_OP_PWCONV_F32 = 3,   /* 1x1 conv as fp32-MFMA GEMM + shift + act                                */
+    HSEFR_OP_GAP = 4,          /* mean over H,W                                                           */
+    HSEFR_OP_DENSE = 5,        /* x[N,K] . W[K,Cout] + b, act                                             */
+    HSEFR_OP_SOFTMAX = 6,      /* row softmax                                                             */
+    HSEFR_OP_CONV_BF16 = 7,    /* KxK conv (1x1/3x3, stride 1|2) as bf16-MFMA implicit GEMM, fp32 acc,
+                                  + shift (+ residual) + act; bf16 activations                            */
+    HSEFR_OP_MAXPOOL_BF16 = 8, /* 3x3/2 max-pool, bf16                                                    */
+    HSEFR_OP_GAP_BF16 = 9      /* mean over H,W of bf16 activations -> fp32                               */
+} hsefr_op_kind;
+
+typedef enum hsefr_output_slot {
+    HSEFR_OUT_FEATURES = 0, /* facerec_test.py:120 output_tensor / 'global_pooling/Mean:0' */
+    HSEFR_OUT_AGE = 1,      /* 'age_pred/Softmax:0'                                          */
+    HSEFR_OUT_GENDER = 2,   /* 'gender_pred/Sigmoid:0'                                       */
+    HSEFR_N_OUTPUT_SLOTS = 3
+} hsefr_output_slot;
+
+typedef struct hsefr_plan_header {
+    uint64_t magic;
+    uint32_t version; /* 1 */
+    uint32_t n_buffers;
+    uint32_t n_ops;
+    uint32_t in_h, in_w, in_c;
+    int32_t out_buffer[HSEFR_N_OUTPUT_SLOTS]; /* buffer id per output slot, HSEFR_BUF_NONE if absent */
+    uint32_t out_elems[HSEFR_N_OUTPUT_SLOTS]; /* elements per image of that output                   */
+    uint64_t blob_bytes;
+} hsefr_plan_header;
+
+typedef struct hsefr_plan_buffer {
+    uint64_t elems_per_image;
+    uint32_t elem_bytes; /* 4 = fp32, 2 = bf16 */
+    uint32_t reserved;
+} hsefr_plan_buffer;
+
+typedef struct hsefr_plan_op {
+    uint32_t kind; /* hsefr_op_kind */
+    uint32_t act;  /* hsefr_act     */
+    int32_t in_buf, out_buf, res_buf;
+    int32_t h, w, cin;    /* input spatial / channels (DENSE/SOFTMAX: h=w=1, cin=K) */
+    int32_t oh, ow, cout; /* output                                                    */
+    int32_t kh, kw, stride;
+    int32_t pad_t, pad_l; /* TF SAME: pad_total//2 on top/left (0 for even input, k=3, s=2) */
+    int32_t reserved;
+    uint64_t w_off;     /* weights; layout depends on kind (see the per-kernel entry points) */
+    uint64_t scale_off; /* per-channel scale (DWCONV only)                                   */
+    uint64_t shift_off; /* per-channel shift / bias                                          */
+} hsefr_plan_op;
+
+/* ------------------------------------------------------------------------------------ */
+/* Engine                                                                                */
+/* ------------------------------------------------------------------------------------ */
+typedef struct hsefr_engine hsefr_engine;
+
+/* Builds an engine on the CURRENT HIP device: copies the plan's blob to the device and
+ * allocates the activation workspace for `max_batch` images.  `plan` is host memory and may
+ * be freed after the call.  Replaces tf.import_graph_def + tf.Session (facerec_test.py:41-58). */
+int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsefr_engine** out);
+
+/* Total device bytes the engine holds (weights + workspace). */
+size_t hsefr_engine_workspace_bytes(const hsefr_engine* e);
+int hsefr_engine_max_batch(const hsefr_engine* e);
+
+/* One pass of the hot path over `n` preprocessed images (d_input: [n,in_h,in_w,in_c] fp32 NHWC,
+ * BGR mean-subtracted exactly as facerec_test.py:95-106 leaves it).  Any output pointer may be
+ * NULL; a non-NULL pointer for an output the plan does not produce is HSEFR_ERR_INVALID.
+ * d_features [n,D] fp32, d_age_probs [n,100] fp32, d_gender [n,1] fp32.
+ * Replaces tf_sess.run (facerec_test.py:120; facial_analysis.py:109). */
+int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_features,
+                         void* d_age_probs, void* d_gender, hsefr_stream_t stream);
+
+/* Device pointer of an intermediate activation buffer (valid until the next forward);
+ * used by the per-layer parity tests.  NULL if `buffer` is out of range. */
+void* hsefr_engine_buffer(hsefr_engine* e, int buffer);
+/* Asynchronous device-to-device copy of the first `bytes` of an activation buffer into d_dst. */
+int hsefr_engine_copy_buffer(hsefr_engine* e, int buffer, void* d_dst, size_t bytes, hsefr_stream_t stream);
+
+/* Per-op device time of the LAST forward run with profiling on (HIP events around every
+ * launch on the forward's stream; synchronises).  `ms` receives n_ops floats. */
+int hsefr_engine_set_profiling(hsefr_engine* e, int on);
+int hsefr_engine_op_times_ms(hsefr_engine* e, float* ms, int n_ops);
+
+int hsefr_engine_destroy(hsefr_engine* e); /* replaces tf_sess.close(), facerec_test.py:124-125 */
+
+/* ------------------------------------------------------------------------------------ */
+/* Per-kernel entry points (unit parity; the engine calls the same launchers)            */
+/* ------------------------------------------------------------------------------------ */
+
+/* Conv2D KxK, Cin=3 -> Cout (multiple of 4, <= 64), stride s, zero padding pad_t/pad_l, + shift + act.
+ * x [n,h,w,3], wgt [kh,kw,3,cout] (TF HWIO, BN scale pre-folded as in graph node #30), y [n,oh,ow,cout]. */
+int hsefr_conv_c3_bias_act(const float* x, const float* wgt, const float* shift, float* y, int n, int h,
+                           int w, int kh, int kw, int stride, int pad_t, int pad_l, int oh, int ow,
+                           int cout, int act, hsefr_stream_t stream);
+
+/* DepthwiseConv2dNative 3x3 (+ Mul scale + Add shift + ReLU6; graph nodes #35-39,#44).
+ * x [n,h,w,c], wgt [3,3,c] (TF [kh,kw,C,1]), c multiple of 4, stride 1|2, y [n,oh,ow,c]. */
+int hsefr_dwconv3x3_bn_relu6(const float* x, const float* wgt, const float* scale, const float* shift,
+                             float* y, int n, int h, int w, int c, int stride, int pad_t, int pad_l,
+                             int oh, int ow, int act, hsefr_stream_t stream);
+
+/* Conv2D 1x1 (+ Add shift + ReLU6; graph nodes #45-49) as an fp32-MFMA GEMM:
+ * x [m,k] (m = n*h*w pixels, NHWC), wgt_t [cout,k] = the TF kernel [1,1,k,cout] TRANSPOSED,
+ * y [m,cout].  k multiple of 32, cout multiple of 64. */
+int hsefr_pwconv1x1_bias_relu6(const float* x, const float* wgt_t, const float* shift, float* y,
+                               long long m, int k, int cout, int act, hsefr_stream_t stream);
+
+/* Mean over H,W (graph node #230): x [n,hw,c] -> y [n,c]; c multiple of 4. */
+int hsefr_gap(const float* x, float* y, int n, int hw, int c, hsefr_stream_t stream);
+
+/* MatMul + BiasAdd (+ Relu | Sigmoid) (graph nodes #232-234, #236-238): x [n,k], wgt [k,cout]
+ * (TF layout), y [n,cout]. */
+int hsefr_dense(const float* x, const float* wgt, const float* bias, float* y, int n, int k, int cout,
+                int act, hsefr_stream_t stream);
+
+/* Softmax over the last axis (graph node #241): x,y [n,c], c <= 1024. */
+int hsefr_softmax(const float* x, float* y, int n, int c, hsefr_stream_t stream);
+
+/* preprocessing.normalize(X, 'l2') (facerec_test.py:401): rows of x [n,d] scaled in place-free
+ * fashion into y; zero rows stay zero (sklearn divides by 1 then). */
+int hsefr_l2_normalize(const float* x, float* y, int n, int d, hsefr_stream_t stream);
+
+/* KNeighborsClassifier(n_neighbors=1, p=2).kneighbors (facerec_test.py:422,200-207): for every
+ * query row q [nq,d] the index (int32) and squared L2 distance of its nearest gallery row g [ng,d];
+ * ties resolve to the lowest gallery index.  d multiple of 4. */
+int hsefr_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2,
+              hsefr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSEFR_H */

@@ -1,0 +1,68 @@
+"""Oracle part 4: the post-extract identification protocol, run on scikit-learn itself.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows facerec_test.py:401-414 (L2-normalise, keep classes with more than one image,
+re-encode labels) and facerec_test.py:200-207 / :430 (``StratifiedShuffleSplit(n_splits=1,
+test_size=0.5, random_state=0)`` + ``KNeighborsClassifier(n_neighbors=1, p=2)`` accuracy).
+scikit-learn IS importable on this image, so this leg is the reference's own library
+calls, not a restatement; ``tests/golden/make_golden.py`` freezes its split indices and
+predictions into fixtures.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def filter_and_encode(X: np.ndarray, y: np.ndarray):
+    """facerec_test.py:403-414."""
+    from sklearn import preprocessing
+    X_norm = preprocessing.normalize(X, norm="l2")
+    y_l = list(y)
+    counts = {}
+    for el in y_l:
+        counts[el] = counts.get(el, 0) + 1
+    indices = [i for i, el in enumerate(y_l) if counts[el] > 1]   # == y_l.count(el) > 1, without the O(N^2)
+    y2 = np.asarray(y)[indices]
+    enc = preprocessing.LabelEncoder()
+    enc.fit(y2)
+    y2 = enc.transform(y2)
+    return X_norm[indices, :], y2, np.asarray(indices)
+
+
+def split_indices(X_norm: np.ndarray, y: np.ndarray):
+    """facerec_test.py:202: the one stratified 50/50 split, random_state=0."""
+    from sklearn import model_selection
+    sss = model_selection.StratifiedShuffleSplit(n_splits=1, test_size=0.5, random_state=0)
+    (train, test), = sss.split(X_norm, y)
+    return train, test
+
+
+def one_nn(X_norm: np.ndarray, y: np.ndarray):
+    """facerec_test.py:200-207 with the classifier of :422 -> (accuracy, train, test, y_pred, nn_index)."""
+    from sklearn.neighbors import KNeighborsClassifier
+    train, test = split_indices(X_norm, y)
+    clf = KNeighborsClassifier(n_neighbors=1, p=2)
+    clf.fit(X_norm[train], y[train])
+    dist, idx = clf.kneighbors(X_norm[test], n_neighbors=1)
+    y_pred = y[train][idx[:, 0]]
+    acc = float((y_pred == y[test]).mean())
+    return acc, train, test, y_pred, idx[:, 0], dist[:, 0]
+
+
+def synthetic_gallery(n_classes: int = 200, dim: int = 1024, seed: int = 123, noise: float = 0.35):
+    """LFW-shaped synthetic embeddings: Gaussian class centroids, a
+    long-tailed class-size histogram with singletons (which the protocol must drop),
+    non-negative like post-ReLU6 GAP features."""
+    rs = np.random.RandomState(seed)
+    sizes = np.maximum(1, np.round(rs.pareto(1.2, n_classes) + 1).astype(int))
+    sizes = np.minimum(sizes, 40)
+    cent = rs.randn(n_classes, dim).astype(np.float32)
+    X, y = [], []
+    for c, s in enumerate(sizes):
+        X.append(np.maximum(cent[c] + noise * rs.randn(s, dim).astype(np.float32), 0))
+        y += [c] * s
+    X = np.concatenate(X).astype(np.float32)
+    y = np.asarray(y)
+    perm = rs.permutation(len(y))
+    return X[perm], y[perm]

@@ -1,0 +1,96 @@
+"""CPU execution of a lowered hsefr plan with the ORACLE's NumPy ops -- test infrastructure.
+
+Lets the CPU suite check the product's graph lowering (BN folding, weight decode, padding,
+buffer assignment, serialisation) against the unfused graph interpreter without a GPU.  It
+reads the plan back from its SERIALISED bytes, so the struct layout and the weight layouts the
+kernels expect (pointwise kernel transposed, depthwise squeezed) are what is being executed.
+"""
+import struct
+
+import numpy as np
+
+from oracle import tf_graph as tfo
+
+HEADER = struct.Struct("<QIIIIII3i3IQ")
+BUFFER = struct.Struct("<QII")
+OP = struct.Struct("<II3i3i3i3i2ii4x3Q")
+NO_OFFSET = 0xFFFFFFFFFFFFFFFF
+
+
+def _act(x, act):
+    if act == 1:
+        return np.maximum(x, 0)
+    if act == 2:
+        return np.minimum(np.maximum(x, 0), 6)
+    if act == 3:
+        return 1.0 / (1.0 + np.exp(-x))
+    return x
+
+
+def parse(blob: bytes):
+    h = HEADER.unpack_from(blob, 0)
+    magic, version, n_buf, n_ops, in_h, in_w, in_c = h[:7]
+    out_buf, out_elems, blob_bytes = h[7:10], h[10:13], h[13]
+    off = HEADER.size
+    bufs = [BUFFER.unpack_from(blob, off + i * BUFFER.size) for i in range(n_buf)]
+    off += n_buf * BUFFER.size
+    ops = [OP.unpack_from(blob, off + i * OP.size) for i in range(n_ops)]
+    off += n_ops * OP.size
+    data = blob[off:]
+    assert len(data) == blob_bytes
+    return dict(magic=magic, version=version, in_hwc=(in_h, in_w, in_c), out_buf=out_buf, out_elems=out_elems,
+                bufs=bufs, ops=ops, data=data)
+
+
+def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
+    p = parse(blob)
+    n = x.shape[0]
+    data = p["data"]
+
+    def arr(off, count):
+        assert off != NO_OFFSET and off % 16 == 0
+        return np.frombuffer(data, np.float32, count, off).astype(dtype)
+
+    mem = {}
+    owner = {}
+    x = x.astype(dtype)
+    for i, o in enumerate(p["ops"]):
+        (kind, act, in_buf, out_buf, res_buf, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l, _r,
+         w_off, sc_off, sh_off) = o
+        src = x if in_buf == -1 else mem[in_buf]
+        src = src.reshape(n, h, w, cin)
+        assert in_buf != out_buf, "op %d writes the buffer it reads" % i
+        if check_buffers:
+            assert p["bufs"][out_buf][0] >= oh * ow * cout
+        if kind == 1:
+            k = arr(w_off, kh * kw * cin * cout).reshape(kh, kw, cin, cout)
+            pb = (oh - 1) * stride + kh - h - pad_t
+            pr = (ow - 1) * stride + kw - w - pad_l
+            y = tfo.conv2d(src, k, (stride, stride), "", explicit_pads=(pad_t, max(pb, 0), pad_l, max(pr, 0)))
+            y = _act(y + arr(sh_off, cout), act)
+        elif kind == 2:
+            k = arr(w_off, 9 * cin).reshape(3, 3, cin, 1)
+            pb = max((oh - 1) * stride + 3 - h - pad_t, 0)
+            pr = max((ow - 1) * stride + 3 - w - pad_l, 0)
+            xp = np.pad(src, ((0, 0), (pad_t, pb), (pad_l, pr), (0, 0)))
+            y = tfo.depthwise_conv2d(xp, k, (stride, stride), "VALID")
+            y = _act(y * arr(sc_off, cin) + arr(sh_off, cin), act)
+        elif kind == 3:
+            wt = arr(w_off, cin * cout).reshape(cout, cin)
+            y = _act(src.reshape(-1, cin).dot(wt.T) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
+        elif kind == 4:
+            y = src.mean(axis=(1, 2)).reshape(n, 1, 1, cin)
+        elif kind == 5:
+            k = arr(w_off, cin * cout).reshape(cin, cout)
+            y = _act(src.reshape(n, cin).dot(k) + arr(sh_off, cout), act).reshape(n, 1, 1, cout)
+        elif kind == 6:
+            y = tfo.softmax(src.reshape(n, -1)).reshape(n, 1, 1, -1)
+        else:
+            raise AssertionError("unknown op kind %d" % kind)
+        assert y.shape[1:] == (oh, ow, cout), (i, y.shape, (oh, ow, cout))
+        mem[out_buf] = y
+    outs = {}
+    for slot, name in enumerate(("features", "age_probs", "gender")):
+        if p["out_buf"][slot] >= 0:
+            outs[name] = mem[p["out_buf"][slot]].reshape(n, -1)[:, :p["out_elems"][slot]]
+    return outs

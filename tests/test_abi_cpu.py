@@ -1,0 +1,60 @@
+"""CPU suite, part 3: the C-ABI library loads without a GPU and exports exactly what
+include/hsefr.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "hsefr.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hsefr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_documented_surface():
+    names = declared_functions()
+    for must in ("hsefr_version", "hsefr_engine_create", "hsefr_engine_forward", "hsefr_engine_destroy",
+                 "hsefr_last_error_string", "hsefr_dwconv3x3_bn_relu6", "hsefr_pwconv1x1_bias_relu6",
+                 "hsefr_conv_c3_bias_act", "hsefr_gap", "hsefr_dense", "hsefr_nn1"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from hse_facerec_tf_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    L = _lib.lib()
+    for name in declared_functions():
+        assert hasattr(L, name), "libhsefr.so does not export %s" % name
+    # and the binding table covers the header one-to-one
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    assert L.hsefr_version() == 100
+
+
+def test_code_object_targets_gfx950_only():
+    from hse_facerec_tf_amd import _lib
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", _lib.LIB_PATH], capture_output=True, text=True)
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_90", b"gfx1100"):
+        assert other not in blob
+
+
+def test_argument_validation_needs_no_gpu():
+    """Status codes and error strings work before any device is touched."""
+    from hse_facerec_tf_amd import _lib
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    rc = L.hsefr_engine_create(None, 0, 1, ctypes.byref(h))
+    assert rc == _lib.ERR_INVALID and "null" in _lib.last_error()
+    junk = ctypes.create_string_buffer(b"\0" * 128, 128)
+    rc = L.hsefr_engine_create(ctypes.cast(junk, ctypes.c_void_p), 128, 4, ctypes.byref(h))
+    assert rc == _lib.ERR_INVALID and "magic" in _lib.last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, "hsefr_engine_create")
+    assert L.hsefr_engine_destroy(None) == 0

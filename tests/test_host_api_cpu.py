@@ -1,0 +1,102 @@
+"""CPU suite, part 4: the host-side mirror of the reference API (everything that does not need
+the device), checked against the oracle's restatement of the same reference lines."""
+import os
+
+import numpy as np
+import pytest
+
+from hse_facerec_tf_amd import facial_analysis, identification, preprocess, tf_inference
+from oracle import identification as oid
+from oracle import pipeline as opl
+
+from conftest import GOLDEN, MODEL_PB, TEST_IMAGE
+
+
+def test_imread_imresize_and_model_input_match_reference_restatement():
+    img = preprocess.imread_rgb(TEST_IMAGE)
+    assert img.shape == (588, 784, 3) and img.dtype == np.uint8
+    for bgr, imagenet in ((True, True), (True, False), (False, True)):
+        ref = opl.preprocess_image(img, 192, 192, bgr, imagenet)
+        got = preprocess.to_model_input(preprocess.imresize_bilinear(img, (192, 192)), bgr, imagenet)
+        assert got.dtype == np.float64 and np.array_equal(got, ref)
+    ref = opl.preprocess_image(img, 224, 224, True, True, crop_center=True)
+    got = preprocess.to_model_input(preprocess.imresize_bilinear(preprocess.center_crop_250_128(img), (224, 224)), True, True)
+    assert np.array_equal(got, ref)
+
+
+def test_linear_resize_matches_oracle_restatement_bit_exactly():
+    rs = np.random.RandomState(0)
+    for (h, w, oh, ow) in [(37, 53, 224, 224), (300, 200, 224, 224), (224, 224, 224, 224), (500, 448, 224, 224), (5, 7, 3, 2)]:
+        img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        assert np.array_equal(preprocess.resize_linear_u8(img, ow, oh), opl.cv2_resize_linear(img, ow, oh))
+
+
+def test_constructor_error_behaviour_before_any_device_work(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        tf_inference.TensorFlowInference(str(tmp_path / "nope.pb"), "input_1:0", "global_pooling/Mean:0")
+    with pytest.raises(KeyError):       # graph.get_tensor_by_name on an unknown tensor (facerec_test.py:62)
+        tf_inference.TensorFlowInference(MODEL_PB, "input_1:0", "reshape_1/Reshape:0")
+    with pytest.raises(KeyError):
+        tf_inference.TensorFlowInference(MODEL_PB, "input:0", "global_pooling/Mean:0")
+    with pytest.raises(KeyError):
+        tf_inference.TensorFlowInference(MODEL_PB, "input_1:0", "global_pooling/Mean:0",
+                                         learning_phase_tensor="conv1_bn/keras_learning_phase:0")
+
+
+def test_no_cpu_fallback_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tf_inference.TensorFlowInference(MODEL_PB, "input_1:0", "global_pooling/Mean:0")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        facial_analysis.FacialImageProcessing()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        identification.one_nn_identification(np.zeros((4, 8), np.float32), np.array([0, 0, 1, 1]))
+
+
+def test_product_never_imports_the_oracle():
+    import ast
+    root = os.path.join(os.path.dirname(GOLDEN), "..", "hse_facerec_tf_amd")
+    for fn in os.listdir(root):
+        if fn.endswith(".py"):
+            tree = ast.parse(open(os.path.join(root, fn)).read())
+            for node in ast.walk(tree):
+                mods = []
+                if isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    mods = [node.module or ""]
+                assert not any(m.split(".")[0] == "oracle" for m in mods), "%s imports the oracle" % fn
+
+
+def test_age_decode_and_box_geometry():
+    p = np.random.RandomState(1).dirichlet(np.ones(100)).astype(np.float32)
+    assert facial_analysis.decode_age(p)[0] == opl.decode_age(p)[0]
+    boxes = facial_analysis.FacialImageProcessing.face_boxes(
+        [[100.7, 60.2, 260.9, 260.1, 0.99], [-5, 400, 150, 600], [50, 50, 50, 80], [770, 570, 800, 600]], 784, 588)
+    assert boxes == [[90, 50, 270, 270], [0, 390, 160, 588], [760, 560, 784, 588]]    # pad 10, clip, drop empty
+    assert facial_analysis.FacialImageProcessing.is_male(np.array([0.6]))[0]
+
+
+def test_filter_classes_and_split_match_sklearn_protocol():
+    X, y = oid.synthetic_gallery(n_classes=60, dim=32, seed=5, noise=1.0)
+    Xn, y_ref, kept_ref = oid.filter_and_encode(X, y)
+    kept, y_enc = identification.filter_classes(y)
+    assert np.array_equal(kept, kept_ref) and np.array_equal(y_enc, y_ref)
+    tr_ref, te_ref = oid.split_indices(Xn, y_ref)
+    tr, te = identification.stratified_half_split(y_enc)
+    assert np.array_equal(tr, tr_ref) and np.array_equal(te, te_ref)
+    # the reference's O(N^2) list.count filter (facerec_test.py:408-409), literally
+    y_l = list(y)
+    assert [i for i, el in enumerate(y_l) if y_l.count(el) > 1] == list(kept)
+
+
+def test_get_files_walks_like_the_reference(tmp_path):
+    for d, files in (("bob", ["b.jpg", "a.PNG", ".hidden.jpg", "notes.txt"]), ("alice", ["1.jpeg"])):
+        os.makedirs(tmp_path / d)
+        for f in files:
+            (tmp_path / d / f).write_bytes(b"x")
+    got = tf_inference.get_files(str(tmp_path))
+    assert got == [["alice", os.path.join("alice", "1.jpeg")], ["bob", os.path.join("bob", "a.PNG")],
+                   ["bob", os.path.join("bob", "b.jpg")]]

@@ -1,0 +1,171 @@
+"""CPU suite, part 2: the product's TF-free reader + lowering, executed on CPU by tests/plan_ref.py
+(oracle ops over the SERIALISED plan) and compared with the oracle's unfused graph interpreter."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import plan_ref
+from hse_facerec_tf_amd import graphdef, lowering
+from hse_facerec_tf_amd.lowering import OUT_AGE, OUT_FEATURES, OUT_GENDER
+from oracle import tf_graph as tfo
+
+from conftest import GOLDEN, MODEL_PB
+
+ALL_OUTS = {OUT_FEATURES: "global_pooling/Mean:0", OUT_AGE: "age_pred/Softmax:0", OUT_GENDER: "gender_pred/Sigmoid:0"}
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def graph():
+    return graphdef.read_graph(MODEL_PB)
+
+
+def test_product_reader_agrees_with_oracle_reader(graph):
+    nodes = tfo.load_graphdef(MODEL_PB)
+    assert [n.name for n in nodes] == [n.name for n in graph.nodes]
+    assert [n.op for n in nodes] == [n.op for n in graph.nodes]
+    assert [n.inputs for n in nodes] == [n.inputs for n in graph.nodes]
+    for a, b in zip(nodes, graph.nodes):
+        if a.op == "Const":
+            va, vb = a.attr["value"].tensor, graph.const_value(b)
+            assert va.dtype == vb.dtype and va.shape == vb.shape and np.array_equal(va, vb)
+    assert graph.placeholder_shape("input_1") == [-1, 224, 224, 3]
+
+
+def test_get_tensor_by_name_error_behaviour(graph):
+    with pytest.raises(KeyError):
+        graph.get_tensor_by_name("no_such_op:0")
+    with pytest.raises(ValueError):
+        graph.get_tensor_by_name("input_1")            # op name, not a tensor name
+    node, idx = graph.get_tensor_by_name("global_pooling/Mean:0")
+    assert node.op == "Mean" and idx == 0
+
+
+def test_plan_layer_table_matches_survey(graph):
+    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192))
+    kinds = [L.kind for L in plan.layers]
+    assert kinds[0] == lowering.OP_CONV_C3 and kinds.count(lowering.OP_DWCONV3X3) == 13
+    assert kinds.count(lowering.OP_PWCONV_F32) == 13 and kinds.count(lowering.OP_GAP) == 1
+    dw = [L for L in plan.layers if L.kind == lowering.OP_DWCONV3X3]
+    assert [L.stride for L in dw] == [1, 2, 1, 2, 1, 2, 1, 1, 1, 1, 1, 2, 1]
+    assert [L.in_shape[2] for L in dw] == [32, 64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 512, 1024]
+    assert all((L.pad_t, L.pad_l) == ((1, 1) if L.stride == 1 else (0, 0)) for L in dw)     # TF SAME, even inputs
+    assert all(L.act == lowering.ACT_RELU6 for L in plan.layers[:27])
+    # SURVEY 8d per-face figures for MobileNet-192
+    assert abs(plan.bytes_per_image([lowering.OP_DWCONV3X3]) / 1e6 - 14.672) < 0.01
+    assert abs(plan.bytes_per_image(range(1, 5)) / 1e6 - 30.085) < 0.01
+    assert abs(plan.flops_per_image([lowering.OP_PWCONV_F32]) / 1e6 - 792.7) < 0.5
+    plan224 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS)
+    assert plan224.in_hwc == (224, 224, 3)
+    assert abs(plan224.bytes_per_image([lowering.OP_DWCONV3X3]) / 1e6 - 19.970) < 0.01
+
+
+@pytest.mark.parametrize("size,n", [(96, 3), (100, 2)])
+def test_lowered_plan_equals_unfused_graph(graph, size, n):
+    z = np.load(os.path.join(GOLDEN, "e2e_synthetic.npz"))
+    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (size, size))
+    x = np.random.RandomState(123).uniform(-128, 128, (n, size, size, 3)).astype(np.float32)
+    out = plan_ref.run(plan.serialize(), x)
+    assert rel(out["features"], z["feat_%d" % size]) < 1e-6
+    assert rel(out["age_probs"], z["age_%d" % size]) < 1e-6
+    assert rel(out["gender"], z["gender_%d" % size]) < 1e-6
+
+
+def test_features_only_plan_and_intermediate_outputs(graph):
+    plan = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0"}, (64, 64))
+    assert len(plan.layers) == 28 and OUT_AGE not in plan.outputs
+    x = np.random.RandomState(5).uniform(-128, 128, (1, 64, 64, 3)).astype(np.float32)
+    ref = tfo.GraphOracle(MODEL_PB).run("global_pooling/Mean:0", {"input_1:0": x})
+    assert rel(plan_ref.run(plan.serialize(), x)["features"], ref) < 1e-6
+    # an intermediate trunk tensor can be the output too
+    plan2 = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "conv_pw_3_relu/clip_by_value:0"}, (64, 64))
+    ref2 = tfo.GraphOracle(MODEL_PB).run("conv_pw_3_relu/clip_by_value:0", {"input_1:0": x})
+    assert rel(plan_ref.run(plan2.serialize(), x)["features"], ref2.reshape(1, -1)) < 1e-6
+    # a pre-activation tensor alone is fine (the layer simply ends there) ...
+    plan3 = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "conv_pw_3_bn/batchnorm_1/add_1:0"}, (64, 64))
+    assert plan3.layers[-1].act == lowering.ACT_NONE
+    ref3 = tfo.GraphOracle(MODEL_PB).run("conv_pw_3_bn/batchnorm_1/add_1:0", {"input_1:0": x})
+    assert rel(plan_ref.run(plan3.serialize(), x)["features"], ref3.reshape(1, -1)) < 1e-6
+    # ... but not together with a later tensor of the same fused layer
+    with pytest.raises(lowering.LoweringError):
+        lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "conv_pw_3_bn/batchnorm_1/add_1:0",
+                                                  OUT_AGE: "conv_pw_3_relu/clip_by_value:0"}, (64, 64))
+
+
+def test_plan_struct_layout_matches_header():
+    hdr = open(os.path.join(os.path.dirname(MODEL_PB), "..", "include", "hsefr.h")).read()
+    assert "HSEFR_PLAN_MAGIC 0x314c505246455348ull" in hdr
+    assert lowering._HEADER.size == 64 and lowering._BUFFER.size == 16 and lowering._OP.size == 96
+    assert struct.pack("<Q", lowering.PLAN_MAGIC) == b"HSEFRPL1"
+    for name, val in (("HSEFR_OP_CONV_C3", lowering.OP_CONV_C3), ("HSEFR_OP_DWCONV3X3", lowering.OP_DWCONV3X3),
+                      ("HSEFR_OP_PWCONV_F32", lowering.OP_PWCONV_F32), ("HSEFR_OP_GAP", lowering.OP_GAP),
+                      ("HSEFR_OP_DENSE", lowering.OP_DENSE), ("HSEFR_OP_SOFTMAX", lowering.OP_SOFTMAX),
+                      ("HSEFR_ACT_RELU6", lowering.ACT_RELU6), ("HSEFR_ACT_SIGMOID", lowering.ACT_SIGMOID)):
+        assert "%s = %d" % (name, val) in hdr
+
+
+def test_buffers_never_alias_input_and_output(graph):
+    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192))
+    for L in plan.layers:
+        if L.src >= 0:
+            assert plan.layers[L.src].out_buf != L.out_buf
+    pinned = {plan.layers[li].out_buf for li, _ in plan.outputs.values()}
+    assert len(pinned) == 3
+    # the two big ping-pong buffers + three small output buffers
+    assert sorted(plan.buffers, reverse=True)[:2] == [96 * 96 * 64, 96 * 96 * 32]
+
+
+def test_unfolded_batchnorm_and_learning_phase_graph():
+    """vgg2_mobilenet.pb (missing) keeps BN un-folded behind a keras_learning_phase Switch/Merge
+    (facerec_test.py:212).  Build a tiny graph of that shape by hand and lower it."""
+    import gb
+    rs = np.random.RandomState(11)
+    b = gb.GraphBuilder()
+    b.placeholder("input_1", [-1, 8, 8, 3])
+    b.placeholder("conv1_bn/keras_learning_phase", None, dtype=10)
+    k = (rs.randn(3, 3, 3, 8) * 0.1).astype(np.float32)
+    b.const("conv1/kernel", k)
+    b.node("conv1/convolution", "Conv2D", ["input_1", "conv1/kernel"], strides=[1, 2, 2, 1], padding="SAME", data_format="NHWC")
+    gamma, beta = rs.uniform(0.5, 1.5, 8).astype(np.float32), rs.randn(8).astype(np.float32)
+    mean, var = rs.randn(8).astype(np.float32), rs.uniform(0.5, 2, 8).astype(np.float32)
+    for nm, v in (("gamma", gamma), ("beta", beta), ("moving_mean", mean), ("moving_variance", var)):
+        b.const("conv1_bn/" + nm, v)
+    b.const("conv1_bn/eps", np.float32(1e-3))
+    # inference branch: (x - mean) * gamma * rsqrt(var + eps) + beta, as Keras emits it
+    b.node("conv1_bn/cond/Switch_1", "Switch", ["conv1/convolution", "conv1_bn/keras_learning_phase"])
+    b.node("conv1_bn/batchnorm/add", "Add", ["conv1_bn/moving_variance", "conv1_bn/eps"])
+    b.node("conv1_bn/batchnorm/Rsqrt", "Rsqrt", ["conv1_bn/batchnorm/add"])
+    b.node("conv1_bn/batchnorm/mul", "Mul", ["conv1_bn/batchnorm/Rsqrt", "conv1_bn/gamma"])
+    b.node("conv1_bn/batchnorm/mul_1", "Mul", ["conv1_bn/cond/Switch_1", "conv1_bn/batchnorm/mul"])
+    b.node("conv1_bn/batchnorm/mul_2", "Mul", ["conv1_bn/moving_mean", "conv1_bn/batchnorm/mul"])
+    b.node("conv1_bn/batchnorm/sub", "Sub", ["conv1_bn/beta", "conv1_bn/batchnorm/mul_2"])
+    b.node("conv1_bn/batchnorm/add_1", "Add", ["conv1_bn/batchnorm/mul_1", "conv1_bn/batchnorm/sub"])
+    # training branch hangs off port 1 and must be dead
+    b.node("conv1_bn/cond/train", "Neg", ["conv1_bn/cond/Switch_1:1"])
+    b.node("conv1_bn/cond/Merge", "Merge", ["conv1_bn/batchnorm/add_1", "conv1_bn/cond/train"])
+    b.node("conv1_relu/Relu6", "Relu6", ["conv1_bn/cond/Merge"])
+    b.const("gap/axes", np.array([1, 2], np.int32))
+    b.node("global_average_pooling2d_1/Mean", "Mean", ["conv1_relu/Relu6", "gap/axes"])
+    b.const("reshape_1/shape", np.array([-1, 1, 1, 8], np.int32))
+    b.node("reshape_1/Reshape", "Reshape", ["global_average_pooling2d_1/Mean", "reshape_1/shape"])
+    data = b.serialize()
+
+    g = graphdef.read_graph(data)
+    plan = lowering.lower_graph(g, "input_1:0", {OUT_FEATURES: "reshape_1/Reshape:0"}, None,
+                                {"conv1_bn/keras_learning_phase:0": 0})
+    assert [L.kind for L in plan.layers] == [lowering.OP_CONV_C3, lowering.OP_GAP]
+    assert plan.layers[0].act == lowering.ACT_RELU6
+    x = rs.uniform(-128, 128, (2, 8, 8, 3)).astype(np.float32)
+    got = plan_ref.run(plan.serialize(), x)["features"]
+    # oracle: same bytes through the unfused interpreter, learning phase fed 0 (facerec_test.py:118-119)
+    ref = tfo.GraphOracle(tfo.parse_graphdef(data)).run("reshape_1/Reshape:0",
+                                                        {"input_1:0": x, "conv1_bn/keras_learning_phase:0": 0})
+    assert ref.shape == (2, 1, 1, 8)
+    assert rel(got, ref.reshape(2, -1)) < 1e-5
+    with pytest.raises(lowering.LoweringError):        # predicate not fed -> cannot resolve the Merge
+        lowering.lower_graph(g, "input_1:0", {OUT_FEATURES: "reshape_1/Reshape:0"})
