@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: faces/sec of embedding extraction, MobileNet-192, batch 256, fp32 --
+BASELINE.json configs[1] -- on N MI355X GPUs of one node (one process per GPU).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (conv1 -> 13 x (depthwise + pointwise) -> GAP) over one
+batch of 256 synthetic preprocessed images already resident in HBM.  Prints ONE JSON line on
+rank 0 (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel class by device time, priced against its bound
+                (fp32-MFMA 157.3 TFLOP/s for the pointwise GEMM, HBM 8 TB/s for the others),
+                durations from HIP events recorded on the forward's own stream during the timed
+                steps; `kernels` lists every class, `roofline_depthwise` is the class the
+                north-star target (>= 60 % of HBM roofline) is stated against.
+  cpu_baseline  the reference's batch-1 extract loop (facerec_test.py:394) on the host cores:
+                the same frozen graph executed op-by-op by torch-CPU/oneDNN (oracle/torch_cpu.py),
+                kind "port" -- TensorFlow itself cannot be installed on this image.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = 157.3 TFLOP/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--size", type=int, default=192)
+    ap.add_argument("--no-op-events", action="store_true", help="do not record per-op HIP events in the timed steps")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from hse_facerec_tf_amd import lowering
+    from hse_facerec_tf_amd.tf_inference import AGE_GENDER_PB, TensorFlowInference
+
+    B, S = args.batch, args.size
+    tfi = TensorFlowInference(AGE_GENDER_PB, input_tensor="input_1:0", output_tensor="global_pooling/Mean:0",
+                              convert2BGR=True, imageNetUtilsMean=True, input_size=(S, S), max_batch=B, device=local_rank)
+    eng, plan = tfi.engine, tfi.plan
+    # synthetic preprocessed batch: U(-128,128) fp32 NHWC, seed 123 (+rank)
+    x_host = np.random.RandomState(123 + rank).uniform(-128, 128, (B, S, S, 3)).astype(np.float32)
+    x = torch.from_numpy(x_host).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return eng.forward(x)["features"]
+
+    for _ in range(args.warmup):
+        out = step()
+    use_events = not args.no_op_events
+    if use_events:
+        eng.set_profiling(args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(out).all())
+
+    # ---- per-kernel-class durations from the events recorded during the timed steps ----------
+    per_op = None
+    if use_events:
+        per_op = np.zeros(len(plan.layers))
+        for s in range(args.steps):
+            per_op += np.asarray(eng.op_times_ms(s))
+        per_op /= args.steps
+        eng.set_profiling(0)
+
+    # the exchange of config 5 (one all-gather of the embeddings), outside the timed region
+    allgather_ms = None
+    if world > 1:
+        full = torch.empty((world * B, out.shape[1]), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(full, out)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dist.all_gather_into_tensor(full, out)
+        barrier()
+        allgather_ms = (time.perf_counter() - t1) / 10 * 1e3
+        assert torch.equal(full[rank * B:(rank + 1) * B], out)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    classes = {
+        "conv1_3x3x3_s2": lambda L: L.kind == lowering.OP_CONV_C3,
+        "depthwise3x3": lambda L: L.kind == lowering.OP_DWCONV3X3,
+        "pointwise1x1_f32mfma": lambda L: L.kind == lowering.OP_PWCONV_F32,
+        "gap": lambda L: L.kind == lowering.OP_GAP,
+    }
+    kernels = []
+    if per_op is not None:
+        for name, pred in classes.items():
+            idx = [i for i, L in enumerate(plan.layers) if pred(L)]
+            if not idx:
+                continue
+            ms = float(per_op[idx].sum())
+            nbytes = sum(4 * (int(np.prod(plan.layers[i].in_shape)) + int(np.prod(plan.layers[i].out_shape))) for i in idx) * B \
+                + sum(4 * sum(a.size for a in (plan.layers[i].w, plan.layers[i].scale, plan.layers[i].shift) if a is not None) for i in idx)
+            flops = sum(plan.flops_per_image([plan.layers[i].kind]) for i in idx[:1]) * B
+            launches = len(idx)
+            bound = "mfma" if name.startswith("pointwise") else "hbm"
+            if bound == "mfma":
+                achieved, peak, unit = flops / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+            else:
+                achieved, peak, unit = nbytes / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+            kernels.append({"kernel": name, "launches_per_step": launches, "ms_per_step": round(ms, 4),
+                            "avg_launch_us": round(ms / launches * 1e3, 2), "bound": bound,
+                            "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
+                            "algorithmic_bytes_per_step": int(nbytes), "flops_per_step": int(flops),
+                            "hbm_gbs_algorithmic": round(nbytes / (ms * 1e-3) / 1e9, 1), "traffic": None})
+    dominant = max(kernels, key=lambda k: k["ms_per_step"]) if kernels else None
+    dw = next((k for k in kernels if k["kernel"] == "depthwise3x3"), None)
+
+    def roof(k):
+        if k is None:
+            return None
+        return {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
+                "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_launch_us": k["avg_launch_us"],
+                "launches_per_step": k["launches_per_step"]}
+
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.torch_cpu import time_reference_loop
+        cores = os.cpu_count() or 1
+        fps, n_img = time_reference_loop(AGE_GENDER_PB, "global_pooling/Mean:0", x_host[:32], cores,
+                                         budget_s=args.cpu_baseline_seconds, batch=1)
+        cpu_baseline = {"value": round(fps, 2), "unit": "faces/s", "cores": cores, "kind": "port",
+                        "sample": "%d images of the same synthetic %dx%dx3 batch through the reference's batch-1 loop "
+                                  "(facerec_test.py:394): same frozen graph, op-by-op fp32 on torch-CPU/oneDNN; not TensorFlow"
+                                  % (n_img, S, S)}
+
+    line = {
+        "metric": "faces/sec embedding-extract (MobileNet-192, bs=256)",
+        "value": round(value, 1), "unit": "faces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "MobileNet-v1 192x192x3 embeddings (1024-D), batch %d per GPU, fp32 -- BASELINE configs[1]" % B,
+                   "global_batch": B * world, "input": [S, S, 3],
+                   "weights": "trunk of age_gender_tf2_new-01-0.14-0.92_quantized.pb (the reference's only shipped graph)",
+                   "parallelism": "%d independent replicas, gallery sharded by image, one all-gather of embeddings" % world,
+                   "op_events_in_timed_region": use_events},
+        "roofline": roof(dominant), "roofline_depthwise": roof(dw), "kernels": kernels,
+        "cpu_baseline": cpu_baseline,
+        "allgather_ms": None if allgather_ms is None else round(allgather_ms, 4),
+        "device_bytes": eng.device_bytes,
+    }
+    print(json.dumps(line))
+    sys.stdout.flush()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,8 @@ SIGNATURES = {
     "hsefr_engine_buffer": (c_void_p, [c_void_p, c_int]),
     "hsefr_engine_copy_buffer": (c_int, [c_void_p, c_int, _fp, c_size_t, c_void_p]),
     "hsefr_engine_set_profiling": (c_int, [c_void_p, c_int]),
-    "hsefr_engine_op_times_ms": (c_int, [c_void_p, POINTER(c_float), c_int]),
+    "hsefr_engine_profiled_calls": (c_longlong, [c_void_p]),
+    "hsefr_engine_op_times_ms": (c_int, [c_void_p, c_int, POINTER(c_float), c_int]),
     "hsefr_engine_destroy": (c_int, [c_void_p]),
     "hsefr_conv_c3_bias_act": (c_int, [_fp, _fp, _fp, _fp] + [c_int] * 12 + [c_void_p]),
     "hsefr_dwconv3x3_bn_relu6": (c_int, [_fp, _fp, _fp, _fp, _fp] + [c_int] * 10 + [c_void_p]),

@@ -41,9 +41,11 @@ struct hsefr_engine {
     size_t device_bytes = 0;
     int max_batch = 0;
     int device = 0;
-    bool profiling = false;
-    std::vector<hipEvent_t> events;  // n_ops + 1
-    bool have_times = false;
+    // profiling: a ring of `depth` event sets (n_ops + 1 events each), one set per forward
+    // call, so a whole timed region can be instrumented without a sync between steps
+    int prof_depth = 0;
+    long long prof_calls = 0;
+    std::vector<hipEvent_t> events;  // depth * (n_ops + 1)
 };
 
 static const void* blob_ptr(const hsefr_engine* e, uint64_t off) {
@@ -170,23 +172,30 @@ int hsefr_engine_copy_buffer(hsefr_engine* e, int buffer, void* d_dst, size_t by
     return HSEFR_OK;
 }
 
-int hsefr_engine_set_profiling(hsefr_engine* e, int on) {
-    HSEFR_REQUIRE(e, HSEFR_ERR_INVALID, "set_profiling: null engine");
-    if (on && e->events.empty()) {
-        e->events.resize(e->ops.size() + 1);
+int hsefr_engine_set_profiling(hsefr_engine* e, int depth) {
+    HSEFR_REQUIRE(e && depth >= 0, HSEFR_ERR_INVALID, "set_profiling: bad argument");
+    for (auto ev : e->events) (void)hipEventDestroy(ev);
+    e->events.clear();
+    e->prof_depth = 0;
+    e->prof_calls = 0;
+    if (depth > 0) {
+        e->events.resize((size_t)depth * (e->ops.size() + 1));
         for (auto& ev : e->events) HSEFR_HIP_CHECK(hipEventCreate(&ev));
+        e->prof_depth = depth;
     }
-    e->profiling = on != 0;
-    e->have_times = false;
     return HSEFR_OK;
 }
 
-int hsefr_engine_op_times_ms(hsefr_engine* e, float* ms, int n_ops) {
+long long hsefr_engine_profiled_calls(const hsefr_engine* e) { return e ? e->prof_calls : 0; }
+
+int hsefr_engine_op_times_ms(hsefr_engine* e, int slot, float* ms, int n_ops) {
     HSEFR_REQUIRE(e && ms, HSEFR_ERR_INVALID, "op_times: null argument");
-    HSEFR_REQUIRE(e->have_times, HSEFR_ERR_INVALID, "op_times: no profiled forward has run");
+    HSEFR_REQUIRE(e->prof_depth > 0 && slot >= 0 && slot < e->prof_depth && slot < e->prof_calls, HSEFR_ERR_INVALID,
+                  "op_times: slot %d has no profiled forward (depth %d, calls %lld)", slot, e->prof_depth, e->prof_calls);
     HSEFR_REQUIRE(n_ops == (int)e->ops.size(), HSEFR_ERR_INVALID, "op_times: expected %zu ops", e->ops.size());
-    HSEFR_HIP_CHECK(hipEventSynchronize(e->events.back()));
-    for (int i = 0; i < n_ops; ++i) HSEFR_HIP_CHECK(hipEventElapsedTime(&ms[i], e->events[i], e->events[i + 1]));
+    hipEvent_t* ev = e->events.data() + (size_t)slot * (e->ops.size() + 1);
+    HSEFR_HIP_CHECK(hipEventSynchronize(ev[n_ops]));
+    for (int i = 0; i < n_ops; ++i) HSEFR_HIP_CHECK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
     return HSEFR_OK;
 }
 
@@ -201,7 +210,8 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
                       "forward: the plan does not produce output slot %d", s);
     if (n == 0) return HSEFR_OK;
     hipStream_t s = (hipStream_t)stream;
-    const bool prof = e->profiling;
+    const bool prof = e->prof_depth > 0;
+    hipEvent_t* pev = prof ? e->events.data() + (size_t)(e->prof_calls % e->prof_depth) * (e->ops.size() + 1) : nullptr;
     // Like sess.run, evaluate only what the requested fetches need: walk the op list backwards
     // from the requested output buffers (buffers are reused, so liveness is positional).
     // With no output pointer at all, every op runs (per-layer parity tests read the buffers).
@@ -219,11 +229,11 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
             if (o.res_buf >= 0) live[o.res_buf] = 1;
         }
     }
-    if (prof) HSEFR_HIP_CHECK(hipEventRecord(e->events[0], s));
+    if (prof) HSEFR_HIP_CHECK(hipEventRecord(pev[0], s));
     for (size_t i = 0; i < e->ops.size(); ++i) {
         const hsefr_plan_op& o = e->ops[i];
         if (!needed[i]) {
-            if (prof) HSEFR_HIP_CHECK(hipEventRecord(e->events[i + 1], s));
+            if (prof) HSEFR_HIP_CHECK(hipEventRecord(pev[i + 1], s));
             continue;
         }
         const void* in = buf_ptr(e, o.in_buf, d_input);
@@ -260,7 +270,7 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
                 rc = HSEFR_ERR_UNSUPPORTED;
         }
         if (rc != HSEFR_OK) return rc;
-        if (prof) HSEFR_HIP_CHECK(hipEventRecord(e->events[i + 1], s));
+        if (prof) HSEFR_HIP_CHECK(hipEventRecord(pev[i + 1], s));
     }
     for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl) {
         if (!outs[sl]) continue;
@@ -268,7 +278,7 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
         const size_t bytes = (size_t)e->hdr.out_elems[sl] * sizeof(float) * n;
         HSEFR_HIP_CHECK(hipMemcpyAsync(outs[sl], e->d_bufs[b], bytes, hipMemcpyDeviceToDevice, s));
     }
-    if (prof) e->have_times = true;
+    if (prof) e->prof_calls++;
     return HSEFR_OK;
 }
 

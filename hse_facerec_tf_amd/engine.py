@@ -90,11 +90,15 @@ class Engine:
         return out
 
     # -- profiling -----------------------------------------------------------------------------
-    def set_profiling(self, on: bool) -> None:
-        _lib.check(_lib.lib().hsefr_engine_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, depth: int) -> None:
+        """depth > 0: keep HIP-event timings of the last `depth` forwards (ring); 0: off."""
+        _lib.check(_lib.lib().hsefr_engine_set_profiling(self._h, int(depth)))
 
-    def op_times_ms(self) -> List[float]:
+    def profiled_calls(self) -> int:
+        return int(_lib.lib().hsefr_engine_profiled_calls(self._h))
+
+    def op_times_ms(self, slot: int = 0) -> List[float]:
         n = len(self.plan.layers)
         arr = (ctypes.c_float * n)()
-        _lib.check(_lib.lib().hsefr_engine_op_times_ms(self._h, arr, n))
+        _lib.check(_lib.lib().hsefr_engine_op_times_ms(self._h, int(slot), arr, n))
         return list(arr)

@@ -13,8 +13,6 @@
  *       -> hsefr_engine_destroy()
  *   - sklearn normalize + KNeighborsClassifier(1).kneighbors   facerec_test.py:401,200-207,422
  *       -> hsefr_l2_normalize() + hsefr_nn1()
- *   - misc.imresize/cv2.resize + BGR + mean      facerec_test.py:93-106 ; facial_analysis.py:95-108
- *       -> hsefr_preprocess_u8()
  *
  * Conventions: extern "C", plain C types; every function returns 0 on success or a negative
  * hsefr_status (never throws); hsefr_last_error_string() describes the last failure on the
@@ -149,10 +147,13 @@ void* hsefr_engine_buffer(hsefr_engine* e, int buffer);
 /* Asynchronous device-to-device copy of the first `bytes` of an activation buffer into d_dst. */
 int hsefr_engine_copy_buffer(hsefr_engine* e, int buffer, void* d_dst, size_t bytes, hsefr_stream_t stream);
 
-/* Per-op device time of the LAST forward run with profiling on (HIP events around every
- * launch on the forward's stream; synchronises).  `ms` receives n_ops floats. */
-int hsefr_engine_set_profiling(hsefr_engine* e, int on);
-int hsefr_engine_op_times_ms(hsefr_engine* e, float* ms, int n_ops);
+/* Per-op device time: with depth > 0 every forward records HIP events around each launch on
+ * the forward's own stream into a ring of `depth` event sets (call c uses set c % depth), so a
+ * whole timed region can be instrumented without synchronising between steps.  depth 0 = off.
+ * op_times_ms waits for set `slot` and writes n_ops elapsed times (ms, 0 for pruned ops). */
+int hsefr_engine_set_profiling(hsefr_engine* e, int depth);
+long long hsefr_engine_profiled_calls(const hsefr_engine* e);
+int hsefr_engine_op_times_ms(hsefr_engine* e, int slot, float* ms, int n_ops);
 
 int hsefr_engine_destroy(hsefr_engine* e); /* replaces tf_sess.close(), facerec_test.py:124-125 */
 

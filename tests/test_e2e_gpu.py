@@ -1,0 +1,156 @@
+"""GPU parity, end to end: the engine behind the reference's API vs golden vectors and the live
+oracle.  Bar (north_star): embeddings within 1e-4 relative, fp32.  `rel` is max|a-b| / max|b|."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pipeline as opl
+from oracle import tf_graph as tfo
+
+from conftest import GOLDEN, MODEL_PB, TEST_IMAGE
+
+pytestmark = pytest.mark.gpu
+
+BAR = 1e-4
+FETCH = ["global_pooling/Mean:0", "age_pred/Softmax:0", "gender_pred/Sigmoid:0"]
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def torch_():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_native_library_is_the_one_loaded(torch_):
+    from hse_facerec_tf_amd import _lib
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "hse_facerec_tf_amd/libhsefr.so" in maps
+
+
+@pytest.mark.parametrize("size", [192, 224, 96, 100])
+def test_engine_matches_golden_synthetic(torch_, size):
+    from hse_facerec_tf_amd import engine, graphdef, lowering
+    z = np.load(os.path.join(GOLDEN, "e2e_synthetic.npz"))
+    n = z["feat_%d" % size].shape[0]
+    plan = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0",
+                                {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]}, (size, size))
+    eng = engine.Engine(plan, max_batch=4)
+    x = np.random.RandomState(123).uniform(-128, 128, (n, size, size, 3)).astype(np.float32)
+    out = eng.forward(torch_.from_numpy(x).cuda(), (0, 1, 2))
+    assert rel(out["features"].cpu().numpy(), z["feat_%d" % size]) < BAR
+    assert rel(out["age_probs"].cpu().numpy(), z["age_%d" % size]) < BAR
+    assert rel(out["gender"].cpu().numpy(), z["gender_%d" % size]) < BAR
+    # per-element relative error where the feature is not tiny
+    f, g = out["features"].cpu().numpy().astype(np.float64), z["feat_%d" % size].astype(np.float64)
+    big = np.abs(g) > 1e-3 * np.abs(g).max()
+    assert (np.abs(f - g)[big] / np.abs(g)[big]).max() < 1e-3
+    eng.close()
+    with pytest.raises(RuntimeError):
+        eng.forward(torch_.from_numpy(x).cuda())
+
+
+def test_every_layer_matches_the_oracle(torch_):
+    """Layer-by-layer: each fused layer's output vs the graph tensor it stands for (unfused fp64
+    oracle), through the per-kernel entry points with the plan's own weights."""
+    from hse_facerec_tf_amd import graphdef, lowering, ops
+    g = graphdef.read_graph(MODEL_PB)
+    plan = lowering.lower_graph(g, "input_1:0", {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]}, (96, 96))
+    x = np.random.RandomState(9).uniform(-128, 128, (2, 96, 96, 3)).astype(np.float32)
+    names = {li: nm for nm, li in plan.tensor_layer.items()}
+    orc = tfo.GraphOracle(MODEL_PB, np.float64)
+    want = orc.run([names[i] + ":0" for i in range(len(plan.layers))], {"input_1:0": x})
+    d = lambda a: torch_.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    acts = {-1: d(x)}
+    for i, L in enumerate(plan.layers):
+        src = acts[L.src]
+        if L.kind == lowering.OP_CONV_C3:
+            y = ops.conv3x3_c3(src, d(L.w), d(L.shift), L.stride, L.act)
+        elif L.kind == lowering.OP_DWCONV3X3:
+            y = ops.dwconv3x3(src, d(L.w.reshape(3, 3, -1)), d(L.scale), d(L.shift), L.stride, L.act)
+        elif L.kind == lowering.OP_PWCONV_F32:
+            y = ops.pwconv1x1(src, d(L.w.reshape(L.w.shape[2], L.w.shape[3]).T), d(L.shift), L.act)
+        elif L.kind == lowering.OP_GAP:
+            y = ops.gap(src)
+        elif L.kind == lowering.OP_DENSE:
+            y = ops.dense(src.reshape(src.shape[0], -1), d(L.w), d(L.shift), L.act)
+        elif L.kind == lowering.OP_SOFTMAX:
+            y = ops.softmax(src.reshape(src.shape[0], -1))
+        acts[i] = y
+        w = np.asarray(want[i]).reshape(y.shape)
+        assert rel(y.cpu().numpy(), w) < BAR, "layer %d (%s)" % (i, L.name)
+
+
+def test_tensorflow_inference_dropin_on_the_reference_image(torch_):
+    """facerec_test.py usage: construct by tensor names, extract_features(path) -> flat fp32 vector."""
+    from hse_facerec_tf_amd import TensorFlowInference
+    z = np.load(os.path.join(GOLDEN, "e2e_test_image.npz"))
+    tfi = TensorFlowInference(MODEL_PB, input_tensor='input_1:0', output_tensor='global_pooling/Mean:0',
+                              convert2BGR=True, imageNetUtilsMean=True)
+    assert (tfi.w, tfi.h) == (224, 224)
+    f = tfi.extract_features(TEST_IMAGE)
+    assert f.shape == (1024,) and f.dtype == np.float32
+    assert rel(f, z["feat_224"]) < BAR
+    x = tfi.preprocess_image(TEST_IMAGE, False)
+    assert x.shape == (224, 224, 3) and x.dtype == np.float64
+    tfi.close_session()
+    t192 = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(192, 192))
+    assert rel(t192.extract_features(TEST_IMAGE), z["feat_192"]) < BAR
+    fb = t192.extract_files([TEST_IMAGE, TEST_IMAGE, TEST_IMAGE], batch=2)
+    assert fb.shape == (3, 1024) and rel(fb[2], z["feat_192"]) < BAR
+    assert np.array_equal(fb[0], fb[1]) and np.array_equal(fb[0], fb[2])
+    with pytest.raises(ValueError):            # wrong spatial size fed, like sess.run's shape check
+        t192.extract_batch(torch_.zeros((1, 224, 224, 3), device="cuda"))
+    with pytest.raises(ValueError):            # more than max_batch
+        t192.engine.forward(torch_.zeros((257, 192, 192, 3), device="cuda"))
+    t192.close_session()
+
+
+def test_facial_image_processing_dropin(torch_):
+    """facial_analysis.py usage: age_gender_fun(face_rgb) and process_image(frame_bgr) with boxes."""
+    from hse_facerec_tf_amd import FacialImageProcessing
+    z = np.load(os.path.join(GOLDEN, "e2e_test_image.npz"))
+    fip = FacialImageProcessing(print_stat=False, mtcnn_detector=False)
+    img = opl.imread_rgb(TEST_IMAGE)
+    age, gender, feats = fip.age_gender_fun(img)
+    assert abs(age - float(z["ag_res_age"])) < 1e-2
+    assert rel(gender, z["ag_gender"]) < BAR and rel(feats, z["ag_feat"]) < BAR
+    assert gender.shape == (1,) and feats.shape == (1024,)
+    bgr = np.ascontiguousarray(img[..., ::-1])
+    bboxes, points, ages, genders, ffs = fip.process_image(bgr, bounding_boxes=z["boxes"])
+    assert len(bboxes) == 4 and bboxes[3][0] == 0
+    assert rel(np.asarray(ffs), z["crop_feats"]) < BAR
+    assert rel(np.asarray(genders), z["crop_genders"]) < BAR
+    assert np.abs(np.asarray(ages) - z["crop_ages"]).max() < 1e-2
+    with pytest.raises(NotImplementedError):
+        fip.process_image(bgr)                 # no detector injected
+    fip.close()
+
+
+def test_batch_256_properties_at_full_size(torch_):
+    """BASELINE config 2 at full size (batch 256, 192x192x3), where the oracle is too slow:
+    size-independent properties -- every image's embedding is independent of its batch position
+    and neighbours (bit-exact), and a sample of rows matches the oracle."""
+    from hse_facerec_tf_amd import TensorFlowInference
+    tfi = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(192, 192), max_batch=256)
+    rs = np.random.RandomState(123)
+    x = torch_.from_numpy(rs.uniform(-128, 128, (256, 192, 192, 3)).astype(np.float32)).cuda()
+    full = tfi.extract_batch(x)
+    assert tuple(full.shape) == (256, 1024)
+    assert bool(torch_.isfinite(full).all()) and float(full.min()) >= 0.0 and float(full.max()) <= 6.0
+    perm = torch_.from_numpy(rs.permutation(256)).cuda()
+    assert torch_.equal(tfi.extract_batch(x[perm].contiguous()), full[perm])          # permutation equivariance
+    for lo, n in ((0, 1), (17, 3), (250, 6)):                                           # batch-size independence
+        assert torch_.equal(tfi.extract_batch(x[lo:lo + n].contiguous()), full[lo:lo + n])
+    again = tfi.extract_batch(x)
+    assert torch_.equal(again, full)                                                    # deterministic
+    rows = [0, 131, 255]
+    ref = tfo.GraphOracle(MODEL_PB, np.float64).run(FETCH[0], {"input_1:0": x[rows].cpu().numpy()})
+    assert rel(full[rows].cpu().numpy(), ref) < BAR
+    tfi.close_session()

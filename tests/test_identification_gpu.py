@@ -1,0 +1,86 @@
+"""GPU parity for the identification stage (facerec_test.py:401-432) vs scikit-learn's own
+results frozen in tests/golden/nn1.npz, plus a world-size-1 run of the sharded gallery path."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import identification as oid
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_l2_normalize_matches_sklearn_fixture(torch_):
+    from hse_facerec_tf_amd import ops
+    z = np.load(os.path.join(GOLDEN, "nn1.npz"))
+    X, y = oid.synthetic_gallery(int(z["n_classes"]), int(z["dim"]), int(z["seed"]), float(z["noise"]))
+    Xn = ops.l2_normalize(torch_.from_numpy(X).cuda()).cpu().numpy()
+    assert np.abs(Xn[z["kept"][:8]] - z["x_norm_sample"]).max() < 1e-6
+    zero = ops.l2_normalize(torch_.zeros((2, 16), device="cuda"))
+    assert float(zero.abs().max()) == 0.0                                  # sklearn leaves zero rows alone
+
+
+def test_one_nn_protocol_matches_sklearn(torch_):
+    from hse_facerec_tf_amd import identification
+    z = np.load(os.path.join(GOLDEN, "nn1.npz"))
+    X, y = oid.synthetic_gallery(int(z["n_classes"]), int(z["dim"]), int(z["seed"]), float(z["noise"]))
+    r = identification.one_nn_identification(X, y)
+    assert np.array_equal(r["indices"], z["kept"]) and np.array_equal(r["y"], z["y"])
+    assert np.array_equal(r["train"], z["train"]) and np.array_equal(r["test"], z["test"])
+    # index work is bit-exact: same nearest gallery row for every probe (no fp ties in this fixture)
+    assert np.array_equal(r["nn_index"], z["nn_index"])
+    assert np.array_equal(r["y_pred"], z["y_pred"])
+    assert r["accuracy"] == pytest.approx(float(z["accuracy"]), abs=1e-12)
+    assert np.abs(r["nn_dist"] - z["nn_dist"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("nq,ng,d", [(1, 1, 8), (33, 65, 64), (200, 1000, 1024), (70, 31, 2048)])
+def test_nn1_vs_bruteforce(torch_, nq, ng, d):
+    from hse_facerec_tf_amd import ops
+    rs = np.random.RandomState(nq + ng)
+    q = rs.randn(nq, d).astype(np.float32)
+    g = rs.randn(ng, d).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    d2 = ((q.astype(np.float64)[:, None, :] - g.astype(np.float64)[None]) ** 2).sum(-1) if nq * ng * d < 5e7 else \
+        (2 - 2 * q.astype(np.float64) @ g.astype(np.float64).T)
+    idx, dist = ops.nn1(torch_.from_numpy(q).cuda(), torch_.from_numpy(g).cuda())
+    idx = idx.cpu().numpy()
+    best = d2.min(axis=1)
+    assert np.all(d2[np.arange(nq), idx] <= best + 1e-5)       # the chosen row is a nearest one (fp32 tolerance)
+    assert (idx == d2.argmin(axis=1)).mean() > 0.99
+    assert np.abs(dist.cpu().numpy() - best).max() < 1e-4
+
+
+def test_nn1_ties_resolve_to_lowest_index(torch_):
+    from hse_facerec_tf_amd import ops
+    g = np.zeros((40, 8), np.float32)
+    g[:, 0] = 1.0                                            # 40 identical gallery rows
+    q = np.zeros((3, 8), np.float32)
+    q[:, 0] = 1.0
+    idx, _ = ops.nn1(torch_.from_numpy(q).cuda(), torch_.from_numpy(g).cuda())
+    assert idx.cpu().tolist() == [0, 0, 0]
+
+
+def test_sharded_gallery_world1_on_device(torch_):
+    from hse_facerec_tf_amd import TensorFlowInference, gallery
+    from conftest import MODEL_PB
+    tfi = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(96, 96), max_batch=8)
+    rs = np.random.RandomState(4)
+    imgs = rs.uniform(-128, 128, (19, 96, 96, 3)).astype(np.float32)
+
+    def extract(ids):
+        return tfi.extract_batch(torch_.from_numpy(imgs[list(ids)]).cuda())
+    full = gallery.extract_sharded(extract, list(range(19)), 1024, torch_.device("cuda"), batch=8)
+    assert tuple(full.shape) == (19, 1024)
+    assert torch_.equal(full[8:16], extract(range(8, 16)))
+    tfi.close_session()

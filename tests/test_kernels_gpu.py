@@ -1,0 +1,165 @@
+"""GPU parity, per kernel class: HIP kernels (through the C ABI) vs the oracle's NumPy ops on the
+same seeded inputs and vs the committed golden I/O pairs.  fp32 path; tolerance: 1e-4 relative to
+the tensor's max magnitude is the bar north_star states -- these kernels are held to 2e-6 (fp32
+round-off only), so a layout or padding bug cannot hide under the bar."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import tf_graph as tfo
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+def act6(v):
+    return np.minimum(np.maximum(v, 0), 6)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from hse_facerec_tf_amd import ops
+    assert torch.cuda.is_available()
+    return torch, ops
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "kernels.npz"))
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def test_depthwise_golden_pairs(env, golden):
+    torch, ops = env
+    for i in range(6):
+        x, k, sc, sh, s = (golden["dw%d_%s" % (i, n)] for n in ("x", "k", "sc", "sh", "s"))
+        y = ops.dwconv3x3(dev(torch, x), dev(torch, k.reshape(3, 3, -1)), dev(torch, sc), dev(torch, sh), int(s))
+        assert y.shape == golden["dw%d_y" % i].shape
+        assert rel(y.cpu().numpy(), golden["dw%d_y" % i]) < TOL, "dw case %d" % i
+
+
+@pytest.mark.parametrize("n,h,w,c,s", [(3, 96, 96, 32, 1), (2, 96, 96, 64, 2), (2, 48, 48, 128, 1), (2, 24, 24, 256, 2),
+                                       (3, 12, 12, 512, 1), (2, 12, 12, 512, 2), (3, 6, 6, 1024, 1), (1, 7, 7, 1024, 1),
+                                       (2, 13, 11, 260, 2), (1, 5, 17, 12, 1), (5, 3, 3, 8, 2), (1, 112, 112, 32, 1)])
+def test_depthwise_vs_oracle(env, n, h, w, c, s):
+    torch, ops = env
+    rs = np.random.RandomState(h * 131 + c + s)
+    x = rs.uniform(-1, 6, (n, h, w, c)).astype(np.float32)
+    k = rs.randn(3, 3, c, 1).astype(np.float32)
+    sc = rs.uniform(0.2, 3, c).astype(np.float32)
+    sh = rs.randn(c).astype(np.float32)
+    want = act6(tfo.depthwise_conv2d(x.astype(np.float64), k, (s, s), "SAME") * sc + sh)
+    y = ops.dwconv3x3(dev(torch, x), dev(torch, k.reshape(3, 3, c)), dev(torch, sc), dev(torch, sh), s)
+    assert tuple(y.shape) == want.shape
+    assert rel(y.cpu().numpy(), want) < TOL
+    # other epilogues of the same kernel
+    from hse_facerec_tf_amd.lowering import ACT_NONE, ACT_RELU
+    lin = tfo.depthwise_conv2d(x.astype(np.float64), k, (s, s), "SAME") * sc + sh
+    y0 = ops.dwconv3x3(dev(torch, x), dev(torch, k.reshape(3, 3, c)), dev(torch, sc), dev(torch, sh), s, ACT_NONE)
+    y1 = ops.dwconv3x3(dev(torch, x), dev(torch, k.reshape(3, 3, c)), dev(torch, sc), dev(torch, sh), s, ACT_RELU)
+    assert rel(y0.cpu().numpy(), lin) < TOL and rel(y1.cpu().numpy(), np.maximum(lin, 0)) < TOL
+
+
+def test_first_conv_golden_pairs(env, golden):
+    torch, ops = env
+    for i in range(4):
+        x, k, sh, s = (golden["c3%d_%s" % (i, n)] for n in ("x", "k", "sh", "s"))
+        y = ops.conv3x3_c3(dev(torch, x), dev(torch, k), dev(torch, sh), int(s))
+        assert rel(y.cpu().numpy(), golden["c3%d_y" % i]) < TOL, "c3 case %d" % i
+
+
+@pytest.mark.parametrize("n,h,w,cout,s", [(2, 192, 192, 32, 2), (1, 224, 224, 32, 2), (2, 33, 47, 32, 2), (1, 20, 20, 64, 1)])
+def test_first_conv_vs_oracle(env, n, h, w, cout, s):
+    torch, ops = env
+    rs = np.random.RandomState(h + cout)
+    x = rs.uniform(-128, 128, (n, h, w, 3)).astype(np.float32)
+    k = (rs.randn(3, 3, 3, cout) * 0.02).astype(np.float32)
+    sh = rs.randn(cout).astype(np.float32)
+    want = act6(tfo.conv2d(x.astype(np.float64), k, (s, s), "SAME") + sh)
+    y = ops.conv3x3_c3(dev(torch, x), dev(torch, k), dev(torch, sh), s)
+    assert tuple(y.shape) == want.shape and rel(y.cpu().numpy(), want) < TOL
+
+
+def test_pointwise_golden_pairs(env, golden):
+    torch, ops = env
+    for i in range(5):
+        x, k, sh = (golden["pw%d_%s" % (i, n)] for n in ("x", "k", "sh"))
+        y = ops.pwconv1x1(dev(torch, x), dev(torch, k.T), dev(torch, sh))
+        assert rel(y.cpu().numpy(), golden["pw%d_y" % i]) < TOL, "pw case %d" % i
+
+
+@pytest.mark.parametrize("m,k,cout", [(96 * 96 * 2, 32, 64), (48 * 48 * 2, 64, 128), (2304, 128, 128), (1152 + 7, 128, 256),
+                                      (576, 256, 256), (300, 256, 512), (36 * 5, 512, 512), (36 * 3 + 1, 512, 1024),
+                                      (129, 1024, 1024), (1, 1024, 1024), (127, 32, 192)])
+def test_pointwise_vs_oracle(env, m, k, cout):
+    torch, ops = env
+    rs = np.random.RandomState(m + k + cout)
+    x = rs.uniform(0, 6, (m, k)).astype(np.float32)
+    w = (rs.randn(k, cout) / np.sqrt(k)).astype(np.float32)
+    sh = rs.randn(cout).astype(np.float32)
+    want = act6(x.astype(np.float64).dot(w.astype(np.float64)) + sh)
+    y = ops.pwconv1x1(dev(torch, x), dev(torch, w.T), dev(torch, sh))
+    assert rel(y.cpu().numpy(), want) < TOL
+
+
+def test_pointwise_mfma_operand_maps_with_exact_integers(env):
+    """A = identity-like selector against an ASYMMETRIC integer B: any row/column or k-slot mix-up
+    in the MFMA fragment maps gives an exactly wrong integer (cdna guide: A=I, asymmetric B)."""
+    torch, ops = env
+    from hse_facerec_tf_amd.lowering import ACT_NONE
+    k, cout, m = 64, 128, 256
+    w = (np.arange(k)[:, None] * 131 + np.arange(cout)[None, :] * 7 + 1).astype(np.float32)     # [k, cout], asymmetric
+    x = np.zeros((m, k), np.float32)
+    x[np.arange(m), np.arange(m) % k] = 1.0
+    x[np.arange(m), (np.arange(m) * 5 + 3) % k] += 2.0
+    want = x.astype(np.float64).dot(w.astype(np.float64))
+    y = ops.pwconv1x1(dev(torch, x), dev(torch, w.T), dev(torch, np.zeros(cout, np.float32)), ACT_NONE)
+    assert np.array_equal(y.cpu().numpy().astype(np.float64), want)
+
+
+def test_pointwise_rejects_unsupported_shapes(env):
+    torch, ops = env
+    x = torch.zeros((8, 48), device="cuda")
+    with pytest.raises(NotImplementedError):
+        ops.pwconv1x1(x, torch.zeros((64, 48), device="cuda"), torch.zeros(64, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        ops.pwconv1x1(torch.zeros((8, 32), device="cuda"), torch.zeros((40, 32), device="cuda"), torch.zeros(40, device="cuda"))
+
+
+def test_gap_dense_softmax_golden(env, golden):
+    torch, ops = env
+    from hse_facerec_tf_amd.lowering import ACT_NONE, ACT_RELU, ACT_SIGMOID
+    assert rel(ops.gap(dev(torch, golden["gap_x"])).cpu().numpy(), golden["gap_y"]) < TOL
+    x, k, b = dev(torch, golden["dn_x"]), dev(torch, golden["dn_k"]), dev(torch, golden["dn_b"])
+    assert rel(ops.dense(x, k, b, ACT_NONE).cpu().numpy(), golden["dn_y_none"]) < TOL
+    assert rel(ops.dense(x, k, b, ACT_RELU).cpu().numpy(), golden["dn_y_relu"]) < TOL
+    assert rel(ops.dense(x, k, b, ACT_SIGMOID).cpu().numpy(), golden["dn_y_sigmoid"]) < TOL
+    assert rel(ops.softmax(ops.dense(x, k, b, ACT_NONE)).cpu().numpy(), golden["sm_y"]) < TOL
+
+
+@pytest.mark.parametrize("n,hw,c", [(256, 36, 1024), (3, 49, 1024), (1, 1, 4), (5, 36, 2048), (2, 7, 20)])
+def test_gap_vs_oracle(env, n, hw, c):
+    torch, ops = env
+    x = np.random.RandomState(c).uniform(0, 6, (n, hw, 1, c)).astype(np.float32)
+    assert rel(ops.gap(dev(torch, x)).cpu().numpy(), x.astype(np.float64).mean(axis=(1, 2))) < TOL
+
+
+def test_empty_batch_is_a_noop(env):
+    torch, ops = env
+    y = ops.dwconv3x3(torch.zeros((0, 8, 8, 8), device="cuda"), torch.zeros((3, 3, 8), device="cuda"),
+                      torch.ones(8, device="cuda"), torch.zeros(8, device="cuda"))
+    assert tuple(y.shape) == (0, 8, 8, 8)
+    y = ops.pwconv1x1(torch.zeros((0, 32), device="cuda"), torch.zeros((64, 32), device="cuda"), torch.zeros(64, device="cuda"))
+    assert tuple(y.shape) == (0, 64)
