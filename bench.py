@@ -39,9 +39,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--size", type=int, default=192)
-    ap.add_argument("--no-op-events", action="store_true", help="do not record per-op HIP events in the timed steps")
+    ap.add_argument("--no-op-events", action="store_true", help="skip the instrumented second pass (no roofline objects)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="also print per-layer times to stderr")
     args = ap.parse_args()
 
     import torch
@@ -82,9 +83,7 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    use_events = not args.no_op_events
-    if use_events:
-        eng.set_profiling(args.steps)
+    # ---- timed region: EXACTLY `steps` forwards, barrier + synchronize on both sides -----------------
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -97,14 +96,34 @@ def main():
         elapsed = float(t.item())
     assert bool(torch.isfinite(out).all())
 
-    # ---- per-kernel-class durations from the events recorded during the timed steps ----------
+    # ---- the same `steps` forwards again with HIP events around every launch, recorded on the
+    # forward's own stream into a ring (no sync inside the region).  Kept out of the region above
+    # because the event packets cost ~4 % of a step; `ms_per_step_instrumented` reports that run.
     per_op = None
+    instrumented_ms = None
+    use_events = not args.no_op_events
     if use_events:
+        eng.set_profiling(args.steps)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        instrumented_ms = (time.perf_counter() - t1) / args.steps * 1e3
         per_op = np.zeros(len(plan.layers))
         for s in range(args.steps):
             per_op += np.asarray(eng.op_times_ms(s))
         per_op /= args.steps
         eng.set_profiling(0)
+        if args.layers and rank == 0:
+            for i, L in enumerate(plan.layers):
+                nb = 4 * B * (int(np.prod(L.in_shape)) + int(np.prod(L.out_shape)))
+                oh, ow, co = L.out_shape
+                fl = 2 * oh * ow * co * L.kh * L.kw * (L.in_shape[2] if L.kind != lowering.OP_DWCONV3X3 else 1) * B
+                print("layer %2d kind %d %-34s in %-16s out %-16s s%d  %8.2f us  %7.1f GB/s  %6.1f TF" %
+                      (i, L.kind, L.name[:34], L.in_shape, L.out_shape, L.stride, per_op[i] * 1e3,
+                       nb / (per_op[i] * 1e-3) / 1e9 if per_op[i] > 0 else 0, fl / (per_op[i] * 1e-3) / 1e12 if per_op[i] > 0 else 0),
+                      file=sys.stderr)
 
     # the exchange of config 5 (one all-gather of the embeddings), outside the timed region
     allgather_ms = None
@@ -167,7 +186,13 @@ def main():
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle.torch_cpu import time_reference_loop
-        cores = os.cpu_count() or 1
+        # threads actually used: the cores this process may run on, capped at 32 (batch-1 convolutions
+        # of this size stop scaling long before that; oversubscribing a cgroup-limited box is far slower)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(avail, 32))
         fps, n_img = time_reference_loop(AGE_GENDER_PB, "global_pooling/Mean:0", x_host[:32], cores,
                                          budget_s=args.cpu_baseline_seconds, batch=1)
         cpu_baseline = {"value": round(fps, 2), "unit": "faces/s", "cores": cores, "kind": "port",
@@ -184,7 +209,8 @@ def main():
                    "global_batch": B * world, "input": [S, S, 3],
                    "weights": "trunk of age_gender_tf2_new-01-0.14-0.92_quantized.pb (the reference's only shipped graph)",
                    "parallelism": "%d independent replicas, gallery sharded by image, one all-gather of embeddings" % world,
-                   "op_events_in_timed_region": use_events},
+                   "op_events": "second pass of the same %d steps, HIP events on the forward stream" % args.steps if use_events else None},
+        "ms_per_step_instrumented": None if instrumented_ms is None else round(instrumented_ms, 4),
         "roofline": roof(dominant), "roofline_depthwise": roof(dw), "kernels": kernels,
         "cpu_baseline": cpu_baseline,
         "allgather_ms": None if allgather_ms is None else round(allgather_ms, 4),

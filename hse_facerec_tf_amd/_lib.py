@@ -20,6 +20,8 @@ _fp = c_void_p   # device pointers travel as integers (tensor.data_ptr())
 SIGNATURES = {
     "hsefr_version": (c_int, []),
     "hsefr_last_error_string": (c_char_p, []),
+    "hsefr_debug_set": (c_int, [c_char_p, c_int]),
+    "hsefr_debug_copy": (c_int, [_fp, _fp, c_size_t, c_void_p]),
     "hsefr_engine_create": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
     "hsefr_engine_workspace_bytes": (c_size_t, [c_void_p]),
     "hsefr_engine_max_batch": (c_int, [c_void_p]),

@@ -85,4 +85,11 @@ int launch_l2_normalize(const float* x, float* y, int n, int d, hipStream_t s);
 int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2,
                hipStream_t s);
 
+void set_pw_tile(int v);
+void set_dw_th(int v);
+void set_dw_variant(int v);
+void set_copy_variant(int v);
+int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
+void set_c3_impl(int v);
+
 }  // namespace hsefr

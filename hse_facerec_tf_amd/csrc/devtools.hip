@@ -1,0 +1,76 @@
+// Calibration kernels (tuning/debug only): what a plain float4 copy reaches on this GPU, i.e. the
+// practical HBM ceiling the streaming kernels are compared against (MI355X_MICROARCH.md quotes
+// 6.29 TB/s for a float4 copy against the 8.0 TB/s spec).
+#include "common.h"
+
+namespace hsefr {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// variant bits: 1 = nontemporal loads, 2 = nontemporal stores; U = float4s in flight per thread
+template <int U, int NT>
+__global__ __launch_bounds__(256) void copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    for (size_t base = (size_t)blockIdx.x * 256 * U + threadIdx.x; base < n; base += stride) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * 256;
+            if (i < n) v[u] = (NT & 1) ? __builtin_nontemporal_load(src + i) : src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * 256;
+            if (i < n) {
+                if (NT & 2) __builtin_nontemporal_store(v[u], dst + i);
+                else dst[i] = v[u];
+            }
+        }
+    }
+}
+
+int g_copy_variant = 0;  // unroll: (v & 3) -> {1, 2, 4, 8}; nt bits: (v >> 2) & 3; grid: (v >> 4) & 3 -> {8, 4, 16, 32} WG/CU
+
+template <int U, int NT>
+void launch_v(const f32x4* s, f32x4* d, size_t n, unsigned blocks, hipStream_t st) {
+    hipLaunchKernelGGL((copy_kernel<U, NT>), dim3(blocks), dim3(256), 0, st, s, d, n);
+}
+
+template <int U>
+void launch_u(int nt, const f32x4* s, f32x4* d, size_t n, unsigned blocks, hipStream_t st) {
+    switch (nt) {
+        case 0: launch_v<U, 0>(s, d, n, blocks, st); break;
+        case 1: launch_v<U, 1>(s, d, n, blocks, st); break;
+        case 2: launch_v<U, 2>(s, d, n, blocks, st); break;
+        default: launch_v<U, 3>(s, d, n, blocks, st); break;
+    }
+}
+
+}  // namespace
+
+void set_copy_variant(int v) { g_copy_variant = v; }
+
+int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s) {
+    HSEFR_REQUIRE(bytes % 16 == 0, HSEFR_ERR_INVALID, "copy: bytes must be a multiple of 16");
+    if (!bytes) return HSEFR_OK;
+    const size_t n = bytes / 16;
+    const int v = g_copy_variant;
+    const int u = 1 << (v & 3), nt = (v >> 2) & 3;
+    const unsigned per_cu[4] = {8, 4, 16, 32};
+    size_t blocks = (n + (size_t)256 * u - 1) / ((size_t)256 * u);
+    const size_t cap = 256u * per_cu[(v >> 4) & 3];
+    if (blocks > cap) blocks = cap;
+    const f32x4* sp = (const f32x4*)src;
+    f32x4* dp = (f32x4*)dst;
+    switch (u) {
+        case 1: launch_u<1>(nt, sp, dp, n, (unsigned)blocks, s); break;
+        case 2: launch_u<2>(nt, sp, dp, n, (unsigned)blocks, s); break;
+        case 4: launch_u<4>(nt, sp, dp, n, (unsigned)blocks, s); break;
+        default: launch_u<8>(nt, sp, dp, n, (unsigned)blocks, s); break;
+    }
+    return launch_status("copy");
+}
+
+}  // namespace hsefr

@@ -21,6 +21,9 @@ namespace hsefr {
 
 namespace {
 
+extern int g_dw_th;
+extern int g_dw_variant;
+
 struct DwParams {
     const float4* x;
     const float4* w;      // [9][C4] float4 (TF [3,3,C,1] viewed as float4 over C)
@@ -29,6 +32,7 @@ struct DwParams {
     float4* y;
     int H, W, C4, OH, OW, pad_t, pad_l, TH, tiles_h, tiles_x;
     unsigned nwg;
+    int variant;  // 0 = real kernel; timing-only ablations: 1 = one load per row, 2 = no stores
 };
 
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
@@ -36,7 +40,7 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 }
 
 template <int STRIDE, int ACT>
-__global__ __launch_bounds__(256) void dwconv3x3_kernel(DwParams p) {
+__global__ __launch_bounds__(256, 4) void dwconv3x3_kernel(DwParams p) {
     const unsigned bid = xcd_remap(blockIdx.x, p.nwg);
     const int tx = bid % p.tiles_x;
     const int th = (bid / p.tiles_x) % p.tiles_h;
@@ -46,72 +50,89 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwParams p) {
     const int ow = t / p.C4;
     const int c4 = t - ow * p.C4;
 
+    // Branch-free borders: every load uses a clamped (always valid) address, and the padding is
+    // applied arithmetically -- out-of-image COLUMNS by zeroing this thread's tap weights once
+    // (they are constant down the strip), out-of-image ROWS by a 0/1 factor on that row's partial
+    // sum.  No control flow in the row loop, so the compiler keeps counted s_waitcnt vmcnt(N) and
+    // the row prefetches really stay in flight (a branch per load made it emit vmcnt(0) each time).
+    const int iw0 = ow * STRIDE - p.pad_l;  // column of the left tap
+    const float ml = iw0 >= 0 ? 1.f : 0.f, mm = (iw0 + 1 >= 0 && iw0 + 1 < p.W) ? 1.f : 0.f,
+                mr = iw0 + 2 < p.W ? 1.f : 0.f;
     float4 wk[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) wk[i] = p.w[i * p.C4 + c4];
+    for (int i = 0; i < 9; ++i) {
+        const float4 w = p.w[i * p.C4 + c4];
+        const float m = (i % 3 == 0) ? ml : (i % 3 == 1 ? mm : mr);
+        wk[i] = make_float4(w.x * m, w.y * m, w.z * m, w.w * m);
+    }
     const float4 sc = p.scale[c4];
     const float4 sh = p.shift[c4];
-
-    const int iw0 = ow * STRIDE - p.pad_l;  // column of the left tap
-    const bool okl = iw0 >= 0, okm = (iw0 + 1 >= 0) && (iw0 + 1 < p.W), okr = iw0 + 2 < p.W;
+    const int cl = max(iw0, 0) * p.C4, cm = min(max(iw0 + 1, 0), p.W - 1) * p.C4, cr = min(iw0 + 2, p.W - 1) * p.C4;
     const float4* xin = p.x + (size_t)n * p.H * p.W * p.C4 + c4;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    auto load_row = [&](int ih, float4* r) {
-        if (ih >= 0 && ih < p.H) {
-            const float4* row = xin + ((long long)ih * p.W + iw0) * p.C4;
-            r[0] = okl ? row[0] : zero;
-            r[1] = okm ? row[p.C4] : zero;
-            r[2] = okr ? row[2 * p.C4] : zero;
-        } else {
-            r[0] = r[1] = r[2] = zero;
-        }
+    struct Row { float4 l, m, r; float k; };
+    auto load_row = [&](int ih) {
+        Row q;
+        const int ihc = min(max(ih, 0), p.H - 1);
+        const float4* row = xin + (size_t)ihc * p.W * p.C4;
+        q.m = row[cm];
+        if (p.variant == 1) { q.l = q.m; q.r = q.m; } else { q.l = row[cl]; q.r = row[cr]; }
+        q.k = (ih >= 0 && ih < p.H) ? 1.f : 0.f;
+        return q;
+    };
+    auto row_sum = [&](const Row& q, int base) {
+        float4 a = make_float4(q.l.x * wk[base].x, q.l.y * wk[base].y, q.l.z * wk[base].z, q.l.w * wk[base].w);
+        a = fma4(q.m, wk[base + 1], a);
+        a = fma4(q.r, wk[base + 2], a);
+        return a;
     };
 
     const int oh0 = th * p.TH;
     const int oh1 = min(oh0 + p.TH, p.OH);
     float4* yout = p.y + ((size_t)n * p.OH * p.OW + ow) * p.C4 + c4;
 
-    float4 r0[3], r1[3], r2[3];
-    if (STRIDE == 1) {
-        load_row(oh0 - p.pad_t, r0);
-        load_row(oh0 - p.pad_t + 1, r1);
-    } else {
-        load_row(oh0 * 2 - p.pad_t, r0);
-    }
-    for (int oh = oh0; oh < oh1; ++oh) {
-        if (STRIDE == 1) {
-            load_row(oh - p.pad_t + 2, r2);
-        } else {
-            load_row(oh * 2 - p.pad_t + 1, r1);
-            load_row(oh * 2 - p.pad_t + 2, r2);
-        }
-        float4 acc = make_float4(r0[0].x * wk[0].x, r0[0].y * wk[0].y, r0[0].z * wk[0].z, r0[0].w * wk[0].w);
-        acc = fma4(r0[1], wk[1], acc);
-        acc = fma4(r0[2], wk[2], acc);
-        acc = fma4(r1[0], wk[3], acc);
-        acc = fma4(r1[1], wk[4], acc);
-        acc = fma4(r1[2], wk[5], acc);
-        acc = fma4(r2[0], wk[6], acc);
-        acc = fma4(r2[1], wk[7], acc);
-        acc = fma4(r2[2], wk[8], acc);
+    auto compute_store = [&](int oh, const Row& a, const Row& b, const Row& c) {
+        const float4 sa = row_sum(a, 0), sb = row_sum(b, 3), sc2 = row_sum(c, 6);
+        float4 acc = make_float4(sa.x * a.k, sa.y * a.k, sa.z * a.k, sa.w * a.k);
+        acc = make_float4(fmaf(sb.x, b.k, acc.x), fmaf(sb.y, b.k, acc.y), fmaf(sb.z, b.k, acc.z), fmaf(sb.w, b.k, acc.w));
+        acc = make_float4(fmaf(sc2.x, c.k, acc.x), fmaf(sc2.y, c.k, acc.y), fmaf(sc2.z, c.k, acc.z), fmaf(sc2.w, c.k, acc.w));
         float4 o = fma4(acc, sc, sh);
         o.x = apply_act<ACT>(o.x);
         o.y = apply_act<ACT>(o.y);
         o.z = apply_act<ACT>(o.z);
         o.w = apply_act<ACT>(o.w);
+        if (p.variant == 2) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); return; }
         yout[(size_t)oh * p.OW * p.C4] = o;
-        if (STRIDE == 1) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { r0[i] = r1[i]; r1[i] = r2[i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) r0[i] = r2[i];
+    };
+
+    if (STRIDE == 1) {
+        // sliding window, rows requested TWO iterations before they are consumed
+        const int ih = oh0 - p.pad_t;
+        Row r0 = load_row(ih), r1 = load_row(ih + 1), r2 = load_row(ih + 2), r3 = load_row(ih + 3);
+        for (int oh = oh0; oh < oh1; ++oh) {
+            const Row r4 = load_row(oh - p.pad_t + 4);
+            compute_store(oh, r0, r1, r2);
+            r0 = r1; r1 = r2; r2 = r3; r3 = r4;
+        }
+    } else {
+        // stride 2: two new rows per output row, requested ONE iteration ahead
+        const int ih = oh0 * 2 - p.pad_t;
+        Row r0 = load_row(ih), r1 = load_row(ih + 1), r2 = load_row(ih + 2);
+        for (int oh = oh0; oh < oh1; ++oh) {
+            const Row n1 = load_row(oh * 2 - p.pad_t + 3), n2 = load_row(oh * 2 - p.pad_t + 4);
+            compute_store(oh, r0, r1, r2);
+            r0 = r2; r1 = n1; r2 = n2;
         }
     }
 }
 
+int g_dw_th = 0;
+int g_dw_variant = 0;
+
 }  // namespace
+
+void set_dw_th(int v) { g_dw_th = v; }
+void set_dw_variant(int v) { g_dw_variant = v; }
 
 int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const float* shift, float* y,
                      int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
@@ -123,12 +144,15 @@ int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const
     DwParams p;
     p.x = (const float4*)x; p.w = (const float4*)wgt; p.scale = (const float4*)scale;
     p.shift = (const float4*)shift; p.y = (float4*)y;
+    p.variant = g_dw_variant;
     p.H = h; p.W = w; p.C4 = c / 4; p.OH = oh; p.OW = ow; p.pad_t = pad_t; p.pad_l = pad_l;
     p.tiles_x = (ow * p.C4 + 255) / 256;
-    // Strip height: as tall as possible (halo re-read = 2/TH of the input for stride 1)
-    // while keeping >= ~4 workgroups per CU in flight.
-    int th = oh;
-    while (th > 4 && (long long)n * p.tiles_x * ((oh + th - 1) / th) < 1024) th = (th + 1) / 2;
+    // Strip height: tall strips amortise the 2-row halo, short ones balance the CUs.
+    // measured on MI355X (tools/kbench.py dw): 24-row strips for the big stride-1 maps, 12 otherwise
+    int th = (stride == 1 && oh >= 48) ? 24 : 12;
+    if (th > oh) th = oh;
+    while (th > 4 && (long long)n * p.tiles_x * ((oh + th - 1) / th) < 512) th = (th + 1) / 2;
+    if (g_dw_th > 0) th = g_dw_th < oh ? g_dw_th : oh;  // tuning/debug only (hsefr_debug_set "dw_th")
     p.TH = th;
     p.tiles_h = (oh + th - 1) / th;
     const long long nwg = (long long)n * p.tiles_x * p.tiles_h;

@@ -102,6 +102,17 @@ int hsefr_version(void) { return HSEFR_VERSION; }
 
 const char* hsefr_last_error_string(void) { return g_err; }
 
+int hsefr_debug_set(const char* key, int value) {
+    HSEFR_REQUIRE(key, HSEFR_ERR_INVALID, "debug_set: null key");
+    if (!strcmp(key, "pw_tile")) { set_pw_tile(value); return HSEFR_OK; }
+    if (!strcmp(key, "dw_th")) { set_dw_th(value); return HSEFR_OK; }
+    if (!strcmp(key, "dw_variant")) { set_dw_variant(value); return HSEFR_OK; }
+    if (!strcmp(key, "copy_variant")) { set_copy_variant(value); return HSEFR_OK; }
+    if (!strcmp(key, "c3_impl")) { set_c3_impl(value); return HSEFR_OK; }
+    set_error("debug_set: unknown key %s", key);
+    return HSEFR_ERR_INVALID;
+}
+
 int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsefr_engine** out) {
     HSEFR_REQUIRE(plan && out, HSEFR_ERR_INVALID, "engine_create: null argument");
     *out = nullptr;
@@ -292,51 +303,56 @@ int hsefr_engine_destroy(hsefr_engine* e) {
     return HSEFR_OK;
 }
 
+int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(bytes == 0 || (d_src && d_dst), HSEFR_ERR_INVALID, "debug_copy: null pointer");
+    return launch_copy(d_src, d_dst, bytes, (hipStream_t)stream);
+}
+
 // ---- per-kernel entry points ---------------------------------------------------------------
 int hsefr_conv_c3_bias_act(const float* x, const float* wgt, const float* shift, float* y, int n, int h, int w,
                            int kh, int kw, int stride, int pad_t, int pad_l, int oh, int ow, int cout, int act,
                            hsefr_stream_t stream) {
-    HSEFR_REQUIRE(x && wgt && shift && y, HSEFR_ERR_INVALID, "conv_c3: null pointer");
+    HSEFR_REQUIRE(n == 0 || (x && wgt && shift && y), HSEFR_ERR_INVALID, "conv_c3: null pointer");
     return launch_conv_c3(x, wgt, shift, y, n, h, w, kh, kw, stride, pad_t, pad_l, oh, ow, cout, act, (hipStream_t)stream);
 }
 
 int hsefr_dwconv3x3_bn_relu6(const float* x, const float* wgt, const float* scale, const float* shift, float* y,
                              int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
                              hsefr_stream_t stream) {
-    HSEFR_REQUIRE(x && wgt && scale && shift && y, HSEFR_ERR_INVALID, "dwconv3x3: null pointer");
+    HSEFR_REQUIRE(n == 0 || (x && wgt && scale && shift && y), HSEFR_ERR_INVALID, "dwconv3x3: null pointer");
     return launch_dwconv3x3(x, wgt, scale, shift, y, n, h, w, c, stride, pad_t, pad_l, oh, ow, act, (hipStream_t)stream);
 }
 
 int hsefr_pwconv1x1_bias_relu6(const float* x, const float* wgt_t, const float* shift, float* y, long long m, int k,
                                int cout, int act, hsefr_stream_t stream) {
-    HSEFR_REQUIRE(x && wgt_t && shift && y, HSEFR_ERR_INVALID, "pwconv: null pointer");
+    HSEFR_REQUIRE(m == 0 || (x && wgt_t && shift && y), HSEFR_ERR_INVALID, "pwconv: null pointer");
     return launch_pwconv_f32(x, wgt_t, shift, y, m, k, cout, act, (hipStream_t)stream);
 }
 
 int hsefr_gap(const float* x, float* y, int n, int hw, int c, hsefr_stream_t stream) {
-    HSEFR_REQUIRE(x && y, HSEFR_ERR_INVALID, "gap: null pointer");
+    HSEFR_REQUIRE(n == 0 || (x && y), HSEFR_ERR_INVALID, "gap: null pointer");
     return launch_gap(x, y, n, hw, c, (hipStream_t)stream);
 }
 
 int hsefr_dense(const float* x, const float* wgt, const float* bias, float* y, int n, int k, int cout, int act,
                 hsefr_stream_t stream) {
-    HSEFR_REQUIRE(x && wgt && y, HSEFR_ERR_INVALID, "dense: null pointer");
+    HSEFR_REQUIRE(n == 0 || (x && wgt && y), HSEFR_ERR_INVALID, "dense: null pointer");
     return launch_dense(x, wgt, bias, y, n, k, cout, act, (hipStream_t)stream);
 }
 
 int hsefr_softmax(const float* x, float* y, int n, int c, hsefr_stream_t stream) {
-    HSEFR_REQUIRE(x && y, HSEFR_ERR_INVALID, "softmax: null pointer");
+    HSEFR_REQUIRE(n == 0 || (x && y), HSEFR_ERR_INVALID, "softmax: null pointer");
     return launch_softmax(x, y, n, c, (hipStream_t)stream);
 }
 
 int hsefr_l2_normalize(const float* x, float* y, int n, int d, hsefr_stream_t stream) {
-    HSEFR_REQUIRE(x && y, HSEFR_ERR_INVALID, "l2_normalize: null pointer");
+    HSEFR_REQUIRE(n == 0 || (x && y), HSEFR_ERR_INVALID, "l2_normalize: null pointer");
     return launch_l2_normalize(x, y, n, d, (hipStream_t)stream);
 }
 
 int hsefr_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2,
               hsefr_stream_t stream) {
-    HSEFR_REQUIRE(q && g && nn_index, HSEFR_ERR_INVALID, "nn1: null pointer");
+    HSEFR_REQUIRE(nq == 0 || (q && g && nn_index), HSEFR_ERR_INVALID, "nn1: null pointer");
     return launch_nn1(q, g, nq, ng, d, nn_index, nn_dist2, (hipStream_t)stream);
 }
 

@@ -10,18 +10,26 @@
 // at 64 FLOP/clk/SIMD = the 157 TF/s fp32-matrix peak that bounds layers pw_3..pw_13; pw_1/2
 // (K = 32/64) are HBM-bound.
 //
-// Tile: 128(M) x BN(N) x 32(K) per 256-thread workgroup, 4 waves as 2x2, each wave owning
-// 64 x BN/2 as 32x32 MFMA blocks.  Both operands are K-contiguous in memory (X is NHWC, the
-// weight is stored transposed [Cout][K]), so LDS tiles keep the global row layout and are
-// filled by full-line float4 copies (8 lanes = one 128-B row segment).  The MFMA K index is
-// a free permutation: lane (i, h) reads ONE float4 = k {8s+4h .. 8s+4h+3} of row i
-// (ds_read_b128) and feeds element j to the j-th of four MFMAs; A and B use the same
-// permutation, so each MFMA contracts k in {8s+j, 8s+4+j}.  LDS rows are padded to 36 floats
-// (144 B): the 16 rows of every ds_read_b128 lane group then start on 16 distinct 4-bank
-// slots -> conflict-free reads, and the float4 staging writes (8 lanes per row) are too.
-// Global->LDS is register-staged and double-buffered: tile k+1 is loaded before the MFMAs of
-// tile k and written after them (one barrier per K-tile).
-// Workgroup ids are XCD-remapped so the N-tiles that re-read one X tile share an L2.
+// Structure (256 threads = 4 waves as 2x2 over a BM x BN tile, BK = 32):
+//  * Both operands are K-contiguous in memory (X is NHWC, the weight is stored transposed
+//    [Cout][K]); LDS tiles keep that row layout (128-B rows) and are filled by full-line float4
+//    copies -- 8 lanes = one 128-B row segment.
+//  * The MFMA K index is a free permutation: lane (i, h) reads ONE float4 = k {8s+4h..8s+4h+3}
+//    of row i (ds_read_b128) and feeds element j to the j-th of four MFMAs; A and B use the same
+//    permutation, so MFMA j of chunk s contracts k in {8s+j, 8s+4+j}.
+//  * LDS rows are unpadded; the 16-B chunk c of row r lives at chunk position c ^ ((r >> 1) & 7).
+//    With 128-B rows two consecutive rows cover the 64 banks, and every ds_read_b128 lane group
+//    (16 rows, one logical chunk) then hits 16 distinct (row parity, position) slots:
+//    conflict-free reads; the staging writes (8 lanes = 8 chunks of one row) are too.
+//  * Persistent workgroups walk tiles t = blockIdx.x, +gridDim.x, ...; the (tile, k-tile) steps
+//    form ONE software pipeline: the global loads of the next step (also across a tile boundary)
+//    are issued before the MFMAs of the current one and written to the other LDS buffer after
+//    them (one barrier per step), so the epilogue stores and the next tile's first loads overlap.
+//  * Tile ids are XCD-remapped: the N-tiles that re-read one X tile run on one XCD (shared L2).
+//  * Tile shape is chosen per layer so that tiles divide evenly over 256 CUs x resident
+//    workgroups (tile quantisation cost 25-44 % with one fixed 128x128 tile).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hsefr {
@@ -31,123 +39,198 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;
 constexpr int BK = 32;
-constexpr int LDS_ROW = 36;  // floats per LDS row (32 + 4 pad)
 
-template <int BN, int ACT>
-__global__ __launch_bounds__(256) void pwconv_f32_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + 4 * (chunk ^ ((row >> 1) & 7)); }
+
+template <int BM, int BN, int OCC, int ACT>
+__global__ __launch_bounds__(256, OCC) void pwconv_f32_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                          const float* __restrict__ shift, float* __restrict__ y,
                                                          long long M, int K, int Cout, unsigned tiles_n,
-                                                         unsigned nwg) {
-    constexpr int WN = BN / 2;    // columns per wave
-    constexpr int NT = WN / 32;   // 32-wide MFMA blocks per wave along N
-    constexpr int BP = BN / 32;   // staging passes for the weight tile
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_ROW];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_ROW];
-
-    const unsigned bid = xcd_remap(blockIdx.x, nwg);
-    const unsigned tile_n = bid % tiles_n;
-    const unsigned tile_m = bid / tiles_n;
-    const long long m0 = (long long)tile_m * BM;
-    const int n0 = tile_n * BN;
+                                                         unsigned total_tiles) {
+    constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int AP = BM / 32, BP = BN / 32;  // staging passes (32 rows x 8 float4 per pass)
+    __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-
-    // staging: thread -> (row srow + 32p, float4 column skq)
     const int srow = tid >> 3, skq = tid & 7;
-    const float* ag[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        long long r = m0 + srow + 32 * p;
-        if (r > M - 1) r = M - 1;  // tail rows: read a valid row, never stored
-        ag[p] = x + r * K + 4 * skq;
-    }
-    const float* bg = wt + (long long)(n0 + srow) * K + 4 * skq;
+    const int KT = K / BK;
 
-    f32x4 ra[4], rb[BP];
+    unsigned t = blockIdx.x;
+    if (t >= total_tiles) return;
+
+    // global pointers of the staging thread for a tile
+    const float* ag[AP];
+    const float* bg;
+    long long m0;
+    int n0;
+    auto setup = [&](unsigned tile) {
+        const unsigned lt = xcd_remap(tile, total_tiles);
+        const unsigned tn = lt % tiles_n, tm = lt / tiles_n;
+        m0 = (long long)tm * BM;
+        n0 = tn * BN;
+    };
+    auto setup_ptrs = [&](long long mm0, int nn0) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            long long r = mm0 + srow + 32 * p;
+            if (r > M - 1) r = M - 1;  // tail rows: read a valid row, never stored
+            ag[p] = x + r * K + 4 * skq;
+        }
+        bg = wt + (long long)(nn0 + srow) * K + 4 * skq;
+    };
+
+    f32x4 ra[AP], rb[BP];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) ra[p] = *(const f32x4*)(ag[p] + kt * BK);
+        for (int p = 0; p < AP; ++p) ra[p] = *(const f32x4*)(ag[p] + kt * BK);
 #pragma unroll
         for (int p = 0; p < BP; ++p) rb[p] = *(const f32x4*)(bg + (long long)32 * p * K + kt * BK);
     };
     auto swrite = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *(f32x4*)(&As[buf][(srow + 32 * p) * LDS_ROW + 4 * skq]) = ra[p];
+        for (int p = 0; p < AP; ++p) *(f32x4*)(&As[buf][swz(srow + 32 * p, skq)]) = ra[p];
 #pragma unroll
-        for (int p = 0; p < BP; ++p) *(f32x4*)(&Bs[buf][(srow + 32 * p) * LDS_ROW + 4 * skq]) = rb[p];
+        for (int p = 0; p < BP; ++p) *(f32x4*)(&Bs[buf][swz(srow + 32 * p, skq)]) = rb[p];
     };
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MI][NI];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    };
+    zero_acc();
 
-    const int KT = K / BK;
+    setup(t);
+    setup_ptrs(m0, n0);
     gload(0);
     swrite(0);
     __syncthreads();
+    int buf = 0;
 
-    const int a_off = (wm * 64 + li) * LDS_ROW + 4 * lh;
-    const int b_off = (wn * WN + li) * LDS_ROW + 4 * lh;
+    const int arow = wm * WM + li, brow = wn * WN + li;
 
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) gload(kt + 1);
+    while (true) {
+        const unsigned tnext = t + gridDim.x;
+        const bool more_tiles = tnext < total_tiles;
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool last = kt + 1 == KT;
+            const bool has_next = !last || more_tiles;
+            long long m0n = m0;
+            int n0n = n0;
+            if (has_next) {
+                if (last) {
+                    const unsigned lt = xcd_remap(tnext, total_tiles);
+                    m0n = (long long)(lt / tiles_n) * BM;
+                    n0n = (lt % tiles_n) * BN;
+                    setup_ptrs(m0n, n0n);
+                    gload(0);
+                } else {
+                    gload(kt + 1);
+                }
+            }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            f32x4 a[2], b[NT];
+            for (int s = 0; s < 4; ++s) {
+                f32x4 a[MI], b[NI];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const f32x4*)(&As[cur][a_off + mi * 32 * LDS_ROW + 8 * s]);
+                for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)(&As[buf][swz(arow + mi * 32, 2 * s + lh)]);
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) b[ni] = *(const f32x4*)(&Bs[cur][b_off + ni * 32 * LDS_ROW + 8 * s]);
+                for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4*)(&Bs[buf][swz(brow + ni * 32, 2 * s + lh)]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NT; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
-        }
-        if (kt + 1 < KT) swrite(cur ^ 1);
-        __syncthreads();
-    }
-
-    // Epilogue.  C/D map of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+            }
+            if (has_next) swrite(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+            if (last) {
+                // Epilogue of tile (m0, n0).  C/D map of the 32x32 MFMA: column = lane & 31,
+                // row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).  Full tiles store unconditionally:
+                // a per-store bounds branch makes hipcc put s_waitcnt vmcnt(0) in front of EVERY
+                // store (each one then waits for the previous to retire).
+                const bool full_tile = m0 + BM <= M;
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-        const int col = n0 + wn * WN + ni * 32 + li;
-        const float sh = shift[col];
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int col = n0 + wn * WN + ni * 32 + li;
+                    const float sh = shift[col];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const long long rbase = m0 + wm * 64 + mi * 32 + 4 * lh;
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const long long rbase = m0 + wm * WM + mi * 32 + 4 * lh;
+                        float* yp = y + rbase * Cout + col;
+                        if (full_tile) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < M) y[row * Cout + col] = apply_act<ACT>(acc[mi][ni][r] + sh);
+                            for (int r = 0; r < 16; ++r)
+                                yp[(long long)((r & 3) + 8 * (r >> 2)) * Cout] = apply_act<ACT>(acc[mi][ni][r] + sh);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int dr = (r & 3) + 8 * (r >> 2);
+                                if (rbase + dr < M) yp[(long long)dr * Cout] = apply_act<ACT>(acc[mi][ni][r] + sh);
+                            }
+                        }
+                    }
+                }
+                zero_acc();
+                m0 = m0n;
+                n0 = n0n;
             }
         }
+        if (!more_tiles) break;
+        t = tnext;
     }
 }
 
-template <int BN>
-int launch_bn(const float* x, const float* wt, const float* shift, float* y, long long m, int k, int cout,
-              int act, hipStream_t s) {
+struct TileCfg { int bm, bn, occ; };
+
+// Work per CU if tiles are dealt evenly: ceil(T / 256) tiles of bm*bn; relative tile efficiency
+// favours big tiles (less L2->LDS traffic per MFMA).
+TileCfg choose_tile(long long m, int cout, int forced) {
+    const TileCfg cands[3] = {{128, 128, 2}, {128, 64, 3}, {64, 64, 3}};
+    const double eff[3] = {1.00, 0.97, 0.88};
+    if (forced >= 0 && forced < 3 && cout % cands[forced].bn == 0) return cands[forced];
+    int best = -1;
+    double best_cost = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (cout % cands[i].bn) continue;
+        const long long tiles = ((m + cands[i].bm - 1) / cands[i].bm) * (cout / cands[i].bn);
+        const long long slots = 256ll * cands[i].occ;
+        const long long rounds = (tiles + slots - 1) / slots;
+        // time ~ rounds * (work of `occ` co-resident tiles on one CU)
+        const double cost = (double)rounds * cands[i].occ * cands[i].bm * cands[i].bn / eff[i];
+        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+    }
+    return cands[best];
+}
+
+int g_forced_tile = -1;  // tuning/debug only (hsefr_debug_set "pw_tile"): 0 = 128x128, 1 = 128x64, 2 = 64x64
+
+template <int BM, int BN, int OCC>
+int launch_cfg(const float* x, const float* wt, const float* shift, float* y, long long m, int k, int cout,
+               int act, hipStream_t s) {
+    constexpr int occ = OCC;
     const long long tiles_m = (m + BM - 1) / BM;
     const unsigned tiles_n = cout / BN;
-    const long long nwg = tiles_m * tiles_n;
-    HSEFR_REQUIRE(nwg < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv: grid too large");
-    dim3 grid((unsigned)nwg), block(256);
-#define HSEFR_PW_LAUNCH(A) \
-    hipLaunchKernelGGL((pwconv_f32_kernel<BN, A>), grid, block, 0, s, x, wt, shift, y, m, k, cout, tiles_n, (unsigned)nwg)
+    const long long total = tiles_m * tiles_n;
+    HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv: too many tiles");
+    const long long g = total < 256ll * occ ? total : 256ll * occ;
+    dim3 grid((unsigned)g), block(256);
+#define HSEFR_PW_LAUNCH(A)                                                                                   \
+    hipLaunchKernelGGL((pwconv_f32_kernel<BM, BN, OCC, A>), grid, block, 0, s, x, wt, shift, y, m, k, cout, tiles_n, \
+                       (unsigned)total)
     if (act == HSEFR_ACT_RELU6) HSEFR_PW_LAUNCH(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_PW_LAUNCH(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_PW_LAUNCH(HSEFR_ACT_NONE);
@@ -158,14 +241,18 @@ int launch_bn(const float* x, const float* wt, const float* shift, float* y, lon
 
 }  // namespace
 
+void set_pw_tile(int v) { g_forced_tile = v; }
+
 int launch_pwconv_f32(const float* x, const float* wgt_t, const float* shift, float* y, long long m, int k,
                       int cout, int act, hipStream_t s) {
     HSEFR_REQUIRE(k > 0 && k % BK == 0, HSEFR_ERR_UNSUPPORTED, "pwconv: k=%d must be a multiple of %d", k, BK);
     HSEFR_REQUIRE(cout > 0 && cout % 64 == 0, HSEFR_ERR_UNSUPPORTED, "pwconv: cout=%d must be a multiple of 64", cout);
     HSEFR_REQUIRE(m >= 0, HSEFR_ERR_INVALID, "pwconv: m=%lld", m);
     if (m == 0) return HSEFR_OK;
-    if (cout % 128 == 0) return launch_bn<128>(x, wgt_t, shift, y, m, k, cout, act, s);
-    return launch_bn<64>(x, wgt_t, shift, y, m, k, cout, act, s);
+    const TileCfg c = choose_tile(m, cout, g_forced_tile);
+    if (c.bm == 128 && c.bn == 128) return launch_cfg<128, 128, 2>(x, wgt_t, shift, y, m, k, cout, act, s);
+    if (c.bm == 128 && c.bn == 64) return launch_cfg<128, 64, 3>(x, wgt_t, shift, y, m, k, cout, act, s);
+    return launch_cfg<64, 64, 3>(x, wgt_t, shift, y, m, k, cout, act, s);
 }
 
 }  // namespace hsefr

@@ -57,6 +57,16 @@ typedef void* hsefr_stream_t; /* hipStream_t */
 
 int hsefr_version(void);
 const char* hsefr_last_error_string(void);
+/* Tuning/debug knobs, process-wide, never needed for correct results.
+ * "pw_tile": -1 = choose per layer (default), 0 = 128x128, 1 = 128x64, 2 = 64x64 GEMM tile.
+ * "dw_th":   0 = choose per layer (default), >0 = output rows per depthwise strip.
+ * "dw_variant": timing-only ablations of the depthwise kernel (results are WRONG): 1 = one load per
+ *            row, 2 = no stores.  0 = the real kernel (default).
+ * "copy_variant": shape of the hsefr_debug_copy calibration kernel (unroll / nontemporal / grid bits).
+ * "c3_impl": 0 = auto (default), 1 = VALU first-conv kernel, 2 = im2col fp32-MFMA first-conv kernel. */
+int hsefr_debug_set(const char* key, int value);
+/* Calibration: plain float4 device-to-device copy kernel (the practical HBM ceiling on this GPU). */
+int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* Plan: the lowered frozen graph handed to hsefr_engine_create (host memory).           */

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on one MI355X: every layer shape of MobileNet-192 @ batch 256 through
+the per-kernel C-ABI entry points, interleaved variants in ONE process (cdna guide rule 24).
+    python tools/kbench.py [pw] [dw] [c3]
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from hse_facerec_tf_amd import _lib, ops
+
+B = int(os.environ.get("KB_BATCH", "256"))
+PW = [(96, 32, 64), (48, 64, 128), (48, 128, 128), (24, 128, 256), (24, 256, 256), (12, 256, 512), (12, 512, 512),
+      (6, 512, 1024), (6, 1024, 1024)]
+DW = [(96, 32, 1), (96, 64, 2), (48, 128, 1), (48, 128, 2), (24, 256, 1), (24, 256, 2), (12, 512, 1), (12, 512, 2), (6, 1024, 1)]
+
+
+ITERS = int(os.environ.get("KB_ITERS", "20"))
+
+
+def timeit(fn, iters=None, warm=3):
+    iters = iters or ITERS
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+    return ts[len(ts) // 2] * 1e3, ts[0] * 1e3     # median, min in us
+
+
+def bench_pw():
+    print("pointwise fp32-MFMA GEMM, batch %d: us (median) per tile config" % B)
+    print("%-22s %10s %10s %10s %10s   best-TF  GB/s" % ("M x K x N", "auto", "128x128", "128x64", "64x64"))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for hw, k, n in PW:
+        m = B * hw * hw
+        x = torch.rand((m, k), device="cuda", generator=g) * 6
+        w = torch.randn((n, k), device="cuda", generator=g) / k ** 0.5
+        sh = torch.randn((n,), device="cuda", generator=g)
+        res = []
+        for tile in (-1, 0, 1, 2):
+            if tile == 0 and n % 128:
+                res.append(float("nan"))
+                continue
+            _lib.lib().hsefr_debug_set(b"pw_tile", tile)
+            res.append(timeit(lambda: ops.pwconv1x1(x, w, sh))[0])
+        _lib.lib().hsefr_debug_set(b"pw_tile", -1)
+        best = np.nanmin(res)
+        fl = 2.0 * m * k * n
+        by = 4.0 * (m * k + m * n + k * n)
+        print("%-22s %10.1f %10.1f %10.1f %10.1f   %6.1f  %6.0f" % ("%dx%dx%d" % (m, k, n), *res, fl / best / 1e6, by / best / 1e3))
+
+
+def bench_dw():
+    ths = [0, 4, 8, 12, 16, 24, 48]
+    print("depthwise 3x3, batch %d: us (median) per strip height; 0 = heuristic" % B)
+    print("%-18s" % "layer" + "".join("%9s" % ("th=%d" % t) for t in ths) + "   best GB/s")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for hw, c, s in DW:
+        x = torch.rand((B, hw, hw, c), device="cuda", generator=g) * 6
+        w = torch.randn((3, 3, c), device="cuda", generator=g)
+        sc = torch.rand((c,), device="cuda", generator=g) + 0.5
+        sh = torch.randn((c,), device="cuda", generator=g)
+        oh = (hw + s - 1) // s
+        res = []
+        for th in ths:
+            if th > oh:
+                res.append(float("nan"))
+                continue
+            _lib.lib().hsefr_debug_set(b"dw_th", th)
+            res.append(timeit(lambda: ops.dwconv3x3(x, w, sc, sh, s))[0])
+        _lib.lib().hsefr_debug_set(b"dw_th", 0)
+        by = 4.0 * B * c * (hw * hw + oh * oh)
+        print("%3dx%-3d c=%-4d s%d " % (hw, hw, c, s) + "".join("%9.1f" % r for r in res) + "   %7.0f" % (by / np.nanmin(res) / 1e3))
+
+
+def bench_c3():
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for hw in (192, 224):
+        x = (torch.rand((B, hw, hw, 3), device="cuda", generator=g) - 0.5) * 256
+        w = torch.randn((3, 3, 3, 32), device="cuda", generator=g) * 0.05
+        sh = torch.randn((32,), device="cuda", generator=g)
+        by = 4.0 * B * (hw * hw * 3 + (hw // 2) ** 2 * 32)
+        for impl, name in ((1, "valu"), (2, "mfma")):
+            _lib.lib().hsefr_debug_set(b"c3_impl", impl)
+            med, mn = timeit(lambda: ops.conv3x3_c3(x, w, sh, 2))
+            print("conv1 %d %s: %8.1f us (min %8.1f)  %7.0f GB/s" % (hw, name, med, mn, by / med / 1e3))
+        _lib.lib().hsefr_debug_set(b"c3_impl", 0)
+
+
+def bench_copy():
+    print("copy calibration, GB/s read+write (median): rows = variant (unroll, nt-load, nt-store, WG/CU), cols = MB")
+    sizes = (64, 302, 604, 1208)
+    bufs = []
+    for mb in sizes:
+        n = mb * 1000 * 1000 // 16 * 16
+        a = torch.rand((n // 4,), device="cuda")
+        bufs.append((n, a, torch.empty_like(a)))
+    for grid_bits, wg in ((1, 4), (0, 8), (2, 16), (3, 32)):
+        for nt in (0, 2, 3):
+            for ub, u in ((0, 1), (2, 4), (3, 8)):
+                v = ub | (nt << 2) | (grid_bits << 4)
+                _lib.lib().hsefr_debug_set(b"copy_variant", v)
+                row = []
+                for n, a, b in bufs:
+                    med, mn = timeit(lambda: _lib.check(_lib.lib().hsefr_debug_copy(a.data_ptr(), b.data_ptr(), n, _lib.current_stream_ptr())), iters=10)
+                    row.append(2.0 * n / med / 1e3)
+                print("u=%d ntld=%d ntst=%d wg/cu=%-2d " % (u, nt & 1, nt >> 1, wg) + "".join("%8.0f" % r for r in row))
+    _lib.lib().hsefr_debug_set(b"copy_variant", 0)
+
+
+def bench_dwv():
+    print("depthwise ablations (timing only): us median; real / one-load-per-row / no-stores")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for hw, c, s in DW[:5]:
+        x = torch.rand((B, hw, hw, c), device="cuda", generator=g) * 6
+        w = torch.randn((3, 3, c), device="cuda", generator=g)
+        sc = torch.rand((c,), device="cuda", generator=g) + 0.5
+        sh = torch.randn((c,), device="cuda", generator=g)
+        res = []
+        for v in (0, 1, 2):
+            _lib.lib().hsefr_debug_set(b"dw_variant", v)
+            res.append(timeit(lambda: ops.dwconv3x3(x, w, sc, sh, s))[0])
+        _lib.lib().hsefr_debug_set(b"dw_variant", 0)
+        print("%3dx%-3d c=%-4d s%d " % (hw, hw, c, s) + "".join("%9.1f" % r for r in res))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["pw", "dw", "c3"]
+    for w in what:
+        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv}[w]()
