@@ -152,6 +152,25 @@ def main():
         "pointwise1x1_f32mfma": lambda L: L.kind == lowering.OP_PWCONV_F32,
         "gap": lambda L: L.kind == lowering.OP_GAP,
     }
+    # HBM traffic per launch measured with rocprofv3 PMC counters (separate --pmc FETCH_SIZE / WRITE_SIZE
+    # passes, FETCH_SIZE doubled per the gfx950 correction) and committed under profiles/ -- counters cannot
+    # be read from inside this process, so the latest committed profile is what is reported.
+    traffic_by_class, traffic_src = {}, None
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+        if cands:
+            traffic_src = os.path.relpath(cands[-1], ROOT)
+            prof = json.load(open(cands[-1]))["kernels"]
+            prefixes = {"conv1_3x3x3_s2": "conv3x3_c3", "depthwise3x3": "dwconv3x3_kernel",
+                        "pointwise1x1_f32mfma": "pwconv_f32_kernel", "gap": "hsefr::gap_kernel"}
+            for cls, pre in prefixes.items():
+                rows = [v for k, v in prof.items() if k.startswith(pre)]
+                n = sum(r["launches"] for r in rows)
+                if n:
+                    traffic_by_class[cls] = sum(r["launches"] * r["hbm_bytes_per_launch"] for r in rows) / n
+    except Exception:
+        traffic_by_class = {}
     kernels = []
     if per_op is not None:
         for name, pred in classes.items():
@@ -172,7 +191,10 @@ def main():
                             "avg_launch_us": round(ms / launches * 1e3, 2), "bound": bound,
                             "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
                             "algorithmic_bytes_per_step": int(nbytes), "flops_per_step": int(flops),
-                            "hbm_gbs_algorithmic": round(nbytes / (ms * 1e-3) / 1e9, 1), "traffic": None})
+                            "hbm_gbs_algorithmic": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                            "algorithmic_bytes_per_launch": int(nbytes / launches),
+                            "traffic": None if name not in traffic_by_class else int(traffic_by_class[name]),
+                            "traffic_unit": "HBM bytes per launch (class average)", "traffic_source": traffic_src})
     dominant = max(kernels, key=lambda k: k["ms_per_step"]) if kernels else None
     dw = next((k for k in kernels if k["kernel"] == "depthwise3x3"), None)
 

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Copy the judged artefacts of a gpurun profiling directory (tools/gpu_pmc.sh output) into profiles/:
+    python tools/make_profile_summary.py gpurun_out/prof_r01b r01
+writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), profiles/<tag>_pmc_summary.txt
+(per-kernel averages of every --pmc pass) and profiles/<tag>_traffic.json (HBM bytes per launch per kernel,
+FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md, WRITE_SIZE as reported)."""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(out, "%s_kernel_stats.csv" % tag))
+shutil.copy(os.path.join(src, "summary.txt"), os.path.join(out, "%s_pmc_summary.txt" % tag))
+traffic = {}
+cur = None
+for line in open(os.path.join(src, "summary.txt")):
+    if not line.startswith(" "):
+        cur = line.split(" n=")[0].strip()
+        m = re.search(r"n=(\d+)\s+avg_us=\s*([\d.]+)", line)
+        traffic[cur] = {"launches": int(m.group(1)) if m else None, "avg_us": float(m.group(2)) if m else None}
+    else:
+        m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\d+\s+avg=\s*([\d.]+)", line)
+        if m and cur:
+            kib = float(m.group(2))
+            if m.group(1) == "FETCH_SIZE":
+                traffic[cur]["fetch_bytes_x2_corrected"] = kib * 1024 * 2
+            else:
+                traffic[cur]["write_bytes"] = kib * 1024
+for k, v in traffic.items():
+    if "fetch_bytes_x2_corrected" in v and "write_bytes" in v:
+        v["hbm_bytes_per_launch"] = v["fetch_bytes_x2_corrected"] + v["write_bytes"]
+traffic = {k: v for k, v in traffic.items() if "hbm_bytes_per_launch" in v and not k.startswith("void at::") and not k.startswith("__amd")}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request)",
+           "kernels": traffic}, open(os.path.join(out, "%s_traffic.json" % tag), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
