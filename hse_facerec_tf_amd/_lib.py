@@ -38,6 +38,10 @@ SIGNATURES = {
     "hsefr_gap": (c_int, [_fp, _fp, c_int, c_int, c_int, c_void_p]),
     "hsefr_dense": (c_int, [_fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, c_void_p]),
     "hsefr_softmax": (c_int, [_fp, _fp, c_int, c_int, c_void_p]),
+    "hsefr_conv_bf16": (c_int, [_fp, _fp, _fp, _fp, _fp, _fp] + [c_int] * 13 + [c_void_p]),
+    "hsefr_stem7x7_bf16": (c_int, [_fp, _fp, _fp, _fp, _fp] + [c_int] * 6 + [c_void_p]),
+    "hsefr_maxpool3x3s2_bf16": (c_int, [_fp, _fp] + [c_int] * 8 + [c_void_p]),
+    "hsefr_gap_bf16": (c_int, [_fp, _fp, c_int, c_int, c_int, c_void_p]),
     "hsefr_l2_normalize": (c_int, [_fp, _fp, c_int, c_int, c_void_p]),
     "hsefr_nn1": (c_int, [_fp, _fp, c_int, c_int, c_int, _fp, _fp, c_void_p]),
 }

@@ -85,6 +85,15 @@ int launch_l2_normalize(const float* x, float* y, int n, int d, hipStream_t s);
 int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2,
                hipStream_t s);
 
+int launch_conv_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
+                     int n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t,
+                     int pad_l, int act, hipStream_t s);
+int launch_stem7x7_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h,
+                        int w, int oh, int ow, int act, hipStream_t s);
+int launch_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int pad_t, int pad_l,
+                             hipStream_t s);
+int launch_gap_bf16(const void* x, float* y, int n, int hw, int c, hipStream_t s);
+
 void set_pw_tile(int v);
 void set_dw_th(int v);
 void set_dw_variant(int v);

@@ -71,19 +71,22 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
         for (uint64_t off : {o.w_off, o.scale_off, o.shift_off})
             HSEFR_REQUIRE(off == HSEFR_NO_OFFSET || (off < h.blob_bytes && off % 16 == 0), HSEFR_ERR_INVALID,
                           "plan op %u: blob offset %llu out of range / unaligned", i, (unsigned long long)off);
-        const uint64_t out_elems = (uint64_t)o.oh * o.ow * o.cout;
-        HSEFR_REQUIRE(out_elems <= bufs[o.out_buf].elems_per_image, HSEFR_ERR_INVALID,
-                      "plan op %u: output %llu elems/image exceeds buffer %d (%llu)", i,
-                      (unsigned long long)out_elems, o.out_buf,
-                      (unsigned long long)bufs[o.out_buf].elems_per_image);
+        const bool out_bf16 = o.kind == HSEFR_OP_CONV_BF16 || o.kind == HSEFR_OP_MAXPOOL_BF16 || o.kind == HSEFR_OP_STEM7X7_BF16;
+        const bool in_bf16 = o.kind == HSEFR_OP_CONV_BF16 || o.kind == HSEFR_OP_MAXPOOL_BF16 || o.kind == HSEFR_OP_GAP_BF16;
+        const uint64_t out_bytes = (uint64_t)o.oh * o.ow * o.cout * (out_bf16 ? 2 : 4);
+        const uint64_t out_cap = bufs[o.out_buf].elems_per_image * bufs[o.out_buf].elem_bytes;
+        HSEFR_REQUIRE(out_bytes <= out_cap, HSEFR_ERR_INVALID, "plan op %u: output %llu bytes/image exceeds buffer %d (%llu)", i,
+                      (unsigned long long)out_bytes, o.out_buf, (unsigned long long)out_cap);
         if (o.in_buf >= 0) {
-            const uint64_t in_elems = (uint64_t)o.h * o.w * o.cin;
-            HSEFR_REQUIRE(in_elems <= bufs[o.in_buf].elems_per_image, HSEFR_ERR_INVALID,
+            const uint64_t in_bytes = (uint64_t)o.h * o.w * o.cin * (in_bf16 ? 2 : 4);
+            HSEFR_REQUIRE(in_bytes <= bufs[o.in_buf].elems_per_image * bufs[o.in_buf].elem_bytes, HSEFR_ERR_INVALID,
                           "plan op %u: input exceeds buffer %d", i, o.in_buf);
         }
+        HSEFR_REQUIRE(o.res_buf != o.out_buf, HSEFR_ERR_INVALID, "plan op %u: residual aliases the output", i);
         switch (o.kind) {
             case HSEFR_OP_CONV_C3: case HSEFR_OP_DWCONV3X3: case HSEFR_OP_PWCONV_F32: case HSEFR_OP_GAP:
-            case HSEFR_OP_DENSE: case HSEFR_OP_SOFTMAX:
+            case HSEFR_OP_DENSE: case HSEFR_OP_SOFTMAX: case HSEFR_OP_CONV_BF16: case HSEFR_OP_MAXPOOL_BF16:
+            case HSEFR_OP_GAP_BF16: case HSEFR_OP_STEM7X7_BF16:
                 break;
             default:
                 set_error("plan op %u: unknown kind %u", i, o.kind);
@@ -276,6 +279,22 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
             case HSEFR_OP_SOFTMAX:
                 rc = launch_softmax((const float*)in, (float*)out, n, o.cout, s);
                 break;
+            case HSEFR_OP_CONV_BF16:
+                rc = launch_conv_bf16(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
+                                      (const float*)blob_ptr(e, o.shift_off),
+                                      o.res_buf >= 0 ? e->d_bufs[o.res_buf] : nullptr, out, n, o.h, o.w, o.cin, o.oh,
+                                      o.ow, o.cout, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.act, s);
+                break;
+            case HSEFR_OP_STEM7X7_BF16:
+                rc = launch_stem7x7_bf16((const float*)in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
+                                         (const float*)blob_ptr(e, o.shift_off), out, n, o.h, o.w, o.oh, o.ow, o.act, s);
+                break;
+            case HSEFR_OP_MAXPOOL_BF16:
+                rc = launch_maxpool3x3s2_bf16(in, out, n, o.h, o.w, o.cin, o.oh, o.ow, o.pad_t, o.pad_l, s);
+                break;
+            case HSEFR_OP_GAP_BF16:
+                rc = launch_gap_bf16(in, (float*)out, n, o.h * o.w, o.cin, s);
+                break;
             default:
                 set_error("forward: op %zu has unknown kind %u", i, o.kind);
                 rc = HSEFR_ERR_UNSUPPORTED;
@@ -343,6 +362,31 @@ int hsefr_dense(const float* x, const float* wgt, const float* bias, float* y, i
 int hsefr_softmax(const float* x, float* y, int n, int c, hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || (x && y), HSEFR_ERR_INVALID, "softmax: null pointer");
     return launch_softmax(x, y, n, c, (hipStream_t)stream);
+}
+
+int hsefr_conv_bf16(const void* x, const void* wgt_t, const float* scale, const float* shift, const void* res, void* y,
+                    int n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t,
+                    int pad_l, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wgt_t && scale && shift && y), HSEFR_ERR_INVALID, "conv_bf16: null pointer");
+    return launch_conv_bf16(x, wgt_t, scale, shift, res, y, n, h, w, c, oh, ow, cout, kh, kw, stride, pad_t, pad_l, act,
+                            (hipStream_t)stream);
+}
+
+int hsefr_stem7x7_bf16(const float* x, const void* wgt_t, const float* scale, const float* shift, void* y, int n, int h,
+                       int w, int oh, int ow, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wgt_t && scale && shift && y), HSEFR_ERR_INVALID, "stem7x7: null pointer");
+    return launch_stem7x7_bf16(x, wgt_t, scale, shift, y, n, h, w, oh, ow, act, (hipStream_t)stream);
+}
+
+int hsefr_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int pad_t, int pad_l,
+                            hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && y), HSEFR_ERR_INVALID, "maxpool: null pointer");
+    return launch_maxpool3x3s2_bf16(x, y, n, h, w, c, oh, ow, pad_t, pad_l, (hipStream_t)stream);
+}
+
+int hsefr_gap_bf16(const void* x, float* y, int n, int hw, int c, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && y), HSEFR_ERR_INVALID, "gap_bf16: null pointer");
+    return launch_gap_bf16(x, y, n, hw, c, (hipStream_t)stream);
 }
 
 int hsefr_l2_normalize(const float* x, float* y, int n, int d, hsefr_stream_t stream) {

@@ -28,6 +28,8 @@ from .graphdef import Graph, GraphNode
 # mirrors include/hsefr.h
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_GAP, OP_DENSE, OP_SOFTMAX = 1, 2, 3, 4, 5, 6
+OP_CONV_BF16, OP_MAXPOOL_BF16, OP_GAP_BF16, OP_STEM7X7_BF16 = 7, 8, 9, 10
+_BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
 BUF_INPUT, BUF_NONE = -1, -2
 PLAN_MAGIC = 0x314C505246455348
@@ -88,14 +90,19 @@ class Layer:
     tensors: List[str] = field(default_factory=list)   # graph tensors this layer's OUTPUT stands for
     sealed: bool = False                               # output materialised; no more epilogue folding
     version: int = 0                                   # bumped by every op folded into the epilogue
+    res: int = -1                                      # layer whose output is added before the activation (ResNet)
     out_buf: int = BUF_NONE
+
+    @property
+    def out_bytes(self) -> int:
+        return int(np.prod(self.out_shape)) * (2 if self.kind in _BF16_OUT else 4)
 
 
 @dataclass
 class Plan:
     layers: List[Layer]
     in_hwc: Tuple[int, int, int]
-    buffers: List[int]                     # elems per image
+    buffers: List[int]                     # BYTES per image
     outputs: Dict[int, Tuple[int, int]]    # slot -> (layer index, elems per image)
     tensor_layer: Dict[str, int]           # graph tensor name (no ':0') -> layer whose output it is
 
@@ -108,7 +115,10 @@ class Plan:
             while len(blob) % 16:
                 blob.append(0)
             off = len(blob)
-            blob.extend(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+            a = np.ascontiguousarray(a)
+            if a.dtype != np.uint16:               # uint16 = bf16 bit patterns, everything else is fp32
+                a = a.astype(np.float32)
+            blob.extend(a.tobytes())
             return off
 
         ops = []
@@ -119,9 +129,10 @@ class Plan:
             elif L.kind == OP_DWCONV3X3:
                 w = w.reshape(3, 3, -1)
             in_buf = BUF_INPUT if L.src < 0 else self.layers[L.src].out_buf
+            res_buf = BUF_NONE if L.res < 0 else self.layers[L.res].out_buf
             h, wd, cin = L.in_shape
             oh, ow, cout = L.out_shape
-            ops.append(_OP.pack(L.kind, L.act, in_buf, L.out_buf, BUF_NONE, h, wd, cin, oh, ow, cout,
+            ops.append(_OP.pack(L.kind, L.act, in_buf, L.out_buf, res_buf, h, wd, cin, oh, ow, cout,
                                 L.kh, L.kw, L.stride, L.pad_t, L.pad_l, 0, put(w), put(L.scale), put(L.shift)))
         while len(blob) % 16:
             blob.append(0)
@@ -132,7 +143,7 @@ class Plan:
             out_elems[slot] = elems
         head = _HEADER.pack(PLAN_MAGIC, 1, len(self.buffers), len(ops), self.in_hwc[0], self.in_hwc[1],
                             self.in_hwc[2], *out_buf, *out_elems, len(blob))
-        bufs = b"".join(_BUFFER.pack(e, 4, 0) for e in self.buffers)
+        bufs = b"".join(_BUFFER.pack(e, 1, 0) for e in self.buffers)
         return head + bufs + b"".join(ops) + bytes(blob)
 
     # algorithmic cost model: every layer reads its input once, writes its output once
@@ -458,6 +469,35 @@ class _Lowerer:
         return li >= 0 and self.ver.get(name, 0) == self.layers[li].version
 
 
+def assign_buffers(layers: List[Layer], pinned) -> List[int]:
+    """Buffer assignment by liveness (sizes in bytes per image).  A layer's output is allocated BEFORE its
+    inputs are released, so no kernel ever writes a buffer it reads; `pinned` layers (the requested
+    outputs) keep their buffer to the end."""
+    last_use = list(range(len(layers)))
+    for i, L in enumerate(layers):
+        for s in (L.src, L.res):
+            if s >= 0:
+                last_use[s] = i
+    buffers: List[int] = []
+    free: List[int] = []
+    for i, L in enumerate(layers):
+        need = L.out_bytes
+        pick = None
+        if i not in pinned and free:
+            fits = [b for b in free if buffers[b] >= need]
+            pick = min(fits, key=lambda b: buffers[b]) if fits else max(free, key=lambda b: buffers[b])
+            free.remove(pick)
+            buffers[pick] = max(buffers[pick], need)
+        if pick is None:
+            buffers.append(need)
+            pick = len(buffers) - 1
+        L.out_buf = pick
+        for j in range(i + 1):
+            if last_use[j] == i and j not in pinned and layers[j].out_buf not in free:
+                free.append(layers[j].out_buf)
+    return buffers
+
+
 def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
                 feeds: Optional[Dict[str, object]] = None) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase."""
@@ -500,28 +540,5 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
                                 % (tname, layers[low.where[nm]].name))
     tensor_layer = {name: li for name, li in low.where.items() if li >= 0 and low.is_final(name)}
 
-    # Buffer assignment by liveness.  A layer's output is allocated BEFORE its input is released,
-    # so no kernel ever writes the buffer it reads; requested outputs are pinned to the end.
-    last_use = list(range(len(layers)))
-    for i, L in enumerate(layers):
-        if L.src >= 0:
-            last_use[L.src] = i
-    pinned = {li for li, _ in out_layers.values()}
-    buffers: List[int] = []
-    free: List[int] = []
-    for i, L in enumerate(layers):
-        need = int(np.prod(L.out_shape))
-        pick = None
-        if i not in pinned and free:
-            fits = [b for b in free if buffers[b] >= need]
-            pick = min(fits, key=lambda b: buffers[b]) if fits else max(free, key=lambda b: buffers[b])
-            free.remove(pick)
-            buffers[pick] = max(buffers[pick], need)
-        if pick is None:
-            buffers.append(need)
-            pick = len(buffers) - 1
-        L.out_buf = pick
-        for j in range(i + 1):
-            if last_use[j] == i and j not in pinned and layers[j].out_buf not in free:
-                free.append(layers[j].out_buf)
+    buffers = assign_buffers(layers, {li for li, _ in out_layers.values()})
     return Plan(layers, (input_hw[0], input_hw[1], low.in_c), buffers, out_layers, tensor_layer)

@@ -118,3 +118,69 @@ def nn1(queries, gallery):
     _lib.check(_lib.lib().hsefr_nn1(queries.data_ptr(), gallery.data_ptr(), nq, ng, d, idx.data_ptr(), dist.data_ptr(),
                                     _lib.current_stream_ptr()), "hsefr_nn1")
     return idx, dist
+
+
+# ---- bf16 ResNet-50 kernels -------------------------------------------------------------------------
+def _bf16c(t, name):
+    torch = _lib.require_gpu()
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous bfloat16 CUDA tensor" % name)
+    return t
+
+
+def bf16_from_bits(bits_u16):
+    """NumPy uint16 bf16 bit patterns -> CUDA bfloat16 tensor (a container; no arithmetic)."""
+    torch = _lib.require_gpu()
+    import numpy as np
+    return torch.from_numpy(np.ascontiguousarray(bits_u16).view(np.int16)).cuda().view(torch.bfloat16)
+
+
+def conv_bf16(x, w_packed, scale, shift, kh: int, kw: int, stride: int = 1, pad: int = 0, res=None, act: int = ACT_RELU):
+    """x [n,h,w,c] bf16; w_packed [cout, kh*kw*c] bf16 (resnet50.pack_conv_weight); -> [n,oh,ow,cout] bf16."""
+    torch = _lib.require_gpu()
+    _bf16c(x, "x"), _bf16c(w_packed, "w"), _f32c(scale, "scale"), _f32c(shift, "shift")
+    n, h, w, c = x.shape
+    cout = w_packed.shape[0]
+    oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    y = torch.empty((n, oh, ow, cout), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().hsefr_conv_bf16(x.data_ptr(), w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                          None if res is None else _bf16c(res, "res").data_ptr(), y.data_ptr(),
+                                          n, h, w, c, oh, ow, cout, kh, kw, stride, pad, pad, act,
+                                          _lib.current_stream_ptr()), "hsefr_conv_bf16")
+    return y
+
+
+def stem7x7_bf16(x, w_packed, scale, shift, act: int = ACT_RELU):
+    torch = _lib.require_gpu()
+    _f32c(x, "x"), _bf16c(w_packed, "w")
+    n, h, w, c = x.shape
+    oh, ow = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    y = torch.empty((n, oh, ow, 64), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().hsefr_stem7x7_bf16(x.data_ptr(), w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                             y.data_ptr(), n, h, w, oh, ow, act, _lib.current_stream_ptr()),
+               "hsefr_stem7x7_bf16")
+    return y
+
+
+def maxpool3x3s2_bf16(x, ceil_mode: bool = True):
+    torch = _lib.require_gpu()
+    _bf16c(x, "x")
+    n, h, w, c = x.shape
+    if ceil_mode:
+        oh, ow = -(-(h - 3) // 2) + 1, -(-(w - 3) // 2) + 1
+    else:
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    y = torch.empty((n, oh, ow, c), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().hsefr_maxpool3x3s2_bf16(x.data_ptr(), y.data_ptr(), n, h, w, c, oh, ow, 0, 0,
+                                                  _lib.current_stream_ptr()), "hsefr_maxpool3x3s2_bf16")
+    return y
+
+
+def gap_bf16(x):
+    torch = _lib.require_gpu()
+    _bf16c(x, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_gap_bf16(x.data_ptr(), y.data_ptr(), n, h * w, c, _lib.current_stream_ptr()),
+               "hsefr_gap_bf16")
+    return y

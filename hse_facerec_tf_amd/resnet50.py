@@ -1,0 +1,173 @@
+"""ResNet-50 (VGGFace2 `resnet50_ft`) on the bf16 MFMA path.
+
+The reference reaches this network through ``TensorFlowInference('models/vgg2_resnet.pb',
+input_tensor='input:0', output_tensor='pool5_7x7_s1:0', convert2BGR=True, imageNetUtilsMean=False)``
+(facerec_test.py:213); the 95 MB file itself is one of the reference's missing blobs
+(.MISSING_LARGE_BLOBS), so the topology is built here from the Caffe `resnet50_ft` layer names that
+the output tensor name (`pool5/7x7_s1`) belongs to:
+
+    conv1/7x7_s2 (64, /2, pad 3) + BN + ReLU -> pool1/3x3_s2 (max, Caffe ceil mode: 112 -> 56)
+    -> conv2_1..3 | conv3_1..4 | conv4_1..6 | conv5_1..3   bottlenecks (mid, out) = (64,256) (128,512)
+       (256,1024) (512,2048); each = 1x1_reduce(+BN+ReLU) -> 3x3(+BN+ReLU) -> 1x1_increase(+BN),
+       + shortcut (identity, or 1x1_proj+BN on the first block of a stage), ReLU;
+       the stride-2 of stages 3-5 sits on the FIRST 1x1 (`_reduce`) and on `_proj`
+    -> pool5/7x7_s1 (average) -> 2048-D
+
+Weights are a dict {name: array}: ``<conv>/kernel`` [kh,kw,cin,cout] fp32 (TF HWIO) and the folded
+BatchNorm ``<conv>/scale``, ``<conv>/shift`` [cout] (scale = gamma/sqrt(var+eps), shift = beta -
+mean*scale).  ``synthetic_weights`` produces a seeded random set of the right shapes for benchmarks
+(there is no real file to load); a user who has vgg2_resnet.pb's tensors can pass them in this form.
+Activations are bf16 in HBM, accumulation is fp32 (BASELINE config 3).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import lowering
+from .lowering import (ACT_NONE, ACT_RELU, OP_CONV_BF16, OP_GAP_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16, OUT_FEATURES,
+                       Layer, Plan, assign_buffers)
+
+STAGES = [("conv2", 3, 64, 256, 1), ("conv3", 4, 128, 512, 2), ("conv4", 6, 256, 1024, 2), ("conv5", 3, 512, 2048, 2)]
+
+
+def conv_names() -> List[Tuple[str, int, int, int, int]]:
+    """[(name, k, cin, cout, stride)] of every convolution, in execution order."""
+    out = [("conv1_7x7_s2", 7, 3, 64, 2)]
+    cin = 64
+    for stage, blocks, mid, cout, stride in STAGES:
+        for b in range(1, blocks + 1):
+            s = stride if b == 1 else 1
+            pre = "%s_%d" % (stage, b)
+            out.append((pre + "_1x1_reduce", 1, cin, mid, s))
+            out.append((pre + "_3x3", 3, mid, mid, 1))
+            out.append((pre + "_1x1_increase", 1, mid, cout, 1))
+            if b == 1:
+                out.append((pre + "_1x1_proj", 1, cin, cout, s))
+            cin = cout
+    return out
+
+
+def synthetic_weights(seed: int = 123) -> Dict[str, np.ndarray]:
+    """He-normal kernels; folded-BN scale ~ 1 and shift ~ 0 with a little spread; the last BN of every
+    bottleneck is damped so the residual sum keeps O(1) magnitude through 16 blocks."""
+    rs = np.random.RandomState(seed)
+    w: Dict[str, np.ndarray] = {}
+    for name, k, cin, cout, _ in conv_names():
+        fan_in = k * k * cin
+        w[name + "/kernel"] = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        damp = 0.3 if name.endswith("_increase") else 1.0
+        w[name + "/scale"] = (damp * rs.uniform(0.8, 1.2, cout)).astype(np.float32)
+        w[name + "/shift"] = (0.05 * rs.randn(cout)).astype(np.float32)
+    return w
+
+
+def to_bf16_bits(a: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bit patterns (uint16), round-to-nearest-even."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
+def pack_conv_weight(kernel_hwio: np.ndarray) -> np.ndarray:
+    """[kh,kw,cin,cout] -> [cout][kh*kw*cin] bf16 bits (k = (kh*KW + kw)*cin + ci)."""
+    kh, kw, cin, cout = kernel_hwio.shape
+    return to_bf16_bits(kernel_hwio.reshape(kh * kw * cin, cout).T)
+
+
+def pack_stem_weight(kernel_hwio: np.ndarray) -> np.ndarray:
+    """[7,7,3,64] -> [64][256] bf16 bits with k = dy*32 + dx*3 + ci, zero padded."""
+    assert kernel_hwio.shape == (7, 7, 3, 64)
+    img = np.zeros((64, 8, 32), np.float32)
+    img[:, :7, :21] = kernel_hwio.reshape(7, 21, 64).transpose(2, 0, 1)
+    return to_bf16_bits(img.reshape(64, 256))
+
+
+def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224, 224), pool: str = "caffe") -> Plan:
+    """pool='caffe': pad-0 ceil-mode max-pool (112 -> 56); pool='valid': keras_vggface's valid pool (112 -> 55)."""
+    H, W = input_hw
+    layers: List[Layer] = []
+
+    def add(L: Layer) -> int:
+        layers.append(L)
+        return len(layers) - 1
+
+    def conv_out(h, k, s, pad):
+        return (h + 2 * pad - k) // s + 1
+
+    oh, ow = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
+    cur = add(Layer(OP_STEM7X7_BF16, "conv1_7x7_s2", -1, (H, W, 3), (oh, ow, 64), w=pack_stem_weight(weights["conv1_7x7_s2/kernel"]),
+                    scale=weights["conv1_7x7_s2/scale"], shift=weights["conv1_7x7_s2/shift"], act=ACT_RELU, kh=7, kw=7,
+                    stride=2, pad_t=3, pad_l=3))
+    if pool == "caffe":
+        ph, pw = -(-(oh - 3) // 2) + 1, -(-(ow - 3) // 2) + 1
+    elif pool == "valid":
+        ph, pw = (oh - 3) // 2 + 1, (ow - 3) // 2 + 1
+    else:
+        raise ValueError(pool)
+    cur = add(Layer(OP_MAXPOOL_BF16, "pool1_3x3_s2", cur, (oh, ow, 64), (ph, pw, 64), kh=3, kw=3, stride=2))
+    h, w_, cin = ph, pw, 64
+
+    def conv(name, src, hwc, k, cout, stride, act, res=-1):
+        hh, ww, cc = hwc
+        pad = (k - 1) // 2
+        o = (conv_out(hh, k, stride, pad), conv_out(ww, k, stride, pad), cout)
+        return add(Layer(OP_CONV_BF16, name, src, hwc, o, w=pack_conv_weight(weights[name + "/kernel"]),
+                         scale=weights[name + "/scale"], shift=weights[name + "/shift"], act=act, kh=k, kw=k,
+                         stride=stride, pad_t=pad, pad_l=pad, res=res))
+
+    for stage, blocks, mid, cout, stride in STAGES:
+        for b in range(1, blocks + 1):
+            s = stride if b == 1 else 1
+            pre = "%s_%d" % (stage, b)
+            x_in, x_shape = cur, (h, w_, cin)
+            r = conv(pre + "_1x1_reduce", x_in, x_shape, 1, mid, s, ACT_RELU)
+            t = conv(pre + "_3x3", r, layers[r].out_shape, 3, mid, 1, ACT_RELU)
+            sc = conv(pre + "_1x1_proj", x_in, x_shape, 1, cout, s, ACT_NONE) if b == 1 else x_in
+            cur = conv(pre + "_1x1_increase", t, layers[t].out_shape, 1, cout, 1, ACT_RELU, res=sc)
+            h, w_, cin = layers[cur].out_shape
+    gap = add(Layer(OP_GAP_BF16, "pool5_7x7_s1", cur, (h, w_, cin), (1, 1, cin)))
+    for L in layers:
+        L.sealed = True
+    buffers = assign_buffers(layers, {gap})
+    names = {L.name: i for i, L in enumerate(layers)}
+    return Plan(layers, (H, W, 3), buffers, {OUT_FEATURES: (gap, cin)}, names)
+
+
+def flops_per_image(plan: Plan) -> int:
+    tot = 0
+    for L in plan.layers:
+        if L.kind in (OP_CONV_BF16, OP_STEM7X7_BF16):
+            oh, ow, cout = L.out_shape
+            tot += 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
+    return tot
+
+
+def activation_bytes_per_image(plan: Plan) -> int:
+    tot = 0
+    for L in plan.layers:
+        in_b = 4 if L.kind == OP_STEM7X7_BF16 else 2
+        tot += int(np.prod(L.in_shape)) * in_b + L.out_bytes
+        if L.res >= 0:
+            tot += plan.layers[L.res].out_bytes
+    return tot
+
+
+class ResNet50Extractor:
+    """Batched extractor with the TensorFlowInference surface used by the hot loop (w, h, extract_batch,
+    close_session); preprocessing flags are those of facerec_test.py:213 (BGR, VGGFace2 mean)."""
+
+    def __init__(self, weights: Optional[Dict[str, np.ndarray]] = None, input_size: Tuple[int, int] = (224, 224),
+                 max_batch: int = 128, device: Optional[int] = None, pool: str = "caffe", seed: int = 123):
+        from .engine import Engine
+        self.w, self.h = input_size
+        self.convert2BGR, self.imageNetUtilsMean = True, False
+        self.plan = build_plan(weights if weights is not None else synthetic_weights(seed), (self.h, self.w), pool)
+        self.engine = Engine(self.plan, max_batch=max_batch, device=device)
+        self.feature_dim = 2048
+
+    def extract_batch(self, x):
+        return self.engine.forward(x, (OUT_FEATURES,))["features"]
+
+    def close_session(self):
+        self.engine.close()

@@ -88,7 +88,8 @@ typedef enum hsefr_op_kind {
     HSEFR_OP_CONV_BF16 = 7,    /* KxK conv (1x1/3x3, stride 1|2) as bf16-MFMA implicit GEMM, fp32 acc,
                                   + shift (+ residual) + act; bf16 activations                            */
     HSEFR_OP_MAXPOOL_BF16 = 8, /* 3x3/2 max-pool, bf16                                                    */
-    HSEFR_OP_GAP_BF16 = 9      /* mean over H,W of bf16 activations -> fp32                               */
+    HSEFR_OP_GAP_BF16 = 9,     /* mean over H,W of bf16 activations -> fp32                               */
+    HSEFR_OP_STEM7X7_BF16 = 10 /* 7x7/2 pad-3 conv over the fp32 3-channel image -> 64 ch bf16 (+scale+shift+ReLU) */
 } hsefr_op_kind;
 
 typedef enum hsefr_output_slot {
@@ -199,6 +200,27 @@ int hsefr_dense(const float* x, const float* wgt, const float* bias, float* y, i
 
 /* Softmax over the last axis (graph node #241): x,y [n,c], c <= 1024. */
 int hsefr_softmax(const float* x, float* y, int n, int c, hsefr_stream_t stream);
+
+/* ---- bf16 ResNet-50 path (vgg2_resnet.pb, facerec_test.py:213): activations bf16 NHWC, fp32 accumulate ---- */
+
+/* KxK convolution (1x1 / 3x3, stride 1|2, explicit zero padding) as a bf16-MFMA implicit GEMM with the folded
+ * BatchNorm in the epilogue: y = act(scale[n]*conv + shift[n] (+ res)).  x [n,h,w,c] bf16, wgt_t [cout][kh*kw*c]
+ * bf16 (k = (kh*KW + kw)*c + ci), res/y [n,oh,ow,cout] bf16 (res may be NULL); c and cout multiples of 64. */
+int hsefr_conv_bf16(const void* x, const void* wgt_t, const float* scale, const float* shift, const void* res, void* y,
+                    int n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t,
+                    int pad_l, int act, hsefr_stream_t stream);
+
+/* ResNet stem: 7x7 / stride 2 / pad 3 conv over the fp32 image [n,h,w,3] -> [n,oh,ow,64] bf16, + scale + shift + act.
+ * wgt_t [64][256] bf16 with k = dy*32 + dx*3 + ci, zero padded. */
+int hsefr_stem7x7_bf16(const float* x, const void* wgt_t, const float* scale, const float* shift, void* y, int n, int h,
+                       int w, int oh, int ow, int act, hsefr_stream_t stream);
+
+/* 3x3 / stride 2 max-pool, bf16 NHWC; windows are clipped to the image (Caffe ceil mode = pad 0, TF SAME = its pads). */
+int hsefr_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int pad_t, int pad_l,
+                            hsefr_stream_t stream);
+
+/* Mean over H,W of bf16 activations -> fp32 [n,c] (pool5/7x7_s1). */
+int hsefr_gap_bf16(const void* x, float* y, int n, int hw, int c, hsefr_stream_t stream);
 
 /* preprocessing.normalize(X, 'l2') (facerec_test.py:401): rows of x [n,d] scaled in place-free
  * fashion into y; zero rows stay zero (sklearn divides by 1 then). */

@@ -51,6 +51,13 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
         assert off != NO_OFFSET and off % 16 == 0
         return np.frombuffer(data, np.float32, count, off).astype(dtype)
 
+    def arr_bf16(off, count):
+        assert off != NO_OFFSET and off % 16 == 0
+        u = np.frombuffer(data, np.uint16, count, off).astype(np.uint32) << 16
+        return u.view(np.float32).astype(dtype)
+
+    from oracle.resnet50 import bf16_round
+
     mem = {}
     owner = {}
     x = x.astype(dtype)
@@ -59,9 +66,11 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
          w_off, sc_off, sh_off) = o
         src = x if in_buf == -1 else mem[in_buf]
         src = src.reshape(n, h, w, cin)
+        res = None if res_buf < 0 else mem[res_buf]
         assert in_buf != out_buf, "op %d writes the buffer it reads" % i
+        assert res_buf != out_buf
         if check_buffers:
-            assert p["bufs"][out_buf][0] >= oh * ow * cout
+            assert p["bufs"][out_buf][0] * p["bufs"][out_buf][1] >= oh * ow * cout * (2 if kind in (7, 8, 10) else 4)
         if kind == 1:
             k = arr(w_off, kh * kw * cin * cout).reshape(kh, kw, cin, cout)
             pb = (oh - 1) * stride + kh - h - pad_t
@@ -85,6 +94,33 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             y = _act(src.reshape(n, cin).dot(k) + arr(sh_off, cout), act).reshape(n, 1, 1, cout)
         elif kind == 6:
             y = tfo.softmax(src.reshape(n, -1)).reshape(n, 1, 1, -1)
+        elif kind == 7:      # bf16 implicit-GEMM conv: weights [cout][kh*kw*cin] bf16, fp32 scale/shift, optional residual
+            k = arr_bf16(w_off, kh * kw * cin * cout).reshape(cout, kh, kw, cin).transpose(1, 2, 3, 0)
+            pb = max((oh - 1) * stride + kh - h - pad_t, 0)
+            pr = max((ow - 1) * stride + kw - w - pad_l, 0)
+            y = tfo.conv2d(src, k, (stride, stride), "", explicit_pads=(pad_t, pb, pad_l, pr))
+            y = bf16_round(y * arr(sc_off, cout) + arr(sh_off, cout))
+            if res is not None:
+                y = y + res.reshape(y.shape)
+            y = bf16_round(_act(y, act))
+        elif kind == 10:     # 7x7/2 pad-3 stem on the fp32 image: weights [64][8][32] bf16 (k = dy*32 + dx*3 + ci)
+            wimg = arr_bf16(w_off, 64 * 256).reshape(64, 8, 32)
+            assert np.all(wimg[:, 7] == 0) and np.all(wimg[:, :, 21:] == 0)
+            k = wimg[:, :7, :21].reshape(64, 7, 7, 3).transpose(1, 2, 3, 0)
+            pb = max((oh - 1) * 2 + 7 - h - 3, 0)
+            pr = max((ow - 1) * 2 + 7 - w - 3, 0)
+            y = tfo.conv2d(bf16_round(src), k, (2, 2), "", explicit_pads=(3, pb, 3, pr))
+            y = bf16_round(_act(y * arr(sc_off, 64) + arr(sh_off, 64), act))
+        elif kind == 8:      # 3x3/2 max-pool with clipped windows
+            pb = max((oh - 1) * 2 + 3 - h - pad_t, 0)
+            pr = max((ow - 1) * 2 + 3 - w - pad_l, 0)
+            xp = np.pad(src, ((0, 0), (pad_t, pb), (pad_l, pr), (0, 0)), constant_values=-np.inf)
+            y = np.full((n, oh, ow, cin), -np.inf)
+            for dy in range(3):
+                for dx in range(3):
+                    y = np.maximum(y, xp[:, dy:dy + 2 * (oh - 1) + 1:2, dx:dx + 2 * (ow - 1) + 1:2, :])
+        elif kind == 9:
+            y = src.mean(axis=(1, 2)).reshape(n, 1, 1, cin)
         else:
             raise AssertionError("unknown op kind %d" % kind)
         assert y.shape[1:] == (oh, ow, cout), (i, y.shape, (oh, ow, cout))

@@ -117,7 +117,7 @@ def test_buffers_never_alias_input_and_output(graph):
     pinned = {plan.layers[li].out_buf for li, _ in plan.outputs.values()}
     assert len(pinned) == 3
     # the two big ping-pong buffers + three small output buffers
-    assert sorted(plan.buffers, reverse=True)[:2] == [96 * 96 * 64, 96 * 96 * 32]
+    assert sorted(plan.buffers, reverse=True)[:2] == [4 * 96 * 96 * 64, 4 * 96 * 96 * 32]
 
 
 def test_unfolded_batchnorm_and_learning_phase_graph():

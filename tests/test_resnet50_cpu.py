@@ -1,0 +1,56 @@
+"""CPU suite, part 6: the ResNet-50 plan builder (topology, weight packing, buffer plan) executed
+from its SERIALISED bytes by tests/plan_ref.py and compared with the independently written oracle
+(oracle/resnet50.py).  Both emulate bf16 storage, so agreement is expected to ~1e-6."""
+import numpy as np
+import pytest
+
+import plan_ref
+from hse_facerec_tf_amd import resnet50
+from oracle import resnet50 as ores
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_topology_counts_and_sizes():
+    convs = resnet50.conv_names()
+    assert len(convs) == 1 + 3 * 16 + 4                      # stem + 16 bottlenecks x 3 + 4 projections = 53 convs
+    params = sum(k * k * ci * co for _, k, ci, co, _ in convs)
+    assert abs(params / 1e6 - 23.45) < 0.1                   # 23.45 M parameters (95 MB fp32 file)
+    plan = resnet50.build_plan(resnet50.synthetic_weights(1), (224, 224), "caffe")
+    assert plan.layers[1].out_shape == (56, 56, 64)           # Caffe ceil-mode pool: 112 -> 56
+    assert plan.layers[-2].out_shape == (7, 7, 2048) and plan.layers[-1].out_shape == (1, 1, 2048)
+    assert abs(resnet50.flops_per_image(plan) / 1e9 - 7.71) < 0.05     # 7.71 GFLOP / image
+    assert abs(resnet50.activation_bytes_per_image(plan) / 1e6 - 54.7) < 8   # ~54.7 MB / image in bf16
+    valid = resnet50.build_plan(resnet50.synthetic_weights(1), (224, 224), "valid")
+    assert valid.layers[1].out_shape == (55, 55, 64)          # keras_vggface valid pool: 112 -> 55
+    # stride placement: on the first 1x1 (reduce) and on the projection of stages 3-5
+    by = {L.name: L for L in plan.layers}
+    assert by["conv3_1_1x1_reduce"].stride == 2 and by["conv3_1_1x1_proj"].stride == 2 and by["conv3_1_3x3"].stride == 1
+    assert by["conv2_1_1x1_reduce"].stride == 1 and by["conv3_2_1x1_reduce"].stride == 1
+    for L in plan.layers:                                      # no op writes a buffer it reads
+        for s in (L.src, L.res):
+            if s >= 0:
+                assert plan.layers[s].out_buf != L.out_buf
+
+
+def test_bf16_bit_conversion_matches_oracle_rounding():
+    rs = np.random.RandomState(0)
+    a = np.concatenate([rs.randn(1000).astype(np.float32) * 10, np.float32([0, 1, -1, 1.00390625, 1.01171875, 3.0e38])])
+    bits = resnet50.to_bf16_bits(a)
+    back = (bits.astype(np.uint32) << 16).view(np.float32)
+    assert np.array_equal(back.astype(np.float64), ores.bf16_round(a))
+    assert back[-3] == np.float32(1.0) and back[-2] == np.float32(1.015625)     # ties to even
+
+
+@pytest.mark.parametrize("size,pool", [(64, "caffe"), (70, "valid")])
+def test_plan_equals_oracle(size, pool):
+    w = resnet50.synthetic_weights(7)
+    x = np.random.RandomState(3).uniform(-120, 130, (1, size, size, 3)).astype(np.float32)
+    plan = resnet50.build_plan(w, (size, size), pool)
+    got = plan_ref.run(plan.serialize(), x)["features"]
+    want = ores.forward(w, x, pool)
+    assert got.shape == want.shape == (1, 2048)
+    assert np.isfinite(want).all() and np.abs(want).max() > 1e-3
+    assert rel(got, want) < 1e-6

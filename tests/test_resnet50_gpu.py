@@ -1,0 +1,140 @@
+"""GPU parity for the bf16 ResNet-50 path (BASELINE config 3) vs oracle/resnet50.py.
+Tolerance: tensors are STORED as bf16 (8-bit mantissa, ulp = 2^-8 relative), accumulation is fp32 on
+the GPU and exact in the oracle, so a stored value may differ by one bf16 ulp where the pre-rounding
+sum sits next to a rounding boundary.  Per kernel: |got-want| <= 2^-7*|want| + 2^-9*max|want|; end to
+end (53 rounded layers deep): 2e-2 of the feature's max magnitude (~1e-2 for bf16)."""
+import numpy as np
+import pytest
+
+from oracle import resnet50 as ores
+from oracle import tf_graph as tfo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from hse_facerec_tf_amd import ops, resnet50
+    assert torch.cuda.is_available()
+    return torch, ops, resnet50
+
+
+def to_dev_bf16(torch, ops, resnet50, a):
+    return ops.bf16_from_bits(resnet50.to_bf16_bits(a))
+
+
+def close_bf16(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    tol = 2.0 ** -7 * np.abs(want) + 2.0 ** -9 * np.abs(want).max()
+    bad = np.abs(got - want) > tol
+    return not bad.any(), float((np.abs(got - want) / (np.abs(want).max() + 1e-30)).max())
+
+
+@pytest.mark.parametrize("n,h,w,c,cout,k,s,res,act", [
+    (2, 14, 14, 64, 64, 1, 1, False, 1), (2, 14, 14, 64, 256, 1, 1, True, 1), (1, 28, 28, 256, 128, 1, 2, False, 1),
+    (2, 13, 11, 128, 128, 3, 1, False, 1), (1, 56, 56, 64, 64, 3, 1, False, 1), (3, 7, 7, 512, 512, 3, 1, False, 1),
+    (2, 7, 7, 512, 2048, 1, 1, True, 1), (1, 15, 15, 256, 512, 1, 2, False, 0), (1, 9, 9, 1024, 256, 1, 1, False, 1),
+    (5, 5, 5, 64, 192, 3, 1, True, 0)])
+def test_conv_bf16_vs_oracle(env, n, h, w, c, cout, k, s, res, act):
+    torch, ops, resnet50 = env
+    rs = np.random.RandomState(h * 7 + c + cout + k)
+    x = ores.bf16_round(rs.uniform(0, 2, (n, h, w, c)))
+    kern = (rs.randn(k, k, c, cout) * np.sqrt(2.0 / (k * k * c))).astype(np.float32)
+    sc = rs.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rs.randn(cout).astype(np.float32) * 0.1
+    pad = (k - 1) // 2
+    y = tfo.conv2d(x, ores.bf16_round(kern), (s, s), "", explicit_pads=(pad,) * 4) * sc + sh
+    y = ores.bf16_round(y)
+    r = None
+    if res:
+        r = ores.bf16_round(rs.uniform(-1, 1, y.shape))
+        y = y + r
+    if act == 1:
+        y = np.maximum(y, 0)
+    want = ores.bf16_round(y)
+    d = lambda a: to_dev_bf16(torch, ops, resnet50, a.astype(np.float32))
+    got = ops.conv_bf16(d(x), ops.bf16_from_bits(resnet50.pack_conv_weight(kern)), torch.from_numpy(sc).cuda(),
+                        torch.from_numpy(sh).cuda(), k, k, s, pad, None if r is None else d(r), act)
+    assert tuple(got.shape) == want.shape
+    ok, err = close_bf16(got.float().cpu().numpy(), want)
+    assert ok, "max rel err %.3e" % err
+
+
+def test_conv_bf16_exact_integers(env):
+    """Small integers are exact in bf16 and fp32: any im2col / fragment-map / swizzle mix-up shows as an exact mismatch."""
+    torch, ops, resnet50 = env
+    rs = np.random.RandomState(1)
+    for (n, h, w, c, cout, k, s) in [(1, 6, 5, 64, 64, 3, 1), (2, 8, 8, 128, 128, 1, 2), (1, 4, 4, 64, 128, 3, 1)]:
+        x = rs.randint(-2, 3, (n, h, w, c)).astype(np.float64)
+        kern = rs.randint(-1, 2, (k, k, c, cout)).astype(np.float32)
+        pad = (k - 1) // 2
+        want = tfo.conv2d(x, kern.astype(np.float64), (s, s), "", explicit_pads=(pad,) * 4)
+        assert np.abs(want).max() < 256                      # exactly representable in bf16
+        d = lambda a: to_dev_bf16(torch, ops, resnet50, a.astype(np.float32))
+        got = ops.conv_bf16(d(x), ops.bf16_from_bits(resnet50.pack_conv_weight(kern)), torch.ones(cout, device="cuda"),
+                            torch.zeros(cout, device="cuda"), k, k, s, pad, None, 0)
+        assert np.array_equal(got.float().cpu().numpy().astype(np.float64), want)
+
+
+@pytest.mark.parametrize("n,hw", [(2, 64), (1, 224), (3, 37)])
+def test_stem_vs_oracle(env, n, hw):
+    torch, ops, resnet50 = env
+    rs = np.random.RandomState(hw)
+    x = rs.uniform(-130, 150, (n, hw, hw, 3)).astype(np.float32)
+    kern = (rs.randn(7, 7, 3, 64) * 0.02).astype(np.float32)
+    sc = rs.uniform(0.5, 1.5, 64).astype(np.float32)
+    sh = rs.randn(64).astype(np.float32)
+    want = ores.bf16_round(np.maximum(tfo.conv2d(ores.bf16_round(x), ores.bf16_round(kern), (2, 2), "", explicit_pads=(3, 3, 3, 3)) * sc + sh, 0))
+    got = ops.stem7x7_bf16(torch.from_numpy(x).cuda(), ops.bf16_from_bits(resnet50.pack_stem_weight(kern)),
+                           torch.from_numpy(sc).cuda(), torch.from_numpy(sh).cuda())
+    assert tuple(got.shape) == want.shape
+    ok, err = close_bf16(got.float().cpu().numpy(), want)
+    assert ok, "max rel err %.3e" % err
+
+
+@pytest.mark.parametrize("h,w,ceil", [(112, 112, True), (112, 112, False), (9, 7, True), (8, 8, True)])
+def test_maxpool_bit_exact(env, h, w, ceil):
+    torch, ops, resnet50 = env
+    x = ores.bf16_round(np.random.RandomState(h).randn(2, h, w, 64))
+    want = ores._maxpool_3x3_s2(x, "caffe" if ceil else "valid")
+    got = ops.maxpool3x3s2_bf16(to_dev_bf16(torch, ops, resnet50, x.astype(np.float32)), ceil)
+    assert np.array_equal(got.float().cpu().numpy().astype(np.float64), want)
+
+
+def test_gap_bf16(env):
+    torch, ops, resnet50 = env
+    x = ores.bf16_round(np.random.RandomState(2).uniform(0, 4, (3, 7, 7, 2048)))
+    got = ops.gap_bf16(to_dev_bf16(torch, ops, resnet50, x.astype(np.float32))).cpu().numpy()
+    assert np.abs(got - x.mean(axis=(1, 2))).max() < 2e-6 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("size,pool,n", [(64, "caffe", 2), (96, "valid", 1), (224, "caffe", 1)])
+def test_resnet50_end_to_end_vs_oracle(env, size, pool, n):
+    torch, ops, resnet50 = env
+    w = resnet50.synthetic_weights(123)
+    ext = resnet50.ResNet50Extractor(w, (size, size), max_batch=4, pool=pool)
+    x = np.random.RandomState(size).uniform(-120, 130, (n, size, size, 3)).astype(np.float32)
+    got = ext.extract_batch(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = ores.forward(w, x, pool)
+    assert got.shape == want.shape == (n, 2048)
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err < 2e-2, err
+    # direction of the embedding (what 1-NN uses) is preserved far better than the bar
+    cos = (got * want).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(want, axis=1)
+    assert cos.min() > 0.9995
+    ext.close_session()
+
+
+def test_resnet50_batch_128_properties(env):
+    """BASELINE config 3 at full size (batch 128, 224x224x3): batch-position independence, bit-exact."""
+    torch, ops, resnet50 = env
+    ext = resnet50.ResNet50Extractor(None, (224, 224), max_batch=128)
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.uniform(-120, 130, (128, 224, 224, 3)).astype(np.float32)).cuda()
+    full = ext.extract_batch(x)
+    assert tuple(full.shape) == (128, 2048) and bool(torch.isfinite(full).all()) and float(full.min()) >= 0
+    perm = torch.from_numpy(rs.permutation(128)).cuda()
+    assert torch.equal(ext.extract_batch(x[perm].contiguous()), full[perm])
+    assert torch.equal(ext.extract_batch(x[40:43].contiguous()), full[40:43])
+    ext.close_session()
