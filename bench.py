@@ -65,6 +65,13 @@ def main():
     from hse_facerec_tf_amd import lowering
     from hse_facerec_tf_amd.tf_inference import AGE_GENDER_PB, TensorFlowInference
 
+    # tuning/debug knobs (never needed for correct results), e.g. HSEFR_DEBUG="dw_variant=3,pw_tile=1"
+    if os.environ.get("HSEFR_DEBUG"):
+        from hse_facerec_tf_amd import _lib
+        for kv in os.environ["HSEFR_DEBUG"].split(","):
+            k, v = kv.split("=")
+            _lib.check(_lib.lib().hsefr_debug_set(k.strip().encode(), int(v)), "hsefr_debug_set")
+
     B, S = args.batch, args.size
     tfi = TensorFlowInference(AGE_GENDER_PB, input_tensor="input_1:0", output_tensor="global_pooling/Mean:0",
                               convert2BGR=True, imageNetUtilsMean=True, input_size=(S, S), max_batch=B, device=local_rank)

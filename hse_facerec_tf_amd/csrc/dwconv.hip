@@ -24,6 +24,8 @@ namespace {
 extern int g_dw_th;
 extern int g_dw_variant;
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+
 struct DwParams {
     const float4* x;
     const float4* w;      // [9][C4] float4 (TF [3,3,C,1] viewed as float4 over C)
@@ -35,11 +37,21 @@ struct DwParams {
     int variant;  // 0 = real kernel; timing-only ablations: 1 = one load per row, 2 = no stores
 };
 
+__device__ __forceinline__ float4 ntload(const float4* p) {
+    const f4 v = __builtin_nontemporal_load((const f4*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void ntstore(float4 v, float4* p) {
+    f4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, (f4*)p);
+}
+
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
 
-template <int STRIDE, int ACT>
+template <int STRIDE, int ACT, int NT>
 __global__ __launch_bounds__(256, 4) void dwconv3x3_kernel(DwParams p) {
     const unsigned bid = xcd_remap(blockIdx.x, p.nwg);
     const int tx = bid % p.tiles_x;
@@ -75,8 +87,15 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_kernel(DwParams p) {
         Row q;
         const int ihc = min(max(ih, 0), p.H - 1);
         const float4* row = xin + (size_t)ihc * p.W * p.C4;
-        q.m = row[cm];
-        if (p.variant == 1) { q.l = q.m; q.r = q.m; } else { q.l = row[cl]; q.r = row[cr]; }
+        if (NT & 1) {
+            q.l = ntload(row + cl);
+            q.m = ntload(row + cm);
+            q.r = ntload(row + cr);
+        } else {
+            q.l = row[cl];
+            q.m = row[cm];
+            q.r = row[cr];
+        }
         q.k = (ih >= 0 && ih < p.H) ? 1.f : 0.f;
         return q;
     };
@@ -101,8 +120,8 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_kernel(DwParams p) {
         o.y = apply_act<ACT>(o.y);
         o.z = apply_act<ACT>(o.z);
         o.w = apply_act<ACT>(o.w);
-        if (p.variant == 2) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); return; }
-        yout[(size_t)oh * p.OW * p.C4] = o;
+        if (NT & 2) ntstore(o, yout + (size_t)oh * p.OW * p.C4);
+        else yout[(size_t)oh * p.OW * p.C4] = o;
     };
 
     if (STRIDE == 1) {
@@ -159,7 +178,15 @@ int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const
     HSEFR_REQUIRE(nwg < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "dwconv3x3: grid too large");
     p.nwg = (unsigned)nwg;
     dim3 grid((unsigned)nwg), block(256);
-#define HSEFR_DW_LAUNCH(S, A) hipLaunchKernelGGL((dwconv3x3_kernel<S, A>), grid, block, 0, s, p)
+#define HSEFR_DW_LAUNCH(S, A)                                                                      \
+    do {                                                                                            \
+        switch (g_dw_variant & 3) {                                                                 \
+            case 0: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0>), grid, block, 0, s, p); break;   \
+            case 1: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 1>), grid, block, 0, s, p); break;   \
+            case 2: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 2>), grid, block, 0, s, p); break;   \
+            default: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 3>), grid, block, 0, s, p); break;  \
+        }                                                                                           \
+    } while (0)
     if (stride == 1) {
         if (act == HSEFR_ACT_RELU6) HSEFR_DW_LAUNCH(1, HSEFR_ACT_RELU6);
         else if (act == HSEFR_ACT_RELU) HSEFR_DW_LAUNCH(1, HSEFR_ACT_RELU);

@@ -31,8 +31,11 @@ def stratified_half_split(y: np.ndarray, random_state: int = 0) -> Tuple[np.ndar
     return train, test
 
 
-def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np.ndarray]] = None) -> Dict:
-    """The protocol of facerec_test.py:401-432 for the plain 1-NN classifier.
+def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np.ndarray]] = None,
+                          pca_components: Optional[int] = None) -> Dict:
+    """The protocol of facerec_test.py:401-432: 'k-NN' (pca_components=None) or 'k-NN+PCA'
+    (pca_components=128, the Pipeline of :421 -- PCA is fitted on the gallery half by scikit-learn on
+    the host, exactly as the reference does, and the projected vectors go back to the device for the search).
 
     X: [N, D] float32 embeddings, CUDA tensor or NumPy array (uploaded); y: [N] labels.
     Returns accuracy, the split, predictions and nearest-gallery indices."""
@@ -46,6 +49,15 @@ def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np
     train, test = split if split is not None else stratified_half_split(y_enc)
     gal = Xn[torch.from_numpy(train).to(Xn.device)].contiguous()
     qry = Xn[torch.from_numpy(test).to(Xn.device)].contiguous()
+    if pca_components:
+        from sklearn.decomposition import PCA
+        pca = PCA(n_components=pca_components).fit(gal.cpu().numpy())
+        pad = (-pca_components) % 8                      # hsefr_nn1 wants d % 8 == 0: zero columns change no distance
+
+        def proj(t):
+            z = pca.transform(t.cpu().numpy()).astype(np.float32)
+            return torch.from_numpy(np.pad(z, ((0, 0), (0, pad)))).to(Xn.device).contiguous()
+        gal, qry = proj(gal), proj(qry)
     nn_idx, nn_d2 = ops.nn1(qry, gal)
     nn_idx_h = nn_idx.cpu().numpy()
     y_pred = y_enc[train][nn_idx_h]

@@ -116,6 +116,24 @@ class TensorFlowInference:
         return np.concatenate(feats) if feats else np.zeros((0, self.feature_dim), np.float32)
 
 
+def extract_dataset(tfInference, dataset_path: str, features_file: Optional[str] = None, batch: int = 256,
+                    crop_center: bool = False):
+    """The extract stage of facerec_test.py:377-401: walk ``dataset_path`` (one sub-directory per subject),
+    label-encode the directory names, extract every image, cache ``np.savez(features_file, x=X, y=y)`` and
+    reuse the cache when the file exists (:308,:399-401).  Returns (X [N,D] float32, y [N] int)."""
+    if features_file is not None and os.path.exists(features_file):
+        data = np.load(features_file)
+        return data['x'], data['y']
+    dirs_and_files = np.array(get_files(dataset_path))
+    dirs = dirs_and_files[:, 0]
+    files = dirs_and_files[:, 1]
+    classes, y = np.unique(dirs, return_inverse=True)          # == LabelEncoder().fit(dirs).transform(dirs)
+    X = tfInference.extract_files([os.path.join(dataset_path, f) for f in files], batch=batch, crop_center=crop_center)
+    if features_file is not None:
+        np.savez(features_file, x=X, y=y)
+    return X, y
+
+
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models")
 AGE_GENDER_PB = os.path.join(_MODELS_DIR, "age_gender_tf2_new-01-0.14-0.92_quantized.pb")
 

@@ -60,8 +60,7 @@ const char* hsefr_last_error_string(void);
 /* Tuning/debug knobs, process-wide, never needed for correct results.
  * "pw_tile": -1 = choose per layer (default), 0 = 128x128, 1 = 128x64, 2 = 64x64 GEMM tile.
  * "dw_th":   0 = choose per layer (default), >0 = output rows per depthwise strip.
- * "dw_variant": timing-only ablations of the depthwise kernel (results are WRONG): 1 = one load per
- *            row, 2 = no stores.  0 = the real kernel (default).
+ * "dw_variant": cache policy of the depthwise kernel: bit 0 = nontemporal loads, bit 1 = nontemporal stores.
  * "copy_variant": shape of the hsefr_debug_copy calibration kernel (unroll / nontemporal / grid bits).
  * "c3_impl": 0 = auto (default), 1 = VALU first-conv kernel, 2 = im2col fp32-MFMA first-conv kernel. */
 int hsefr_debug_set(const char* key, int value);

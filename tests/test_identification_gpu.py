@@ -84,3 +84,41 @@ def test_sharded_gallery_world1_on_device(torch_):
     assert tuple(full.shape) == (19, 1024)
     assert torch_.equal(full[8:16], extract(range(8, 16)))
     tfi.close_session()
+
+
+def test_pca_variant_matches_sklearn_pipeline(torch_):
+    """facerec_test.py:421 'k-NN+PCA': Pipeline(PCA(n), KNeighborsClassifier(1)) scored on the same split."""
+    from sklearn.decomposition import PCA
+    from sklearn.neighbors import KNeighborsClassifier
+    from sklearn.pipeline import Pipeline
+    from hse_facerec_tf_amd import identification
+    X, y = oid.synthetic_gallery(80, 64, 11, 1.2)
+    Xn, y2, kept = oid.filter_and_encode(X, y)
+    train, test = oid.split_indices(Xn, y2)
+    pipe = Pipeline(steps=[('pca', PCA(n_components=20)), ('classifier', KNeighborsClassifier(n_neighbors=1, p=2))])
+    pipe.fit(Xn[train], y2[train])
+    want = pipe.predict(Xn[test])
+    r = identification.one_nn_identification(X, y, pca_components=20)
+    assert (r["y_pred"] == want).mean() > 0.98            # PCA sign/rounding may flip a near-tie
+    assert abs(r["accuracy"] - float((want == y2[test]).mean())) < 0.02
+
+
+def test_extract_dataset_walk_cache_and_labels(torch_, tmp_path):
+    """facerec_test.py:377-401 on a tiny synthetic 'LFW': directory walk, labels, batched extract, npz cache."""
+    from PIL import Image
+    from hse_facerec_tf_amd import TensorFlowInference, extract_dataset
+    from conftest import MODEL_PB
+    rs = np.random.RandomState(0)
+    for person, k in (("carol", 2), ("alice", 3), ("bob", 1)):
+        (tmp_path / person).mkdir()
+        for i in range(k):
+            Image.fromarray(rs.randint(0, 256, (250, 250, 3), dtype=np.uint8)).save(str(tmp_path / person / ("%d.jpg" % i)))
+    tfi = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(96, 96), max_batch=4)
+    cache = str(tmp_path / "feats.npz")
+    X, y = extract_dataset(tfi, str(tmp_path), cache, batch=4)
+    assert X.shape == (6, 1024) and list(y) == [0, 0, 0, 1, 2, 2]          # sorted subjects: alice, bob, carol
+    one = tfi.extract_features(str(tmp_path / "alice" / "1.jpg"))
+    assert np.array_equal(one, X[1])                                        # batched == per-image path, bit for bit
+    tfi.close_session()
+    X2, y2 = extract_dataset(None, str(tmp_path), cache)                    # cache hit: extractor is not touched
+    assert np.array_equal(X, X2) and np.array_equal(y, y2)

@@ -119,15 +119,15 @@ def bench_copy():
 
 
 def bench_dwv():
-    print("depthwise ablations (timing only): us median; real / one-load-per-row / no-stores")
+    print("depthwise cache-policy variants: us median; plain / nt-load / nt-store / both")
     g = torch.Generator(device="cuda").manual_seed(0)
-    for hw, c, s in DW[:5]:
+    for hw, c, s in DW:
         x = torch.rand((B, hw, hw, c), device="cuda", generator=g) * 6
         w = torch.randn((3, 3, c), device="cuda", generator=g)
         sc = torch.rand((c,), device="cuda", generator=g) + 0.5
         sh = torch.randn((c,), device="cuda", generator=g)
         res = []
-        for v in (0, 1, 2):
+        for v in (0, 1, 2, 3):
             _lib.lib().hsefr_debug_set(b"dw_variant", v)
             res.append(timeit(lambda: ops.dwconv3x3(x, w, sc, sh, s))[0])
         _lib.lib().hsefr_debug_set(b"dw_variant", 0)
