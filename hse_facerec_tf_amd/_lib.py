@@ -42,6 +42,9 @@ SIGNATURES = {
     "hsefr_stem7x7_bf16": (c_int, [_fp, _fp, _fp, _fp, _fp] + [c_int] * 6 + [c_void_p]),
     "hsefr_maxpool3x3s2_bf16": (c_int, [_fp, _fp] + [c_int] * 8 + [c_void_p]),
     "hsefr_gap_bf16": (c_int, [_fp, _fp, c_int, c_int, c_int, c_void_p]),
+    "hsefr_preprocess_pil_u8": (c_int, [_fp, _fp, _fp] + [c_int] * 5 + [_fp, _fp, _fp, c_int, _fp, _fp, _fp, c_int, c_int,
+                                        POINTER(ctypes.c_double), c_void_p]),
+    "hsefr_preprocess_cv_u8": (c_int, [_fp, _fp] + [c_int] * 5 + [_fp] * 6 + [c_int, POINTER(ctypes.c_double), c_void_p]),
     "hsefr_l2_normalize": (c_int, [_fp, _fp, c_int, c_int, c_void_p]),
     "hsefr_nn1": (c_int, [_fp, _fp, c_int, c_int, c_int, _fp, _fp, c_void_p]),
 }

@@ -94,6 +94,12 @@ int launch_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c,
                              hipStream_t s);
 int launch_gap_bf16(const void* x, float* y, int n, int hw, int c, hipStream_t s);
 
+int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, int n, int H, int W, int oh, int ow, const int* xmin,
+                      const int* xcnt, const int* xcoef, int xk, const int* ymin, const int* ycnt, const int* ycoef, int yk,
+                      int mode, const double* mean, hipStream_t s);
+int launch_cv_resize(const unsigned char* in, float* out, int n, int H, int W, int oh, int ow, const int* x0, const int* x1,
+                     const int* wx1, const int* y0, const int* y1, const int* wy1, int mode, const double* mean, hipStream_t s);
+
 void set_pw_tile(int v);
 void set_dw_th(int v);
 void set_dw_variant(int v);

@@ -389,6 +389,26 @@ int hsefr_gap_bf16(const void* x, float* y, int n, int hw, int c, hsefr_stream_t
     return launch_gap_bf16(x, y, n, hw, c, (hipStream_t)stream);
 }
 
+int hsefr_preprocess_pil_u8(const unsigned char* d_in, unsigned char* d_tmp, float* d_out, int n, int H, int W, int oh, int ow,
+                            const int* d_xmin, const int* d_xcnt, const int* d_xcoef, int xksize, const int* d_ymin,
+                            const int* d_ycnt, const int* d_ycoef, int yksize, int color_mode, const double* mean3,
+                            hsefr_stream_t stream) {
+    HSEFR_REQUIRE(mean3 && (n == 0 || (d_in && d_tmp && d_out && d_xmin && d_xcnt && d_xcoef && d_ymin && d_ycnt && d_ycoef)),
+                  HSEFR_ERR_INVALID, "preprocess_pil: null pointer");
+    return launch_pil_resize(d_in, d_tmp, d_out, n, H, W, oh, ow, d_xmin, d_xcnt, d_xcoef, xksize, d_ymin, d_ycnt, d_ycoef, yksize,
+                             color_mode, mean3, (hipStream_t)stream);
+}
+
+int hsefr_preprocess_cv_u8(const unsigned char* d_in, float* d_out, int n, int H, int W, int oh, int ow, const int* d_x0,
+                           const int* d_x1, const int* d_wx1, const int* d_y0, const int* d_y1, const int* d_wy1,
+                           int color_mode, const double* mean3, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(mean3 && (n == 0 || (d_in && d_out)), HSEFR_ERR_INVALID, "preprocess_cv: null pointer");
+    HSEFR_REQUIRE((H == oh && W == ow) || (d_x0 && d_x1 && d_wx1 && d_y0 && d_y1 && d_wy1), HSEFR_ERR_INVALID,
+                  "preprocess_cv: null tap table");
+    return launch_cv_resize(d_in, d_out, n, H, W, oh, ow, d_x0, d_x1, d_wx1, d_y0, d_y1, d_wy1, color_mode, mean3,
+                            (hipStream_t)stream);
+}
+
 int hsefr_l2_normalize(const float* x, float* y, int n, int d, hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || (x && y), HSEFR_ERR_INVALID, "l2_normalize: null pointer");
     return launch_l2_normalize(x, y, n, d, (hipStream_t)stream);

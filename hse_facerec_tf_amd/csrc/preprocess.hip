@@ -1,0 +1,155 @@
+// Device-side image preparation: uint8 RGB frames -> resized, BGR, mean-subtracted fp32
+// NHWC network input, bit-exact with the reference's host code:
+//   * facerec_test.py:93-106   misc.imresize(img, size, 'bilinear') = PIL's antialiasing BILINEAR on 8-bit
+//     images (two separable fixed-point passes, 22-bit coefficients, each pass rounded to uint8), then
+//     float64 BGR - mean, fed to a float32 placeholder;
+//   * facial_analysis.py:95-107 cv2.resize INTER_LINEAR on 8-bit images (2x2 taps, 11-bit weights, OpenCV's
+//     two-stage rounding), then float32 BGR - mean.
+// Integer arithmetic end to end, so parity with PIL / the OpenCV restatement is exact, not a tolerance.
+// Coefficient tables are computed on the host in double precision exactly as Pillow's precompute_coeffs
+// does (hse_facerec_tf_amd/preprocess_device.py) and cached per (input size, output size).
+#include "common.h"
+
+namespace hsefr {
+
+namespace {
+
+// Horizontal PIL pass: in [n,H,W,3] u8 -> out [n,H,ow,3] u8.  thread = one output pixel (3 channels).
+__global__ __launch_bounds__(256) void pil_resample_h_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                                             const int* __restrict__ xmin, const int* __restrict__ cnt,
+                                                             const int* __restrict__ coef, int ksize, int H, int W, int ow,
+                                                             long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int xx = (int)(i % ow);
+    const long long row = i / ow;  // n*H + y
+    const unsigned char* src = in + (row * W + xmin[xx]) * 3;
+    const int* k = coef + (long long)xx * ksize;
+    const int c = cnt[xx];
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;  // 1 << (PRECISION_BITS - 1), PRECISION_BITS = 22
+    for (int x = 0; x < c; ++x) {
+        const int w = k[x];
+        s0 += src[x * 3 + 0] * w;
+        s1 += src[x * 3 + 1] * w;
+        s2 += src[x * 3 + 2] * w;
+    }
+    unsigned char* dst = out + i * 3;
+    dst[0] = (unsigned char)min(max(s0 >> 22, 0), 255);
+    dst[1] = (unsigned char)min(max(s1 >> 22, 0), 255);
+    dst[2] = (unsigned char)min(max(s2 >> 22, 0), 255);
+}
+
+// mode: 0 = BGR - mean in float64 then cast (facerec_test.py:95-106), 1 = RGB x/127.5 - 1 (:108-110),
+//       2 = BGR - mean in float32 (facial_analysis.py:101-107)
+__device__ __forceinline__ void emit(float* dst, int r, int g, int b, int mode, float m0, float m1, float m2, double d0, double d1,
+                                     double d2) {
+    if (mode == 0) {
+        dst[0] = (float)((double)b - d0);
+        dst[1] = (float)((double)g - d1);
+        dst[2] = (float)((double)r - d2);
+    } else if (mode == 1) {
+        dst[0] = (float)((double)r / 127.5 - 1.0);
+        dst[1] = (float)((double)g / 127.5 - 1.0);
+        dst[2] = (float)((double)b / 127.5 - 1.0);
+    } else {
+        dst[0] = (float)b - m0;
+        dst[1] = (float)g - m1;
+        dst[2] = (float)r - m2;
+    }
+}
+
+// Vertical PIL pass + colour handling: in [n,H,ow,3] u8 -> out [n,oh,ow,3] f32.
+__global__ __launch_bounds__(256) void pil_resample_v_kernel(const unsigned char* __restrict__ in, float* __restrict__ out,
+                                                             const int* __restrict__ ymin, const int* __restrict__ cnt,
+                                                             const int* __restrict__ coef, int ksize, int H, int oh, int ow,
+                                                             long long total, int mode, float m0, float m1, float m2, double d0,
+                                                             double d1, double d2) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int xx = (int)(i % ow);
+    const long long t = i / ow;
+    const int yy = (int)(t % oh);
+    const long long n = t / oh;
+    const unsigned char* src = in + ((n * H + ymin[yy]) * ow + xx) * 3;
+    const int* k = coef + (long long)yy * ksize;
+    const int c = cnt[yy];
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int y = 0; y < c; ++y) {
+        const int w = k[y];
+        const unsigned char* p = src + (long long)y * ow * 3;
+        s0 += p[0] * w;
+        s1 += p[1] * w;
+        s2 += p[2] * w;
+    }
+    emit(out + i * 3, min(max(s0 >> 22, 0), 255), min(max(s1 >> 22, 0), 255), min(max(s2 >> 22, 0), 255), mode, m0, m1, m2, d0, d1, d2);
+}
+
+// cv2.resize INTER_LINEAR (8-bit): taps/weights per axis from the host (OpenCV's float32 coordinate
+// arithmetic), out = ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2 with S = horizontal 11-bit sums.
+__global__ __launch_bounds__(256) void cv_resize_linear_kernel(const unsigned char* __restrict__ in, float* __restrict__ out,
+                                                               const int* __restrict__ x0, const int* __restrict__ x1,
+                                                               const int* __restrict__ wx1, const int* __restrict__ y0,
+                                                               const int* __restrict__ y1, const int* __restrict__ wy1, int H, int W,
+                                                               int oh, int ow, long long total, int mode, float m0, float m1,
+                                                               float m2, double d0, double d1, double d2) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int xx = (int)(i % ow);
+    const long long t = i / ow;
+    const int yy = (int)(t % oh);
+    const long long n = t / oh;
+    const int a1 = wx1[xx], a0 = 2048 - a1, b1 = wy1[yy], b0 = 2048 - b1;
+    const unsigned char* r0 = in + (n * H + y0[yy]) * (long long)W * 3;
+    const unsigned char* r1 = in + (n * H + y1[yy]) * (long long)W * 3;
+    int v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int s0 = r0[x0[xx] * 3 + c] * a0 + r0[x1[xx] * 3 + c] * a1;
+        const int s1 = r1[x0[xx] * 3 + c] * a0 + r1[x1[xx] * 3 + c] * a1;
+        v[c] = min(max((((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2, 0), 255);
+    }
+    emit(out + i * 3, v[0], v[1], v[2], mode, m0, m1, m2, d0, d1, d2);
+}
+
+// no resize (input already at network size): colour handling only
+__global__ __launch_bounds__(256) void u8_to_input_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, long long total,
+                                                          int mode, float m0, float m1, float m2, double d0, double d1, double d2) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    emit(out + i * 3, in[i * 3], in[i * 3 + 1], in[i * 3 + 2], mode, m0, m1, m2, d0, d1, d2);
+}
+
+unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, int n, int H, int W, int oh, int ow, const int* xmin,
+                      const int* xcnt, const int* xcoef, int xk, const int* ymin, const int* ycnt, const int* ycoef, int yk,
+                      int mode, const double* mean, hipStream_t s) {
+    HSEFR_REQUIRE(n >= 0 && H > 0 && W > 0 && oh > 0 && ow > 0, HSEFR_ERR_INVALID, "pil_resize: bad shape");
+    HSEFR_REQUIRE(mode >= 0 && mode <= 2, HSEFR_ERR_INVALID, "preprocess: mode %d", mode);
+    if (n == 0) return HSEFR_OK;
+    const long long t1 = (long long)n * H * ow, t2 = (long long)n * oh * ow;
+    HSEFR_REQUIRE(t1 < (1ll << 39) && t2 < (1ll << 39), HSEFR_ERR_UNSUPPORTED, "pil_resize: too large");
+    hipLaunchKernelGGL(pil_resample_h_kernel, dim3(blocks_for(t1)), dim3(256), 0, s, in, tmp, xmin, xcnt, xcoef, xk, H, W, ow, t1);
+    hipLaunchKernelGGL(pil_resample_v_kernel, dim3(blocks_for(t2)), dim3(256), 0, s, tmp, out, ymin, ycnt, ycoef, yk, H, oh, ow, t2,
+                       mode, (float)mean[0], (float)mean[1], (float)mean[2], mean[0], mean[1], mean[2]);
+    return launch_status("pil_resize");
+}
+
+int launch_cv_resize(const unsigned char* in, float* out, int n, int H, int W, int oh, int ow, const int* x0, const int* x1,
+                     const int* wx1, const int* y0, const int* y1, const int* wy1, int mode, const double* mean, hipStream_t s) {
+    HSEFR_REQUIRE(n >= 0 && H > 0 && W > 0 && oh > 0 && ow > 0, HSEFR_ERR_INVALID, "cv_resize: bad shape");
+    HSEFR_REQUIRE(mode >= 0 && mode <= 2, HSEFR_ERR_INVALID, "preprocess: mode %d", mode);
+    if (n == 0) return HSEFR_OK;
+    const long long t = (long long)n * oh * ow;
+    if (H == oh && W == ow)
+        hipLaunchKernelGGL(u8_to_input_kernel, dim3(blocks_for(t)), dim3(256), 0, s, in, out, t, mode, (float)mean[0], (float)mean[1],
+                           (float)mean[2], mean[0], mean[1], mean[2]);
+    else
+        hipLaunchKernelGGL(cv_resize_linear_kernel, dim3(blocks_for(t)), dim3(256), 0, s, in, out, x0, x1, wx1, y0, y1, wy1, H, W, oh,
+                           ow, t, mode, (float)mean[0], (float)mean[1], (float)mean[2], mean[0], mean[1], mean[2]);
+    return launch_status("cv_resize");
+}
+
+}  // namespace hsefr

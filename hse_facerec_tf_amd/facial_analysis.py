@@ -37,7 +37,9 @@ def decode_age(age_preds: np.ndarray, min_age: int = 1):
 class FacialImageProcessing:
     # minsize: minimum of faces' size
     def __init__(self, print_stat=False, mtcnn_detector=True, minsize=32, model_file: Optional[str] = None,
-                 detector: Optional[Callable] = None, max_batch: int = 64, device: Optional[int] = None):
+                 detector: Optional[Callable] = None, max_batch: int = 64, device: Optional[int] = None,
+                 device_preprocess: bool = True):
+        self.device_preprocess = device_preprocess
         self.mtcnn_detector = mtcnn_detector
         self.print_stat = print_stat
         self.minsize = minsize
@@ -86,13 +88,18 @@ class FacialImageProcessing:
         ages, genders, feats = [], [], []
         mb = self.sess.max_batch
         for i in range(0, len(faces_rgb_u8), mb):
-            x = np.stack([self.preprocess_face(f) for f in faces_rgb_u8[i:i + mb]])
-            xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.sess.device)
+            chunk = faces_rgb_u8[i:i + mb]
+            if self.device_preprocess:      # cv2.resize + BGR + mean on the GPU (integer resize: same bits)
+                from . import preprocess_device
+                xd = preprocess_device.preprocess_faces_cv(chunk, (self.h, self.w))
+            else:
+                x = np.stack([self.preprocess_face(f) for f in chunk])
+                xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.sess.device)
             r = self.sess.forward(xd, (OUT_FEATURES, OUT_AGE, OUT_GENDER))
             age_p = r["age_probs"].cpu().numpy()
             gen = r["gender"].cpu().numpy()
             fea = r["features"].cpu().numpy()
-            for j in range(x.shape[0]):
+            for j in range(len(chunk)):
                 ages.append(decode_age(age_p[j])[0])
                 genders.append(gen[j])
                 feats.append(fea[j])

@@ -45,9 +45,11 @@ def to_model_input(resized_u8: np.ndarray, convert2BGR: bool, imageNetUtilsMean:
     if convert2BGR:
         x = x[..., ::-1].copy()
         mean = IMAGENET_CAFFE_BGR_MEAN if imageNetUtilsMean else VGGFACE2_BGR_MEAN
-        x[..., 0] -= mean[0]
-        x[..., 1] -= mean[1]
-        x[..., 2] -= mean[2]
+        # Python floats, as in the reference (`x[..., 0] -= 103.939`): with a float32 image the subtraction
+        # is float32 arithmetic (a NumPy float64 scalar would silently promote it under NumPy >= 2)
+        x[..., 0] -= float(mean[0])
+        x[..., 1] -= float(mean[1])
+        x[..., 2] -= float(mean[2])
     else:
         x /= 127.5
         x -= 1.0

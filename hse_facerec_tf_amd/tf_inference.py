@@ -106,13 +106,34 @@ class TensorFlowInference:
             return np.concatenate(out) if out else np.zeros((0, self.feature_dim), np.float32)
         return self.engine.forward(x, (OUT_FEATURES,))["features"]
 
-    def extract_files(self, paths: Sequence[str], batch: int = 256, crop_center: bool = False) -> np.ndarray:
-        """The loop of facerec_test.py:394 with the per-image sess.run replaced by batched forwards."""
+    def extract_images(self, imgs_u8):
+        """Decoded RGB uint8 images [n,H,W,3] (same size; NumPy or CUDA) -> CUDA features [n,D]: the resize +
+        BGR + mean of preprocess_image run on the device (bit-exact with the PIL path), then one forward."""
+        from . import preprocess_device
+        x = preprocess_device.preprocess_pil(imgs_u8, (self.w, self.h), self.convert2BGR, self.imageNetUtilsMean)
+        return self.engine.forward(x, (OUT_FEATURES,))["features"]
+
+    def extract_files(self, paths: Sequence[str], batch: int = 256, crop_center: bool = False,
+                      device_preprocess: bool = True) -> np.ndarray:
+        """The loop of facerec_test.py:394 with the per-image sess.run replaced by batched forwards.
+        With device_preprocess the host only decodes the files; runs of same-size images are resized
+        on the GPU (identical results: the resize is integer arithmetic)."""
         batch = min(batch, self.engine.max_batch)
         feats: List[np.ndarray] = []
         for i in range(0, len(paths), batch):
-            xs = np.stack([self.preprocess_image(p, crop_center) for p in paths[i:i + batch]]).astype(np.float32)
-            feats.append(self.extract_batch(xs))
+            chunk = paths[i:i + batch]
+            if device_preprocess and not crop_center:
+                imgs = [preprocess.imread_rgb(p) for p in chunk]
+                out = np.empty((len(imgs), self.feature_dim), np.float32)
+                groups = {}
+                for j, im in enumerate(imgs):
+                    groups.setdefault(im.shape[:2], []).append(j)
+                for _, idx in groups.items():
+                    out[idx] = self.extract_images(np.stack([imgs[j] for j in idx])).cpu().numpy()
+                feats.append(out)
+            else:
+                xs = np.stack([self.preprocess_image(p, crop_center) for p in chunk]).astype(np.float32)
+                feats.append(self.extract_batch(xs))
         return np.concatenate(feats) if feats else np.zeros((0, self.feature_dim), np.float32)
 
 

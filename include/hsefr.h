@@ -13,6 +13,8 @@
  *       -> hsefr_engine_destroy()
  *   - sklearn normalize + KNeighborsClassifier(1).kneighbors   facerec_test.py:401,200-207,422
  *       -> hsefr_l2_normalize() + hsefr_nn1()
+ *   - misc.imresize / cv2.resize + BGR + mean   facerec_test.py:93-106 ; facial_analysis.py:95-107
+ *       -> hsefr_preprocess_pil_u8() / hsefr_preprocess_cv_u8()
  *
  * Conventions: extern "C", plain C types; every function returns 0 on success or a negative
  * hsefr_status (never throws); hsefr_last_error_string() describes the last failure on the
@@ -220,6 +222,28 @@ int hsefr_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, 
 
 /* Mean over H,W of bf16 activations -> fp32 [n,c] (pool5/7x7_s1). */
 int hsefr_gap_bf16(const void* x, float* y, int n, int hw, int c, hsefr_stream_t stream);
+
+/* ---- device-side image preparation (facerec_test.py:80-112, facial_analysis.py:95-107), bit-exact ---------------- */
+
+/* colour/mean handling after the resize:
+ * 0 = BGR - mean3 evaluated in float64 then cast (facerec_test.py:95-106 feeding a float32 placeholder),
+ * 1 = RGB, x/127.5 - 1 (facerec_test.py:108-110), 2 = BGR - mean3 in float32 (facial_analysis.py:101-107). */
+typedef enum hsefr_color_mode { HSEFR_COLOR_BGR_MEAN_F64 = 0, HSEFR_COLOR_RGB_UNIT = 1, HSEFR_COLOR_BGR_MEAN_F32 = 2 } hsefr_color_mode;
+
+/* misc.imresize(img, (oh, ow), 'bilinear') (= PIL BILINEAR, antialiased, 8-bit fixed point) + colour handling.
+ * d_in [n,H,W,3] u8 RGB, d_tmp [n,H,ow,3] u8 scratch, d_out [n,oh,ow,3] f32.  The per-axis coefficient tables are
+ * Pillow's precompute_coeffs/normalize_coeffs_8bpc output (device int32 arrays): first tap, tap count and
+ * `ksize` 22-bit weights per output coordinate.  mean3 is HOST memory (3 doubles, BGR order). */
+int hsefr_preprocess_pil_u8(const unsigned char* d_in, unsigned char* d_tmp, float* d_out, int n, int H, int W, int oh, int ow,
+                            const int* d_xmin, const int* d_xcnt, const int* d_xcoef, int xksize, const int* d_ymin,
+                            const int* d_ycnt, const int* d_ycoef, int yksize, int color_mode, const double* mean3,
+                            hsefr_stream_t stream);
+
+/* cv2.resize(img, (ow, oh)) INTER_LINEAR on 8-bit images + colour handling.  Per-axis tap tables (device int32):
+ * the two source indices and the 11-bit weight of the second tap for every output coordinate. */
+int hsefr_preprocess_cv_u8(const unsigned char* d_in, float* d_out, int n, int H, int W, int oh, int ow, const int* d_x0,
+                           const int* d_x1, const int* d_wx1, const int* d_y0, const int* d_y1, const int* d_wy1,
+                           int color_mode, const double* mean3, hsefr_stream_t stream);
 
 /* preprocessing.normalize(X, 'l2') (facerec_test.py:401): rows of x [n,d] scaled in place-free
  * fashion into y; zero rows stay zero (sklearn divides by 1 then). */

@@ -100,3 +100,11 @@ def test_get_files_walks_like_the_reference(tmp_path):
     got = tf_inference.get_files(str(tmp_path))
     assert got == [["alice", os.path.join("alice", "1.jpeg")], ["bob", os.path.join("bob", "a.PNG")],
                    ["bob", os.path.join("bob", "b.jpg")]]
+
+
+def test_float32_face_preprocessing_matches_reference_arithmetic():
+    """facial_analysis.py:101-107 subtracts Python floats from a float32 image (float32 arithmetic)."""
+    img = np.random.RandomState(0).randint(0, 256, (300, 200, 3)).astype(np.uint8)
+    got = preprocess.to_model_input(preprocess.resize_linear_u8(img, 224, 224), True, True, dtype=np.float32)
+    want = opl.age_gender_preprocess(img, 224, 224)[0]
+    assert got.dtype == np.float32 and np.array_equal(got, want)
