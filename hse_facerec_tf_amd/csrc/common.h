@@ -100,6 +100,8 @@ int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, i
 int launch_cv_resize(const unsigned char* in, float* out, int n, int H, int W, int oh, int ow, const int* x0, const int* x1,
                      const int* wx1, const int* y0, const int* y1, const int* wy1, int mode, const double* mean, hipStream_t s);
 
+int launch_pairwise_dist(const float* x, const float* y, int n, int m, int d, float* out, hipStream_t s);
+
 void set_pw_tile(int v);
 void set_dw_th(int v);
 void set_dw_variant(int v);

@@ -420,4 +420,9 @@ int hsefr_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_ind
     return launch_nn1(q, g, nq, ng, d, nn_index, nn_dist2, (hipStream_t)stream);
 }
 
+int hsefr_pairwise_dist(const float* x, const float* y, int n, int m, int d, float* out, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || m == 0 || (x && y && out), HSEFR_ERR_INVALID, "pairwise_dist: null pointer");
+    return launch_pairwise_dist(x, y, n, m, d, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

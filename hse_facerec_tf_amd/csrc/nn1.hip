@@ -117,7 +117,55 @@ __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ q, c
     }
 }
 
+// Full Euclidean distance matrix D[i,j] = |x_i - y_j| (sklearn pairwise_distances at
+// facial_clustering_test.py:396; the feature term of process_photos.py:46-51's O(N^2) Python loop),
+// same MFMA contraction as nn1_kernel.  Workgroup = 64x64 outputs, wave = 32x32.
+__global__ __launch_bounds__(256) void pairwise_dist_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, int m,
+                                                            int d, float* __restrict__ out, int same) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int i0 = blockIdx.y * 64 + (wave >> 1) * 32, j0 = blockIdx.x * 64 + (wave & 1) * 32;
+    if (i0 >= n || j0 >= m) return;
+    const float* xp = x + (size_t)min(i0 + li, n - 1) * d + 4 * lh;
+    const float* yp = y + (size_t)min(j0 + li, m - 1) * d + 4 * lh;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float xx = 0.f, yy = 0.f;
+    for (int k = 0; k < d; k += 8) {
+        const f32x4 a = *(const f32x4*)(xp + k);
+        const f32x4 b = *(const f32x4*)(yp + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+            xx = fmaf(a[e], a[e], xx);
+            yy = fmaf(b[e], b[e], yy);
+        }
+    }
+    xx += __shfl_xor(xx, 32);
+    yy += __shfl_xor(yy, 32);
+    const int col = j0 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float xr = __shfl(xx, rr);
+        const int row = i0 + rr;
+        float v = sqrtf(fmaxf(xr + yy - 2.f * acc[r], 0.f));
+        if (same && row == col) v = 0.f;     // pairwise_distances(X) has an exact zero diagonal
+        if (row < n && col < m) out[(size_t)row * m + col] = v;
+    }
+}
+
 }  // namespace
+
+int launch_pairwise_dist(const float* x, const float* y, int n, int m, int d, float* out, hipStream_t s) {
+    HSEFR_REQUIRE(d > 0 && d % 8 == 0, HSEFR_ERR_UNSUPPORTED, "pairwise_dist: d=%d must be a multiple of 8", d);
+    HSEFR_REQUIRE(n >= 0 && m >= 0, HSEFR_ERR_INVALID, "pairwise_dist: bad shape");
+    if (n == 0 || m == 0) return HSEFR_OK;
+    dim3 grid((m + 63) / 64, (n + 63) / 64), block(256);
+    hipLaunchKernelGGL(pairwise_dist_kernel, grid, block, 0, s, x, y, n, m, d, out, x == y ? 1 : 0);
+    return launch_status("pairwise_dist");
+}
 
 int launch_l2_normalize(const float* x, float* y, int n, int d, hipStream_t s) {
     HSEFR_REQUIRE(n >= 0 && d > 0, HSEFR_ERR_INVALID, "l2_normalize: bad shape");

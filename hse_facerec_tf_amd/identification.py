@@ -64,3 +64,22 @@ def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np
     acc = float((y_pred == y_enc[test]).mean()) if len(test) else float("nan")
     return {"accuracy": acc, "indices": indices, "y": y_enc, "train": train, "test": test, "y_pred": y_pred,
             "nn_index": nn_idx_h, "nn_dist": np.sqrt(nn_d2.cpu().numpy()), "num_classes": int(y_enc.max() + 1) if len(y_enc) else 0}
+
+
+def feature_distance_matrix(features, born_years=None, photo_years=None) -> np.ndarray:
+    """The dist_matrix of process_photos.perform_clustering (process_photos.py:45-60): Euclidean distance
+    between facial features (on the GPU) plus 0.1 x the age term (cur_age_i - cur_age_j)^2 / (cur_age_i +
+    cur_age_j), cur_age = max(year_i, year_j) - born_year, clipped at 0.  Returns a host float64 matrix as the
+    clustering code (facial_clustering.get_facial_clusters) expects."""
+    from . import _lib, ops
+    torch = _lib.require_gpu()
+    f = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).cuda()
+    dist = ops.pairwise_distances(f).cpu().numpy().astype(np.float64)
+    if born_years is not None:
+        by = np.asarray(born_years, dtype=np.float64)
+        yr = np.asarray(photo_years, dtype=np.float64)
+        max_year = np.maximum(yr[:, None], yr[None, :])
+        ai, aj = max_year - by[:, None], max_year - by[None, :]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dist = dist + 0.1 * (ai - aj) ** 2 / (ai + aj)
+    return np.clip(dist, a_min=0, a_max=None)

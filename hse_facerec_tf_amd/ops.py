@@ -120,6 +120,19 @@ def nn1(queries, gallery):
     return idx, dist
 
 
+def pairwise_distances(x, y=None):
+    """sklearn pairwise_distances(X[, Y]) (euclidean) -> CUDA float32 [n, m] (facial_clustering_test.py:396)."""
+    torch = _lib.require_gpu()
+    _f32c(x, "x")
+    y = x if y is None else _f32c(y, "y")
+    n, d = x.shape
+    m = y.shape[0]
+    out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_pairwise_dist(x.data_ptr(), y.data_ptr(), n, m, d, out.data_ptr(), _lib.current_stream_ptr()),
+               "hsefr_pairwise_dist")
+    return out
+
+
 # ---- bf16 ResNet-50 kernels -------------------------------------------------------------------------
 def _bf16c(t, name):
     torch = _lib.require_gpu()

@@ -255,6 +255,12 @@ int hsefr_l2_normalize(const float* x, float* y, int n, int d, hsefr_stream_t st
 int hsefr_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2,
               hsefr_stream_t stream);
 
+/* sklearn.metrics.pairwise_distances(X[, Y]) (euclidean; facial_clustering_test.py:396, and the feature term of
+ * process_photos.py:46-51): out[i,j] = |x_i - y_j|, x [n,d], y [m,d], out [n,m]; d multiple of 8.  Passing the same
+ * pointer for x and y gives an exactly zero diagonal.  Computed as |x|^2+|y|^2-2x.y on the fp32 MFMA: absolute error
+ * ~1e-7*(|x|^2+|y|^2) on the SQUARED distance, i.e. distances below ~1e-2 (near-duplicates) carry up to 6e-4. */
+int hsefr_pairwise_dist(const float* x, const float* y, int n, int m, int d, float* out, hsefr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,3 +122,42 @@ def test_extract_dataset_walk_cache_and_labels(torch_, tmp_path):
     tfi.close_session()
     X2, y2 = extract_dataset(None, str(tmp_path), cache)                    # cache hit: extractor is not touched
     assert np.array_equal(X, X2) and np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("n,m,d", [(100, 100, 1024), (65, 130, 64), (1, 1, 8), (257, 33, 2048)])
+def test_pairwise_distances_vs_sklearn(torch_, n, m, d):
+    from sklearn.metrics import pairwise_distances
+    from hse_facerec_tf_amd import ops
+    rs = np.random.RandomState(n + m)
+    x = rs.randn(n, d).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = rs.randn(m, d).astype(np.float32)
+    y /= np.linalg.norm(y, axis=1, keepdims=True)
+    got = ops.pairwise_distances(torch_.from_numpy(x).cuda(), torch_.from_numpy(y).cuda()).cpu().numpy()
+    want = pairwise_distances(x.astype(np.float64), y.astype(np.float64))
+    assert np.abs(got - want).max() < 1e-5                     # distances here are ~1.4: squared-form error is ~1e-7
+    if n == m:
+        xs = torch_.from_numpy(x).cuda()
+        self_d = ops.pairwise_distances(xs).cpu().numpy()
+        assert np.all(np.diag(self_d) == 0.0) and np.abs(self_d - pairwise_distances(x.astype(np.float64))).max() < 1e-5
+        assert np.abs(self_d - self_d.T).max() < 1e-5
+
+
+def test_feature_distance_matrix_matches_reference_loop(torch_):
+    """process_photos.py:46-60 literally (the O(N^2) Python double loop) on a small album."""
+    from hse_facerec_tf_amd import identification
+    rs = np.random.RandomState(3)
+    feats = rs.rand(12, 1024).astype(np.float32)
+    born = rs.randint(1950, 2010, 12)
+    years = rs.randint(2012, 2019, 12)
+
+    def feature_distance(i, j):
+        dist = np.sqrt(np.sum((feats[i] - feats[j]) ** 2))
+        max_year = max(years[i], years[j])
+        cur_age_i, cur_age_j = max_year - born[i], max_year - born[j]
+        age_dist = (cur_age_i - cur_age_j) ** 2 / (cur_age_i + cur_age_j)
+        return [dist, age_dist * 0.1]
+    pair = np.array([[feature_distance(i, j) for j in range(12)] for i in range(12)])
+    want = np.clip(np.sum(pair, axis=2), a_min=0, a_max=None)
+    got = identification.feature_distance_matrix(feats, born, years)
+    assert np.abs(got - want).max() < 2e-4
