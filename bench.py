@@ -156,6 +156,7 @@ def main():
     classes = {
         "conv1_3x3x3_s2": lambda L: L.kind == lowering.OP_CONV_C3,
         "depthwise3x3": lambda L: L.kind == lowering.OP_DWCONV3X3,
+        "fused_dw3x3_pw1x1": lambda L: L.kind == lowering.OP_DWPW_F32,
         "pointwise1x1_f32mfma": lambda L: L.kind == lowering.OP_PWCONV_F32,
         "gap": lambda L: L.kind == lowering.OP_GAP,
     }
@@ -170,7 +171,8 @@ def main():
             traffic_src = os.path.relpath(cands[-1], ROOT)
             prof = json.load(open(cands[-1]))["kernels"]
             prefixes = {"conv1_3x3x3_s2": "conv3x3_c3", "depthwise3x3": "dwconv3x3_kernel",
-                        "pointwise1x1_f32mfma": "pwconv_f32_kernel", "gap": "hsefr::gap_kernel"}
+                        "pointwise1x1_f32mfma": "pwconv_f32_kernel", "gap": "hsefr::gap_kernel",
+                        "fused_dw3x3_pw1x1": "dwpw_fused_kernel"}
             for cls, pre in prefixes.items():
                 rows = [v for k, v in prof.items() if k.startswith(pre)]
                 n = sum(r["launches"] for r in rows)
@@ -188,6 +190,9 @@ def main():
             nbytes = sum(4 * (int(np.prod(plan.layers[i].in_shape)) + int(np.prod(plan.layers[i].out_shape))) for i in idx) * B \
                 + sum(4 * sum(a.size for a in (plan.layers[i].w, plan.layers[i].scale, plan.layers[i].shift) if a is not None) for i in idx)
             flops = sum(plan.flops_per_image([plan.layers[i].kind]) for i in idx[:1]) * B
+            # a fused block also saves writing + re-reading the depthwise result: report both byte counts
+            unfused_extra = sum(2 * 4 * int(np.prod(plan.layers[i].out_shape[:2])) * plan.layers[i].in_shape[2] for i in idx
+                                if plan.layers[i].kind == lowering.OP_DWPW_F32) * B
             launches = len(idx)
             bound = "mfma" if name.startswith("pointwise") else "hbm"
             if bound == "mfma":
@@ -200,6 +205,7 @@ def main():
                             "algorithmic_bytes_per_step": int(nbytes), "flops_per_step": int(flops),
                             "hbm_gbs_algorithmic": round(nbytes / (ms * 1e-3) / 1e9, 1),
                             "algorithmic_bytes_per_launch": int(nbytes / launches),
+                            "unfused_equivalent_gbs": round((nbytes + unfused_extra) / (ms * 1e-3) / 1e9, 1) if unfused_extra else None,
                             "traffic": None if name not in traffic_by_class else int(traffic_by_class[name]),
                             "traffic_unit": "HBM bytes per launch (class average)", "traffic_source": traffic_src})
     dominant = max(kernels, key=lambda k: k["ms_per_step"]) if kernels else None

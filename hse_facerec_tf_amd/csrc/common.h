@@ -102,6 +102,11 @@ int launch_cv_resize(const unsigned char* in, float* out, int n, int H, int W, i
 
 int launch_pairwise_dist(const float* x, const float* y, int n, int m, int d, float* out, hipStream_t s);
 
+bool dwpw_fused_supported(int c, int cout, int stride, int act_dw, int act_pw);
+int launch_dwpw_fused(const float* x, const float* wd, const float* dscale, const float* dshift, const float* wp_t,
+                      const float* pshift, float* y, int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh,
+                      int ow, int cout, int act_dw, int act_pw, hipStream_t s);
+
 void set_pw_tile(int v);
 void set_dw_th(int v);
 void set_dw_variant(int v);

@@ -30,7 +30,7 @@ using namespace hsefr;
 
 static_assert(sizeof(hsefr_plan_header) == 64, "plan header layout is part of the ABI");
 static_assert(sizeof(hsefr_plan_buffer) == 16, "plan buffer layout is part of the ABI");
-static_assert(sizeof(hsefr_plan_op) == 96, "plan op layout is part of the ABI");
+static_assert(sizeof(hsefr_plan_op) == 112, "plan op layout is part of the ABI");
 
 struct hsefr_engine {
     hsefr_plan_header hdr;
@@ -68,7 +68,7 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                       "plan op %u: bad buffer ids (%d -> %d)", i, o.in_buf, o.out_buf);
         HSEFR_REQUIRE(o.res_buf == HSEFR_BUF_NONE || okbuf(o.res_buf, false), HSEFR_ERR_INVALID,
                       "plan op %u: bad residual buffer %d", i, o.res_buf);
-        for (uint64_t off : {o.w_off, o.scale_off, o.shift_off})
+        for (uint64_t off : {o.w_off, o.scale_off, o.shift_off, o.w2_off, o.shift2_off})
             HSEFR_REQUIRE(off == HSEFR_NO_OFFSET || (off < h.blob_bytes && off % 16 == 0), HSEFR_ERR_INVALID,
                           "plan op %u: blob offset %llu out of range / unaligned", i, (unsigned long long)off);
         const bool out_bf16 = o.kind == HSEFR_OP_CONV_BF16 || o.kind == HSEFR_OP_MAXPOOL_BF16 || o.kind == HSEFR_OP_STEM7X7_BF16;
@@ -87,6 +87,10 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
             case HSEFR_OP_CONV_C3: case HSEFR_OP_DWCONV3X3: case HSEFR_OP_PWCONV_F32: case HSEFR_OP_GAP:
             case HSEFR_OP_DENSE: case HSEFR_OP_SOFTMAX: case HSEFR_OP_CONV_BF16: case HSEFR_OP_MAXPOOL_BF16:
             case HSEFR_OP_GAP_BF16: case HSEFR_OP_STEM7X7_BF16:
+                break;
+            case HSEFR_OP_DWPW_F32:
+                HSEFR_REQUIRE(dwpw_fused_supported(o.cin, o.cout, o.stride, HSEFR_ACT_RELU6, (int)o.act), HSEFR_ERR_UNSUPPORTED,
+                              "plan op %u: fused depthwise-pointwise block cin=%d cout=%d not covered", i, o.cin, o.cout);
                 break;
             default:
                 set_error("plan op %u: unknown kind %u", i, o.kind);
@@ -123,7 +127,7 @@ int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsef
     HSEFR_REQUIRE(plan_bytes >= sizeof(hsefr_plan_header), HSEFR_ERR_INVALID, "engine_create: plan too short");
     hsefr_plan_header h;
     memcpy(&h, plan, sizeof(h));
-    HSEFR_REQUIRE(h.magic == HSEFR_PLAN_MAGIC && h.version == 1, HSEFR_ERR_INVALID,
+    HSEFR_REQUIRE(h.magic == HSEFR_PLAN_MAGIC && h.version == 2, HSEFR_ERR_INVALID,
                   "engine_create: bad plan magic/version");
     const size_t need = sizeof(h) + (size_t)h.n_buffers * sizeof(hsefr_plan_buffer) +
                         (size_t)h.n_ops * sizeof(hsefr_plan_op) + h.blob_bytes;
@@ -295,6 +299,12 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
             case HSEFR_OP_GAP_BF16:
                 rc = launch_gap_bf16(in, (float*)out, n, o.h * o.w, o.cin, s);
                 break;
+            case HSEFR_OP_DWPW_F32:
+                rc = launch_dwpw_fused((const float*)in, (const float*)blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
+                                       (const float*)blob_ptr(e, o.shift_off), (const float*)blob_ptr(e, o.w2_off),
+                                       (const float*)blob_ptr(e, o.shift2_off), (float*)out, n, o.h, o.w, o.cin, o.stride,
+                                       o.pad_t, o.pad_l, o.oh, o.ow, o.cout, HSEFR_ACT_RELU6, o.act, s);
+                break;
             default:
                 set_error("forward: op %zu has unknown kind %u", i, o.kind);
                 rc = HSEFR_ERR_UNSUPPORTED;
@@ -346,6 +356,14 @@ int hsefr_pwconv1x1_bias_relu6(const float* x, const float* wgt_t, const float* 
                                int cout, int act, hsefr_stream_t stream) {
     HSEFR_REQUIRE(m == 0 || (x && wgt_t && shift && y), HSEFR_ERR_INVALID, "pwconv: null pointer");
     return launch_pwconv_f32(x, wgt_t, shift, y, m, k, cout, act, (hipStream_t)stream);
+}
+
+int hsefr_dwpw_fused(const float* x, const float* wd, const float* dscale, const float* dshift, const float* wp_t,
+                     const float* pshift, float* y, int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh,
+                     int ow, int cout, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wd && dscale && dshift && wp_t && pshift && y), HSEFR_ERR_INVALID, "dwpw_fused: null pointer");
+    return launch_dwpw_fused(x, wd, dscale, dshift, wp_t, pshift, y, n, h, w, c, stride, pad_t, pad_l, oh, ow, cout,
+                             HSEFR_ACT_RELU6, HSEFR_ACT_RELU6, (hipStream_t)stream);
 }
 
 int hsefr_gap(const float* x, float* y, int n, int hw, int c, hsefr_stream_t stream) {

@@ -28,7 +28,7 @@ from .graphdef import Graph, GraphNode
 # mirrors include/hsefr.h
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_GAP, OP_DENSE, OP_SOFTMAX = 1, 2, 3, 4, 5, 6
-OP_CONV_BF16, OP_MAXPOOL_BF16, OP_GAP_BF16, OP_STEM7X7_BF16 = 7, 8, 9, 10
+OP_CONV_BF16, OP_MAXPOOL_BF16, OP_GAP_BF16, OP_STEM7X7_BF16, OP_DWPW_F32 = 7, 8, 9, 10, 11
 _BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
 BUF_INPUT, BUF_NONE = -1, -2
@@ -37,7 +37,7 @@ NO_OFFSET = 0xFFFFFFFFFFFFFFFF
 
 _HEADER = struct.Struct("<QIIIIII3i3IQ")          # hsefr_plan_header
 _BUFFER = struct.Struct("<QII")                   # hsefr_plan_buffer
-_OP = struct.Struct("<II3i3i3i3i2ii4x3Q")        # hsefr_plan_op (96 bytes, 8-aligned tail)
+_OP = struct.Struct("<II3i3i3i3i2ii4x5Q")        # hsefr_plan_op (112 bytes, 8-aligned tail)
 
 
 class LoweringError(NotImplementedError):
@@ -91,6 +91,8 @@ class Layer:
     sealed: bool = False                               # output materialised; no more epilogue folding
     version: int = 0                                   # bumped by every op folded into the epilogue
     res: int = -1                                      # layer whose output is added before the activation (ResNet)
+    w2: Optional[np.ndarray] = None                    # DWPW_F32: the pointwise kernel [1,1,cin,cout]
+    shift2: Optional[np.ndarray] = None                # DWPW_F32: the pointwise shift
     out_buf: int = BUF_NONE
 
     @property
@@ -126,14 +128,16 @@ class Plan:
             w = L.w
             if L.kind == OP_PWCONV_F32:
                 w = np.ascontiguousarray(w.reshape(w.shape[-2], w.shape[-1]).T)      # [1,1,K,Cout] -> [Cout,K]
-            elif L.kind == OP_DWCONV3X3:
+            elif L.kind in (OP_DWCONV3X3, OP_DWPW_F32):
                 w = w.reshape(3, 3, -1)
+            w2 = None if L.w2 is None else np.ascontiguousarray(L.w2.reshape(L.w2.shape[-2], L.w2.shape[-1]).T)
             in_buf = BUF_INPUT if L.src < 0 else self.layers[L.src].out_buf
             res_buf = BUF_NONE if L.res < 0 else self.layers[L.res].out_buf
             h, wd, cin = L.in_shape
             oh, ow, cout = L.out_shape
             ops.append(_OP.pack(L.kind, L.act, in_buf, L.out_buf, res_buf, h, wd, cin, oh, ow, cout,
-                                L.kh, L.kw, L.stride, L.pad_t, L.pad_l, 0, put(w), put(L.scale), put(L.shift)))
+                                L.kh, L.kw, L.stride, L.pad_t, L.pad_l, 0, put(w), put(L.scale), put(L.shift),
+                                put(w2), put(L.shift2)))
         while len(blob) % 16:
             blob.append(0)
         out_buf = [BUF_NONE] * 3
@@ -141,7 +145,7 @@ class Plan:
         for slot, (li, elems) in self.outputs.items():
             out_buf[slot] = self.layers[li].out_buf
             out_elems[slot] = elems
-        head = _HEADER.pack(PLAN_MAGIC, 1, len(self.buffers), len(ops), self.in_hwc[0], self.in_hwc[1],
+        head = _HEADER.pack(PLAN_MAGIC, 2, len(self.buffers), len(ops), self.in_hwc[0], self.in_hwc[1],
                             self.in_hwc[2], *out_buf, *out_elems, len(blob))
         bufs = b"".join(_BUFFER.pack(e, 1, 0) for e in self.buffers)
         return head + bufs + b"".join(ops) + bytes(blob)
@@ -158,7 +162,7 @@ class Plan:
         tot = 0
         for L in self.layers:
             if kinds is None or L.kind in kinds:
-                for a in (L.w, L.scale, L.shift):
+                for a in (L.w, L.scale, L.shift, L.w2, L.shift2):
                     if a is not None:
                         tot += 4 * a.size
         return tot
@@ -173,6 +177,8 @@ class Plan:
                 tot += 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
             elif L.kind == OP_DWCONV3X3:
                 tot += 2 * oh * ow * cout * 9
+            elif L.kind == OP_DWPW_F32:
+                tot += 2 * oh * ow * L.in_shape[2] * 9 + 2 * oh * ow * cout * L.in_shape[2]
         return tot
 
 
@@ -498,8 +504,50 @@ def assign_buffers(layers: List[Layer], pinned) -> List[int]:
     return buffers
 
 
+def dwpw_fusable(dw: Layer, pw: Layer) -> bool:
+    """Shapes libhsefr's fused depthwise->pointwise kernel covers (csrc/dwpw_fused.hip)."""
+    return (dw.kind == OP_DWCONV3X3 and pw.kind == OP_PWCONV_F32 and dw.act == ACT_RELU6 and pw.act == ACT_RELU6 and
+            dw.in_shape[2] in (32, 64) and pw.out_shape[2] in (64, 128) and dw.stride in (1, 2))
+
+
+def fuse_dwpw(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
+    """Merge every depthwise layer whose ONLY consumer is a fusable pointwise layer into one DWPW_F32 layer.
+    `keep`: layer indices whose own output must stay materialised (requested outputs).  Returns the new
+    layer list and old-index -> new-index (the merged depthwise maps to -1: its tensor no longer exists)."""
+    consumers: Dict[int, List[int]] = {}
+    for i, L in enumerate(layers):
+        for s in (L.src, L.res):
+            if s >= 0:
+                consumers.setdefault(s, []).append(i)
+    merged_into: Dict[int, int] = {}
+    for i, L in enumerate(layers):
+        cons = consumers.get(i, [])
+        if L.kind == OP_DWCONV3X3 and i not in keep and len(cons) == 1 and layers[cons[0]].src == i and dwpw_fusable(L, layers[cons[0]]):
+            merged_into[i] = cons[0]
+    new_layers: List[Layer] = []
+    remap: Dict[int, int] = {}
+    for i, L in enumerate(layers):
+        if i in merged_into:
+            remap[i] = -1
+            continue
+        dws = [d for d, pwi in merged_into.items() if pwi == i]
+        if dws:
+            dw = layers[dws[0]]
+            L = Layer(OP_DWPW_F32, L.name, dw.src, dw.in_shape, L.out_shape, w=dw.w, scale=dw.scale, shift=dw.shift,
+                      act=L.act, kh=3, kw=3, stride=dw.stride, pad_t=dw.pad_t, pad_l=dw.pad_l, sealed=True,
+                      w2=L.w, shift2=L.shift)
+        new_layers.append(L)
+        remap[i] = len(new_layers) - 1
+    for L in new_layers:
+        if L.src >= 0:
+            L.src = remap[L.src]
+        if L.res >= 0:
+            L.res = remap[L.res]
+    return new_layers, remap
+
+
 def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
-                feeds: Optional[Dict[str, object]] = None) -> Plan:
+                feeds: Optional[Dict[str, object]] = None, fuse: bool = True) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase."""
     in_node, _ = g.get_tensor_by_name(input_tensor)
     shape = g.placeholder_shape(in_node.name)
@@ -539,6 +587,10 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
             raise LoweringError("output %s is an intermediate of fused layer %s; fetch the layer's final tensor"
                                 % (tname, layers[low.where[nm]].name))
     tensor_layer = {name: li for name, li in low.where.items() if li >= 0 and low.is_final(name)}
+    if fuse:   # early MobileNet blocks: depthwise result stays on the CU (csrc/dwpw_fused.hip)
+        layers, remap = fuse_dwpw(layers, [li for li, _ in out_layers.values()])
+        out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
+        tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
 
     buffers = assign_buffers(layers, {li for li, _ in out_layers.values()})
     return Plan(layers, (input_hw[0], input_hw[1], low.in_c), buffers, out_layers, tensor_layer)

@@ -65,6 +65,22 @@ def pwconv1x1(x, w_t, shift, act: int = ACT_RELU6):
     return y
 
 
+def dwpw_fused(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1):
+    """One early MobileNet block in one kernel: depthwise 3x3 SAME + scale + shift + ReLU6 -> pointwise 1x1 + shift +
+    ReLU6 (graph nodes #35-#49).  c in {32, 64}, cout in {64, 128}; wp_t is the pointwise kernel transposed [cout, c]."""
+    torch = _lib.require_gpu()
+    for t, nm in ((x, "x"), (w_hwc, "w"), (dscale, "dscale"), (dshift, "dshift"), (wp_t, "wp_t"), (pshift, "pshift")):
+        _f32c(t, nm)
+    n, h, w, c = x.shape
+    cout = wp_t.shape[0]
+    oh, ow, pt, pl = _same(h, w, 3, stride)
+    y = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_dwpw_fused(x.data_ptr(), w_hwc.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), wp_t.data_ptr(),
+                                           pshift.data_ptr(), y.data_ptr(), n, h, w, c, stride, pt, pl, oh, ow, cout,
+                                           _lib.current_stream_ptr()), "hsefr_dwpw_fused")
+    return y
+
+
 def gap(x):
     torch = _lib.require_gpu()
     _f32c(x, "x")

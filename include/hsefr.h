@@ -90,7 +90,9 @@ typedef enum hsefr_op_kind {
                                   + shift (+ residual) + act; bf16 activations                            */
     HSEFR_OP_MAXPOOL_BF16 = 8, /* 3x3/2 max-pool, bf16                                                    */
     HSEFR_OP_GAP_BF16 = 9,     /* mean over H,W of bf16 activations -> fp32                               */
-    HSEFR_OP_STEM7X7_BF16 = 10 /* 7x7/2 pad-3 conv over the fp32 3-channel image -> 64 ch bf16 (+scale+shift+ReLU) */
+    HSEFR_OP_STEM7X7_BF16 = 10,/* 7x7/2 pad-3 conv over the fp32 3-channel image -> 64 ch bf16 (+scale+shift+ReLU) */
+    HSEFR_OP_DWPW_F32 = 11     /* fused depthwise 3x3 (+scale+shift+ReLU6) -> pointwise 1x1 (+shift+ReLU6), cin 32|64,
+                                  cout 64|128: the depthwise result never leaves the CU                            */
 } hsefr_op_kind;
 
 typedef enum hsefr_output_slot {
@@ -102,7 +104,7 @@ typedef enum hsefr_output_slot {
 
 typedef struct hsefr_plan_header {
     uint64_t magic;
-    uint32_t version; /* 1 */
+    uint32_t version; /* 2 */
     uint32_t n_buffers;
     uint32_t n_ops;
     uint32_t in_h, in_w, in_c;
@@ -129,6 +131,8 @@ typedef struct hsefr_plan_op {
     uint64_t w_off;     /* weights; layout depends on kind (see the per-kernel entry points) */
     uint64_t scale_off; /* per-channel scale (DWCONV only)                                   */
     uint64_t shift_off; /* per-channel shift / bias                                          */
+    uint64_t w2_off;     /* DWPW_F32: pointwise kernel, transposed [cout][cin]                */
+    uint64_t shift2_off; /* DWPW_F32: pointwise shift [cout]                                  */
 } hsefr_plan_op;
 
 /* ------------------------------------------------------------------------------------ */
@@ -190,6 +194,13 @@ int hsefr_dwconv3x3_bn_relu6(const float* x, const float* wgt, const float* scal
  * y [m,cout].  k multiple of 32, cout multiple of 64. */
 int hsefr_pwconv1x1_bias_relu6(const float* x, const float* wgt_t, const float* shift, float* y,
                                long long m, int k, int cout, int act, hsefr_stream_t stream);
+
+/* One whole early MobileNet block (graph nodes #35-#49) fused: depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6
+ * -> pointwise 1x1 + shift + ReLU6.  x [n,h,w,c], wd [3,3,c], wp_t [cout,c] (TF kernel transposed), y [n,oh,ow,cout];
+ * c in {32,64}, cout in {64,128}; HSEFR_ERR_UNSUPPORTED otherwise (callers fall back to the two separate kernels). */
+int hsefr_dwpw_fused(const float* x, const float* wd, const float* dscale, const float* dshift, const float* wp_t,
+                     const float* pshift, float* y, int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh,
+                     int ow, int cout, hsefr_stream_t stream);
 
 /* Mean over H,W (graph node #230): x [n,hw,c] -> y [n,c]; c multiple of 4. */
 int hsefr_gap(const float* x, float* y, int n, int hw, int c, hsefr_stream_t stream);

@@ -13,7 +13,7 @@ from oracle import tf_graph as tfo
 
 HEADER = struct.Struct("<QIIIIII3i3IQ")
 BUFFER = struct.Struct("<QII")
-OP = struct.Struct("<II3i3i3i3i2ii4x3Q")
+OP = struct.Struct("<II3i3i3i3i2ii4x5Q")
 NO_OFFSET = 0xFFFFFFFFFFFFFFFF
 
 
@@ -63,7 +63,7 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
     x = x.astype(dtype)
     for i, o in enumerate(p["ops"]):
         (kind, act, in_buf, out_buf, res_buf, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l, _r,
-         w_off, sc_off, sh_off) = o
+         w_off, sc_off, sh_off, w2_off, sh2_off) = o
         src = x if in_buf == -1 else mem[in_buf]
         src = src.reshape(n, h, w, cin)
         res = None if res_buf < 0 else mem[res_buf]
@@ -94,6 +94,14 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             y = _act(src.reshape(n, cin).dot(k) + arr(sh_off, cout), act).reshape(n, 1, 1, cout)
         elif kind == 6:
             y = tfo.softmax(src.reshape(n, -1)).reshape(n, 1, 1, -1)
+        elif kind == 11:     # fused depthwise (+scale+shift+relu6) -> pointwise (+shift+act)
+            k = arr(w_off, 9 * cin).reshape(3, 3, cin, 1)
+            pb = max((oh - 1) * stride + 3 - h - pad_t, 0)
+            pr = max((ow - 1) * stride + 3 - w - pad_l, 0)
+            xp = np.pad(src, ((0, 0), (pad_t, pb), (pad_l, pr), (0, 0)))
+            mid = _act(tfo.depthwise_conv2d(xp, k, (stride, stride), "VALID") * arr(sc_off, cin) + arr(sh_off, cin), 2)
+            wt = arr(w2_off, cin * cout).reshape(cout, cin)
+            y = _act(mid.reshape(-1, cin).dot(wt.T) + arr(sh2_off, cout), act).reshape(n, oh, ow, cout)
         elif kind == 7:      # bf16 implicit-GEMM conv: weights [cout][kh*kw*cin] bf16, fp32 scale/shift, optional residual
             k = arr_bf16(w_off, kh * kw * cin * cout).reshape(cout, kh, kw, cin).transpose(1, 2, 3, 0)
             pb = max((oh - 1) * stride + kh - h - pad_t, 0)

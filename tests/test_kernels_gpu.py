@@ -164,3 +164,33 @@ def test_empty_batch_is_a_noop(env):
     assert tuple(y.shape) == (0, 8, 8, 8)
     y = ops.pwconv1x1(torch.zeros((0, 32), device="cuda"), torch.zeros((64, 32), device="cuda"), torch.zeros(64, device="cuda"))
     assert tuple(y.shape) == (0, 64)
+
+
+@pytest.mark.parametrize("n,h,w,c,cout,s", [(2, 96, 96, 32, 64, 1), (2, 96, 96, 64, 128, 2), (1, 112, 112, 32, 64, 1), (1, 50, 50, 32, 64, 1),
+                                            (2, 50, 50, 64, 128, 2), (1, 100, 100, 64, 128, 2), (3, 9, 21, 32, 128, 1), (1, 7, 5, 64, 64, 2),
+                                            (1, 1, 1, 32, 64, 1), (2, 33, 17, 64, 64, 1)])
+def test_fused_depthwise_pointwise_vs_oracle(env, n, h, w, c, cout, s):
+    """The fused early-block kernel vs the two-op oracle; patches are 8x16 so odd sizes exercise partial patches."""
+    torch, ops = env
+    rs = np.random.RandomState(h * 13 + c + cout + s)
+    x = rs.uniform(0, 6, (n, h, w, c)).astype(np.float32)
+    kd = rs.randn(3, 3, c, 1).astype(np.float32)
+    sc = rs.uniform(0.2, 2, c).astype(np.float32)
+    sh = rs.randn(c).astype(np.float32)
+    kp = (rs.randn(c, cout) / np.sqrt(c)).astype(np.float32)
+    psh = rs.randn(cout).astype(np.float32)
+    mid = act6(tfo.depthwise_conv2d(x.astype(np.float64), kd, (s, s), "SAME") * sc + sh)
+    want = act6(mid.reshape(-1, c).dot(kp.astype(np.float64)) + psh).reshape(mid.shape[:3] + (cout,))
+    y = ops.dwpw_fused(dev(torch, x), dev(torch, kd.reshape(3, 3, c)), dev(torch, sc), dev(torch, sh), dev(torch, kp.T), dev(torch, psh), s)
+    assert tuple(y.shape) == want.shape
+    assert rel(y.cpu().numpy(), want) < TOL
+    # and bit-compatible in structure with the unfused pair (same arithmetic, different schedule): <= fp32 round-off
+    y2 = ops.pwconv1x1(ops.dwconv3x3(dev(torch, x), dev(torch, kd.reshape(3, 3, c)), dev(torch, sc), dev(torch, sh), s), dev(torch, kp.T), dev(torch, psh))
+    assert rel(y.cpu().numpy(), y2.cpu().numpy()) < TOL
+
+
+def test_fused_kernel_rejects_uncovered_shapes(env):
+    torch, ops = env
+    z = lambda *s: torch.zeros(s, device="cuda")
+    with pytest.raises(NotImplementedError):
+        ops.dwpw_fused(z(1, 8, 8, 128), z(3, 3, 128), z(128), z(128), z(128, 128), z(128))

@@ -47,7 +47,7 @@ def test_get_tensor_by_name_error_behaviour(graph):
 
 
 def test_plan_layer_table_matches_survey(graph):
-    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192))
+    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), fuse=False)
     kinds = [L.kind for L in plan.layers]
     assert kinds[0] == lowering.OP_CONV_C3 and kinds.count(lowering.OP_DWCONV3X3) == 13
     assert kinds.count(lowering.OP_PWCONV_F32) == 13 and kinds.count(lowering.OP_GAP) == 1
@@ -60,7 +60,7 @@ def test_plan_layer_table_matches_survey(graph):
     assert abs(plan.bytes_per_image([lowering.OP_DWCONV3X3]) / 1e6 - 14.672) < 0.01
     assert abs(plan.bytes_per_image(range(1, 5)) / 1e6 - 30.085) < 0.01
     assert abs(plan.flops_per_image([lowering.OP_PWCONV_F32]) / 1e6 - 792.7) < 0.5
-    plan224 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS)
+    plan224 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, fuse=False)
     assert plan224.in_hwc == (224, 224, 3)
     assert abs(plan224.bytes_per_image([lowering.OP_DWCONV3X3]) / 1e6 - 19.970) < 0.01
 
@@ -76,9 +76,28 @@ def test_lowered_plan_equals_unfused_graph(graph, size, n):
     assert rel(out["gender"], z["gender_%d" % size]) < 1e-6
 
 
+def test_fusion_pass_merges_the_early_blocks_only(graph):
+    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192))
+    kinds = [L.kind for L in plan.layers]
+    assert kinds[:3] == [lowering.OP_CONV_C3, lowering.OP_DWPW_F32, lowering.OP_DWPW_F32]      # C = 32 and C = 64 blocks
+    assert kinds.count(lowering.OP_DWPW_F32) == 2 and kinds.count(lowering.OP_DWCONV3X3) == 11
+    f1, f2 = plan.layers[1], plan.layers[2]
+    assert f1.in_shape == (96, 96, 32) and f1.out_shape == (96, 96, 64) and f1.stride == 1
+    assert f2.in_shape == (96, 96, 64) and f2.out_shape == (48, 48, 128) and f2.stride == 2 and (f2.pad_t, f2.pad_l) == (0, 0)
+    assert "conv_dw_1_relu/clip_by_value" not in plan.tensor_layer and plan.tensor_layer["conv_pw_1_relu/clip_by_value"] == 1
+    # same FLOPs, 5.9 MB less HBM traffic per face (the two depthwise outputs are neither written nor re-read)
+    unfused = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), fuse=False)
+    assert plan.flops_per_image() == unfused.flops_per_image()
+    saved = unfused.bytes_per_image() - plan.bytes_per_image()
+    assert saved == 2 * 4 * (96 * 96 * 32 + 48 * 48 * 64)
+    # a depthwise tensor that is itself requested is not fused away
+    keep = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "conv_dw_1_relu/clip_by_value:0"}, (64, 64))
+    assert keep.layers[-1].kind == lowering.OP_DWCONV3X3
+
+
 def test_features_only_plan_and_intermediate_outputs(graph):
     plan = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0"}, (64, 64))
-    assert len(plan.layers) == 28 and OUT_AGE not in plan.outputs
+    assert len(plan.layers) == 26 and OUT_AGE not in plan.outputs
     x = np.random.RandomState(5).uniform(-128, 128, (1, 64, 64, 3)).astype(np.float32)
     ref = tfo.GraphOracle(MODEL_PB).run("global_pooling/Mean:0", {"input_1:0": x})
     assert rel(plan_ref.run(plan.serialize(), x)["features"], ref) < 1e-6
@@ -100,7 +119,7 @@ def test_features_only_plan_and_intermediate_outputs(graph):
 def test_plan_struct_layout_matches_header():
     hdr = open(os.path.join(os.path.dirname(MODEL_PB), "..", "include", "hsefr.h")).read()
     assert "HSEFR_PLAN_MAGIC 0x314c505246455348ull" in hdr
-    assert lowering._HEADER.size == 64 and lowering._BUFFER.size == 16 and lowering._OP.size == 96
+    assert lowering._HEADER.size == 64 and lowering._BUFFER.size == 16 and lowering._OP.size == 112
     assert struct.pack("<Q", lowering.PLAN_MAGIC) == b"HSEFRPL1"
     for name, val in (("HSEFR_OP_CONV_C3", lowering.OP_CONV_C3), ("HSEFR_OP_DWCONV3X3", lowering.OP_DWCONV3X3),
                       ("HSEFR_OP_PWCONV_F32", lowering.OP_PWCONV_F32), ("HSEFR_OP_GAP", lowering.OP_GAP),
@@ -118,6 +137,8 @@ def test_buffers_never_alias_input_and_output(graph):
     assert len(pinned) == 3
     # the two big ping-pong buffers + three small output buffers
     assert sorted(plan.buffers, reverse=True)[:2] == [4 * 96 * 96 * 64, 4 * 96 * 96 * 32]
+    unfused = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), fuse=False)
+    assert sorted(unfused.buffers, reverse=True)[:2] == [4 * 96 * 96 * 64, 4 * 96 * 96 * 32]
 
 
 def test_unfolded_batchnorm_and_learning_phase_graph():
