@@ -42,164 +42,232 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 }
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 
-template <int STRIDE, int C, int BN, int OCC>
-__global__ __launch_bounds__(256, OCC) void dwpw_fused_kernel(DwPwParams p) {
-    constexpr int KT = C / 32, C4 = C / 4, TW = 16, TH = 8, BM = TW * TH;
+// ---- phase 1: depthwise result of patch (n, oh0.., ow0..) -> A operand tile in LDS; `ptid` in [0,256) ----------------
+template <int STRIDE, int C>
+__device__ __forceinline__ void dw_phase(const DwPwParams& p, float (*As)[128 * 32], int ptid, int n, int oh0, int ow0) {
+    constexpr int C4 = C / 4, TW = 16, TH = 8;
     constexpr int U = TW * C4;                 // (column, channel-quad) work items per patch row: 128 or 256
     constexpr int ROWS_PER_THREAD = U >= 256 ? TH : TH / 2;
     static_assert(U == 128 || U == 256, "C must be 32 or 64");
-    constexpr int WN = BN / 2, NI = WN / 32;
-    __shared__ __attribute__((aligned(16))) float As[KT][BM * 32];
-    __shared__ __attribute__((aligned(16))) float Bs[KT][BN * 32];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-
-    // pointwise weights -> LDS once (K-tile major, rows = output channels)
-    for (int i = tid; i < KT * BN * 8; i += 256) {
-        const int ch = i & 7, r = (i >> 3) % BN, kt = i / (BN * 8);
-        *(f32x4*)(&Bs[kt][swz(r, ch)]) = *(const f32x4*)(p.wp + (size_t)r * C + kt * 32 + ch * 4);
-    }
-
-    // depthwise role of this thread: column tw, channel quad c4, rows [row0, row0 + ROWS_PER_THREAD)
-    const int u = tid % U;
+    const int u = ptid % U;
     const int tw = u / C4, c4 = u % C4;
-    const int row0 = (U >= 256) ? 0 : (tid / U) * ROWS_PER_THREAD;
+    const int row0 = (U >= 256) ? 0 : (ptid / U) * ROWS_PER_THREAD;
     const float4 dsc = p.dscale[c4], dsh = p.dshift[c4];
-    float psh[NI];
-
-    for (unsigned t = blockIdx.x; t < p.total; t += gridDim.x) {
-        const unsigned lt = xcd_remap(t, p.total);
-        const int pw_ = lt % p.tiles_w, ph = (lt / p.tiles_w) % p.tiles_h, n = lt / (p.tiles_w * p.tiles_h);
-        const int oh0 = ph * TH, ow0 = pw_ * TW;
-        __syncthreads();   // previous tile's MFMA reads of As are done (first pass: Bs is written)
-
-        // ---------------- phase 1: depthwise patch -> As ----------------
-        {
-            const int ow = min(ow0 + tw, p.OW - 1);            // clamped: out-of-range columns are computed, never stored
-            const int iw0 = ow * STRIDE - p.pad_l;
-            const float ml = iw0 >= 0 ? 1.f : 0.f, mm = (iw0 + 1 >= 0 && iw0 + 1 < p.W) ? 1.f : 0.f, mr = iw0 + 2 < p.W ? 1.f : 0.f;
-            float4 wk[9];
+    const int ow = min(ow0 + tw, p.OW - 1);            // clamped: out-of-range columns are computed, never stored
+    const int iw0 = ow * STRIDE - p.pad_l;
+    const float ml = iw0 >= 0 ? 1.f : 0.f, mm = (iw0 + 1 >= 0 && iw0 + 1 < p.W) ? 1.f : 0.f, mr = iw0 + 2 < p.W ? 1.f : 0.f;
+    float4 wk[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const float m = (i % 3 == 0) ? ml : (i % 3 == 1 ? mm : mr);
-                const float4 wr = p.wd[i * C4 + c4];   // 9 L1-resident loads per patch; keeps 36 VGPRs free
-                wk[i] = make_float4(wr.x * m, wr.y * m, wr.z * m, wr.w * m);
-            }
-            const int cl = max(iw0, 0) * C4, cm = min(max(iw0 + 1, 0), p.W - 1) * C4, cr = min(iw0 + 2, p.W - 1) * C4;
-            const float4* xin = p.x + (size_t)n * p.H * p.W * C4 + c4;
-            struct Row { float4 l, m, r; float k; };
-            auto load_row = [&](int ih) {
-                Row q;
-                const int ihc = min(max(ih, 0), p.H - 1);
-                const float4* row = xin + (size_t)ihc * p.W * C4;
-                q.l = row[cl]; q.m = row[cm]; q.r = row[cr];
-                q.k = (ih >= 0 && ih < p.H) ? 1.f : 0.f;
-                return q;
-            };
-            auto row_sum = [&](const Row& q, int b) {
-                float4 a = make_float4(q.l.x * wk[b].x, q.l.y * wk[b].y, q.l.z * wk[b].z, q.l.w * wk[b].w);
-                a = fma4(q.m, wk[b + 1], a);
-                return fma4(q.r, wk[b + 2], a);
-            };
-            auto emit = [&](int th, const Row& a, const Row& b, const Row& c) {
-                const float4 sa = row_sum(a, 0), sb = row_sum(b, 3), sc = row_sum(c, 6);
-                float4 acc = make_float4(sa.x * a.k, sa.y * a.k, sa.z * a.k, sa.w * a.k);
-                acc = make_float4(fmaf(sb.x, b.k, acc.x), fmaf(sb.y, b.k, acc.y), fmaf(sb.z, b.k, acc.z), fmaf(sb.w, b.k, acc.w));
-                acc = make_float4(fmaf(sc.x, c.k, acc.x), fmaf(sc.y, c.k, acc.y), fmaf(sc.z, c.k, acc.z), fmaf(sc.w, c.k, acc.w));
-                const float4 o = fma4(acc, dsc, dsh);
-                f32x4 v;
-                v[0] = relu6(o.x); v[1] = relu6(o.y); v[2] = relu6(o.z); v[3] = relu6(o.w);
-                *(f32x4*)(&As[c4 >> 3][swz(th * TW + tw, c4 & 7)]) = v;
-            };
-            const int ohb = oh0 + row0;
-            if (STRIDE == 1) {
-                const int ih = ohb - p.pad_t;
-                Row r0 = load_row(ih), r1 = load_row(ih + 1), r2 = load_row(ih + 2), r3 = load_row(ih + 3);
+    for (int i = 0; i < 9; ++i) {
+        const float m = (i % 3 == 0) ? ml : (i % 3 == 1 ? mm : mr);
+        const float4 wr = p.wd[i * C4 + c4];   // 9 L1-resident loads per patch; keeps 36 VGPRs free
+        wk[i] = make_float4(wr.x * m, wr.y * m, wr.z * m, wr.w * m);
+    }
+    const int cl = max(iw0, 0) * C4, cm = min(max(iw0 + 1, 0), p.W - 1) * C4, cr = min(iw0 + 2, p.W - 1) * C4;
+    const float4* xin = p.x + (size_t)n * p.H * p.W * C4 + c4;
+    struct Row { float4 l, m, r; float k; };
+    auto load_row = [&](int ih) {
+        Row q;
+        const int ihc = min(max(ih, 0), p.H - 1);
+        const float4* row = xin + (size_t)ihc * p.W * C4;
+        q.l = row[cl]; q.m = row[cm]; q.r = row[cr];
+        q.k = (ih >= 0 && ih < p.H) ? 1.f : 0.f;
+        return q;
+    };
+    auto row_sum = [&](const Row& q, int b) {
+        float4 a = make_float4(q.l.x * wk[b].x, q.l.y * wk[b].y, q.l.z * wk[b].z, q.l.w * wk[b].w);
+        a = fma4(q.m, wk[b + 1], a);
+        return fma4(q.r, wk[b + 2], a);
+    };
+    auto emit = [&](int th, const Row& a, const Row& b, const Row& c) {
+        const float4 sa = row_sum(a, 0), sb = row_sum(b, 3), sc = row_sum(c, 6);
+        float4 acc = make_float4(sa.x * a.k, sa.y * a.k, sa.z * a.k, sa.w * a.k);
+        acc = make_float4(fmaf(sb.x, b.k, acc.x), fmaf(sb.y, b.k, acc.y), fmaf(sb.z, b.k, acc.z), fmaf(sb.w, b.k, acc.w));
+        acc = make_float4(fmaf(sc.x, c.k, acc.x), fmaf(sc.y, c.k, acc.y), fmaf(sc.z, c.k, acc.z), fmaf(sc.w, c.k, acc.w));
+        const float4 o = fma4(acc, dsc, dsh);
+        f32x4 v;
+        v[0] = relu6(o.x); v[1] = relu6(o.y); v[2] = relu6(o.z); v[3] = relu6(o.w);
+        *(f32x4*)(&As[c4 >> 3][swz(th * TW + tw, c4 & 7)]) = v;
+    };
+    const int ohb = oh0 + row0;
+    if (STRIDE == 1) {
+        const int ih = ohb - p.pad_t;
+        Row r0 = load_row(ih), r1 = load_row(ih + 1), r2 = load_row(ih + 2), r3 = load_row(ih + 3);
 #pragma unroll
-                for (int j = 0; j < ROWS_PER_THREAD; ++j) {
-                    const Row r4 = load_row(ih + j + 4);
-                    emit(row0 + j, r0, r1, r2);
-                    r0 = r1; r1 = r2; r2 = r3; r3 = r4;
-                }
-            } else {
-                const int ih = ohb * 2 - p.pad_t;
-                Row r0 = load_row(ih), r1 = load_row(ih + 1), r2 = load_row(ih + 2);
-#pragma unroll
-                for (int j = 0; j < ROWS_PER_THREAD; ++j) {
-                    const Row n1 = load_row(ih + 2 * j + 3), n2 = load_row(ih + 2 * j + 4);
-                    emit(row0 + j, r0, r1, r2);
-                    r0 = r2; r1 = n1; r2 = n2;
-                }
-            }
+        for (int j = 0; j < ROWS_PER_THREAD; ++j) {
+            const Row r4 = load_row(ih + j + 4);
+            emit(row0 + j, r0, r1, r2);
+            r0 = r1; r1 = r2; r2 = r3; r3 = r4;
         }
-        __syncthreads();
-
-        // ---------------- phase 2: [128 x C] . [C x BN] on the fp32 MFMA ----------------
-        f32x16 acc[2][NI];
+    } else {
+        const int ih = ohb * 2 - p.pad_t;
+        Row r0 = load_row(ih), r1 = load_row(ih + 1), r2 = load_row(ih + 2);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                f32x4 a[2], b[NI];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) a[mi] = *(const f32x4*)(&As[kt][swz(wm * 64 + mi * 32 + li, 2 * s + lh)]);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4*)(&Bs[kt][swz(wn * WN + ni * 32 + li, 2 * s + lh)]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
-            }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) psh[ni] = p.pshift[wn * WN + ni * 32 + li];
-        // epilogue: tile row R = th*16 + tw; accumulator register r of lane-half lh -> R = base + (r&3) + 8*(r>>2) + 4*lh
-        // (full patches store unconditionally: a per-store bounds branch costs an s_waitcnt vmcnt(0) per store)
-        const bool full = oh0 + TH <= p.OH && ow0 + TW <= p.OW;
-        float* ybase = p.y + ((size_t)n * p.OH * p.OW) * BN;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int col = wn * WN + ni * 32 + li;
-                const int Rb = wm * 64 + mi * 32 + 4 * lh;
-                if (full) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int R = Rb + (r & 3) + 8 * (r >> 2);
-                        ybase[((size_t)(oh0 + (R >> 4)) * p.OW + ow0 + (R & 15)) * BN + col] = relu6(acc[mi][ni][r] + psh[ni]);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int R = Rb + (r & 3) + 8 * (r >> 2);
-                        const int oh = oh0 + (R >> 4), ow = ow0 + (R & 15);
-                        if (oh < p.OH && ow < p.OW) ybase[((size_t)oh * p.OW + ow) * BN + col] = relu6(acc[mi][ni][r] + psh[ni]);
-                    }
-                }
-            }
+        for (int j = 0; j < ROWS_PER_THREAD; ++j) {
+            const Row n1 = load_row(ih + 2 * j + 3), n2 = load_row(ih + 2 * j + 4);
+            emit(row0 + j, r0, r1, r2);
+            r0 = r2; r1 = n1; r2 = n2;
+        }
     }
 }
 
+// ---- phase 2: [128 x C] . [C x BN] on the fp32 MFMA + shift + ReLU6 + store; `wave4` in [0,4), lane in [0,64) ---------
+template <int C, int BN>
+__device__ __forceinline__ void mfma_phase(const DwPwParams& p, const float (*As)[128 * 32], const float (*Bs)[BN * 32], int wave4,
+                                           int lane, int n, int oh0, int ow0) {
+    constexpr int KT = C / 32, TW = 16, TH = 8, WN = BN / 2, NI = WN / 32;
+    const int wm = wave4 >> 1, wn = wave4 & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 a[2], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const f32x4*)(&As[kt][swz(wm * 64 + mi * 32 + li, 2 * s + lh)]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4*)(&Bs[kt][swz(wn * WN + ni * 32 + li, 2 * s + lh)]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+        }
+    float psh[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) psh[ni] = p.pshift[wn * WN + ni * 32 + li];
+    // epilogue: tile row R = th*16 + tw; accumulator register r of lane-half lh -> R = base + (r&3) + 8*(r>>2) + 4*lh
+    // (full patches store unconditionally: a per-store bounds branch costs an s_waitcnt vmcnt(0) per store)
+    const bool full = oh0 + TH <= p.OH && ow0 + TW <= p.OW;
+    float* ybase = p.y + ((size_t)n * p.OH * p.OW) * BN;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = wn * WN + ni * 32 + li;
+            const int Rb = wm * 64 + mi * 32 + 4 * lh;
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int R = Rb + (r & 3) + 8 * (r >> 2);
+                    ybase[((size_t)(oh0 + (R >> 4)) * p.OW + ow0 + (R & 15)) * BN + col] = relu6(acc[mi][ni][r] + psh[ni]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int R = Rb + (r & 3) + 8 * (r >> 2);
+                    const int oh = oh0 + (R >> 4), ow = ow0 + (R & 15);
+                    if (oh < p.OH && ow < p.OW) ybase[((size_t)oh * p.OW + ow) * BN + col] = relu6(acc[mi][ni][r] + psh[ni]);
+                }
+            }
+        }
+}
+
+__device__ __forceinline__ void decode_patch(const DwPwParams& p, unsigned t, int& n, int& oh0, int& ow0) {
+    const unsigned lt = xcd_remap(t, p.total);
+    ow0 = (lt % p.tiles_w) * 16;
+    oh0 = ((lt / p.tiles_w) % p.tiles_h) * 8;
+    n = lt / (p.tiles_w * p.tiles_h);
+}
+
+template <int C, int BN>
+__device__ __forceinline__ void load_pw_weights(const DwPwParams& p, float (*Bs)[BN * 32], int tid, int nthreads) {
+    constexpr int KT = C / 32;
+    for (int i = tid; i < KT * BN * 8; i += nthreads) {
+        const int ch = i & 7, r = (i >> 3) % BN, kt = i / (BN * 8);
+        *(f32x4*)(&Bs[kt][swz(r, ch)]) = *(const f32x4*)(p.wp + (size_t)r * C + kt * 32 + ch * 4);
+    }
+}
+
+// Variant A: 256 threads, the two phases alternate inside each workgroup; co-resident workgroups overlap them.
+template <int STRIDE, int C, int BN, int OCC>
+__global__ __launch_bounds__(256, OCC) void dwpw_fused_kernel(DwPwParams p) {
+    constexpr int KT = C / 32;
+    __shared__ __attribute__((aligned(16))) float As[KT][128 * 32];
+    __shared__ __attribute__((aligned(16))) float Bs[KT][BN * 32];
+    const int tid = threadIdx.x;
+    load_pw_weights<C, BN>(p, Bs, tid, 256);
+    for (unsigned t = blockIdx.x; t < p.total; t += gridDim.x) {
+        int n, oh0, ow0;
+        decode_patch(p, t, n, oh0, ow0);
+        __syncthreads();   // previous tile's MFMA reads of As are done (first pass: Bs is written)
+        dw_phase<STRIDE, C>(p, As, tid, n, oh0, ow0);
+        __syncthreads();
+        mfma_phase<C, BN>(p, As, Bs, tid >> 6, tid & 63, n, oh0, ow0);
+    }
+}
+
+// Variant B: 512 threads = 4 producer waves (depthwise of patch i+1 into the other A buffer) + 4 consumer waves (MFMA +
+// store of patch i), one workgroup barrier per patch: inside ONE workgroup the HBM reads, the MFMAs and the HBM writes
+// of consecutive patches overlap, instead of relying on neighbours being out of phase.
+template <int STRIDE, int C, int BN, int OCC>
+__global__ __launch_bounds__(512, OCC) void dwpw_fused_ws_kernel(DwPwParams p) {
+    constexpr int KT = C / 32;
+    __shared__ __attribute__((aligned(16))) float As[2][KT][128 * 32];
+    __shared__ __attribute__((aligned(16))) float Bs[KT][BN * 32];
+    const int tid = threadIdx.x;
+    const bool producer = tid < 256;            // waves 0-3; provably wave-uniform
+    const int ptid = tid & 255;
+    load_pw_weights<C, BN>(p, Bs, tid, 512);
+    unsigned t = blockIdx.x;
+    if (t >= p.total) return;
+    int n, oh0, ow0;
+    decode_patch(p, t, n, oh0, ow0);
+    if (producer) dw_phase<STRIDE, C>(p, As[0], ptid, n, oh0, ow0);
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+        const unsigned tn = t + gridDim.x;
+        const bool more = tn < p.total;
+        if (producer) {
+            if (more) {
+                int n2, oh2, ow2;
+                decode_patch(p, tn, n2, oh2, ow2);
+                dw_phase<STRIDE, C>(p, As[buf ^ 1], ptid, n2, oh2, ow2);
+            }
+        } else {
+            mfma_phase<C, BN>(p, As[buf], Bs, (tid >> 6) & 3, tid & 63, n, oh0, ow0);
+        }
+        if (!more) break;
+        __syncthreads();
+        buf ^= 1;
+        t = tn;
+        decode_patch(p, t, n, oh0, ow0);
+    }
+}
+
+int g_dwpw_impl = 0;  // tuning/debug only (hsefr_debug_set "dwpw_impl"): 0 = auto, 1 = alternating phases, 2 = producer/consumer waves
+
 template <int STRIDE, int C, int BN, int OCC>
 int launch_t(const DwPwParams& p, hipStream_t s) {
-    const unsigned cap = 256u * OCC;
-    const unsigned g = p.total < cap ? p.total : cap;
-    hipLaunchKernelGGL((dwpw_fused_kernel<STRIDE, C, BN, OCC>), dim3(g), dim3(256), 0, s, p);
+    constexpr int KT = C / 32;
+    constexpr int ws_lds = (2 * KT * 128 * 32 + KT * BN * 32) * 4;
+    constexpr int ws_blocks = (160 * 1024 / ws_lds) < 2 ? (160 * 1024 / ws_lds) : 2;     // 512-thread groups per CU
+    const bool use_ws = g_dwpw_impl == 2;   // measured: the alternating-phase kernel at 4 WG/CU is as fast or faster
+    if (use_ws) {
+        const unsigned cap = 256u * ws_blocks;
+        const unsigned g = p.total < cap ? p.total : cap;
+        hipLaunchKernelGGL((dwpw_fused_ws_kernel<STRIDE, C, BN, 2 * ws_blocks>), dim3(g), dim3(512), 0, s, p);
+    } else {
+        const unsigned cap = 256u * OCC;
+        const unsigned g = p.total < cap ? p.total : cap;
+        hipLaunchKernelGGL((dwpw_fused_kernel<STRIDE, C, BN, OCC>), dim3(g), dim3(256), 0, s, p);
+    }
     return launch_status("dwpw_fused");
 }
 
 }  // namespace
+
+void set_dwpw_impl(int v) { g_dwpw_impl = v; }
 
 bool dwpw_fused_supported(int c, int cout, int stride, int act_dw, int act_pw) {
     return (c == 32 || c == 64) && (cout == 64 || cout == 128) && (stride == 1 || stride == 2) &&

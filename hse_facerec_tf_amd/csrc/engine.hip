@@ -113,6 +113,7 @@ int hsefr_debug_set(const char* key, int value) {
     HSEFR_REQUIRE(key, HSEFR_ERR_INVALID, "debug_set: null key");
     if (!strcmp(key, "pw_tile")) { set_pw_tile(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_th")) { set_dw_th(value); return HSEFR_OK; }
+    if (!strcmp(key, "dwpw_impl")) { set_dwpw_impl(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_variant")) { set_dw_variant(value); return HSEFR_OK; }
     if (!strcmp(key, "copy_variant")) { set_copy_variant(value); return HSEFR_OK; }
     if (!strcmp(key, "c3_impl")) { set_c3_impl(value); return HSEFR_OK; }

@@ -64,6 +64,7 @@ const char* hsefr_last_error_string(void);
  * "dw_th":   0 = choose per layer (default), >0 = output rows per depthwise strip.
  * "dw_variant": cache policy of the depthwise kernel: bit 0 = nontemporal loads, bit 1 = nontemporal stores.
  * "copy_variant": shape of the hsefr_debug_copy calibration kernel (unroll / nontemporal / grid bits).
+ * "dwpw_impl": 0 = auto (default), 1 = alternating-phase fused block kernel, 2 = producer/consumer-wave kernel.
  * "c3_impl": 0 = auto (default), 1 = VALU first-conv kernel, 2 = im2col fp32-MFMA first-conv kernel. */
 int hsefr_debug_set(const char* key, int value);
 /* Calibration: plain float4 device-to-device copy kernel (the practical HBM ceiling on this GPU). */
