@@ -186,8 +186,9 @@ class Plan:
 # lowering
 # --------------------------------------------------------------------------------------
 class _Lowerer:
-    def __init__(self, g: Graph, input_name: str, in_hw: Tuple[int, int], feeds: Dict[str, object]):
+    def __init__(self, g: Graph, input_name: str, in_hw: Tuple[int, int], feeds: Dict[str, object], dtype: str = "f32"):
         self.g = g
+        self.bf16 = dtype == "bf16"
         self.input_name = input_name
         self.in_hw = in_hw
         self.feeds = feeds
@@ -307,6 +308,20 @@ class _Lowerer:
     def live_consumers(self, name: str) -> int:
         return self.live.get(name, 0)
 
+    def _move_to_end(self, i: int) -> int:
+        """Reorder: layer i (which nothing consumes yet) becomes the last layer; indices above i shift down."""
+        L = self.layers.pop(i)
+        self.layers.append(L)
+        new = len(self.layers) - 1
+
+        def fix(j):
+            return new if j == i else (j - 1 if j > i else j)
+        for M in self.layers:
+            M.src = fix(M.src) if M.src >= 0 else M.src
+            M.res = fix(M.res) if M.res >= 0 else M.res
+        self.where = {k: (fix(v) if v >= 0 else v) for k, v in self.where.items()}
+        return new
+
     def new_layer(self, L: Layer, node: GraphNode) -> int:
         self.layers.append(L)
         idx = len(self.layers) - 1
@@ -347,6 +362,85 @@ class _Lowerer:
             r = self.lower_node(acts[0][0])
             self.where[node.name] = r
             return r
+        if op == "Pad":
+            # explicit zero padding in front of a VALID conv / pool (Caffe-converted graphs): folded into the consumer
+            pads = np.asarray(consts[0]).astype(int).reshape(-1, 2)
+            if pads.shape[0] != 4 or pads[0].any() or pads[3].any():
+                raise LoweringError("%s: padding of batch/channel axes" % node.name)
+            r = self.lower_node(acts[0][0])
+            self.where[node.name] = r
+            self.pending_pad = getattr(self, "pending_pad", {})
+            self.pending_pad[node.name] = (int(pads[1][0]), int(pads[1][1]), int(pads[2][0]), int(pads[2][1]))
+            return r
+        if op in ("MaxPool", "AvgPool") and self.bf16:
+            src_node = acts[0][0]
+            src = self.finished(self.lower_node(src_node))
+            h, wd, c = self.shape_of(src)
+            k, st = node.attr_ints("ksize"), node.attr_ints("strides")
+            epad = getattr(self, "pending_pad", {}).get(src_node.name)
+            if op == "AvgPool":
+                if (k[1], k[2]) != (h, wd) or node.attr_s("padding") != "VALID" or epad:
+                    raise LoweringError("%s: only a global VALID AvgPool is supported" % node.name)
+                return self.new_layer(Layer(OP_GAP_BF16, node.name, src, (h, wd, c), (1, 1, c), sealed=True), node)
+            if (k[1], k[2]) != (3, 3) or (st[1], st[2]) != (2, 2) or c % 8:
+                raise LoweringError("%s: only 3x3/2 max-pooling is supported" % node.name)
+            if epad:
+                if node.attr_s("padding") != "VALID" or (src >= 0 and self.layers[src].act not in (ACT_RELU, ACT_RELU6)):
+                    raise LoweringError("%s: zero-padded max-pool needs a VALID pool over a non-negative tensor" % node.name)
+                pt, pb, pl, pr = epad
+                oh, ow = (h + pt + pb - 3) // 2 + 1, (wd + pl + pr - 3) // 2 + 1
+            elif node.attr_s("padding") == "SAME":
+                oh, pt = tf_same_padding(h, 3, 2)
+                ow, pl = tf_same_padding(wd, 3, 2)
+            else:
+                oh, ow, pt, pl = (h - 3) // 2 + 1, (wd - 3) // 2 + 1, 0, 0
+            return self.new_layer(Layer(OP_MAXPOOL_BF16, node.name, src, (h, wd, c), (oh, ow, c), kh=3, kw=3, stride=2, pad_t=pt,
+                                        pad_l=pl, sealed=True), node)
+        if op == "Conv2D" and self.bf16:
+            if node.attr_s("data_format", "NHWC") != "NHWC":
+                raise LoweringError("%s: only NHWC graphs are supported" % node.name)
+            src_node = acts[0][0]
+            src = self.finished(self.lower_node(src_node))
+            w = consts[0].astype(np.float32)
+            h, wd, c = self.shape_of(src)
+            s = node.attr_ints("strides")
+            kh, kw, cout = int(w.shape[0]), int(w.shape[1]), int(w.shape[3])
+            if s[1] != s[2] or w.shape[2] != c:
+                raise LoweringError("%s: strides %r / kernel %r on %d channels" % (node.name, s, w.shape, c))
+            epad = getattr(self, "pending_pad", {}).get(src_node.name)
+            if epad:
+                if node.attr_s("padding") != "VALID":
+                    raise LoweringError("%s: Pad followed by a %s convolution" % (node.name, node.attr_s("padding")))
+                pt, pb, pl, pr = epad
+                oh, ow = (h + pt + pb - kh) // s[1] + 1, (wd + pl + pr - kw) // s[1] + 1
+            elif node.attr_s("padding") == "SAME":
+                oh, pt = tf_same_padding(h, kh, s[1])
+                ow, pl = tf_same_padding(wd, kw, s[1])
+            else:
+                oh, ow, pt, pl = (h - kh) // s[1] + 1, (wd - kw) // s[1] + 1, 0, 0
+            if c == 3 and (kh, kw) == (7, 7) and s[1] == 2 and (pt, pl) == (3, 3) and cout == 64 and src < 0:
+                kind = OP_STEM7X7_BF16
+            elif c % 64 == 0 and cout % 64 == 0 and kh <= 7 and kw <= 7:
+                kind = OP_CONV_BF16
+            else:
+                raise LoweringError("%s: no bf16 kernel for Conv2D k=%r stride %d pads (%d,%d)" % (node.name, w.shape, s[1], pt, pl))
+            return self.new_layer(Layer(kind, node.name, src, (h, wd, c), (oh, ow, cout), w=w, kh=kh, kw=kw, stride=s[1],
+                                        pad_t=pt, pad_l=pl), node)
+        if op in ("Add", "AddV2") and self.bf16 and len(acts) == 2:
+            # residual sum: folded into the epilogue of whichever branch ends in an open conv layer
+            ia, ib = self.lower_node(acts[0][0]), self.lower_node(acts[1][0])
+            for (i_main, n_main, i_res) in ((ia, acts[0][0], ib), (ib, acts[1][0], ia)):
+                L = self.layers[i_main] if i_main >= 0 else None
+                if (L is not None and L.kind == OP_CONV_BF16 and not L.sealed and L.act == ACT_NONE and L.res < 0 and
+                        self.live_consumers(n_main.name) == 1 and i_res >= 0 and i_res != i_main):
+                    self.finished(i_res)
+                    if i_res > i_main:      # the shortcut branch was lowered after this conv: run the conv last
+                        i_main, i_res = self._move_to_end(i_main), i_res - 1
+                    L.res = i_res
+                    L.version += 1
+                    self.where[node.name] = i_main
+                    return i_main
+            raise LoweringError("%s: residual Add whose branches cannot be fused into a convolution epilogue" % node.name)
         if op in ("Conv2D", "DepthwiseConv2dNative"):
             if node.attr_s("data_format", "NHWC") != "NHWC":
                 raise LoweringError("%s: only NHWC graphs are supported" % node.name)
@@ -401,7 +495,7 @@ class _Lowerer:
                 raise LoweringError("%s: Mean over axes %r" % (node.name, axes))
             src = self.finished(self.lower_node(acts[0][0]))
             h, wd, c = self.shape_of(src)
-            L = Layer(OP_GAP, node.name, src, (h, wd, c), (1, 1, c), sealed=True)
+            L = Layer(OP_GAP_BF16 if self.bf16 else OP_GAP, node.name, src, (h, wd, c), (1, 1, c), sealed=True)
             return self.new_layer(L, node)
         if op == "Softmax":
             src = self.finished(self.lower_node(acts[0][0]))
@@ -435,12 +529,14 @@ class _Lowerer:
                 raise LoweringError("%s: operand of %d elements against %d channels" % (node.name, v.size, cout))
             return v
 
-        if op in ("Mul",) and not L.sealed and L.act == ACT_NONE and L.kind in (OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_DENSE):
+        if L.res >= 0 and op not in ("Relu", "Relu6", "Minimum", "Maximum"):
+            raise LoweringError("%s: affine op after a fused residual sum" % node.name)
+        if op in ("Mul",) and not L.sealed and L.act == ACT_NONE and L.kind in (OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16):
             v = vec(consts[0])
             L.scale = v if L.scale is None else L.scale * v
             if L.shift is not None:
                 L.shift = L.shift * v
-        elif op in ("Add", "AddV2", "BiasAdd") and not L.sealed and L.act == ACT_NONE and L.kind in (OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_DENSE):
+        elif op in ("Add", "AddV2", "BiasAdd") and not L.sealed and L.act == ACT_NONE and L.kind in (OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16):
             v = vec(consts[0])
             L.shift = v if L.shift is None else L.shift + v
         elif op == "Sub" and not L.sealed and L.act == ACT_NONE and ins[0][0] is acts[0][0]:
@@ -547,8 +643,10 @@ def fuse_dwpw(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Di
 
 
 def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
-                feeds: Optional[Dict[str, object]] = None, fuse: bool = True) -> Plan:
-    """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase."""
+                feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32") -> Plan:
+    """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase.
+    dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
+    (general KxK Conv2D, Pad, FusedBatchNorm / Mul+Add, residual Add, MaxPool 3x3/2, global AvgPool / Mean)."""
     in_node, _ = g.get_tensor_by_name(input_tensor)
     shape = g.placeholder_shape(in_node.name)
     if input_hw is None:
@@ -558,7 +656,7 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
     feeds_n = {}
     for k, v in (feeds or {}).items():
         feeds_n[g.get_tensor_by_name(k)[0].name] = v
-    low = _Lowerer(g, in_node.name, input_hw, feeds_n)
+    low = _Lowerer(g, in_node.name, input_hw, feeds_n, dtype)
     if shape is not None and len(shape) == 4 and shape[3] > 0:
         low.in_c = int(shape[3])
     out_layers: Dict[int, Tuple[int, int]] = {}
@@ -580,6 +678,14 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
             L.shift = np.zeros(L.out_shape[2], np.float32)
         if L.kind == OP_DWCONV3X3 and L.scale is None:
             L.scale = np.ones(L.out_shape[2], np.float32)
+        if L.kind in (OP_CONV_BF16, OP_STEM7X7_BF16):
+            cout = L.out_shape[2]
+            L.scale = np.ones(cout, np.float32) if L.scale is None else L.scale.astype(np.float32)
+            L.shift = np.zeros(cout, np.float32) if L.shift is None else L.shift.astype(np.float32)
+            if L.act not in (ACT_NONE, ACT_RELU, ACT_RELU6):
+                raise LoweringError("%s: activation %d on a bf16 convolution" % (L.name, L.act))
+            from .resnet50 import pack_conv_weight, pack_stem_weight      # weight images the bf16 kernels read
+            L.w = pack_stem_weight(L.w) if L.kind == OP_STEM7X7_BF16 else pack_conv_weight(L.w)
 
     for slot, tname in outputs.items():
         nm = g.get_tensor_by_name(tname)[0].name

@@ -41,7 +41,8 @@ def load_graph(frozen_graph_filename, prefix='') -> Graph:   # facerec_test.py:4
 class TensorFlowInference:
     def __init__(self, frozen_graph_filename, input_tensor, output_tensor, learning_phase_tensor=None,
                  convert2BGR=True, imageNetUtilsMean=True, additional_input_value=0,
-                 input_size: Optional[Tuple[int, int]] = None, max_batch: int = 256, device: Optional[int] = None):
+                 input_size: Optional[Tuple[int, int]] = None, max_batch: int = 256, device: Optional[int] = None,
+                 dtype: str = "auto"):
         graph = load_graph(frozen_graph_filename, '')
         self.graph = graph
         # graph.get_tensor_by_name semantics: KeyError for unknown names (facerec_test.py:60-64)
@@ -68,7 +69,19 @@ class TensorFlowInference:
         self.tf_learning_phase = learning_phase_tensor
         # NB the reference unpacks the NHWC placeholder shape as (_, w, h, _) and feeds [h?, w?]:
         # rows = self.w.  All models in scope are square.
-        self.plan: Plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds)
+        # dtype: 'f32' = exact fp32 kernels (MobileNet-style graphs), 'bf16' = bf16-MFMA kernels (ResNet-style graphs,
+        # BASELINE config 3), 'auto' = fp32 when the graph is covered by the fp32 kernels, else bf16
+        from .lowering import LoweringError
+        if dtype == "auto":
+            try:
+                self.plan: Plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds)
+                dtype = "f32"
+            except LoweringError:
+                self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype="bf16")
+                dtype = "bf16"
+        else:
+            self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype=dtype)
+        self.dtype = dtype
         self.engine = Engine(self.plan, max_batch=max_batch, device=device)
         self.tf_sess = self.engine           # attribute name kept for callers that poke at it
         self.feature_dim = self.engine.out_elems[OUT_FEATURES]

@@ -54,3 +54,29 @@ def test_plan_equals_oracle(size, pool):
     assert got.shape == want.shape == (1, 2048)
     assert np.isfinite(want).all() and np.abs(want).max() > 1e-3
     assert rel(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("pool,bn,head,hw", [("SAME", "fused", "avgpool", 40), ("PADVALID", "muladd", "mean", 38)])
+def test_generic_lowering_of_a_resnet_style_graph(pool, bn, head, hw):
+    """a Caffe-converted ResNet-style frozen graph lowers to the bf16 plan generically (Pad+VALID
+    stem, FusedBatchNorm or Mul/Add, residual Add fused into the conv epilogue, max-pool, global pool)."""
+    import mini_resnet_graph
+    from hse_facerec_tf_amd import graphdef, lowering
+    from oracle import tf_graph as tfo
+    data, dim = mini_resnet_graph.build(3, hw, pool, bn, 64, head)
+    g = graphdef.read_graph(data)
+    plan = lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"}, dtype="bf16")
+    kinds = [L.kind for L in plan.layers]
+    assert kinds[0] == lowering.OP_STEM7X7_BF16 and kinds[1] == lowering.OP_MAXPOOL_BF16 and kinds[-1] == lowering.OP_GAP_BF16
+    assert kinds.count(lowering.OP_CONV_BF16) == 3 * 3 + 2          # 3 bottlenecks x 3 convs + 2 projections
+    by = {L.name: L for L in plan.layers}
+    assert by["conv2_1_1x1_increase"].res == [i for i, L in enumerate(plan.layers) if L.name == "conv2_1_1x1_proj"][0]
+    assert by["conv2_2_1x1_increase"].res >= 0 and by["conv2_2_1x1_increase"].act == lowering.ACT_RELU
+    assert by["conv3_1_1x1_reduce"].stride == 2 and by["conv1/7x7_s2"].pad_t == 3
+    x = np.random.RandomState(1).uniform(-100, 120, (2, hw, hw, 3)).astype(np.float32)
+    got = plan_ref.run(plan.serialize(), x)["features"]
+    want = tfo.GraphOracle(tfo.parse_graphdef(data), np.float64).run("pool5_7x7_s1:0", {"input:0": x}).reshape(2, -1)
+    assert got.shape == want.shape == (2, dim)
+    assert rel(got, want) < 2e-2                                     # bf16 storage (plan) vs exact fp64 graph (oracle)
+    with pytest.raises(lowering.LoweringError):                      # the fp32 MobileNet kernels do not cover this graph
+        lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"})

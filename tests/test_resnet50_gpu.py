@@ -138,3 +138,26 @@ def test_resnet50_batch_128_properties(env):
     assert torch.equal(ext.extract_batch(x[perm].contiguous()), full[perm])
     assert torch.equal(ext.extract_batch(x[40:43].contiguous()), full[40:43])
     ext.close_session()
+
+
+@pytest.mark.parametrize("pool,bn,head,hw", [("SAME", "fused", "avgpool", 40), ("PADVALID", "muladd", "mean", 38)])
+def test_resnet_style_frozen_graph_through_the_dropin_class(env, tmp_path, pool, bn, head, hw):
+    """A ResNet-style .pb (shape of the reference's missing vgg2_resnet.pb) through TensorFlowInference with the
+    registry arguments of facerec_test.py:213; dtype is picked automatically (bf16 MFMA path)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import mini_resnet_graph
+    from hse_facerec_tf_amd import TensorFlowInference
+    torch, ops, resnet50 = env
+    data, dim = mini_resnet_graph.build(3, hw, pool, bn, 64, head)
+    pb = tmp_path / "mini_resnet.pb"
+    pb.write_bytes(data)
+    tfi = TensorFlowInference(str(pb), input_tensor='input:0', output_tensor='pool5_7x7_s1:0', convert2BGR=True,
+                              imageNetUtilsMean=False, max_batch=4)
+    assert tfi.dtype == "bf16" and (tfi.w, tfi.h) == (hw, hw) and tfi.feature_dim == dim
+    x = np.random.RandomState(1).uniform(-100, 120, (3, hw, hw, 3)).astype(np.float32)
+    got = tfi.extract_batch(x)
+    want = tfo.GraphOracle(tfo.parse_graphdef(data), np.float64).run("pool5_7x7_s1:0", {"input:0": x}).reshape(3, -1)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() / np.abs(want).max() < 2e-2
+    tfi.close_session()
