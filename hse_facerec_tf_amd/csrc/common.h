@@ -107,6 +107,11 @@ int launch_dwpw_fused(const float* x, const float* wd, const float* dscale, cons
                       const float* pshift, float* y, int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh,
                       int ow, int cout, int act_dw, int act_pw, hipStream_t s);
 
+int launch_conv2d_direct(const float* x, const float* w, const float* bias, const float* alpha, float* y, int n, int h, int wd, int c,
+                         int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, hipStream_t s);
+int launch_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, int k, int stride, int pad_t, int pad_l,
+                       hipStream_t s);
+
 void set_dwpw_impl(int v);
 void set_pw_tile(int v);
 void set_dw_th(int v);

@@ -439,6 +439,18 @@ int hsefr_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_ind
     return launch_nn1(q, g, nq, ng, d, nn_index, nn_dist2, (hipStream_t)stream);
 }
 
+int hsefr_conv2d_direct(const float* x, const float* wgt, const float* bias, const float* alpha, float* y, int n, int h, int w, int c,
+                        int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wgt && y), HSEFR_ERR_INVALID, "conv2d_direct: null pointer");
+    return launch_conv2d_direct(x, wgt, bias, alpha, y, n, h, w, c, oh, ow, cout, kh, kw, stride, pad_t, pad_l, (hipStream_t)stream);
+}
+
+int hsefr_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, int k, int stride, int pad_t, int pad_l,
+                      hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && y), HSEFR_ERR_INVALID, "maxpool_f32: null pointer");
+    return launch_maxpool_f32(x, y, n, h, w, c, oh, ow, k, stride, pad_t, pad_l, (hipStream_t)stream);
+}
+
 int hsefr_pairwise_dist(const float* x, const float* y, int n, int m, int d, float* out, hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || m == 0 || (x && y && out), HSEFR_ERR_INVALID, "pairwise_dist: null pointer");
     return launch_pairwise_dist(x, y, n, m, d, out, (hipStream_t)stream);

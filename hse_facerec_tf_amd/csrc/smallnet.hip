@@ -1,0 +1,92 @@
+// Generic small-CNN kernels for the MTCNN face-detection cascade (facial_analysis.py:334-352, 478-604; mtcnn.pb:
+// P-Net 3->10->16->32 channels, R-Net 28/48/64 + FC 128, O-Net 32/64/64/128 + FC 256; 495 832 parameters).
+// Channel counts are 10, 16, 28, 48 ... -- not MFMA shapes, and the whole cascade is a few MFLOP per face, so
+// these are plain NHWC fp32 VALU kernels: one thread per (output pixel, output channel), output channels fastest
+// (weight reads coalesce, the input pixel is a broadcast).  Fully-connected layers run as a VALID convolution
+// whose kernel covers the whole feature map.  PReLU is fused: y = v > 0 ? v : alpha[c] * v (the graph spells it
+// Relu(v) + alpha * -Relu(-v), nodes pnet/PReLU1/*).
+#include "common.h"
+
+namespace hsefr {
+
+namespace {
+
+__global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const float* __restrict__ alpha,
+                                                            float* __restrict__ y, int H, int W, int C, int OH, int OW, int Cout,
+                                                            int KH, int KW, int stride, int pad_t, int pad_l, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int co = (int)(i % Cout);
+    const long long p = i / Cout;
+    const int ow = (int)(p % OW);
+    const long long t = p / OW;
+    const int oh = (int)(t % OH);
+    const long long n = t / OH;
+    float acc = bias ? bias[co] : 0.f;
+    const float* xn = x + n * (long long)H * W * C;
+    for (int kh = 0; kh < KH; ++kh) {
+        const int ih = oh * stride - pad_t + kh;
+        if (ih < 0 || ih >= H) continue;
+        for (int kw = 0; kw < KW; ++kw) {
+            const int iw = ow * stride - pad_l + kw;
+            if (iw < 0 || iw >= W) continue;
+            const float* xp = xn + ((long long)ih * W + iw) * C;
+            const float* wp = w + (long long)((kh * KW + kw) * C) * Cout + co;
+            for (int c = 0; c < C; ++c) acc = fmaf(xp[c], wp[(long long)c * Cout], acc);
+        }
+    }
+    if (alpha) acc = acc > 0.f ? acc : alpha[co] * acc;
+    y[i] = acc;
+}
+
+// max-pool k x k / stride, windows clipped to the image (== TF's -inf padding for SAME)
+__global__ __launch_bounds__(256) void maxpool_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                                                          int OH, int OW, int K, int stride, int pad_t, int pad_l, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    const int ow = (int)(p % OW);
+    const long long t = p / OW;
+    const int oh = (int)(t % OH);
+    const long long n = t / OH;
+    float m = -INFINITY;
+    for (int kh = 0; kh < K; ++kh) {
+        const int ih = oh * stride - pad_t + kh;
+        if (ih < 0 || ih >= H) continue;
+        for (int kw = 0; kw < K; ++kw) {
+            const int iw = ow * stride - pad_l + kw;
+            if (iw < 0 || iw >= W) continue;
+            m = fmaxf(m, x[((n * H + ih) * W + iw) * C + c]);
+        }
+    }
+    y[i] = m;
+}
+
+}  // namespace
+
+int launch_conv2d_direct(const float* x, const float* w, const float* bias, const float* alpha, float* y, int n, int h, int wd, int c,
+                         int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, hipStream_t s) {
+    HSEFR_REQUIRE(n >= 0 && h > 0 && wd > 0 && c > 0 && oh > 0 && ow > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0,
+                  HSEFR_ERR_INVALID, "conv2d_direct: bad shape");
+    if (n == 0) return HSEFR_OK;
+    const long long total = (long long)n * oh * ow * cout;
+    HSEFR_REQUIRE(total < (1ll << 39), HSEFR_ERR_UNSUPPORTED, "conv2d_direct: too large");
+    hipLaunchKernelGGL(conv2d_direct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, alpha, y, h, wd, c,
+                       oh, ow, cout, kh, kw, stride, pad_t, pad_l, total);
+    return launch_status("conv2d_direct");
+}
+
+int launch_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, int k, int stride, int pad_t, int pad_l,
+                       hipStream_t s) {
+    HSEFR_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0 && k > 0 && stride > 0, HSEFR_ERR_INVALID, "maxpool: bad shape");
+    if (n == 0) return HSEFR_OK;
+    const long long total = (long long)n * oh * ow * c;
+    HSEFR_REQUIRE(total < (1ll << 39), HSEFR_ERR_UNSUPPORTED, "maxpool: too large");
+    hipLaunchKernelGGL(maxpool_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, h, w, c, oh, ow, k, stride,
+                       pad_t, pad_l, total);
+    return launch_status("maxpool_f32");
+}
+
+}  // namespace hsefr

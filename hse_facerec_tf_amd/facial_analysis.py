@@ -2,8 +2,9 @@
 (age_gender_identity/facial_analysis.py:36-130,225-294): ``age_gender_fun(img)``,
 ``process_image(draw)``, ``close()``, ``is_male()`` -- on libhsefr instead of ``tf.Session``.
 
-Face *detection* (MTCNN / LBP cascade, facial_analysis.py:210-223,334-604) is the step before
-the hot path: a detector is injected as a callable
+Face *detection* is the step before the hot path: with ``mtcnn_detector=True`` the MTCNN
+cascade of the reference's mtcnn.pb runs on the GPU (hse_facerec_tf_amd/mtcnn.py; facial_analysis.py:334-604);
+any other detector (e.g. the OpenCV LBP cascade of :217-222) can be injected as a callable
 ``detector(img_rgb) -> (bounding_boxes, points)``.
 
 Added for throughput: ``age_gender_batch`` -- all faces of a frame/album in ONE forward (the
@@ -44,6 +45,9 @@ class FacialImageProcessing:
         self.print_stat = print_stat
         self.minsize = minsize
         self.detector = detector
+        if detector is None and mtcnn_detector:        # facial_analysis.py:59-61: the MTCNN cascade of mtcnn.pb
+            from .mtcnn import MTCNNDetector
+            self.detector = MTCNNDetector(minsize=minsize)
         # facial_analysis.py:45 loads a sibling .pb; the one that ships with the reference checkout is
         # the quantised age_gender_tf2_new-01-0.14-0.92 model.
         self.model_file = model_file or AGE_GENDER_PB

@@ -136,6 +136,43 @@ def nn1(queries, gallery):
     return idx, dist
 
 
+def conv2d_direct(x, w_hwio, bias=None, alpha=None, stride: int = 1, padding: str = "VALID"):
+    """Generic Conv2D + BiasAdd + optional PReLU (MTCNN nets).  padding: 'VALID' | 'SAME' (TensorFlow rule)."""
+    torch = _lib.require_gpu()
+    _f32c(x, "x"), _f32c(w_hwio, "w")
+    n, h, w, c = x.shape
+    kh, kw, wc, cout = w_hwio.shape
+    if wc != c:
+        raise ValueError("kernel expects %d input channels, tensor has %d" % (wc, c))
+    if padding == "SAME":
+        oh, pt = tf_same_padding(h, kh, stride)
+        ow, pl = tf_same_padding(w, kw, stride)
+    else:
+        oh, ow, pt, pl = (h - kh) // stride + 1, (w - kw) // stride + 1, 0, 0
+    y = torch.empty((n, max(oh, 0), max(ow, 0), cout), dtype=torch.float32, device=x.device)
+    if y.numel():
+        _lib.check(_lib.lib().hsefr_conv2d_direct(x.data_ptr(), w_hwio.data_ptr(), None if bias is None else bias.data_ptr(),
+                                                  None if alpha is None else alpha.data_ptr(), y.data_ptr(), n, h, w, c, oh, ow,
+                                                  cout, kh, kw, stride, pt, pl, _lib.current_stream_ptr()), "hsefr_conv2d_direct")
+    return y
+
+
+def maxpool(x, k: int, stride: int, padding: str = "SAME"):
+    torch = _lib.require_gpu()
+    _f32c(x, "x")
+    n, h, w, c = x.shape
+    if padding == "SAME":
+        oh, pt = tf_same_padding(h, k, stride)
+        ow, pl = tf_same_padding(w, k, stride)
+    else:
+        oh, ow, pt, pl = (h - k) // stride + 1, (w - k) // stride + 1, 0, 0
+    y = torch.empty((n, max(oh, 0), max(ow, 0), c), dtype=torch.float32, device=x.device)
+    if y.numel():
+        _lib.check(_lib.lib().hsefr_maxpool_f32(x.data_ptr(), y.data_ptr(), n, h, w, c, oh, ow, k, stride, pt, pl,
+                                                _lib.current_stream_ptr()), "hsefr_maxpool_f32")
+    return y
+
+
 def pairwise_distances(x, y=None):
     """sklearn pairwise_distances(X[, Y]) (euclidean) -> CUDA float32 [n, m] (facial_clustering_test.py:396)."""
     torch = _lib.require_gpu()

@@ -87,3 +87,102 @@ def resize_linear_u8(img: np.ndarray, w: int, h: int) -> np.ndarray:
     out = (((a0[:, None, None] * (ht >> 4)) >> 16) + ((a1[:, None, None] * (hb >> 4)) >> 16) + 2) >> 2
     out = np.clip(out, 0, 255).astype(np.uint8)
     return out[..., 0] if img.ndim == 2 else out
+
+
+# ---- cv2.resize(..., interpolation=cv2.INTER_AREA), used by the MTCNN cascade (facial_analysis.py:507,546,575) -------
+def _area_weights(ssize: int, dsize: int):
+    """Per destination index: source taps and coverage weights of OpenCV's decimation table
+    (first partial pixel, fully covered pixels, last partial pixel), padded to a rectangular [dsize, T] table."""
+    import math
+    scale = ssize / dsize
+    taps, wts = [], []
+    for d in range(dsize):
+        lo = d * scale
+        hi = lo + scale
+        cell = min(scale, ssize - lo)
+        a, b = math.ceil(lo), min(math.floor(hi), ssize - 1)
+        a = min(a, b)
+        t, w = [], []
+        if a - lo > 1e-3:
+            t.append(a - 1); w.append((a - lo) / cell)
+        for sx in range(a, b):
+            t.append(sx); w.append(1.0 / cell)
+        if hi - b > 1e-3:
+            t.append(b); w.append(min(min(hi - b, 1.0), cell) / cell)
+        taps.append(t); wts.append(w)
+    T = max(len(t) for t in taps)
+    idx = np.zeros((dsize, T), np.int64)
+    wt = np.zeros((dsize, T), np.float64)
+    for d, (t, w) in enumerate(zip(taps, wts)):
+        idx[d, :len(t)] = t
+        wt[d, :len(t)] = w
+    return idx, wt
+
+
+def _area_linear_taps(ssize: int, dsize: int):
+    """INTER_AREA when enlarging: OpenCV's bilinear taps with the area-mode coordinate rule."""
+    scale = ssize / dsize
+    inv = 1.0 / scale
+    d = np.arange(dsize)
+    s0 = np.floor(d * scale).astype(np.int64)
+    f = ((d + 1) - (s0 + 1) * inv).astype(np.float32)
+    f = np.where(f <= 0, np.float32(0), f - np.floor(f)).astype(np.float32)
+    edge = s0 >= ssize - 1
+    s0 = np.where(edge, ssize - 1, s0)
+    f = np.where(edge, np.float32(0), f)
+    return s0, np.minimum(s0 + 1, ssize - 1), f
+
+
+def resize_area(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_AREA) for uint8 or float64 [H,W,C] images.
+    Shrinking: box/coverage-weighted averaging accumulated tap by tap in OpenCV's order (float32 accumulators for
+    8-bit images, float64 for float64 images); enlarging: the bilinear path with INTER_AREA's coordinates."""
+    src = np.asarray(src)
+    sh, sw = src.shape[:2]
+    if (sh, sw) == (dh, dw):
+        return src.copy()
+    u8 = src.dtype == np.uint8
+    acc_t = np.float32 if u8 else np.float64
+    fx, fy = sw / dw, sh / dh
+    if fx >= 1 and fy >= 1:
+        ix, iy = int(round(fx)), int(round(fy))
+        eps = np.finfo(np.float64).eps
+        if abs(fx - ix) < eps and abs(fy - iy) < eps:            # exact integer factors: plain box filter
+            blk = src.reshape(dh, iy, dw, ix, -1)
+            if not u8:
+                return blk.sum(axis=(1, 3)) * (1.0 / (ix * iy))
+            tot = blk.astype(np.int64).sum(axis=(1, 3))
+            if ix == 2 and iy == 2:
+                return ((tot + 2) >> 2).astype(np.uint8)
+            return np.clip(np.rint(tot.astype(np.float32) * np.float32(1.0 / (ix * iy))), 0, 255).astype(np.uint8)
+        xi, xw = _area_weights(sw, dw)
+        yi, yw = _area_weights(sh, dh)
+        S = src.astype(acc_t)
+        rows = np.zeros((sh, dw, S.shape[2]), acc_t)             # horizontal pass, taps in table order
+        for t in range(xi.shape[1]):
+            rows += S[:, xi[:, t], :] * xw[:, t].astype(acc_t)[None, :, None]
+        out = None
+        for t in range(yi.shape[1]):                              # vertical pass: first tap assigns, later taps add
+            term = rows[yi[:, t]] * yw[:, t].astype(acc_t)[:, None, None]
+            out = term if out is None else out + term
+        return np.clip(np.rint(out), 0, 255).astype(np.uint8) if u8 else out
+    x0, x1, ax = _area_linear_taps(sw, dw)
+    y0, y1, ay = _area_linear_taps(sh, dh)
+    if u8:
+        a1 = np.rint(ax * np.float32(2048)).astype(np.int64)
+        a0 = np.rint((np.float32(1) - ax) * np.float32(2048)).astype(np.int64)
+        b1 = np.rint(ay * np.float32(2048)).astype(np.int64)
+        b0 = np.rint((np.float32(1) - ay) * np.float32(2048)).astype(np.int64)
+        s = src.astype(np.int64)
+        top, bot = s[y0], s[y1]
+        h0 = top[:, x0] * a0[None, :, None] + top[:, x1] * a1[None, :, None]
+        h1 = bot[:, x0] * a0[None, :, None] + bot[:, x1] * a1[None, :, None]
+        v = (((b0[:, None, None] * (h0 >> 4)) >> 16) + ((b1[:, None, None] * (h1 >> 4)) >> 16) + 2) >> 2
+        return np.clip(v, 0, 255).astype(np.uint8)
+    s = src.astype(np.float64)
+    a1, a0 = ax.astype(np.float64), (np.float32(1) - ax).astype(np.float64)
+    b1, b0 = ay.astype(np.float64), (np.float32(1) - ay).astype(np.float64)
+    top, bot = s[y0], s[y1]
+    h0 = top[:, x0] * a0[None, :, None] + top[:, x1] * a1[None, :, None]
+    h1 = bot[:, x0] * a0[None, :, None] + bot[:, x1] * a1[None, :, None]
+    return h0 * b0[:, None, None] + h1 * b1[:, None, None]

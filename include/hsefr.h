@@ -267,6 +267,18 @@ int hsefr_l2_normalize(const float* x, float* y, int n, int d, hsefr_stream_t st
 int hsefr_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2,
               hsefr_stream_t stream);
 
+/* ---- generic small-CNN kernels: the MTCNN detection cascade (facial_analysis.py:334-352,478-604; mtcnn.pb) ---------- */
+
+/* Conv2D (any KxK, stride, explicit top/left zero padding, any channel counts) + BiasAdd + optional PReLU, NHWC fp32.
+ * x [n,h,w,c], wgt [kh,kw,c,cout] (TF HWIO), bias [cout] or NULL, alpha [cout] or NULL (PReLU slope), y [n,oh,ow,cout].
+ * A fully-connected layer is the VALID convolution whose kernel covers the whole map (MatMul weights reshaped). */
+int hsefr_conv2d_direct(const float* x, const float* wgt, const float* bias, const float* alpha, float* y, int n, int h, int w, int c,
+                        int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, hsefr_stream_t stream);
+
+/* MaxPool k x k / stride with windows clipped to the image (TF SAME/VALID: pass the TF pads), NHWC fp32. */
+int hsefr_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, int k, int stride, int pad_t, int pad_l,
+                      hsefr_stream_t stream);
+
 /* sklearn.metrics.pairwise_distances(X[, Y]) (euclidean; facial_clustering_test.py:396, and the feature term of
  * process_photos.py:46-51): out[i,j] = |x_i - y_j|, x [n,d], y [m,d], out [n,m]; d multiple of 8.  Passing the same
  * pointer for x and y gives an exactly zero diagonal.  Computed as |x|^2+|y|^2-2x.y on the fp32 MFMA: absolute error

@@ -134,7 +134,38 @@ def nn1():
     print("nn1: N=%d kept=%d classes=%d acc=%.4f" % (len(y), len(y2), y2.max() + 1, acc))
 
 
+def mtcnn():
+    """Oracle MTCNN cascade (fp32 graph interpreter + restated INTER_AREA) on the reference's demo image, then the
+    oracle age/gender model on the detected faces exactly as process_image crops them (facial_analysis.py:233-271)."""
+    from oracle.mtcnn import OracleMTCNN
+    MT = os.path.join(ROOT, "models", "mtcnn.pb")
+    img = opl.imread_rgb(IMG)
+    det = OracleMTCNN(MT, minsize=32, compute_dtype=np.float32)
+    boxes, points = det.detect(img)
+    ag = opl.OracleAgeGender(PB, np.float64)
+    ages, genders, feats = [], [], []
+    for b in boxes:
+        x1, y1, x2, y2 = [int(v) for v in b[:4]]
+        x1, x2, y1, y2 = max(x1 - 10, 0), min(x2 + 10, img.shape[1]), max(y1 - 10, 0), min(y2 + 10, img.shape[0])
+        a, g_, f = ag.age_gender_fun(img[y1:y2, x1:x2])
+        ages.append(a); genders.append(g_); feats.append(f)
+    rs = np.random.RandomState(5)
+    nets = {}
+    for name, shape, outs in (("pnet", (1, 37, 53, 3), ['pnet/conv4-2/BiasAdd:0', 'pnet/prob1:0']),
+                              ("rnet", (5, 24, 24, 3), ['rnet/conv5-2/conv5-2:0', 'rnet/prob1:0']),
+                              ("onet", (4, 48, 48, 3), ['onet/conv6-2/conv6-2:0', 'onet/conv6-3/conv6-3:0', 'onet/prob1:0'])):
+        x = rs.uniform(-1, 1, shape).astype(np.float32)
+        r = tfo.GraphOracle(MT, np.float64).run(outs, {name + "/input:0": x})
+        nets[name + "_x"] = x
+        for i, a in enumerate(r):
+            nets["%s_out%d" % (name, i)] = np.asarray(a, np.float32)
+    np.savez_compressed(os.path.join(HERE, "mtcnn_test_image.npz"), mtcnn_sha256=sha(MT), img_sha256=sha(IMG), boxes=boxes,
+                        points=points, ages=np.asarray(ages, np.float64), genders=np.asarray(genders, np.float32),
+                        feats=np.asarray(feats, np.float32), **nets)
+    print("mtcnn: %d faces" % boxes.shape[0], np.round(boxes, 2).tolist(), "ages", np.round(ages, 1))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["e2e_image", "e2e_synthetic", "kernels", "nn1"]
+    which = sys.argv[1:] or ["e2e_image", "e2e_synthetic", "kernels", "nn1", "mtcnn"]
     for w in which:
         globals()[w]()

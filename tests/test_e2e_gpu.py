@@ -133,7 +133,7 @@ def test_facial_image_processing_dropin(torch_):
     assert rel(np.asarray(genders), z["crop_genders"]) < BAR
     assert np.abs(np.asarray(ages) - z["crop_ages"]).max() < 1e-2
     with pytest.raises(NotImplementedError):
-        fip.process_image(bgr)                 # no detector injected
+        fip.process_image(bgr)                 # mtcnn_detector=False and no detector injected
     fip.close()
 
 
