@@ -171,7 +171,7 @@ def main():
             traffic_src = os.path.relpath(cands[-1], ROOT)
             prof = json.load(open(cands[-1]))["kernels"]
             prefixes = {"conv1_3x3x3_s2": "conv3x3_c3", "depthwise3x3": "dwconv3x3_kernel",
-                        "pointwise1x1_f32mfma": "pwconv_f32_kernel", "gap": "hsefr::gap_kernel",
+                        "pointwise1x1_f32mfma": "pwconv_f32_", "gap": "hsefr::gap_kernel",
                         "fused_dw3x3_pw1x1": "dwpw_fused_kernel"}
             for cls, pre in prefixes.items():
                 rows = [v for k, v in prof.items() if k.startswith(pre)]

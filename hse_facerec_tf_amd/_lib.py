@@ -21,6 +21,7 @@ SIGNATURES = {
     "hsefr_version": (c_int, []),
     "hsefr_last_error_string": (c_char_p, []),
     "hsefr_debug_set": (c_int, [c_char_p, c_int]),
+    "hsefr_debug_clock_probe": (c_int, [_fp, c_int, c_int, c_void_p]),
     "hsefr_debug_copy": (c_int, [_fp, _fp, c_size_t, c_void_p]),
     "hsefr_engine_create": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
     "hsefr_engine_workspace_bytes": (c_size_t, [c_void_p]),

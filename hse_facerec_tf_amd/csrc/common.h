@@ -114,9 +114,12 @@ int launch_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int
 
 void set_dwpw_impl(int v);
 void set_pw_tile(int v);
+void set_pw_ablate(int v);
+void set_pw_dma(int v);
 void set_dw_th(int v);
 void set_dw_variant(int v);
 void set_copy_variant(int v);
+int launch_clock_probe(unsigned long long* out, int blocks, int iters, hipStream_t s);
 int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 void set_c3_impl(int v);
 

@@ -31,6 +31,34 @@ __global__ __launch_bounds__(256) void copy_kernel(const f32x4* __restrict__ src
     }
 }
 
+// Clock probe (MI355X_MICROARCH.md "DVFS give-back" item 6): a dense fp32-MFMA loop on every CU, stamped with
+// s_memtime (shader clock) and s_memrealtime (100 MHz): clock = d(memtime)/d(memrealtime) * 100 MHz.  The stamps go
+// to a buffer nothing else reads.  mode 0: one wave per SIMD, 4 independent accumulators (peak issue rate);
+// the achieved MFMA rate is also derivable: iters * 4 MFMAs * 4096 FLOP per wave.
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* __restrict__ out, int iters, float seed) {
+    f32x16p a0, a1, a2, a3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = seed * r; a1[r] = seed + r; a2[r] = seed - r; a3[r] = seed * 2 + r; }
+    const float x = seed + (threadIdx.x & 63) * 0.001f, y = seed - (threadIdx.x & 31) * 0.002f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sink = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sink += a0[r] + a1[r] + a2[r] + a3[r];
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 3 + 0] = t1 - t0;
+        out[blockIdx.x * 3 + 1] = r1 - r0;
+        out[blockIdx.x * 3 + 2] = (unsigned long long)__float_as_uint(sink);
+    }
+}
+
 int g_copy_variant = 0;  // unroll: (v & 3) -> {1, 2, 4, 8}; nt bits: (v >> 2) & 3; grid: (v >> 4) & 3 -> {8, 4, 16, 32} WG/CU
 
 template <int U, int NT>
@@ -51,6 +79,12 @@ void launch_u(int nt, const f32x4* s, f32x4* d, size_t n, unsigned blocks, hipSt
 }  // namespace
 
 void set_copy_variant(int v) { g_copy_variant = v; }
+
+int launch_clock_probe(unsigned long long* out, int blocks, int iters, hipStream_t s) {
+    HSEFR_REQUIRE(out && blocks > 0 && iters > 0, HSEFR_ERR_INVALID, "clock_probe: bad argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
+    return launch_status("clock_probe");
+}
 
 int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s) {
     HSEFR_REQUIRE(bytes % 16 == 0, HSEFR_ERR_INVALID, "copy: bytes must be a multiple of 16");

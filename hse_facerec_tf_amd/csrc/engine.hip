@@ -112,6 +112,8 @@ const char* hsefr_last_error_string(void) { return g_err; }
 int hsefr_debug_set(const char* key, int value) {
     HSEFR_REQUIRE(key, HSEFR_ERR_INVALID, "debug_set: null key");
     if (!strcmp(key, "pw_tile")) { set_pw_tile(value); return HSEFR_OK; }
+    if (!strcmp(key, "pw_ablate")) { set_pw_ablate(value); return HSEFR_OK; }
+    if (!strcmp(key, "pw_dma")) { set_pw_dma(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_th")) { set_dw_th(value); return HSEFR_OK; }
     if (!strcmp(key, "dwpw_impl")) { set_dwpw_impl(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_variant")) { set_dw_variant(value); return HSEFR_OK; }
@@ -336,6 +338,10 @@ int hsefr_engine_destroy(hsefr_engine* e) {
 int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_t stream) {
     HSEFR_REQUIRE(bytes == 0 || (d_src && d_dst), HSEFR_ERR_INVALID, "debug_copy: null pointer");
     return launch_copy(d_src, d_dst, bytes, (hipStream_t)stream);
+}
+
+int hsefr_debug_clock_probe(unsigned long long* d_out, int blocks, int iters, hsefr_stream_t stream) {
+    return launch_clock_probe(d_out, blocks, iters, (hipStream_t)stream);
 }
 
 // ---- per-kernel entry points ---------------------------------------------------------------

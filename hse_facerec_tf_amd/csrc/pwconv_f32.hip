@@ -47,7 +47,7 @@ template <int BM, int BN, int OCC, int ACT>
 __global__ __launch_bounds__(256, OCC) void pwconv_f32_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                          const float* __restrict__ shift, float* __restrict__ y,
                                                          long long M, int K, int Cout, unsigned tiles_n,
-                                                         unsigned total_tiles) {
+                                                         unsigned total_tiles, int ablate) {
     constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int AP = BM / 32, BP = BN / 32;  // staging passes (32 rows x 8 float4 per pass)
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, OCC) void pwconv_f32_kernel(const float* __res
             const bool has_next = !last || more_tiles;
             long long m0n = m0;
             int n0n = n0;
-            if (has_next) {
+            if (has_next && !(ablate & 1)) {
                 if (last) {
                     const unsigned lt = xcd_remap(tnext, total_tiles);
                     m0n = (long long)(lt / tiles_n) * BM;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, OCC) void pwconv_f32_kernel(const float* __res
                         for (int ni = 0; ni < NI; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
             }
-            if (has_next) swrite(buf ^ 1);
+            if (has_next && !(ablate & 1)) swrite(buf ^ 1);
             __syncthreads();
             buf ^= 1;
             if (last) {
@@ -162,6 +162,169 @@ __global__ __launch_bounds__(256, OCC) void pwconv_f32_kernel(const float* __res
                 // row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).  Full tiles store unconditionally:
                 // a per-store bounds branch makes hipcc put s_waitcnt vmcnt(0) in front of EVERY
                 // store (each one then waits for the previous to retire).
+                const bool full_tile = m0 + BM <= M;
+                if (ablate & 2) {   // timing-only ablation: keep the accumulators live, skip the stores
+                    float live = 0.f;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) live += acc[mi][ni][r];
+                    if (live == 1.2345e-30f) y[0] = live;
+                } else
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int col = n0 + wn * WN + ni * 32 + li;
+                    const float sh = shift[col];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const long long rbase = m0 + wm * WM + mi * 32 + 4 * lh;
+                        float* yp = y + rbase * Cout + col;
+                        if (full_tile) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                yp[(long long)((r & 3) + 8 * (r >> 2)) * Cout] = apply_act<ACT>(acc[mi][ni][r] + sh);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int dr = (r & 3) + 8 * (r >> 2);
+                                if (rbase + dr < M) yp[(long long)dr * Cout] = apply_act<ACT>(acc[mi][ni][r] + sh);
+                            }
+                        }
+                    }
+                }
+                zero_acc();
+                m0 = m0n;
+                n0 = n0n;
+            }
+        }
+        if (!more_tiles) break;
+        t = tnext;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant: the tiles go global -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass).
+// One wave-instruction deposits 64 x 16 B = 8 consecutive 128-B LDS rows; the XOR swizzle therefore moves to the
+// SOURCE side: lane (row r, position p) fetches logical chunk p ^ ((r >> 1) & 7) of its row (cdna guide rule 21:
+// linear destination + swizzled source + the same swizzle on the ds_read).  All LDS lives in ONE array (a second
+// __shared__ object next to an LDS-DMA target makes hipcc drain vmcnt before every ds_read).  Measured against the
+// register-staged kernel above with tools/kbench.py; selectable with hsefr_debug_set("pw_dma", 0|1).
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int OCC, int ACT>
+__global__ __launch_bounds__(256, OCC) void pwconv_f32_dma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                  const float* __restrict__ shift, float* __restrict__ y,
+                                                                  long long M, int K, int Cout, unsigned tiles_n,
+                                                                  unsigned total_tiles) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int AI = BM / 32, BI = BN / 32;        // DMA wave-instructions per wave per K-tile (8 rows each)
+    constexpr int STAGE = (BM + BN) * BK;            // floats per buffer: A rows then B rows
+    __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int KT = K / BK;
+
+    unsigned t = blockIdx.x;
+    if (t >= total_tiles) return;
+
+    const float* asrc[AI];
+    const float* bsrc[BI];
+    long long m0;
+    int n0;
+    auto setup_ptrs = [&](long long mm0, int nn0) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int r = (wave * AI + i) * 8 + (lane >> 3);
+            long long gr = mm0 + r;
+            if (gr > M - 1) gr = M - 1;            // tail rows: read a valid row, never stored
+            asrc[i] = x + gr * K + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int r = (wave * BI + i) * 8 + (lane >> 3);
+            bsrc[i] = wt + (long long)(nn0 + r) * K + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+        }
+    };
+    auto dma = [&](int kt, int buf) {
+        float* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) glds16(asrc[i] + kt * BK, base + (wave * AI + i) * 8 * BK);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) glds16(bsrc[i] + kt * BK, base + BM * BK + (wave * BI + i) * 8 * BK);
+    };
+
+    f32x16 acc[MI][NI];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    };
+    zero_acc();
+    {
+        const unsigned lt = xcd_remap(t, total_tiles);
+        m0 = (long long)(lt / tiles_n) * BM;
+        n0 = (lt % tiles_n) * BN;
+    }
+    setup_ptrs(m0, n0);
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    const int arow = wm * WM + li, brow = wn * WN + li;
+
+    while (true) {
+        const unsigned tnext = t + gridDim.x;
+        const bool more_tiles = tnext < total_tiles;
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool last = kt + 1 == KT;
+            const bool has_next = !last || more_tiles;
+            long long m0n = m0;
+            int n0n = n0;
+            if (has_next) {
+                if (last) {
+                    const unsigned lt = xcd_remap(tnext, total_tiles);
+                    m0n = (long long)(lt / tiles_n) * BM;
+                    n0n = (lt % tiles_n) * BN;
+                    setup_ptrs(m0n, n0n);
+                    dma(0, buf ^ 1);
+                } else {
+                    dma(kt + 1, buf ^ 1);
+                }
+            }
+            const float* As = smem + buf * STAGE;
+            const float* Bs = As + BM * BK;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f32x4 a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4*)(&As[swz(arow + mi * 32, 2 * s + lh)]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4*)(&Bs[swz(brow + ni * 32, 2 * s + lh)]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next tile have landed
+            __syncthreads();
+            buf ^= 1;
+            if (last) {
                 const bool full_tile = m0 + BM <= M;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
@@ -216,6 +379,8 @@ TileCfg choose_tile(long long m, int cout, int forced) {
     return cands[best];
 }
 
+int g_pw_dma = 1;       // 1 = LDS-DMA staging (default), 0 = register staging
+int g_pw_ablate = 0;    // timing-only ablations (results WRONG): 1 = no global loads after the first tile, 2 = no stores
 int g_forced_tile = -1;  // tuning/debug only (hsefr_debug_set "pw_tile"): 0 = 128x128, 1 = 128x64, 2 = 64x64
 
 template <int BM, int BN, int OCC>
@@ -228,9 +393,15 @@ int launch_cfg(const float* x, const float* wt, const float* shift, float* y, lo
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv: too many tiles");
     const long long g = total < 256ll * occ ? total : 256ll * occ;
     dim3 grid((unsigned)g), block(256);
-#define HSEFR_PW_LAUNCH(A)                                                                                   \
-    hipLaunchKernelGGL((pwconv_f32_kernel<BM, BN, OCC, A>), grid, block, 0, s, x, wt, shift, y, m, k, cout, tiles_n, \
-                       (unsigned)total)
+#define HSEFR_PW_LAUNCH(A)                                                                                          \
+    do {                                                                                                            \
+        if (g_pw_dma && !g_pw_ablate)                                                                               \
+            hipLaunchKernelGGL((pwconv_f32_dma_kernel<BM, BN, OCC, A>), grid, block, 0, s, x, wt, shift, y, m, k, cout, \
+                               tiles_n, (unsigned)total);                                                            \
+        else                                                                                                        \
+            hipLaunchKernelGGL((pwconv_f32_kernel<BM, BN, OCC, A>), grid, block, 0, s, x, wt, shift, y, m, k, cout,  \
+                               tiles_n, (unsigned)total, g_pw_ablate);                                               \
+    } while (0)
     if (act == HSEFR_ACT_RELU6) HSEFR_PW_LAUNCH(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_PW_LAUNCH(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_PW_LAUNCH(HSEFR_ACT_NONE);
@@ -242,6 +413,8 @@ int launch_cfg(const float* x, const float* wt, const float* shift, float* y, lo
 }  // namespace
 
 void set_pw_tile(int v) { g_forced_tile = v; }
+void set_pw_ablate(int v) { g_pw_ablate = v; }
+void set_pw_dma(int v) { g_pw_dma = v; }
 
 int launch_pwconv_f32(const float* x, const float* wgt_t, const float* shift, float* y, long long m, int k,
                       int cout, int act, hipStream_t s) {

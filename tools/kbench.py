@@ -134,7 +134,70 @@ def bench_dwv():
         print("%3dx%-3d c=%-4d s%d " % (hw, hw, c, s) + "".join("%9.1f" % r for r in res))
 
 
+def bench_pwd():
+    print("GEMM staging: us median, auto tile: register-staged / LDS-DMA")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    tot = [0.0, 0.0]
+    for hw, k, n in PW:
+        m = B * hw * hw
+        x = torch.rand((m, k), device="cuda", generator=g) * 6
+        w = torch.randn((n, k), device="cuda", generator=g) / k ** 0.5
+        sh = torch.randn((n,), device="cuda", generator=g)
+        res = []
+        for dma in (0, 1, 0, 1):
+            _lib.lib().hsefr_debug_set(b"pw_dma", dma)
+            res.append(timeit(lambda: ops.pwconv1x1(x, w, sh))[0])
+        _lib.lib().hsefr_debug_set(b"pw_dma", 1)
+        r0, r1 = min(res[0], res[2]), min(res[1], res[3])
+        mult = 5 if (hw, k, n) == (12, 512, 512) else 1
+        tot[0] += r0 * mult
+        tot[1] += r1 * mult
+        fl = 2.0 * m * k * n
+        print("%-22s %9.1f %9.1f   TF: %6.1f %6.1f" % ("%dx%dx%d" % (m, k, n), r0, r1, fl / r0 / 1e6, fl / r1 / 1e6))
+    print("sum over the 13 pointwise layers: %.1f us vs %.1f us" % tuple(tot))
+
+
+def bench_pwa():
+    print("GEMM ablations (timing only), 128x64 tile: us median: real / no-global-loads / no-stores / neither")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for hw, k, n in PW[2:]:
+        m = B * hw * hw
+        x = torch.rand((m, k), device="cuda", generator=g) * 6
+        w = torch.randn((n, k), device="cuda", generator=g) / k ** 0.5
+        sh = torch.randn((n,), device="cuda", generator=g)
+        _lib.lib().hsefr_debug_set(b"pw_tile", 1)
+        res = []
+        for ab in (0, 1, 2, 3):
+            _lib.lib().hsefr_debug_set(b"pw_ablate", ab)
+            res.append(timeit(lambda: ops.pwconv1x1(x, w, sh))[0])
+        _lib.lib().hsefr_debug_set(b"pw_ablate", 0)
+        _lib.lib().hsefr_debug_set(b"pw_tile", -1)
+        fl = 2.0 * m * k * n
+        print("%-22s" % ("%dx%dx%d" % (m, k, n)) + "".join("%9.1f" % r for r in res) + "   TF: " + " ".join("%6.1f" % (fl / r / 1e6) for r in res))
+
+
+def bench_clock():
+    """Shader clock and fp32-MFMA rate the chip sustains with every SIMD issuing MFMAs back to back."""
+    for blocks, label in ((256, "1 wave/SIMD"), (512, "2 waves/SIMD"), (768, "3 waves/SIMD")):
+        iters = 200000
+        out = torch.zeros((blocks * 3,), dtype=torch.int64, device="cuda")
+        for _ in range(2):
+            _lib.check(_lib.lib().hsefr_debug_clock_probe(out.data_ptr(), blocks, iters, _lib.current_stream_ptr()))
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        _lib.check(_lib.lib().hsefr_debug_clock_probe(out.data_ptr(), blocks, iters, _lib.current_stream_ptr()))
+        ev1.record()
+        torch.cuda.synchronize()
+        o = out.cpu().numpy().reshape(blocks, 3)
+        clk = np.median(o[:, 0] / o[:, 1]) * 100e6
+        ms = ev0.elapsed_time(ev1)
+        tf = blocks * 4 * iters * 4 * 4096.0 / (ms * 1e-3) / 1e12
+        print("clock probe %-13s: shader clock %.3f GHz (min %.3f max %.3f), %.2f ms, %.1f TFLOP/s fp32 MFMA" %
+              (label, clk / 1e9, (o[:, 0] / o[:, 1]).min() / 10, (o[:, 0] / o[:, 1]).max() / 10, ms, tf))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["pw", "dw", "c3"]
     for w in what:
-        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv}[w]()
+        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd}[w]()
