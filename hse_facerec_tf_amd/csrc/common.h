@@ -77,6 +77,8 @@ int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const
                      hipStream_t s);
 int launch_pwconv_f32(const float* x, const float* wgt_t, const float* shift, float* y, long long m, int k,
                       int cout, int act, hipStream_t s);
+int launch_pwconv_f16s(const float* x, const void* wsplit, const float* descale, const float* shift, float* y,
+                       long long m, int k, int cout, int a_log2, int act, hipStream_t s);
 int launch_gap(const float* x, float* y, int n, int hw, int c, hipStream_t s);
 int launch_dense(const float* x, const float* wgt, const float* bias, float* y, int n, int k, int cout,
                  int act, hipStream_t s);
@@ -114,6 +116,8 @@ int launch_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int
 
 void set_dwpw_impl(int v);
 void set_pw_tile(int v);
+void set_pws_tile(int v);
+void set_pws_ablate(int v);
 void set_pw_ablate(int v);
 void set_pw_dma(int v);
 void set_dw_th(int v);

@@ -88,6 +88,11 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
             case HSEFR_OP_DENSE: case HSEFR_OP_SOFTMAX: case HSEFR_OP_CONV_BF16: case HSEFR_OP_MAXPOOL_BF16:
             case HSEFR_OP_GAP_BF16: case HSEFR_OP_STEM7X7_BF16:
                 break;
+            case HSEFR_OP_PWCONV_F16S:
+                HSEFR_REQUIRE(o.w_off != HSEFR_NO_OFFSET && o.scale_off != HSEFR_NO_OFFSET && o.shift_off != HSEFR_NO_OFFSET &&
+                                  o.reserved > 0 && o.reserved <= 24,
+                              HSEFR_ERR_INVALID, "plan op %u: split-f16 pointwise needs split rows, descale, shift and a_log2 in (0, 24]", i);
+                break;
             case HSEFR_OP_DWPW_F32:
                 HSEFR_REQUIRE(dwpw_fused_supported(o.cin, o.cout, o.stride, HSEFR_ACT_RELU6, (int)o.act), HSEFR_ERR_UNSUPPORTED,
                               "plan op %u: fused depthwise-pointwise block cin=%d cout=%d not covered", i, o.cin, o.cout);
@@ -112,6 +117,8 @@ const char* hsefr_last_error_string(void) { return g_err; }
 int hsefr_debug_set(const char* key, int value) {
     HSEFR_REQUIRE(key, HSEFR_ERR_INVALID, "debug_set: null key");
     if (!strcmp(key, "pw_tile")) { set_pw_tile(value); return HSEFR_OK; }
+    if (!strcmp(key, "pws_tile")) { set_pws_tile(value); return HSEFR_OK; }
+    if (!strcmp(key, "pws_ablate")) { set_pws_ablate(value); return HSEFR_OK; }
     if (!strcmp(key, "pw_ablate")) { set_pw_ablate(value); return HSEFR_OK; }
     if (!strcmp(key, "pw_dma")) { set_pw_dma(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_th")) { set_dw_th(value); return HSEFR_OK; }
@@ -276,6 +283,11 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
                                        (const float*)blob_ptr(e, o.shift_off), (float*)out,
                                        (long long)n * o.h * o.w, o.cin, o.cout, o.act, s);
                 break;
+            case HSEFR_OP_PWCONV_F16S:
+                rc = launch_pwconv_f16s((const float*)in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
+                                        (const float*)blob_ptr(e, o.shift_off), (float*)out, (long long)n * o.h * o.w,
+                                        o.cin, o.cout, o.reserved, o.act, s);
+                break;
             case HSEFR_OP_GAP:
                 rc = launch_gap((const float*)in, (float*)out, n, o.h * o.w, o.cin, s);
                 break;
@@ -363,6 +375,12 @@ int hsefr_pwconv1x1_bias_relu6(const float* x, const float* wgt_t, const float* 
                                int cout, int act, hsefr_stream_t stream) {
     HSEFR_REQUIRE(m == 0 || (x && wgt_t && shift && y), HSEFR_ERR_INVALID, "pwconv: null pointer");
     return launch_pwconv_f32(x, wgt_t, shift, y, m, k, cout, act, (hipStream_t)stream);
+}
+
+int hsefr_pwconv1x1_f16split(const float* x, const void* w_split, const float* descale, const float* shift, float* y,
+                             long long m, int k, int cout, int a_log2, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(m == 0 || (x && w_split && descale && shift && y), HSEFR_ERR_INVALID, "pwconv_f16split: null pointer");
+    return launch_pwconv_f16s(x, w_split, descale, shift, y, m, k, cout, a_log2, act, (hipStream_t)stream);
 }
 
 int hsefr_dwpw_fused(const float* x, const float* wd, const float* dscale, const float* dshift, const float* wp_t,

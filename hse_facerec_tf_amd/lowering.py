@@ -29,6 +29,7 @@ from .graphdef import Graph, GraphNode
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_GAP, OP_DENSE, OP_SOFTMAX = 1, 2, 3, 4, 5, 6
 OP_CONV_BF16, OP_MAXPOOL_BF16, OP_GAP_BF16, OP_STEM7X7_BF16, OP_DWPW_F32 = 7, 8, 9, 10, 11
+OP_PWCONV_F16S = 12      # wire kind of a pointwise Layer whose a_log2 > 0 (the IR keeps OP_PWCONV_F32 + a_log2)
 _BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
 BUF_INPUT, BUF_NONE = -1, -2
@@ -69,6 +70,48 @@ def tf_same_padding(size: int, k: int, stride: int) -> Tuple[int, int]:
 
 
 # --------------------------------------------------------------------------------------
+# split-f16 weight image of a pointwise kernel (csrc/pwconv_f16s.hip)
+# --------------------------------------------------------------------------------------
+F16S_ACT_LOG2_RELU6 = 12          # x in [0, 6]  ->  x * 2^12 <= 24576 < 32768
+
+
+def split_pointwise_weights(w_t: np.ndarray, a_log2: int = F16S_ACT_LOG2_RELU6) -> Tuple[np.ndarray, np.ndarray]:
+    """w_t [cout, k] fp32 (TF 1x1 kernel transposed, BN scale folded) -> (split rows, descale).
+
+    Per output channel n the row is scaled by 2^e_n so that max|w'| lies in [8192, 16384) (exact), then written as
+    w' = hi + lo with hi = f16(w'), lo = f16(w' - hi) (round to nearest even; residual <= 2^-22 |w'|).  The image is
+    uint16 [cout, k/32, 64]: per 32 input channels one 128-byte row [hi(32) | lo(32)], which is what the kernel's LDS
+    tile holds.  descale[n] = 2^-(e_n + a_log2) undoes both this scaling and the activation scaling 2^a_log2."""
+    w = np.ascontiguousarray(w_t, dtype=np.float32)
+    cout, k = w.shape
+    if k % 32:
+        raise LoweringError("split_pointwise_weights: k=%d must be a multiple of 32" % k)
+    amax = np.abs(w).max(axis=1).astype(np.float64)
+    e = np.zeros(cout, np.int64)
+    nz = amax > 0
+    # max|w| * 2^e in [8192, 16384):  frexp gives amax = f * 2^p with f in [0.5, 1)  ->  e = 14 - p
+    e[nz] = 14 - np.frexp(amax[nz])[1]
+    e = np.clip(e, -100, 100)
+    ws = np.ldexp(w.astype(np.float64), e[:, None]).astype(np.float32)          # exact (power of two)
+    hi = ws.astype(np.float16)
+    lo = (ws - hi.astype(np.float32)).astype(np.float16)
+    assert np.isfinite(hi.astype(np.float32)).all()
+    img = np.empty((cout, k // 32, 64), np.uint16)
+    img[:, :, :32] = hi.view(np.uint16).reshape(cout, k // 32, 32)
+    img[:, :, 32:] = lo.view(np.uint16).reshape(cout, k // 32, 32)
+    descale = np.ldexp(np.ones(cout, np.float64), -(e + a_log2)).astype(np.float32)
+    return img, descale
+
+
+def unsplit_pointwise_weights(img: np.ndarray, descale: np.ndarray, a_log2: int) -> np.ndarray:
+    """Inverse view used by the CPU plan checker: the effective fp64 weights [cout, k] a split image stands for."""
+    cout, kt, _ = img.shape
+    hi = img[:, :, :32].copy().view(np.float16).astype(np.float64).reshape(cout, kt * 32)
+    lo = img[:, :, 32:].copy().view(np.float16).astype(np.float64).reshape(cout, kt * 32)
+    return (hi + lo) * (descale.astype(np.float64) * 2.0 ** a_log2)[:, None]
+
+
+# --------------------------------------------------------------------------------------
 # IR
 # --------------------------------------------------------------------------------------
 @dataclass
@@ -93,6 +136,7 @@ class Layer:
     res: int = -1                                      # layer whose output is added before the activation (ResNet)
     w2: Optional[np.ndarray] = None                    # DWPW_F32: the pointwise kernel [1,1,cin,cout]
     shift2: Optional[np.ndarray] = None                # DWPW_F32: the pointwise shift
+    a_log2: int = 0                                    # PWCONV: > 0 = split-f16 products, input pre-scaled by 2^a_log2
     out_buf: int = BUF_NONE
 
     @property
@@ -126,8 +170,12 @@ class Plan:
         ops = []
         for L in self.layers:
             w = L.w
+            kind, scale, aux = L.kind, L.scale, 0
             if L.kind == OP_PWCONV_F32:
                 w = np.ascontiguousarray(w.reshape(w.shape[-2], w.shape[-1]).T)      # [1,1,K,Cout] -> [Cout,K]
+                if L.a_log2 > 0:
+                    kind, aux = OP_PWCONV_F16S, L.a_log2
+                    w, scale = split_pointwise_weights(w, L.a_log2)
             elif L.kind in (OP_DWCONV3X3, OP_DWPW_F32):
                 w = w.reshape(3, 3, -1)
             w2 = None if L.w2 is None else np.ascontiguousarray(L.w2.reshape(L.w2.shape[-2], L.w2.shape[-1]).T)
@@ -135,8 +183,8 @@ class Plan:
             res_buf = BUF_NONE if L.res < 0 else self.layers[L.res].out_buf
             h, wd, cin = L.in_shape
             oh, ow, cout = L.out_shape
-            ops.append(_OP.pack(L.kind, L.act, in_buf, L.out_buf, res_buf, h, wd, cin, oh, ow, cout,
-                                L.kh, L.kw, L.stride, L.pad_t, L.pad_l, 0, put(w), put(L.scale), put(L.shift),
+            ops.append(_OP.pack(kind, L.act, in_buf, L.out_buf, res_buf, h, wd, cin, oh, ow, cout,
+                                L.kh, L.kw, L.stride, L.pad_t, L.pad_l, aux, put(w), put(scale), put(L.shift),
                                 put(w2), put(L.shift2)))
         while len(blob) % 16:
             blob.append(0)
@@ -642,9 +690,29 @@ def fuse_dwpw(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Di
     return new_layers, remap
 
 
+def choose_pointwise_math(layers: List[Layer], pw_math: str) -> None:
+    """Mark the pointwise layers that may form their products on the f16 MFMA (csrc/pwconv_f16s.hip): the two-term f16
+    split needs a bounded input, which the graph proves when the producing layer ends in ReLU6 ([0, 6] -> a_log2 12)."""
+    if pw_math not in ("auto", "f32", "f16split"):
+        raise ValueError("pw_math must be 'auto', 'f32' or 'f16split', not %r" % (pw_math,))
+    if pw_math == "f32":
+        return
+    for L in layers:
+        if L.kind != OP_PWCONV_F32:
+            continue
+        bounded = L.src >= 0 and layers[L.src].act == ACT_RELU6 and layers[L.src].kind not in _BF16_OUT
+        if bounded and L.in_shape[2] % 32 == 0 and L.out_shape[2] % 64 == 0:
+            L.a_log2 = F16S_ACT_LOG2_RELU6
+        elif pw_math == "f16split":
+            raise LoweringError("%s: split-f16 pointwise needs a ReLU6-bounded input, k %% 32 == 0 and cout %% 64 == 0" % L.name)
+
+
 def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
-                feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32") -> Plan:
+                feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32",
+                pw_math: Optional[str] = None) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase.
+    pw_math: 'auto' (default; env HSEFR_PW_MATH overrides the default) = split-f16 products for every pointwise layer
+    whose input the graph bounds (ReLU6), fp32 MFMA otherwise; 'f32' = fp32 MFMA everywhere.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
     (general KxK Conv2D, Pad, FusedBatchNorm / Mul+Add, residual Add, MaxPool 3x3/2, global AvgPool / Mean)."""
     in_node, _ = g.get_tensor_by_name(input_tensor)
@@ -698,5 +766,8 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
         out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
         tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
 
+    if dtype == "f32":
+        import os
+        choose_pointwise_math(layers, pw_math or os.environ.get("HSEFR_PW_MATH", "auto"))
     buffers = assign_buffers(layers, {li for li, _ in out_layers.values()})
     return Plan(layers, (input_hw[0], input_hw[1], low.in_c), buffers, out_layers, tensor_layer)

@@ -5,6 +5,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import numpy as np
+
 from . import _lib
 from .lowering import ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID, tf_same_padding  # noqa: F401
 
@@ -62,6 +64,32 @@ def pwconv1x1(x, w_t, shift, act: int = ACT_RELU6):
     _lib.check(_lib.lib().hsefr_pwconv1x1_bias_relu6(x.data_ptr(), w_t.data_ptr(), shift.data_ptr(), y.data_ptr(),
                                                      m, k, cout, act, _lib.current_stream_ptr()),
                "hsefr_pwconv1x1_bias_relu6")
+    return y
+
+
+def split_weights_device(w_t, device, a_log2: int = 12):
+    """Host-side split of a pointwise kernel [cout, k] into the device image + descale the f16-split GEMM takes."""
+    torch = _lib.require_gpu()
+    from . import lowering
+    w_np = w_t.detach().cpu().numpy() if hasattr(w_t, "detach") else w_t
+    img, descale = lowering.split_pointwise_weights(w_np, a_log2)
+    return torch.from_numpy(img.view(np.int16)).to(device), torch.from_numpy(descale).to(device)
+
+
+def pwconv1x1_f16split(x, w_t, shift, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
+    """1x1 conv + shift + act with split-f16 products (fp32-grade, csrc/pwconv_f16s.hip).  PRECONDITION:
+    |x| * 2^a_log2 < 32768 (a ReLU6 producer with the default 12).  w_t [cout, k] fp32 is split on the host
+    (or pass prepared=split_weights_device(...))."""
+    torch = _lib.require_gpu()
+    _f32c(x, "x"), _f32c(shift, "shift")
+    d_img, d_ds = prepared if prepared is not None else split_weights_device(w_t, x.device, a_log2)
+    k = x.shape[-1]
+    cout = d_img.shape[0]
+    m = x.numel() // k
+    y = torch.empty(tuple(x.shape[:-1]) + (cout,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_pwconv1x1_f16split(x.data_ptr(), d_img.data_ptr(), d_ds.data_ptr(), shift.data_ptr(),
+                                                   y.data_ptr(), m, k, cout, a_log2, act, _lib.current_stream_ptr()),
+               "hsefr_pwconv1x1_f16split")
     return y
 
 

@@ -98,8 +98,11 @@ typedef enum hsefr_op_kind {
     HSEFR_OP_MAXPOOL_BF16 = 8, /* 3x3/2 max-pool, bf16                                                    */
     HSEFR_OP_GAP_BF16 = 9,     /* mean over H,W of bf16 activations -> fp32                               */
     HSEFR_OP_STEM7X7_BF16 = 10,/* 7x7/2 pad-3 conv over the fp32 3-channel image -> 64 ch bf16 (+scale+shift+ReLU) */
-    HSEFR_OP_DWPW_F32 = 11     /* fused depthwise 3x3 (+scale+shift+ReLU6) -> pointwise 1x1 (+shift+ReLU6), cin 32|64,
+    HSEFR_OP_DWPW_F32 = 11,    /* fused depthwise 3x3 (+scale+shift+ReLU6) -> pointwise 1x1 (+shift+ReLU6), cin 32|64,
                                   cout 64|128: the depthwise result never leaves the CU                            */
+    HSEFR_OP_PWCONV_F16S = 12  /* 1x1 conv + shift + act, fp32 in/out, products on the f16 MFMA from a two-term split of
+                                  both operands (fp32-grade, csrc/pwconv_f16s.hip); input bounded: |x| * 2^a_log2 < 32768.
+                                  w_off = split rows, scale_off = descale, shift_off = shift, `reserved` = a_log2   */
 } hsefr_op_kind;
 
 typedef enum hsefr_output_slot {
@@ -134,9 +137,9 @@ typedef struct hsefr_plan_op {
     int32_t oh, ow, cout; /* output                                                    */
     int32_t kh, kw, stride;
     int32_t pad_t, pad_l; /* TF SAME: pad_total//2 on top/left (0 for even input, k=3, s=2) */
-    int32_t reserved;
+    int32_t reserved;   /* PWCONV_F16S: a_log2 (activation pre-scale exponent); 0 otherwise      */
     uint64_t w_off;     /* weights; layout depends on kind (see the per-kernel entry points) */
-    uint64_t scale_off; /* per-channel scale (DWCONV only)                                   */
+    uint64_t scale_off; /* per-channel scale (DWCONV), descale (PWCONV_F16S)                 */
     uint64_t shift_off; /* per-channel shift / bias                                          */
     uint64_t w2_off;     /* DWPW_F32: pointwise kernel, transposed [cout][cin]                */
     uint64_t shift2_off; /* DWPW_F32: pointwise shift [cout]                                  */
@@ -201,6 +204,15 @@ int hsefr_dwconv3x3_bn_relu6(const float* x, const float* wgt, const float* scal
  * y [m,cout].  k multiple of 32, cout multiple of 64. */
 int hsefr_pwconv1x1_bias_relu6(const float* x, const float* wgt_t, const float* shift, float* y,
                                long long m, int k, int cout, int act, hsefr_stream_t stream);
+
+/* The same Conv2D 1x1 + shift + act with every product formed on the f16 MFMA from a two-term f16 split of both
+ * operands (3 MFMAs per product, fp32 accumulate; error <= 3*2^-22 per product, i.e. fp32-grade -- see
+ * csrc/pwconv_f16s.hip).  x [m,k] fp32 with |x| * 2^a_log2 < 32768 (PRECONDITION: e.g. a ReLU6 producer and a_log2 = 12);
+ * w_split = the transposed kernel, per output channel scaled by 2^e_n and split into f16 hi/lo "split rows"
+ * [cout][k/32][hi(32) | lo(32)] (byte size = cout*k*4; built by hse_facerec_tf_amd.lowering.split_pointwise_weights);
+ * descale[n] = 2^-(e_n + a_log2).  y = act(acc * descale + shift).  k multiple of 32, cout multiple of 64. */
+int hsefr_pwconv1x1_f16split(const float* x, const void* w_split, const float* descale, const float* shift, float* y,
+                             long long m, int k, int cout, int a_log2, int act, hsefr_stream_t stream);
 
 /* One whole early MobileNet block (graph nodes #35-#49) fused: depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6
  * -> pointwise 1x1 + shift + ReLU6.  x [n,h,w,c], wd [3,3,c], wp_t [cout,c] (TF kernel transposed), y [n,oh,ow,cout];

@@ -42,6 +42,11 @@ def parse(blob: bytes):
                 bufs=bufs, ops=ops, data=data)
 
 
+def PW(a, wt):
+    """pointwise product hook: a [M,K] . wt[N,K]^T (tests of split-precision arithmetic replace it)"""
+    return a.dot(wt.T)
+
+
 def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
     p = parse(blob)
     n = x.shape[0]
@@ -86,7 +91,13 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             y = _act(y * arr(sc_off, cin) + arr(sh_off, cin), act)
         elif kind == 3:
             wt = arr(w_off, cin * cout).reshape(cout, cin)
-            y = _act(src.reshape(-1, cin).dot(wt.T) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
+            y = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
+        elif kind == 12:     # split-f16 pointwise: the fp64 weights the two f16 planes stand for
+            from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
+            img = np.frombuffer(data, np.uint16, cout * cin * 2, w_off).reshape(cout, cin // 32, 64)
+            wt = unsplit_pointwise_weights(img, np.frombuffer(data, np.float32, cout, sc_off), _r).astype(dtype)
+            assert 0 < _r <= 24 and float(np.abs(src).max()) * 2.0 ** _r < 32768, "split-f16 input bound violated"
+            y = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
         elif kind == 4:
             y = src.mean(axis=(1, 2)).reshape(n, 1, 1, cin)
         elif kind == 5:
@@ -101,7 +112,7 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             xp = np.pad(src, ((0, 0), (pad_t, pb), (pad_l, pr), (0, 0)))
             mid = _act(tfo.depthwise_conv2d(xp, k, (stride, stride), "VALID") * arr(sc_off, cin) + arr(sh_off, cin), 2)
             wt = arr(w2_off, cin * cout).reshape(cout, cin)
-            y = _act(mid.reshape(-1, cin).dot(wt.T) + arr(sh2_off, cout), act).reshape(n, oh, ow, cout)
+            y = _act(PW(mid.reshape(-1, cin), wt) + arr(sh2_off, cout), act).reshape(n, oh, ow, cout)
         elif kind == 7:      # bf16 implicit-GEMM conv: weights [cout][kh*kw*cin] bf16, fp32 scale/shift, optional residual
             k = arr_bf16(w_off, kh * kw * cin * cout).reshape(cout, kh, kw, cin).transpose(1, 2, 3, 0)
             pb = max((oh - 1) * stride + kh - h - pad_t, 0)

@@ -34,14 +34,16 @@ def test_native_library_is_the_one_loaded(torch_):
     assert "hse_facerec_tf_amd/libhsefr.so" in maps
 
 
+@pytest.mark.parametrize("pw_math", ["auto", "f32"])
 @pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("size", [192, 224, 96, 100])
-def test_engine_matches_golden_synthetic(torch_, size, fuse):
+def test_engine_matches_golden_synthetic(torch_, size, fuse, pw_math):
     from hse_facerec_tf_amd import engine, graphdef, lowering
     z = np.load(os.path.join(GOLDEN, "e2e_synthetic.npz"))
     n = z["feat_%d" % size].shape[0]
     plan = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0",
-                                {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]}, (size, size), fuse=fuse)
+                                {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]}, (size, size), fuse=fuse, pw_math=pw_math)
+    assert any(L.a_log2 for L in plan.layers) == (pw_math == "auto")
     eng = engine.Engine(plan, max_batch=4)
     x = np.random.RandomState(123).uniform(-128, 128, (n, size, size, 3)).astype(np.float32)
     out = eng.forward(torch_.from_numpy(x).cuda(), (0, 1, 2))
@@ -75,6 +77,9 @@ def test_every_layer_matches_the_oracle(torch_):
             y = ops.conv3x3_c3(src, d(L.w), d(L.shift), L.stride, L.act)
         elif L.kind == lowering.OP_DWCONV3X3:
             y = ops.dwconv3x3(src, d(L.w.reshape(3, 3, -1)), d(L.scale), d(L.shift), L.stride, L.act)
+        elif L.kind == lowering.OP_PWCONV_F32 and L.a_log2 > 0:
+            assert float(src.max()) <= 6.0 and float(src.min()) >= 0.0          # the bound the lowering relied on
+            y = ops.pwconv1x1_f16split(src, L.w.reshape(L.w.shape[2], L.w.shape[3]).T, d(L.shift), L.act, L.a_log2)
         elif L.kind == lowering.OP_PWCONV_F32:
             y = ops.pwconv1x1(src, d(L.w.reshape(L.w.shape[2], L.w.shape[3]).T), d(L.shift), L.act)
         elif L.kind == lowering.OP_DWPW_F32:

@@ -115,6 +115,64 @@ def test_pointwise_vs_oracle(env, m, k, cout):
     assert rel(y.cpu().numpy(), want) < TOL * max(1.0, (k / 256.0) ** 0.5)
 
 
+@pytest.mark.parametrize("m,k,cout", [(96 * 96 * 2, 32, 64), (48 * 48 * 2, 64, 128), (2304, 128, 128), (1152 + 7, 128, 256),
+                                      (576, 256, 256), (300, 256, 512), (36 * 5, 512, 512), (36 * 3 + 1, 512, 1024),
+                                      (129, 1024, 1024), (1, 1024, 1024), (127, 32, 192), (128 * 600 + 5, 64, 64)])
+def test_pointwise_f16split_vs_oracle(env, m, k, cout):
+    """Split-f16 products: the result must be fp32-grade (same bar as the fp32 MFMA kernel) on ReLU6-range inputs that
+    include exact zeros, the bound itself, tiny values, and weights spanning 6 decades across output channels."""
+    torch, ops = env
+    rs = np.random.RandomState(m + k + cout + 1)
+    x = rs.uniform(0, 6, (m, k)).astype(np.float32)
+    x[rs.rand(m, k) < 0.3] = 0.0
+    x[rs.rand(m, k) < 0.05] = 6.0
+    x[rs.rand(m, k) < 0.05] *= 1e-5
+    w1 = (rs.randn(k, cout) / np.sqrt(k)).astype(np.float32)
+    w1[:, cout // 2] = 0.0
+    sh = rs.randn(cout).astype(np.float32)
+    tol = TOL * max(1.0, (k / 256.0) ** 0.5)
+    # (a) ReLU6 epilogue, O(1) weights: error against the clipped range
+    y = ops.pwconv1x1_f16split(dev(torch, x), w1.T, dev(torch, sh), 2).cpu().numpy()
+    assert rel(y, act6(x.astype(np.float64).dot(w1.astype(np.float64)) + sh)) < tol
+    # (b) no activation, output channels 6 decades apart (cancellation scales with the channel: compare per channel)
+    w2 = w1 * (10.0 ** rs.uniform(-3, 3, cout)).astype(np.float32)[None, :]
+    want = x.astype(np.float64).dot(w2.astype(np.float64)) + sh
+    y = ops.pwconv1x1_f16split(dev(torch, x), w2.T, dev(torch, sh), 0).cpu().numpy()
+    y32 = ops.pwconv1x1(dev(torch, x), dev(torch, w2.T), dev(torch, sh), 0).cpu().numpy()
+    scale = np.abs(x.astype(np.float64)).dot(np.abs(w2.astype(np.float64))).max(axis=0) + np.abs(sh)     # sum of |terms|
+    err = (np.abs(y - want) / scale).max(axis=0)
+    err32 = (np.abs(y32 - want) / scale).max(axis=0)
+    assert err.max() < tol, "channel %d" % err.argmax()
+    assert err.max() < 4 * max(err32.max(), 2.0 ** -24), "split-f16 %g vs fp32 MFMA %g" % (err.max(), err32.max())
+
+
+def test_pointwise_f16split_operand_maps_with_exact_integers(env):
+    """Selector rows against an asymmetric integer kernel (exact in the split: integers < 2^22 after the per-channel
+    scaling): a row/column or k-slot mix-up in the f16 fragment maps or in the split-row image gives a wrong integer."""
+    torch, ops = env
+    from hse_facerec_tf_amd.lowering import ACT_NONE
+    k, cout, m = 64, 128, 256
+    w = (np.arange(k)[:, None] * 131 + np.arange(cout)[None, :] * 7 + 1).astype(np.float32)
+    x = np.zeros((m, k), np.float32)
+    x[np.arange(m), np.arange(m) % k] = 1.0
+    x[np.arange(m), (np.arange(m) * 5 + 3) % k] += 2.0
+    want = x.astype(np.float64).dot(w.astype(np.float64))
+    y = ops.pwconv1x1_f16split(dev(torch, x), w.T, dev(torch, np.zeros(cout, np.float32)), ACT_NONE)
+    assert np.array_equal(y.cpu().numpy().astype(np.float64), want)
+
+
+def test_pointwise_f16split_rejects_unsupported_shapes(env):
+    torch, ops = env
+    from hse_facerec_tf_amd import lowering
+    with pytest.raises(lowering.LoweringError):
+        ops.pwconv1x1_f16split(torch.zeros((8, 48), device="cuda"), np.zeros((64, 48), np.float32), torch.zeros(64, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        ops.pwconv1x1_f16split(torch.zeros((8, 32), device="cuda"), np.zeros((40, 32), np.float32), torch.zeros(40, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.pwconv1x1_f16split(torch.zeros((8, 32), device="cuda"), np.zeros((64, 32), np.float32), torch.zeros(64, device="cuda"),
+                               a_log2=40)
+
+
 def test_pointwise_mfma_operand_maps_with_exact_integers(env):
     """A = identity-like selector against an ASYMMETRIC integer B: any row/column or k-slot mix-up
     in the MFMA fragment maps gives an exactly wrong integer (cdna guide: A=I, asymmetric B)."""

@@ -124,6 +124,7 @@ def test_plan_struct_layout_matches_header():
     for name, val in (("HSEFR_OP_CONV_C3", lowering.OP_CONV_C3), ("HSEFR_OP_DWCONV3X3", lowering.OP_DWCONV3X3),
                       ("HSEFR_OP_PWCONV_F32", lowering.OP_PWCONV_F32), ("HSEFR_OP_GAP", lowering.OP_GAP),
                       ("HSEFR_OP_DENSE", lowering.OP_DENSE), ("HSEFR_OP_SOFTMAX", lowering.OP_SOFTMAX),
+                      ("HSEFR_OP_DWPW_F32", lowering.OP_DWPW_F32), ("HSEFR_OP_PWCONV_F16S", lowering.OP_PWCONV_F16S),
                       ("HSEFR_ACT_RELU6", lowering.ACT_RELU6), ("HSEFR_ACT_SIGMOID", lowering.ACT_SIGMOID)):
         assert "%s = %d" % (name, val) in hdr
 
@@ -190,3 +191,37 @@ def test_unfolded_batchnorm_and_learning_phase_graph():
     assert rel(got, ref.reshape(2, -1)) < 1e-5
     with pytest.raises(lowering.LoweringError):        # predicate not fed -> cannot resolve the Merge
         lowering.lower_graph(g, "input_1:0", {OUT_FEATURES: "reshape_1/Reshape:0"})
+
+
+def test_pointwise_math_selection_and_split_weight_image(graph):
+    """auto: every pointwise layer of the MobileNet trunk reads a ReLU6 output -> split-f16 products (wire kind 12);
+    'f32' keeps the fp32 MFMA kernel; the split image reproduces the fp32 kernel to 2^-21 and inverts exactly."""
+    import plan_ref
+    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96))
+    pws = [L for L in plan.layers if L.kind == lowering.OP_PWCONV_F32]
+    assert len(pws) == 11 and all(L.a_log2 == 12 for L in pws)
+    wire = [o[0] for o in plan_ref.parse(plan.serialize())["ops"]]
+    assert wire.count(lowering.OP_PWCONV_F16S) == 11 and lowering.OP_PWCONV_F32 not in wire
+    plan32 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), pw_math="f32")
+    assert all(L.a_log2 == 0 for L in plan32.layers)
+    assert lowering.OP_PWCONV_F16S not in [o[0] for o in plan_ref.parse(plan32.serialize())["ops"]]
+    with pytest.raises(ValueError):
+        lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), pw_math="bf16")
+    for L in pws:
+        w_t = np.ascontiguousarray(L.w.reshape(L.w.shape[2], L.w.shape[3]).T)
+        img, descale = lowering.split_pointwise_weights(w_t, 12)
+        assert img.dtype == np.uint16 and img.shape == (w_t.shape[0], w_t.shape[1] // 32, 64) and img.nbytes == w_t.nbytes
+        e = np.log2(descale.astype(np.float64))
+        assert np.array_equal(e, np.round(e))                                   # exact powers of two
+        hi = img[:, :, :32].copy().view(np.float16).astype(np.float64)
+        assert np.isfinite(hi).all() and np.abs(hi).max() < 16384.5
+        amax = np.abs(hi).reshape(w_t.shape[0], -1).max(axis=1)
+        assert (amax[np.abs(w_t).max(axis=1) > 0] >= 8191.5).all()              # every channel sits at the top of f16's range
+        back = lowering.unsplit_pointwise_weights(img, descale, 12)
+        assert np.abs(back - w_t).max() <= 2.0 ** -21 * np.abs(w_t).max(axis=1).max()
+        assert (np.abs(back - w_t) <= 2.0 ** -21 * np.abs(w_t).max(axis=1, keepdims=True)).all()
+    z = np.zeros((64, 32), np.float32)
+    img, descale = lowering.split_pointwise_weights(z)
+    assert not img.any() and np.isfinite(descale).all()
+    with pytest.raises(lowering.LoweringError):
+        lowering.split_pointwise_weights(np.zeros((64, 48), np.float32))

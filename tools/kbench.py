@@ -157,6 +157,59 @@ def bench_pwd():
     print("sum over the 13 pointwise layers: %.1f us vs %.1f us" % tuple(tot))
 
 
+def bench_pws():
+    print("split-f16 GEMM vs fp32-MFMA GEMM, batch %d: us median; error = max|y - y64| / max|y64| on the first 4096 rows" % B)
+    print("%-22s %9s | %9s %9s %9s %9s | %8s %8s" % ("M x K x N", "f32 auto", "f16s auto", "128x128", "128x64", "64x64", "err f32", "err f16s"))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    tot = [0.0, 0.0]
+    for hw, k, n in PW:
+        m = B * hw * hw
+        x = torch.rand((m, k), device="cuda", generator=g) * 6
+        x[::7, ::3] = 0
+        x[1::5, 1::4] *= 1e-3
+        w = torch.randn((n, k), device="cuda", generator=g) / k ** 0.5
+        sh = torch.randn((n,), device="cuda", generator=g)
+        prep = ops.split_weights_device(w, x.device)
+        r32 = timeit(lambda: ops.pwconv1x1(x, w, sh))[0]
+        res = []
+        for tile in (-1, 0, 1, 2):
+            if tile == 0 and n % 128:
+                res.append(float("nan"))
+                continue
+            _lib.lib().hsefr_debug_set(b"pws_tile", tile)
+            res.append(timeit(lambda: ops.pwconv1x1_f16split(x, None, sh, prepared=prep))[0])
+        _lib.lib().hsefr_debug_set(b"pws_tile", -1)
+        y64 = torch.clamp(x[:4096].double() @ w.double().T + sh.double(), 0, 6)
+        e32 = float((ops.pwconv1x1(x, w, sh)[:4096].double() - y64).abs().max() / y64.abs().max())
+        e16 = float((ops.pwconv1x1_f16split(x, None, sh, prepared=prep)[:4096].double() - y64).abs().max() / y64.abs().max())
+        mult = 5 if (hw, k, n) == (12, 512, 512) else 1
+        tot[0] += r32 * mult
+        tot[1] += np.nanmin(res) * mult
+        by = 4.0 * (m * k + m * n + k * n)
+        print("%-22s %9.1f | %9.1f %9.1f %9.1f %9.1f | %8.1e %8.1e  best %5.0f GB/s" % ("%dx%dx%d" % (m, k, n), r32, *res, e32, e16, by / np.nanmin(res) / 1e3))
+    print("sum over the 13 pointwise layers: f32 %.1f us, split-f16 (best tile) %.1f us" % tuple(tot))
+
+
+def bench_pwsa():
+    print("split-f16 GEMM ablations (timing only), us median; columns: real / -gload / -store / -gload-store / -swrite / -gload-swrite / none of the three")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for tile in (0, 1):
+        for hw, k, n in PW[2:]:
+            m = B * hw * hw
+            x = torch.rand((m, k), device="cuda", generator=g) * 6
+            w = torch.randn((n, k), device="cuda", generator=g) / k ** 0.5
+            sh = torch.randn((n,), device="cuda", generator=g)
+            prep = ops.split_weights_device(w, x.device)
+            _lib.lib().hsefr_debug_set(b"pws_tile", tile)
+            res = []
+            for ab in (0, 1, 2, 3, 4, 5, 7):
+                _lib.lib().hsefr_debug_set(b"pws_ablate", ab)
+                res.append(timeit(lambda: ops.pwconv1x1_f16split(x, None, sh, prepared=prep))[0])
+            _lib.lib().hsefr_debug_set(b"pws_ablate", 0)
+            _lib.lib().hsefr_debug_set(b"pws_tile", -1)
+            print("tile %d %-22s" % (tile, "%dx%dx%d" % (m, k, n)) + "".join("%9.1f" % r for r in res))
+
+
 def bench_pwa():
     print("GEMM ablations (timing only), 128x64 tile: us median: real / no-global-loads / no-stores / neither")
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -200,4 +253,4 @@ def bench_clock():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["pw", "dw", "c3"]
     for w in what:
-        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd}[w]()
+        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd, "pws": bench_pws, "pwsa": bench_pwsa}[w]()
