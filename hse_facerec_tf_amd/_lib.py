@@ -21,6 +21,7 @@ SIGNATURES = {
     "hsefr_version": (c_int, []),
     "hsefr_last_error_string": (c_char_p, []),
     "hsefr_debug_set": (c_int, [c_char_p, c_int]),
+    "hsefr_debug_read_stamps": (c_int, [c_void_p, ctypes.c_size_t]),
     "hsefr_debug_clock_probe": (c_int, [_fp, c_int, c_int, c_void_p]),
     "hsefr_debug_copy": (c_int, [_fp, _fp, c_size_t, c_void_p]),
     "hsefr_engine_create": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
@@ -36,6 +37,7 @@ SIGNATURES = {
     "hsefr_conv_c3_bias_act": (c_int, [_fp, _fp, _fp, _fp] + [c_int] * 12 + [c_void_p]),
     "hsefr_dwconv3x3_bn_relu6": (c_int, [_fp, _fp, _fp, _fp, _fp] + [c_int] * 10 + [c_void_p]),
     "hsefr_pwconv1x1_bias_relu6": (c_int, [_fp, _fp, _fp, _fp, c_longlong, c_int, c_int, c_int, c_void_p]),
+    "hsefr_dwpw_f16split": (c_int, [_fp, _fp, _fp, _fp, c_void_p, _fp, _fp, _fp] + [c_int] * 12 + [c_void_p]),
     "hsefr_pwconv1x1_f16split": (c_int, [_fp, c_void_p, _fp, _fp, _fp, c_longlong, c_int, c_int, c_int, c_int, c_void_p]),
     "hsefr_dwpw_fused": (c_int, [_fp] * 7 + [c_int] * 10 + [c_void_p]),
     "hsefr_gap": (c_int, [_fp, _fp, c_int, c_int, c_int, c_void_p]),

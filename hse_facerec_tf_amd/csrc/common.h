@@ -114,15 +114,22 @@ int launch_conv2d_direct(const float* x, const float* w, const float* bias, cons
 int launch_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, int k, int stride, int pad_t, int pad_l,
                        hipStream_t s);
 
+int launch_dwpw_f16s(const float* x, const float* wd, const float* dscale, const float* dshift, const void* wsplit,
+                     const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride, int pad_t,
+                     int pad_l, int oh, int ow, int cout, int a_log2, int act, hipStream_t s);
+bool dwpw_f16s_supported(int c, int cout, int stride);
+void set_dwpws_tw(int v);
+void set_dwpws_bn(int v);
 void set_dwpw_impl(int v);
 void set_pw_tile(int v);
 void set_pws_tile(int v);
-void set_pws_ablate(int v);
+int read_pws_stamps(void* host_out, size_t bytes);
 void set_pw_ablate(int v);
 void set_pw_dma(int v);
 void set_dw_th(int v);
 void set_dw_variant(int v);
 void set_copy_variant(int v);
+void set_clock_mode(int v);
 int launch_clock_probe(unsigned long long* out, int blocks, int iters, hipStream_t s);
 int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 void set_c3_impl(int v);

@@ -59,6 +59,41 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* __
     }
 }
 
+// Same probe with the f16 MFMA (v_mfma_f32_32x32x16_f16) on pseudo-random operands: the clock and matrix rate the
+// split-f16 GEMMs can hope for (a dense 16-bit MFMA stream makes the chip lower its clock far more than the fp32 one).
+typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void clock_probe_f16_kernel(unsigned long long* __restrict__ out, int iters, float seed) {
+    f32x16p a0, a1, a2, a3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = seed * r; a1[r] = seed + r; a2[r] = seed - r; a3[r] = seed * 2 + r; }
+    f16x8p x, y;
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h = h * 1664525u + 1013904223u;
+        x[j] = (_Float16)(((int)(h >> 9) & 0xffff) * (1.f / 65536.f) - 0.5f);
+        h = h * 1664525u + 1013904223u;
+        y[j] = (_Float16)(((int)(h >> 9) & 0xffff) * (1.f / 65536.f) - 0.5f);
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, y, a3, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sink = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sink += a0[r] + a1[r] + a2[r] + a3[r];
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 3 + 0] = t1 - t0;
+        out[blockIdx.x * 3 + 1] = r1 - r0;
+        out[blockIdx.x * 3 + 2] = (unsigned long long)__float_as_uint(sink);
+    }
+}
+
+int g_clock_mode = 0;    // hsefr_debug_set "clock_mode": 0 = fp32 MFMA probe, 1 = f16 MFMA probe
 int g_copy_variant = 0;  // unroll: (v & 3) -> {1, 2, 4, 8}; nt bits: (v >> 2) & 3; grid: (v >> 4) & 3 -> {8, 4, 16, 32} WG/CU
 
 template <int U, int NT>
@@ -79,10 +114,12 @@ void launch_u(int nt, const f32x4* s, f32x4* d, size_t n, unsigned blocks, hipSt
 }  // namespace
 
 void set_copy_variant(int v) { g_copy_variant = v; }
+void set_clock_mode(int v) { g_clock_mode = v; }
 
 int launch_clock_probe(unsigned long long* out, int blocks, int iters, hipStream_t s) {
     HSEFR_REQUIRE(out && blocks > 0 && iters > 0, HSEFR_ERR_INVALID, "clock_probe: bad argument");
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
+    if (g_clock_mode == 1) hipLaunchKernelGGL(clock_probe_f16_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
+    else hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
     return launch_status("clock_probe");
 }
 

@@ -1,0 +1,292 @@
+// Fused depthwise 3x3 (+scale+shift+ReLU6) -> pointwise 1x1 (+shift+act) for ANY channel count, the pointwise products
+// on the f16 MFMA from two-term f16 splits (fp32-grade; arithmetic and weight image: pwconv_f16s.hip), NHWC fp32, gfx950.
+//
+// Replaces one whole MobileNet block of the frozen graph (nodes DepthwiseConv2dNative, Mul, Add, Relu, Minimum, Maximum,
+// Conv2D 1x1, Add, Relu, Minimum, Maximum -- e.g. #35-#49 -- run by tf_sess.run at facerec_test.py:120 /
+// facial_analysis.py:109).  Unfused, the depthwise output makes a round trip through HBM (written by one kernel, read
+// back by the GEMM): on the 96/48/24-pixel maps that is as many bytes as the block's real input and output together.
+// Here it never leaves the CU.  The depthwise result is always in [0, 6] (ReLU6), which is exactly the bound the f16
+// split needs, so this kernel has no fp32-MFMA twin.
+//
+// One workgroup (256 threads, 4 waves as 2 x 2) owns a patch of 128 output pixels (TH x TW = 8 x 16 or 16 x 8) and BN
+// output channels, and walks the input channels in chunks of 32 (= one K-tile of the GEMM):
+//   produce   every thread computes the depthwise result of 4 output rows x 1 column x 4 channels of the chunk with the
+//             sliding-window scheme of dwconv.hip (coalesced float4 loads from clamped addresses, padding folded into
+//             zeroed tap weights / 0-1 row factors, rows requested two iterations ahead), scales it by 2^12, splits it
+//             into f16 hi + lo and keeps the 4 results in registers; the chunk's slice of the split weight rows
+//             (BN x 128 B) is fetched alongside;
+//   publish   barrier (the previous chunk's MFMA reads are done) -> A and B tiles written to LDS in the swizzled
+//             128-B-row layout of pwconv_f16s.hip -> barrier;
+//   contract  24 (BN = 128) v_mfma_f32_32x32x16_f16 per wave: acc += al*bh + ah*bl + ah*bh.
+// After the last chunk: acc * descale + shift, activation, full 128-B row stores.  Two to three co-resident workgroups
+// per CU interleave their produce / contract phases, which overlaps the streaming with the MFMAs.
+// HBM traffic per patch: (TH*s+2) x (TW*s+2) x C in (halo re-reads hit L2; workgroup ids are XCD-remapped so that
+// neighbouring patches and the N-tiles of one patch share an L2) + 128 x Cout out.
+#include "common.h"
+
+namespace hsefr {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct DwPwSParams {
+    const float4* x;       // [N,H,W,C]
+    const float4* wd;      // depthwise [9][C/4]
+    const float4* dscale;  // [C/4]
+    const float4* dshift;  // [C/4]
+    const float* wsplit;   // pointwise split rows [Cout][C/32][64 f16]  (byte-compatible with fp32 [Cout][C])
+    const float* descale;  // [Cout]
+    const float* pshift;   // [Cout]
+    float* y;              // [N,OH,OW,Cout]
+    int H, W, C4, KT, OH, OW, Cout, pad_t, pad_l, tiles_w, tiles_h, tiles_n;
+    unsigned total;        // N * tiles_h * tiles_w * tiles_n work items
+    float a_scale;         // 2^a_log2
+};
+
+constexpr int ROWB = 128;
+__device__ __forceinline__ int swzb(int row, int chunk) { return row * ROWB + 16 * (chunk ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+
+template <int STRIDE, int TW, int BN, int OCC, int ACT>
+__global__ __launch_bounds__(256, OCC) void dwpw_f16s_kernel(DwPwSParams p) {
+    constexpr int TH = 128 / TW;
+    constexpr int U = TW * 8;             // (column, channel-quad) work items per patch row and chunk: 128 or 64
+    constexpr int RG = 256 / U;           // row groups: 2 or 4
+    constexpr int RPT = TH / RG;          // output rows per thread: 4
+    static_assert(RPT == 4, "patch shapes 8x16 and 16x8");
+    constexpr int WN = BN / 2, NI = WN / 32, BP = BN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char As[128 * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * ROWB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int srow = tid >> 3, skq = tid & 7;
+    // producer coordinates inside the patch
+    const int u = tid % U, tw = u >> 3, c4l = u & 7;
+    const int row0 = (tid / U) * RPT;
+    const int arow = wm * 64 + li, brow = wn * WN + li;
+
+    for (unsigned t = blockIdx.x; t < p.total; t += gridDim.x) {
+        const unsigned lt = xcd_remap(t, p.total);
+        const int n0 = (lt % p.tiles_n) * BN;
+        const unsigned pt = lt / p.tiles_n;
+        const int ow0 = (pt % p.tiles_w) * TW;
+        const int oh0 = ((pt / p.tiles_w) % p.tiles_h) * TH;
+        const int n = pt / (p.tiles_w * p.tiles_h);
+
+        // per-patch producer constants: clamped tap columns and their 0/1 padding masks
+        const int ow = min(ow0 + tw, p.OW - 1);            // clamped: out-of-range columns are computed, never stored
+        const int iw0 = ow * STRIDE - p.pad_l;
+        const float ml = iw0 >= 0 ? 1.f : 0.f, mm = (iw0 + 1 >= 0 && iw0 + 1 < p.W) ? 1.f : 0.f, mr = iw0 + 2 < p.W ? 1.f : 0.f;
+        const int cl = max(iw0, 0) * p.C4, cm = min(max(iw0 + 1, 0), p.W - 1) * p.C4, cr = min(iw0 + 2, p.W - 1) * p.C4;
+        const float4* ximg = p.x + (size_t)n * p.H * p.W * p.C4;
+        const int ih0 = (oh0 + row0) * STRIDE - p.pad_t;
+        const float* bsrc = p.wsplit + (size_t)(n0 + srow) * p.KT * 32 + 4 * skq;
+
+        f32x16 acc[2][NI];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+        for (int kc = 0; kc < p.KT; ++kc) {
+            // ---- produce: B slice loads first (longest latency to hide), then the depthwise chunk ----
+            f32x4 rb[BP];
+#pragma unroll
+            for (int q = 0; q < BP; ++q) rb[q] = *(const f32x4*)(bsrc + (size_t)32 * q * p.KT * 32 + kc * 32);
+            const int c4 = kc * 8 + c4l;
+            const float4* xin = ximg + c4;
+            float4 wk[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const float m = (i % 3 == 0) ? ml : (i % 3 == 1 ? mm : mr);
+                const float4 wr = p.wd[i * p.C4 + c4];
+                wk[i] = make_float4(wr.x * m, wr.y * m, wr.z * m, wr.w * m);
+            }
+            const float4 dsc = p.dscale[c4], dsh = p.dshift[c4];
+            struct Row { float4 l, m, r; float k; };
+            auto load_row = [&](int ih) {
+                Row q;
+                const int ihc = min(max(ih, 0), p.H - 1);
+                const float4* row = xin + (size_t)ihc * p.W * p.C4;
+                q.l = row[cl]; q.m = row[cm]; q.r = row[cr];
+                q.k = (ih >= 0 && ih < p.H) ? 1.f : 0.f;
+                return q;
+            };
+            auto row_sum = [&](const Row& q, int b) {
+                float4 a = make_float4(q.l.x * wk[b].x, q.l.y * wk[b].y, q.l.z * wk[b].z, q.l.w * wk[b].w);
+                a = fma4(q.m, wk[b + 1], a);
+                return fma4(q.r, wk[b + 2], a);
+            };
+            f16x4 ohi[RPT], olo[RPT];
+            auto emit = [&](int j, const Row& a, const Row& b, const Row& c) {
+                const float4 sa = row_sum(a, 0), sb = row_sum(b, 3), sc = row_sum(c, 6);
+                float4 s = make_float4(sa.x * a.k, sa.y * a.k, sa.z * a.k, sa.w * a.k);
+                s = make_float4(fmaf(sb.x, b.k, s.x), fmaf(sb.y, b.k, s.y), fmaf(sb.z, b.k, s.z), fmaf(sb.w, b.k, s.w));
+                s = make_float4(fmaf(sc.x, c.k, s.x), fmaf(sc.y, c.k, s.y), fmaf(sc.z, c.k, s.z), fmaf(sc.w, c.k, s.w));
+                const float4 o = fma4(s, dsc, dsh);
+                f32x4 v;
+                v[0] = relu6(o.x); v[1] = relu6(o.y); v[2] = relu6(o.z); v[3] = relu6(o.w);
+                v = v * p.a_scale;
+                ohi[j] = __builtin_convertvector(v, f16x4);
+                olo[j] = __builtin_convertvector(v - __builtin_convertvector(ohi[j], f32x4), f16x4);
+            };
+            if (STRIDE == 1) {
+                Row r0 = load_row(ih0), r1 = load_row(ih0 + 1), r2 = load_row(ih0 + 2), r3 = load_row(ih0 + 3);
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    const Row r4 = load_row(ih0 + j + 4);
+                    emit(j, r0, r1, r2);
+                    r0 = r1; r1 = r2; r2 = r3; r3 = r4;
+                }
+            } else {
+                Row r0 = load_row(ih0), r1 = load_row(ih0 + 1), r2 = load_row(ih0 + 2);
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    const Row n1 = load_row(ih0 + 2 * j + 3), n2 = load_row(ih0 + 2 * j + 4);
+                    emit(j, r0, r1, r2);
+                    r0 = r2; r1 = n1; r2 = n2;
+                }
+            }
+            // ---- publish ----
+            __syncthreads();   // every wave is done reading the previous chunk's tiles
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int R = (row0 + j) * TW + tw;
+                *(f16x4*)(&As[swzb(R, c4l >> 1) + 8 * (c4l & 1)]) = ohi[j];
+                *(f16x4*)(&As[swzb(R, 4 + (c4l >> 1)) + 8 * (c4l & 1)]) = olo[j];
+            }
+#pragma unroll
+            for (int q = 0; q < BP; ++q) *(f32x4*)(&Bs[swzb(srow + 32 * q, skq)]) = rb[q];
+            __syncthreads();
+            // ---- contract ----
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 ah[2], al[2], bh[NI], bl[NI];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    ah[mi] = *(const f16x8*)(&As[swzb(arow + mi * 32, 2 * s + lh)]);
+                    al[mi] = *(const f16x8*)(&As[swzb(arow + mi * 32, 4 + 2 * s + lh)]);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    bh[ni] = *(const f16x8*)(&Bs[swzb(brow + ni * 32, 2 * s + lh)]);
+                    bl[ni] = *(const f16x8*)(&Bs[swzb(brow + ni * 32, 4 + 2 * s + lh)]);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    }
+            }
+        }
+        // ---- epilogue: tile row R = th*TW + tw; accumulator register r of lane-half lh -> R = base + (r&3) + 8*(r>>2) + 4*lh
+        // (full patches store unconditionally: a per-store bounds branch costs an s_waitcnt vmcnt(0) per store)
+        const bool full = oh0 + TH <= p.OH && ow0 + TW <= p.OW;
+        float* ybase = p.y + ((size_t)n * p.OH * p.OW) * p.Cout;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = n0 + wn * WN + ni * 32 + li;
+            const float ds = p.descale[col], sh = p.pshift[col];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int Rb = wm * 64 + mi * 32 + 4 * lh;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int R = Rb + (r & 3) + 8 * (r >> 2);
+                        ybase[((size_t)(oh0 + R / TW) * p.OW + ow0 + (R % TW)) * p.Cout + col] = apply_act<ACT>(fmaf(acc[mi][ni][r], ds, sh));
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int R = Rb + (r & 3) + 8 * (r >> 2);
+                        const int oh = oh0 + R / TW, owc = ow0 + (R % TW);
+                        if (oh < p.OH && owc < p.OW)
+                            ybase[((size_t)oh * p.OW + owc) * p.Cout + col] = apply_act<ACT>(fmaf(acc[mi][ni][r], ds, sh));
+                    }
+                }
+            }
+        }
+    }
+}
+
+int g_tw = 0;   // tuning/debug only (hsefr_debug_set "dwpws_tw"): 0 = auto, 8 | 16 = forced patch width
+int g_bn = 0;   // tuning/debug only (hsefr_debug_set "dwpws_bn"): 0 = auto, 64 | 128 | 256 = forced N tile
+
+template <int STRIDE, int TW, int BN, int OCC>
+int launch_t(DwPwSParams& p, int n, int act, hipStream_t s) {
+    constexpr int TH = 128 / TW;
+    p.tiles_w = (p.OW + TW - 1) / TW;
+    p.tiles_h = (p.OH + TH - 1) / TH;
+    p.tiles_n = p.Cout / BN;
+    const long long total = (long long)n * p.tiles_w * p.tiles_h * p.tiles_n;
+    HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "dwpw_f16split: grid too large");
+    p.total = (unsigned)total;
+    const unsigned cap = 256u * OCC;
+    const unsigned g = p.total < cap ? p.total : cap;
+#define HSEFR_DWPWS(A) hipLaunchKernelGGL((dwpw_f16s_kernel<STRIDE, TW, BN, OCC, A>), dim3(g), dim3(256), 0, s, p)
+    if (act == HSEFR_ACT_RELU6) HSEFR_DWPWS(HSEFR_ACT_RELU6);
+    else if (act == HSEFR_ACT_RELU) HSEFR_DWPWS(HSEFR_ACT_RELU);
+    else if (act == HSEFR_ACT_NONE) HSEFR_DWPWS(HSEFR_ACT_NONE);
+    else { set_error("dwpw_f16split: act %d", act); return HSEFR_ERR_UNSUPPORTED; }
+#undef HSEFR_DWPWS
+    return launch_status("dwpw_f16split");
+}
+
+template <int STRIDE, int TW>
+int launch_bn(DwPwSParams& p, int n, int bn, int act, hipStream_t s) {
+    if (bn == 64) return launch_t<STRIDE, TW, 64, 2>(p, n, act, s);
+    if (bn == 128) return launch_t<STRIDE, TW, 128, 2>(p, n, act, s);
+    return launch_t<STRIDE, TW, 256, 2>(p, n, act, s);
+}
+
+}  // namespace
+
+void set_dwpws_tw(int v) { g_tw = v; }
+void set_dwpws_bn(int v) { g_bn = v; }
+
+bool dwpw_f16s_supported(int c, int cout, int stride) {
+    return c > 0 && c % 32 == 0 && cout > 0 && cout % 64 == 0 && (stride == 1 || stride == 2);
+}
+
+int launch_dwpw_f16s(const float* x, const float* wd, const float* dscale, const float* dshift, const void* wsplit,
+                     const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride, int pad_t,
+                     int pad_l, int oh, int ow, int cout, int a_log2, int act, hipStream_t s) {
+    HSEFR_REQUIRE(dwpw_f16s_supported(c, cout, stride), HSEFR_ERR_UNSUPPORTED,
+                  "dwpw_f16split: c=%d cout=%d stride=%d not covered (c %% 32, cout %% 64, stride 1|2)", c, cout, stride);
+    HSEFR_REQUIRE(n >= 0 && h > 0 && w > 0 && oh > 0 && ow > 0, HSEFR_ERR_INVALID, "dwpw_f16split: bad shape");
+    HSEFR_REQUIRE(a_log2 > 0 && a_log2 <= 12, HSEFR_ERR_INVALID, "dwpw_f16split: a_log2=%d (the depthwise result is in [0,6]: 1..12)", a_log2);
+    if (n == 0) return HSEFR_OK;
+    DwPwSParams p;
+    p.x = (const float4*)x; p.wd = (const float4*)wd; p.dscale = (const float4*)dscale; p.dshift = (const float4*)dshift;
+    p.wsplit = (const float*)wsplit; p.descale = descale; p.pshift = pshift; p.y = y;
+    p.H = h; p.W = w; p.C4 = c / 4; p.KT = c / 32; p.OH = oh; p.OW = ow; p.Cout = cout; p.pad_t = pad_t; p.pad_l = pad_l;
+    p.a_scale = ldexpf(1.f, a_log2);
+    // N tile: 128 output channels (64 accumulator registers; the 256 variant spills); wider layers redo the depthwise
+    // work once per N tile, the tiles of one patch running side by side on one XCD so that the re-read hits its L2
+    int bn = cout % 128 == 0 ? 128 : 64;
+    if (g_bn && cout % g_bn == 0) bn = g_bn;
+    // patch shape: 8 rows x 16 columns unless the width only tiles by 8
+    int tw = (ow % 16 == 0 || ow % 8 != 0) ? 16 : 8;
+    if (ow <= 8) tw = 8;
+    if (g_tw == 8 || g_tw == 16) tw = g_tw;
+    if (stride == 1) return tw == 16 ? launch_bn<1, 16>(p, n, bn, act, s) : launch_bn<1, 8>(p, n, bn, act, s);
+    return tw == 16 ? launch_bn<2, 16>(p, n, bn, act, s) : launch_bn<2, 8>(p, n, bn, act, s);
+}
+
+}  // namespace hsefr

@@ -93,6 +93,13 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                                   o.reserved > 0 && o.reserved <= 24,
                               HSEFR_ERR_INVALID, "plan op %u: split-f16 pointwise needs split rows, descale, shift and a_log2 in (0, 24]", i);
                 break;
+            case HSEFR_OP_DWPW_F16S:
+                HSEFR_REQUIRE(dwpw_f16s_supported(o.cin, o.cout, o.stride) && o.reserved > 0 && o.reserved <= 12 &&
+                                  o.w_off != HSEFR_NO_OFFSET && o.scale_off != HSEFR_NO_OFFSET && o.shift_off != HSEFR_NO_OFFSET &&
+                                  o.w2_off != HSEFR_NO_OFFSET && o.shift2_off != HSEFR_NO_OFFSET,
+                              HSEFR_ERR_UNSUPPORTED, "plan op %u: split-f16 fused block cin=%d cout=%d stride=%d a_log2=%d not covered",
+                              i, o.cin, o.cout, o.stride, o.reserved);
+                break;
             case HSEFR_OP_DWPW_F32:
                 HSEFR_REQUIRE(dwpw_fused_supported(o.cin, o.cout, o.stride, HSEFR_ACT_RELU6, (int)o.act), HSEFR_ERR_UNSUPPORTED,
                               "plan op %u: fused depthwise-pointwise block cin=%d cout=%d not covered", i, o.cin, o.cout);
@@ -118,7 +125,9 @@ int hsefr_debug_set(const char* key, int value) {
     HSEFR_REQUIRE(key, HSEFR_ERR_INVALID, "debug_set: null key");
     if (!strcmp(key, "pw_tile")) { set_pw_tile(value); return HSEFR_OK; }
     if (!strcmp(key, "pws_tile")) { set_pws_tile(value); return HSEFR_OK; }
-    if (!strcmp(key, "pws_ablate")) { set_pws_ablate(value); return HSEFR_OK; }
+    if (!strcmp(key, "clock_mode")) { set_clock_mode(value); return HSEFR_OK; }
+    if (!strcmp(key, "dwpws_tw")) { set_dwpws_tw(value); return HSEFR_OK; }
+    if (!strcmp(key, "dwpws_bn")) { set_dwpws_bn(value); return HSEFR_OK; }
     if (!strcmp(key, "pw_ablate")) { set_pw_ablate(value); return HSEFR_OK; }
     if (!strcmp(key, "pw_dma")) { set_pw_dma(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_th")) { set_dw_th(value); return HSEFR_OK; }
@@ -320,6 +329,14 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
                                        (const float*)blob_ptr(e, o.shift2_off), (float*)out, n, o.h, o.w, o.cin, o.stride,
                                        o.pad_t, o.pad_l, o.oh, o.ow, o.cout, HSEFR_ACT_RELU6, o.act, s);
                 break;
+            case HSEFR_OP_DWPW_F16S: {
+                const float* ds2 = (const float*)blob_ptr(e, o.shift2_off);
+                rc = launch_dwpw_f16s((const float*)in, (const float*)blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
+                                      (const float*)blob_ptr(e, o.shift_off), blob_ptr(e, o.w2_off), ds2, ds2 + o.cout,
+                                      (float*)out, n, o.h, o.w, o.cin, o.stride, o.pad_t, o.pad_l, o.oh, o.ow, o.cout,
+                                      o.reserved, o.act, s);
+                break;
+            }
             default:
                 set_error("forward: op %zu has unknown kind %u", i, o.kind);
                 rc = HSEFR_ERR_UNSUPPORTED;
@@ -352,6 +369,8 @@ int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_
     return launch_copy(d_src, d_dst, bytes, (hipStream_t)stream);
 }
 
+int hsefr_debug_read_stamps(void* host_out, size_t bytes) { return read_pws_stamps(host_out, bytes); }
+
 int hsefr_debug_clock_probe(unsigned long long* d_out, int blocks, int iters, hsefr_stream_t stream) {
     return launch_clock_probe(d_out, blocks, iters, (hipStream_t)stream);
 }
@@ -381,6 +400,15 @@ int hsefr_pwconv1x1_f16split(const float* x, const void* w_split, const float* d
                              long long m, int k, int cout, int a_log2, int act, hsefr_stream_t stream) {
     HSEFR_REQUIRE(m == 0 || (x && w_split && descale && shift && y), HSEFR_ERR_INVALID, "pwconv_f16split: null pointer");
     return launch_pwconv_f16s(x, w_split, descale, shift, y, m, k, cout, a_log2, act, (hipStream_t)stream);
+}
+
+int hsefr_dwpw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,
+                        const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride,
+                        int pad_t, int pad_l, int oh, int ow, int cout, int a_log2, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wd && dscale && dshift && w_split && descale && pshift && y), HSEFR_ERR_INVALID,
+                  "dwpw_f16split: null pointer");
+    return launch_dwpw_f16s(x, wd, dscale, dshift, w_split, descale, pshift, y, n, h, w, c, stride, pad_t, pad_l, oh, ow, cout,
+                            a_log2, act, (hipStream_t)stream);
 }
 
 int hsefr_dwpw_fused(const float* x, const float* wd, const float* dscale, const float* dshift, const float* wp_t,

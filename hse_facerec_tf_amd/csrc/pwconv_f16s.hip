@@ -41,28 +41,65 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef HSEFR_PWS_STAMPS
+// Diagnostic build only (build.sh HSEFR_EXTRA_FLAGS=-DHSEFR_PWS_STAMPS): per-wave s_memtime sums of the step phases.
+__device__ unsigned long long g_pws_stamps[1024 * 8 * 8];
+#define PWS_STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); st[i] += _t - tprev; tprev = _t; } while (0)
+#else
+#define PWS_STAMP(i) do { } while (0)
+#endif
+
 constexpr int BK = 32;          // input channels per K-tile
 constexpr int ROWB = 128;       // LDS bytes per tile row: 32 hi halves | 32 lo halves
 
 // byte offset of 16-B chunk `chunk` of tile row `row`
 __device__ __forceinline__ int swzb(int row, int chunk) { return row * ROWB + 16 * (chunk ^ ((row >> 1) & 7)); }
 
-template <int BM, int BN, int OCC, int ACT>
-__global__ __launch_bounds__(256, OCC) void pwconv_f16s_kernel(const float* __restrict__ x, const float* __restrict__ wsplit,
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer resource over [p, p + bytes): loads beyond it return 0, stores beyond it are dropped -- that is how tail
+// tiles (rows >= M) are handled, with no clamping and no branches.  One VGPR byte offset per thread is constant for the
+// whole kernel; everything that changes (tile, staging pass, K-tile) is uniform and travels in the SGPR offset.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long long bytes) {
+    const unsigned n = bytes <= 0 ? 0u : (bytes > 0xffffffffll ? 0xffffffffu : (unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore16(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
+// sched_group_barrier masks
+#define SG_VALU 0x002
+#define SG_MFMA 0x008
+#define SG_VMEM_RD 0x020
+#define SG_DS_RD 0x100
+#define SG_DS_WR 0x200
+
+template <int BM, int BN, int WAVES_N, int OCC, int ACT>
+__global__ __launch_bounds__(128 * WAVES_N, OCC) void pwconv_f16s_kernel(const float* __restrict__ x, const float* __restrict__ wsplit,
                                                                const float* __restrict__ descale,
                                                                const float* __restrict__ shift, float* __restrict__ y,
                                                                long long M, int K, int Cout, float a_scale,
-                                                               unsigned tiles_n, unsigned total_tiles, int ablate) {
-    constexpr int WM = BM / 2, WN = BN / 2;  // wave tile (4 waves as 2 x 2)
+                                                               unsigned tiles_n, unsigned total_tiles) {
+    constexpr int NT = 128 * WAVES_N;                 // threads: 2 x WAVES_N waves
+    constexpr int WM = BM / 2, WN = BN / WAVES_N;     // wave tile
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int AP = BM / 32, BP = BN / 32;  // staging passes (32 rows x 8 chunks per pass)
-    __shared__ __attribute__((aligned(16))) unsigned char As[2][BM * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][BN * ROWB];
+    constexpr int SR = NT / 8;                        // rows staged per pass (8 threads = one 128-B row)
+    constexpr int AP = BM / SR, BP = BN / SR;         // staging passes
+    constexpr int NMFMA = MI * NI * 6;                // per wave and step
+    static_assert(WAVES_N == 2 && (BM + BN) * ROWB >= 4 * 4096, "epilogue scratch: 4 KB per wave inside one stage");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * ROWB];   // stage = A rows, then B rows
+    __shared__ __attribute__((aligned(16))) float Et[2][2][BN];   // epilogue constants [tile parity][descale | shift][n]
+    auto As = [&](int st) { return &smem[st][0]; };
+    auto Bs = [&](int st) { return &smem[st][BM * ROWB]; };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, lh = lane >> 5;
     const int srow = tid >> 3, skq = tid & 7;
     const int KT = K / BK;
@@ -74,39 +111,38 @@ __global__ __launch_bounds__(256, OCC) void pwconv_f16s_kernel(const float* __re
     // sequence and simply keeps re-reading the last tile once it runs off the end (harmless, never consumed).
     const unsigned ntile = (total_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const unsigned nsteps = ntile * KT;
+    const unsigned rowbytes = (unsigned)K * 4u;
+    const unsigned voff = (unsigned)srow * rowbytes + 16u * skq;     // this thread's 16 B of a staged 8-row group
 
-    const float* ag[AP];
-    const float* bg;
-    unsigned pf_i = 0;   // prefetch cursor: tile ordinal, K-tile
-    int pf_kt = 0;
     auto tile_origin = [&](unsigned i, long long& mm0, int& nn0) {
-        const unsigned lt = xcd_remap(blockIdx.x + i * gridDim.x, total_tiles);
+        const unsigned lt = xcd_remap(blockIdx.x + (i < ntile ? i : ntile - 1) * gridDim.x, total_tiles);
         mm0 = (long long)(lt / tiles_n) * BM;
         nn0 = (lt % tiles_n) * BN;
     };
-    auto setup_ptrs = [&](unsigned i) {
+    __amdgpu_buffer_rsrc_t ra_rsrc, rb_rsrc;
+    unsigned pf_i = 0;   // prefetch cursor: tile ordinal, K-tile
+    int pf_kt = 0;
+    auto setup_rsrc = [&](unsigned i) {
         long long mm0;
         int nn0;
-        tile_origin(i < ntile ? i : ntile - 1, mm0, nn0);
-#pragma unroll
-        for (int p = 0; p < AP; ++p) {
-            long long r = mm0 + srow + 32 * p;
-            if (r > M - 1) r = M - 1;  // tail rows: read a valid row, never stored
-            ag[p] = x + r * K + 4 * skq;
-        }
-        bg = wsplit + (long long)(nn0 + srow) * K + 4 * skq;
+        tile_origin(i, mm0, nn0);
+        ra_rsrc = make_rsrc(x + mm0 * K, (M - mm0) * (long long)rowbytes);
+        rb_rsrc = make_rsrc(wsplit + (long long)nn0 * K, (long long)(Cout - nn0) * rowbytes);
     };
 
     f32x4 ra[2][AP], rb[2][BP];
-    auto gload = [&](auto SET) {   // loads of the prefetch cursor's step into register set SET, then advance the cursor
+    auto gload = [&](auto SET) {   // loads of the prefetch cursor's step into register set SET
         constexpr int S = decltype(SET)::value;
+        const unsigned so = (unsigned)pf_kt * (BK * 4u);
 #pragma unroll
-        for (int p = 0; p < AP; ++p) ra[S][p] = *(const f32x4*)(ag[p] + pf_kt * BK);
+        for (int p = 0; p < AP; ++p) ra[S][p] = bload16(ra_rsrc, voff, so + (unsigned)(SR * p) * rowbytes);
 #pragma unroll
-        for (int p = 0; p < BP; ++p) rb[S][p] = *(const f32x4*)(bg + (long long)32 * p * K + pf_kt * BK);
+        for (int p = 0; p < BP; ++p) rb[S][p] = bload16(rb_rsrc, voff, so + (unsigned)(SR * p) * rowbytes);
+    };
+    auto advance_prefetch = [&]() {
         if (++pf_kt == KT) {
             pf_kt = 0;
-            setup_ptrs(++pf_i);
+            setup_rsrc(++pf_i);
         }
     };
     // activations: 4 fp32 -> 4 hi halves (8 B at k-offset 4*skq of the hi half-row) + 4 lo halves (same place, lo half-row)
@@ -117,12 +153,12 @@ __global__ __launch_bounds__(256, OCC) void pwconv_f16s_kernel(const float* __re
             const f32x4 v = ra[S][p] * a_scale;
             const f16x4 hi = __builtin_convertvector(v, f16x4);
             const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
-            const int row = srow + 32 * p;
-            *(f16x4*)(&As[buf][swzb(row, skq >> 1) + 8 * (skq & 1)]) = hi;
-            *(f16x4*)(&As[buf][swzb(row, 4 + (skq >> 1)) + 8 * (skq & 1)]) = lo;
+            const int row = srow + SR * p;
+            *(f16x4*)(As(buf) + swzb(row, skq >> 1) + 8 * (skq & 1)) = hi;
+            *(f16x4*)(As(buf) + swzb(row, 4 + (skq >> 1)) + 8 * (skq & 1)) = lo;
         }
 #pragma unroll
-        for (int p = 0; p < BP; ++p) *(f32x4*)(&Bs[buf][swzb(srow + 32 * p, skq)]) = rb[S][p];
+        for (int p = 0; p < BP; ++p) *(f32x4*)(Bs(buf) + swzb(srow + SR * p, skq)) = rb[S][p];
     };
 
     f32x16 acc[MI][NI];
@@ -143,112 +179,165 @@ __global__ __launch_bounds__(256, OCC) void pwconv_f16s_kernel(const float* __re
     unsigned ci = 0;   // compute cursor
     int ckt = 0;
     tile_origin(0, m0, n0);
-    setup_ptrs(0);
+    setup_rsrc(0);
     gload(S0());
+    advance_prefetch();
     gload(S1());
+    advance_prefetch();
     swrite(S0(), 0);
     __syncthreads();
     const int arow = wm * WM + li, brow = wn * WN + li;
+    // Epilogue geometry.  The MFMAs run with the operands SWAPPED (weights first): lane (li, lh) then owns output row
+    // m = li of a 32 x 32 block and, in accumulator register r, column n = 4*lh + 8*(r >> 2) + (r & 3): four runs of 4
+    // consecutive channels = four ds_write_b128 into a wave-private 32 x 128 B scratch (the LDS stage the tile's last
+    // step has just finished with).  Read back 8 lanes per row, a block leaves as 4 stores of 8 rows x 128 B: whole
+    // lines, a quarter of the store instructions of the register-per-row layout.
+    const int erow = lane >> 3, ech = lane & 7;
+    const unsigned yvoff = ((unsigned)(wm * WM + erow) * (unsigned)Cout + (unsigned)(wn * WN + 4 * ech)) * 4u;
 
+#ifdef HSEFR_PWS_STAMPS
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#endif
     // one step: compute from LDS stage P, refill register set P with step g+2, move set 1-P (step g+1) into stage 1-P
     auto step = [&](auto PAR) {
         constexpr int P = decltype(PAR)::value;
-        if (!(ablate & 1)) gload(PAR);
+        PWS_STAMP(5);
+        // the tile's epilogue constants go to LDS during its first step (ahead of that step's prefetch in the load queue)
+        f32x4 ec;
+        const bool fill = ckt == 0 && tid < BN / 2;
+        if (fill) {
+            const int j = tid < BN / 4 ? tid : tid - BN / 4;
+            ec = *(const f32x4*)((tid < BN / 4 ? descale : shift) + n0 + 4 * j);
+        }
+        // ---- one scheduling region: MFMAs as the backbone, everything else in their shadow -------------------------
+        f16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            f16x8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                ah[mi] = *(const f16x8*)(&As[P][swzb(arow + mi * 32, 2 * s + lh)]);
-                al[mi] = *(const f16x8*)(&As[P][swzb(arow + mi * 32, 4 + 2 * s + lh)]);
+                ah[s][mi] = *(const f16x8*)(As(P) + swzb(arow + mi * 32, 2 * s + lh));
+                al[s][mi] = *(const f16x8*)(As(P) + swzb(arow + mi * 32, 4 + 2 * s + lh));
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                bh[ni] = *(const f16x8*)(&Bs[P][swzb(brow + ni * 32, 2 * s + lh)]);
-                bl[ni] = *(const f16x8*)(&Bs[P][swzb(brow + ni * 32, 4 + 2 * s + lh)]);
+                bh[s][ni] = *(const f16x8*)(Bs(P) + swzb(brow + ni * 32, 2 * s + lh));
+                bl[s][ni] = *(const f16x8*)(Bs(P) + swzb(brow + ni * 32, 4 + 2 * s + lh));
             }
+        }
+        gload(PAR);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s][ni], al[s][mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[s][ni], ah[s][mi], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[s][ni], ah[s][mi], acc[mi][ni], 0, 0, 0);
                 }
+        swrite(std::integral_constant<int, 1 - P>(), 1 - P);
+        // desired order: fragments, then one prefetch load per MFMA, then the conversion VALU + LDS writes of the
+        // next stage spread under the remaining MFMAs (the wave never queues up 12 loads at once, and the ~60 VALU
+        // of the split are hidden instead of following the MFMAs)
+        __builtin_amdgcn_sched_group_barrier(SG_DS_RD, 4 * (MI + NI), 0);
+#pragma unroll
+        for (int i = 0; i < AP + BP; ++i) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);
         }
-        if (!(ablate & 4)) swrite(std::integral_constant<int, 1 - P>(), 1 - P);
+#pragma unroll
+        for (int i = 0; i < NMFMA - (AP + BP); ++i) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VALU, (14 * AP + NMFMA - (AP + BP) - 1) / (NMFMA - (AP + BP)), 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DS_WR, 1, 0);
+        }
+        if (fill) *(f32x4*)(&Et[ci & 1][tid < BN / 4 ? 0 : 1][4 * (tid < BN / 4 ? tid : tid - BN / 4)]) = ec;
+        PWS_STAMP(1);
         __syncthreads();
+        PWS_STAMP(3);
+        advance_prefetch();
         if (++ckt == KT) {
-            // C/D map of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
-            // Full tiles store unconditionally (a per-store bounds branch costs an s_waitcnt vmcnt(0) per store).
-            const bool full_tile = m0 + BM <= M;
-            if (ablate & 2) {   // timing-only ablation: keep the accumulators live, skip the stores
-                float live = 0.f;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) live += acc[mi][ni][r];
-                if (live == 1.2345e-30f) y[0] = live;
-            } else
+            const float* et = &Et[ci & 1][0][0];
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + m0 * Cout + n0, ((M - m0) * Cout - n0) * 4ll);
+            unsigned char* scr = &smem[P][wave * 4096];       // stage P: every wave is past its last read (barrier above)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int col = n0 + wn * WN + ni * 32 + li;
-                const float ds = descale[col], sh = shift[col];
+                const int nl = wn * WN + ni * 32 + 4 * ech;
+                const f32x4 ds = *(const f32x4*)(et + nl), sh = *(const f32x4*)(et + BN + nl);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    const long long rbase = m0 + wm * WM + mi * 32 + 4 * lh;
-                    float* yp = y + rbase * Cout + col;
-                    if (full_tile) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            yp[(long long)((r & 3) + 8 * (r >> 2)) * Cout] = apply_act<ACT>(fmaf(acc[mi][ni][r], ds, sh));
-                    } else {
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int dr = (r & 3) + 8 * (r >> 2);
-                            if (rbase + dr < M) yp[(long long)dr * Cout] = apply_act<ACT>(fmaf(acc[mi][ni][r], ds, sh));
-                        }
+                        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
+                        *(f32x4*)(scr + li * 128 + 16 * ((2 * j + lh) ^ (li & 7))) = v;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = erow + 8 * i;
+                        const f32x4 v = *(const f32x4*)(scr + r * 128 + 16 * (ech ^ (r & 7)));
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(fmaf(v[e], ds[e], sh[e]));
+                        // rows beyond M fall outside the resource and are dropped by the hardware
+                        bstore16(o, ry, yvoff, (unsigned)(mi * 32 + 8 * i) * (unsigned)Cout * 4u + (unsigned)(ni * 32) * 4u);
                     }
                 }
             }
+            __syncthreads();   // the scratch is the stage the next step refills
             zero_acc();
             ckt = 0;
             ++ci;
-            tile_origin(ci < ntile ? ci : ntile - 1, m0, n0);
+            tile_origin(ci, m0, n0);
         }
     };
     for (unsigned g = 0; g < nsteps; g += 2) {
         step(S0());
+        PWS_STAMP(4);
         if (g + 1 >= nsteps) break;
         step(S1());
+        PWS_STAMP(4);
     }
+#ifdef HSEFR_PWS_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = g_pws_stamps + (blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = st[i];
+        o[6] = __builtin_amdgcn_s_memtime() - tstart;
+        o[7] = nsteps;
+    }
+#endif
 }
 
-struct TileCfg { int bm, bn, occ; };
+struct TileCfg { int bm, bn, occ; double eff; };
 
-TileCfg choose_tile(long long m, int cout, int forced) {
-    const TileCfg cands[3] = {{128, 128, 2}, {128, 64, 3}, {64, 64, 3}};
-    const double eff[3] = {1.00, 0.90, 0.75};   // bigger tiles move fewer L2->LDS bytes per MFMA
-    if (forced >= 0 && forced < 3 && cout % cands[forced].bn == 0) return cands[forced];
+// Candidate tiles and their relative speed per output element (measured, tools/kbench.py pws: bigger tiles move fewer
+// L2->LDS bytes per MFMA).  Resident workgroups per CU: LDS 64/48/32 KB and the launch bounds below.
+const TileCfg kCands[3] = {{128, 128, 2, 1.00}, {128, 64, 3, 0.77}, {64, 64, 3, 0.60}};
+
+// Persistent workgroups deal the tiles out in rounds of 256 CUs x occ.  A partly empty last round does not cost a whole
+// tile time: the workgroups that finish early leave their CU to the stragglers, which then run faster (measured on
+// 36864x512x512: 2.25 rounds of 128x128 beat 3.0 rounds of 128x64; on 9216x1024x1024 1.125 rounds beat 1.5).
+int choose_tile(long long m, int cout, int forced) {
     int best = -1;
     double best_cost = 0;
     for (int i = 0; i < 3; ++i) {
-        if (cout % cands[i].bn) continue;
-        const long long tiles = ((m + cands[i].bm - 1) / cands[i].bm) * (cout / cands[i].bn);
-        const long long slots = 256ll * cands[i].occ;
-        const long long rounds = (tiles + slots - 1) / slots;
-        const double cost = (double)rounds * cands[i].occ * cands[i].bm * cands[i].bn / eff[i];
+        const TileCfg& c = kCands[i];
+        if (cout % c.bn || (forced >= 0 && forced != i)) continue;
+        const double rounds = (double)(((m + c.bm - 1) / c.bm) * (cout / c.bn)) / (256.0 * c.occ);
+        const double up = (double)(long long)(rounds + 0.999999);
+        const double makespan = rounds <= 1.0 ? 1.0 : up - 0.35 * (up - rounds);
+        const double cost = makespan * c.occ * c.bm * c.bn / c.eff;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
     }
-    return cands[best];
+    return best;
 }
 
-int g_ablate = 0;        // timing-only ablations (results WRONG): 1 = no global loads, 2 = no stores, 4 = no LDS staging writes
 int g_forced_tile = -1;  // tuning/debug only (hsefr_debug_set "pws_tile"): 0 = 128x128, 1 = 128x64, 2 = 64x64
 
-template <int BM, int BN, int OCC>
+template <int BM, int BN, int WAVES_N, int OCC>
 int launch_cfg(const float* x, const void* wsplit, const float* descale, const float* shift, float* y, long long m, int k,
                int cout, float a_scale, int act, hipStream_t s) {
     const long long tiles_m = (m + BM - 1) / BM;
@@ -256,10 +345,10 @@ int launch_cfg(const float* x, const void* wsplit, const float* descale, const f
     const long long total = tiles_m * tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_f16split: too many tiles");
     const long long g = total < 256ll * OCC ? total : 256ll * OCC;
-    dim3 grid((unsigned)g), block(256);
+    dim3 grid((unsigned)g), block(128 * WAVES_N);
 #define HSEFR_PWS_LAUNCH(A)                                                                                         \
-    hipLaunchKernelGGL((pwconv_f16s_kernel<BM, BN, OCC, A>), grid, block, 0, s, x, (const float*)wsplit, descale, shift, \
-                       y, m, k, cout, a_scale, tiles_n, (unsigned)total, g_ablate)
+    hipLaunchKernelGGL((pwconv_f16s_kernel<BM, BN, WAVES_N, OCC, A>), grid, block, 0, s, x, (const float*)wsplit, descale, shift, \
+                       y, m, k, cout, a_scale, tiles_n, (unsigned)total)
     if (act == HSEFR_ACT_RELU6) HSEFR_PWS_LAUNCH(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_PWS_LAUNCH(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_PWS_LAUNCH(HSEFR_ACT_NONE);
@@ -271,7 +360,18 @@ int launch_cfg(const float* x, const void* wsplit, const float* descale, const f
 }  // namespace
 
 void set_pws_tile(int v) { g_forced_tile = v; }
-void set_pws_ablate(int v) { g_ablate = v; }
+
+int read_pws_stamps(void* host_out, size_t bytes) {
+#ifdef HSEFR_PWS_STAMPS
+    HSEFR_REQUIRE(bytes <= sizeof(unsigned long long) * 1024 * 8 * 8, HSEFR_ERR_INVALID, "read_pws_stamps: too many bytes");
+    HSEFR_HIP_CHECK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pws_stamps), bytes));
+    return HSEFR_OK;
+#else
+    (void)host_out; (void)bytes;
+    set_error("read_pws_stamps: library built without -DHSEFR_PWS_STAMPS");
+    return HSEFR_ERR_UNSUPPORTED;
+#endif
+}
 
 int launch_pwconv_f16s(const float* x, const void* wsplit, const float* descale, const float* shift, float* y,
                        long long m, int k, int cout, int a_log2, int act, hipStream_t s) {
@@ -281,10 +381,13 @@ int launch_pwconv_f16s(const float* x, const void* wsplit, const float* descale,
     HSEFR_REQUIRE(m >= 0, HSEFR_ERR_INVALID, "pwconv_f16split: m=%lld", m);
     if (m == 0) return HSEFR_OK;
     const float a_scale = ldexpf(1.f, a_log2);
-    const TileCfg c = choose_tile(m, cout, g_forced_tile);
-    if (c.bm == 128 && c.bn == 128) return launch_cfg<128, 128, 2>(x, wsplit, descale, shift, y, m, k, cout, a_scale, act, s);
-    if (c.bm == 128 && c.bn == 64) return launch_cfg<128, 64, 3>(x, wsplit, descale, shift, y, m, k, cout, a_scale, act, s);
-    return launch_cfg<64, 64, 3>(x, wsplit, descale, shift, y, m, k, cout, a_scale, act, s);
+    switch (choose_tile(m, cout, g_forced_tile)) {
+        case 0: return launch_cfg<128, 128, 2, 2>(x, wsplit, descale, shift, y, m, k, cout, a_scale, act, s);
+        case 1: return launch_cfg<128, 64, 2, 3>(x, wsplit, descale, shift, y, m, k, cout, a_scale, act, s);
+        case 2: return launch_cfg<64, 64, 2, 3>(x, wsplit, descale, shift, y, m, k, cout, a_scale, act, s);
+    }
+    set_error("pwconv_f16split: no tile configuration for cout=%d", cout);
+    return HSEFR_ERR_UNSUPPORTED;
 }
 
 }  // namespace hsefr

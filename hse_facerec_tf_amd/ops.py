@@ -93,6 +93,23 @@ def pwconv1x1_f16split(x, w_t, shift, act: int = ACT_RELU6, a_log2: int = 12, pr
     return y
 
 
+def dwpw_f16split(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
+    """One MobileNet block in one kernel, any c % 32 == 0 / cout % 64 == 0: depthwise 3x3 SAME + scale + shift + ReLU6 ->
+    pointwise 1x1 + shift + act with split-f16 products (csrc/dwpw_f16s.hip).  wp_t [cout, c] fp32 is split on the host."""
+    torch = _lib.require_gpu()
+    for t, nm in ((x, "x"), (w_hwc, "w"), (dscale, "dscale"), (dshift, "dshift"), (pshift, "pshift")):
+        _f32c(t, nm)
+    d_img, d_ds = prepared if prepared is not None else split_weights_device(wp_t, x.device, a_log2)
+    n, h, w, c = x.shape
+    cout = d_img.shape[0]
+    oh, ow, pt, pl = _same(h, w, 3, stride)
+    y = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_dwpw_f16split(x.data_ptr(), w_hwc.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), d_img.data_ptr(),
+                                              d_ds.data_ptr(), pshift.data_ptr(), y.data_ptr(), n, h, w, c, stride, pt, pl, oh, ow,
+                                              cout, a_log2, act, _lib.current_stream_ptr()), "hsefr_dwpw_f16split")
+    return y
+
+
 def dwpw_fused(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1):
     """One early MobileNet block in one kernel: depthwise 3x3 SAME + scale + shift + ReLU6 -> pointwise 1x1 + shift +
     ReLU6 (graph nodes #35-#49).  c in {32, 64}, cout in {64, 128}; wp_t is the pointwise kernel transposed [cout, c]."""

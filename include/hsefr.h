@@ -74,6 +74,9 @@ int hsefr_debug_set(const char* key, int value);
 int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_t stream);
 /* Calibration: dense fp32-MFMA loop on `blocks` workgroups; d_out[3*b] = shader-clock ticks, d_out[3*b+1] = 100 MHz
  * ticks of workgroup b (clock under fp32-matrix load = ratio * 100 MHz; 4*iters MFMAs of 4096 FLOP per wave). */
+/* Diagnostic builds only (-DHSEFR_PWS_STAMPS): per-wave phase cycle sums of the last split-f16 GEMM launch;
+ * HSEFR_ERR_UNSUPPORTED in the shipped library. */
+int hsefr_debug_read_stamps(void* host_out, size_t bytes);
 int hsefr_debug_clock_probe(unsigned long long* d_out, int blocks, int iters, hsefr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------ */
@@ -100,9 +103,13 @@ typedef enum hsefr_op_kind {
     HSEFR_OP_STEM7X7_BF16 = 10,/* 7x7/2 pad-3 conv over the fp32 3-channel image -> 64 ch bf16 (+scale+shift+ReLU) */
     HSEFR_OP_DWPW_F32 = 11,    /* fused depthwise 3x3 (+scale+shift+ReLU6) -> pointwise 1x1 (+shift+ReLU6), cin 32|64,
                                   cout 64|128: the depthwise result never leaves the CU                            */
-    HSEFR_OP_PWCONV_F16S = 12  /* 1x1 conv + shift + act, fp32 in/out, products on the f16 MFMA from a two-term split of
+    HSEFR_OP_PWCONV_F16S = 12, /* 1x1 conv + shift + act, fp32 in/out, products on the f16 MFMA from a two-term split of
                                   both operands (fp32-grade, csrc/pwconv_f16s.hip); input bounded: |x| * 2^a_log2 < 32768.
                                   w_off = split rows, scale_off = descale, shift_off = shift, `reserved` = a_log2   */
+    HSEFR_OP_DWPW_F16S = 13    /* fused depthwise 3x3 (+scale+shift+ReLU6) -> pointwise 1x1 (+shift+act) for any cin % 32,
+                                  cout % 64, pointwise products as in PWCONV_F16S (csrc/dwpw_f16s.hip).  w_off/scale_off/
+                                  shift_off = depthwise; w2_off = split rows; shift2_off = [2][cout]: descale, then shift;
+                                  `reserved` = a_log2 (the depthwise result is in [0,6]: 12)                         */
 } hsefr_op_kind;
 
 typedef enum hsefr_output_slot {
@@ -141,8 +148,8 @@ typedef struct hsefr_plan_op {
     uint64_t w_off;     /* weights; layout depends on kind (see the per-kernel entry points) */
     uint64_t scale_off; /* per-channel scale (DWCONV), descale (PWCONV_F16S)                 */
     uint64_t shift_off; /* per-channel shift / bias                                          */
-    uint64_t w2_off;     /* DWPW_F32: pointwise kernel, transposed [cout][cin]                */
-    uint64_t shift2_off; /* DWPW_F32: pointwise shift [cout]                                  */
+    uint64_t w2_off;     /* DWPW_F32: pointwise kernel, transposed [cout][cin]; DWPW_F16S: split rows */
+    uint64_t shift2_off; /* DWPW_F32: pointwise shift [cout]; DWPW_F16S: [2][cout] descale, shift */
 } hsefr_plan_op;
 
 /* ------------------------------------------------------------------------------------ */
@@ -213,6 +220,14 @@ int hsefr_pwconv1x1_bias_relu6(const float* x, const float* wgt_t, const float* 
  * descale[n] = 2^-(e_n + a_log2).  y = act(acc * descale + shift).  k multiple of 32, cout multiple of 64. */
 int hsefr_pwconv1x1_f16split(const float* x, const void* w_split, const float* descale, const float* shift, float* y,
                              long long m, int k, int cout, int a_log2, int act, hsefr_stream_t stream);
+
+/* One whole MobileNet block (graph nodes #35-#49 and their later twins) fused, for any c % 32 == 0 and cout % 64 == 0:
+ * depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6 -> pointwise 1x1 + shift + act with split-f16 products.
+ * x [n,h,w,c], wd [3,3,c], w_split / descale as for hsefr_pwconv1x1_f16split (a_log2 in 1..12: the depthwise result is
+ * in [0,6]), y [n,oh,ow,cout]. */
+int hsefr_dwpw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,
+                        const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride,
+                        int pad_t, int pad_l, int oh, int ow, int cout, int a_log2, int act, hsefr_stream_t stream);
 
 /* One whole early MobileNet block (graph nodes #35-#49) fused: depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6
  * -> pointwise 1x1 + shift + ReLU6.  x [n,h,w,c], wd [3,3,c], wp_t [cout,c] (TF kernel transposed), y [n,oh,ow,cout];

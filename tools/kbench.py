@@ -159,7 +159,7 @@ def bench_pwd():
 
 def bench_pws():
     print("split-f16 GEMM vs fp32-MFMA GEMM, batch %d: us median; error = max|y - y64| / max|y64| on the first 4096 rows" % B)
-    print("%-22s %9s | %9s %9s %9s %9s | %8s %8s" % ("M x K x N", "f32 auto", "f16s auto", "128x128", "128x64", "64x64", "err f32", "err f16s"))
+    print("%-22s %9s | %9s %9s %9s %9s %9s | %8s %8s" % ("M x K x N", "f32 auto", "f16s auto", "128x128", "128x64", "64x64", "-", "err f32", "err f16s"))
     g = torch.Generator(device="cuda").manual_seed(0)
     tot = [0.0, 0.0]
     for hw, k, n in PW:
@@ -172,8 +172,8 @@ def bench_pws():
         prep = ops.split_weights_device(w, x.device)
         r32 = timeit(lambda: ops.pwconv1x1(x, w, sh))[0]
         res = []
-        for tile in (-1, 0, 1, 2):
-            if tile == 0 and n % 128:
+        for tile in (-1, 0, 1, 2, 3):
+            if (tile == 0 and n % 128) or tile == 3:
                 res.append(float("nan"))
                 continue
             _lib.lib().hsefr_debug_set(b"pws_tile", tile)
@@ -186,28 +186,76 @@ def bench_pws():
         tot[0] += r32 * mult
         tot[1] += np.nanmin(res) * mult
         by = 4.0 * (m * k + m * n + k * n)
-        print("%-22s %9.1f | %9.1f %9.1f %9.1f %9.1f | %8.1e %8.1e  best %5.0f GB/s" % ("%dx%dx%d" % (m, k, n), r32, *res, e32, e16, by / np.nanmin(res) / 1e3))
+        print("%-22s %9.1f | %9.1f %9.1f %9.1f %9.1f %9.1f | %8.1e %8.1e  best %5.0f GB/s" % ("%dx%dx%d" % (m, k, n), r32, *res, e32, e16, by / np.nanmin(res) / 1e3))
     print("sum over the 13 pointwise layers: f32 %.1f us, split-f16 (best tile) %.1f us" % tuple(tot))
 
 
-def bench_pwsa():
-    print("split-f16 GEMM ablations (timing only), us median; columns: real / -gload / -store / -gload-store / -swrite / -gload-swrite / none of the three")
+BLOCKS = [(96, 32, 64, 1), (96, 64, 128, 2), (48, 128, 128, 1), (48, 128, 256, 2), (24, 256, 256, 1), (24, 256, 512, 2),
+          (12, 512, 512, 1), (12, 512, 1024, 2), (6, 1024, 1024, 1)]
+
+
+def bench_blk():
+    """One MobileNet block three ways: depthwise kernel + split-f16 GEMM, the fp32 fused kernel (C <= 64), the split-f16 fused kernel."""
+    print("block (in hw, c -> cout, stride), batch %d: us median | unfused dw + pw(f16s) | fused fp32 | fused f16s: auto, tw8, tw16, bn64, bn256 | err" % B)
     g = torch.Generator(device="cuda").manual_seed(0)
-    for tile in (0, 1):
-        for hw, k, n in PW[2:]:
-            m = B * hw * hw
-            x = torch.rand((m, k), device="cuda", generator=g) * 6
-            w = torch.randn((n, k), device="cuda", generator=g) / k ** 0.5
-            sh = torch.randn((n,), device="cuda", generator=g)
-            prep = ops.split_weights_device(w, x.device)
-            _lib.lib().hsefr_debug_set(b"pws_tile", tile)
-            res = []
-            for ab in (0, 1, 2, 3, 4, 5, 7):
-                _lib.lib().hsefr_debug_set(b"pws_ablate", ab)
-                res.append(timeit(lambda: ops.pwconv1x1_f16split(x, None, sh, prepared=prep))[0])
-            _lib.lib().hsefr_debug_set(b"pws_ablate", 0)
-            _lib.lib().hsefr_debug_set(b"pws_tile", -1)
-            print("tile %d %-22s" % (tile, "%dx%dx%d" % (m, k, n)) + "".join("%9.1f" % r for r in res))
+    tot = [0.0, 0.0]
+    for hw, c, n, s in BLOCKS:
+        x = torch.rand((B, hw, hw, c), device="cuda", generator=g) * 6
+        wd = torch.randn((3, 3, c), device="cuda", generator=g) / 3
+        dsc = torch.rand((c,), device="cuda", generator=g) + 0.5
+        dsh = torch.randn((c,), device="cuda", generator=g) * 0.3
+        w = torch.randn((n, c), device="cuda", generator=g) / c ** 0.5
+        sh = torch.randn((n,), device="cuda", generator=g)
+        prep = ops.split_weights_device(w, x.device)
+        t_dw = timeit(lambda: ops.dwconv3x3(x, wd, dsc, dsh, s))[0]
+        mid = ops.dwconv3x3(x, wd, dsc, dsh, s)
+        t_pw = timeit(lambda: ops.pwconv1x1_f16split(mid, None, sh, prepared=prep))[0]
+        ref = ops.pwconv1x1_f16split(mid, None, sh, prepared=prep)
+        t_f32 = float("nan")
+        if c <= 64:
+            t_f32 = timeit(lambda: ops.dwpw_fused(x, wd, dsc, dsh, w, sh, s))[0]
+        res = []
+        for key, val in ((b"dwpws_tw", 0), (b"dwpws_tw", 8), (b"dwpws_tw", 16), (b"dwpws_bn", 64), (b"dwpws_bn", 256)):
+            _lib.lib().hsefr_debug_set(key, val)
+            try:
+                res.append(timeit(lambda: ops.dwpw_f16split(x, wd, dsc, dsh, None, sh, s, prepared=prep))[0])
+            except Exception:
+                res.append(float("nan"))
+            _lib.lib().hsefr_debug_set(key, 0)
+        y = ops.dwpw_f16split(x, wd, dsc, dsh, None, sh, s, prepared=prep)
+        err = float((y - ref).abs().max() / ref.abs().max())
+        mult = 5 if (hw, c, n) == (12, 512, 512) else 1
+        tot[0] += (t_dw + t_pw) * mult
+        tot[1] += min(t_dw + t_pw, np.nanmin(res)) * mult
+        by = 4.0 * B * (hw * hw * c + (hw // s) ** 2 * n)
+        print("%3d c%-4d->%-4d s%d | %7.1f + %7.1f = %7.1f | %7.1f | " % (hw, c, n, s, t_dw, t_pw, t_dw + t_pw, t_f32) +
+              " ".join("%7.1f" % r for r in res) + " | %.1e  best fused %5.0f GB/s" % (err, by / np.nanmin(res) / 1e3))
+    print("sum over the 13 blocks: unfused %.1f us, best-of per block %.1f us" % tuple(tot))
+
+
+def bench_stamps():
+    """Diagnostic build only (libhsefr built with -DHSEFR_PWS_STAMPS): where a split-f16 GEMM wave spends its cycles."""
+    import ctypes
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for hw, k, n in ((12, 512, 512), (48, 128, 128), (6, 1024, 1024)):
+        m = B * hw * hw
+        x = torch.rand((m, k), device="cuda", generator=g) * 6
+        w = torch.randn((n, k), device="cuda", generator=g) / k ** 0.5
+        sh = torch.randn((n,), device="cuda", generator=g)
+        prep = ops.split_weights_device(w, x.device)
+        for _ in range(5):
+            ops.pwconv1x1_f16split(x, None, sh, prepared=prep)
+        torch.cuda.synchronize()
+        buf = np.zeros((1024, 8, 8), np.uint64)
+        _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        used = buf[:, :, 7] > 0
+        b = buf[used].astype(np.float64)
+        names = ["gload issue", "ds_read+mfma issue", "wait+convert+ds_write", "barrier", "epilogue/loop", "step top"]
+        tot = b[:, 6]
+        print("%dx%dx%d: %d waves, lifetime cycles mean %.0f min %.0f max %.0f, steps/wave mean %.1f" %
+              (m, k, n, len(b), tot.mean(), tot.min(), tot.max(), b[:, 7].mean()))
+        for i, nm in enumerate(names):
+            print("   %-24s %6.1f %% of lifetime, %7.0f cycles per step" % (nm, 100 * (b[:, i] / tot).mean(), (b[:, i] / b[:, 7]).mean()))
 
 
 def bench_pwa():
@@ -231,8 +279,10 @@ def bench_pwa():
 
 def bench_clock():
     """Shader clock and fp32-MFMA rate the chip sustains with every SIMD issuing MFMAs back to back."""
-    for blocks, label in ((256, "1 wave/SIMD"), (512, "2 waves/SIMD"), (768, "3 waves/SIMD")):
-        iters = 200000
+    for mode, blocks, label in ((0, 256, "fp32 1 wave/SIMD"), (0, 512, "fp32 2 waves/SIMD"), (0, 768, "fp32 3 waves/SIMD"),
+                                (1, 256, "f16 1 wave/SIMD"), (1, 512, "f16 2 waves/SIMD"), (1, 768, "f16 3 waves/SIMD")):
+        _lib.lib().hsefr_debug_set(b"clock_mode", mode)
+        iters = 200000 if mode == 0 else 400000
         out = torch.zeros((blocks * 3,), dtype=torch.int64, device="cuda")
         for _ in range(2):
             _lib.check(_lib.lib().hsefr_debug_clock_probe(out.data_ptr(), blocks, iters, _lib.current_stream_ptr()))
@@ -245,12 +295,13 @@ def bench_clock():
         o = out.cpu().numpy().reshape(blocks, 3)
         clk = np.median(o[:, 0] / o[:, 1]) * 100e6
         ms = ev0.elapsed_time(ev1)
-        tf = blocks * 4 * iters * 4 * 4096.0 / (ms * 1e-3) / 1e12
-        print("clock probe %-13s: shader clock %.3f GHz (min %.3f max %.3f), %.2f ms, %.1f TFLOP/s fp32 MFMA" %
+        tf = blocks * 4 * iters * 4 * (4096.0 if mode == 0 else 32768.0) / (ms * 1e-3) / 1e12
+        print("clock probe %-18s: shader clock %.3f GHz (min %.3f max %.3f), %.2f ms, %.1f TFLOP/s MFMA" %
               (label, clk / 1e9, (o[:, 0] / o[:, 1]).min() / 10, (o[:, 0] / o[:, 1]).max() / 10, ms, tf))
+    _lib.lib().hsefr_debug_set(b"clock_mode", 0)
 
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["pw", "dw", "c3"]
     for w in what:
-        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd, "pws": bench_pws, "pwsa": bench_pwsa}[w]()
+        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd, "pws": bench_pws, "blk": bench_blk, "stamps": bench_stamps}[w]()
