@@ -68,6 +68,17 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + idx;
 }
 
+// Sweep direction.  Every kernel walks its output (and so its input) in one address order; consecutive layers sweep in
+// OPPOSITE orders, so that a layer starts on the bytes its producer wrote last -- the ones still in the 256 MiB
+// Infinity Cache -- instead of chasing an LRU that evicts every line just before it is needed (a 302 MB activation
+// swept twice in the same order never hits).  Set by the engine per op (op index parity); 0 for direct ABI calls.
+__device__ __forceinline__ unsigned xcd_remap_dir(unsigned bid, unsigned nwg, int reverse) {
+    const unsigned lt = xcd_remap(bid, nwg);
+    return reverse ? nwg - 1u - lt : lt;
+}
+int sweep_reverse();
+void set_sweep_reverse(int v);
+
 // --- launchers implemented in the .hip files (same ones the engine calls) -------------
 int launch_conv_c3(const float* x, const float* wgt, const float* shift, float* y, int n, int h, int w,
                    int kh, int kw, int stride, int pad_t, int pad_l, int oh, int ow, int cout, int act,

@@ -34,6 +34,7 @@ struct DwParams {
     float4* y;
     int H, W, C4, OH, OW, pad_t, pad_l, TH, tiles_h, tiles_x;
     unsigned nwg;
+    int reverse;  // sweep direction (common.h)
     int variant;  // 0 = real kernel; timing-only ablations: 1 = one load per row, 2 = no stores
 };
 
@@ -53,7 +54,7 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 
 template <int STRIDE, int ACT, int NT>
 __global__ __launch_bounds__(256, 4) void dwconv3x3_kernel(DwParams p) {
-    const unsigned bid = xcd_remap(blockIdx.x, p.nwg);
+    const unsigned bid = xcd_remap_dir(blockIdx.x, p.nwg, p.reverse);
     const int tx = bid % p.tiles_x;
     const int th = (bid / p.tiles_x) % p.tiles_h;
     const int n = bid / (p.tiles_x * p.tiles_h);
@@ -164,6 +165,7 @@ int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const
     p.x = (const float4*)x; p.w = (const float4*)wgt; p.scale = (const float4*)scale;
     p.shift = (const float4*)shift; p.y = (float4*)y;
     p.variant = g_dw_variant;
+    p.reverse = sweep_reverse();
     p.H = h; p.W = w; p.C4 = c / 4; p.OH = oh; p.OW = ow; p.pad_t = pad_t; p.pad_l = pad_l;
     p.tiles_x = (ow * p.C4 + 255) / 256;
     // Strip height: tall strips amortise the 2-row halo, short ones balance the CUs.

@@ -45,6 +45,7 @@ struct DwPwSParams {
     int H, W, C4, KT, OH, OW, Cout, pad_t, pad_l, tiles_w, tiles_h, tiles_n;
     unsigned total;        // N * tiles_h * tiles_w * tiles_n work items
     float a_scale;         // 2^a_log2
+    int reverse;           // sweep direction (common.h)
 };
 
 constexpr int ROWB = 128;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_f16s_kernel(DwPwSParams p) {
     const int arow = wm * 64 + li, brow = wn * WN + li;
 
     for (unsigned t = blockIdx.x; t < p.total; t += gridDim.x) {
-        const unsigned lt = xcd_remap(t, p.total);
+        const unsigned lt = xcd_remap_dir(t, p.total, p.reverse);
         const int n0 = (lt % p.tiles_n) * BN;
         const unsigned pt = lt / p.tiles_n;
         const int ow0 = (pt % p.tiles_w) * TW;
@@ -277,6 +278,7 @@ int launch_dwpw_f16s(const float* x, const float* wd, const float* dscale, const
     p.wsplit = (const float*)wsplit; p.descale = descale; p.pshift = pshift; p.y = y;
     p.H = h; p.W = w; p.C4 = c / 4; p.KT = c / 32; p.OH = oh; p.OW = ow; p.Cout = cout; p.pad_t = pad_t; p.pad_l = pad_l;
     p.a_scale = ldexpf(1.f, a_log2);
+    p.reverse = sweep_reverse();
     // N tile: 128 output channels (64 accumulator registers; the 256 variant spills); wider layers redo the depthwise
     // work once per N tile, the tiles of one patch running side by side on one XCD so that the re-read hits its L2
     int bn = cout % 128 == 0 ? 128 : 64;

@@ -34,6 +34,7 @@ struct DwPwParams {
     float* y;              // [N,OH,OW,Cout]
     int H, W, OH, OW, pad_t, pad_l, tiles_w, tiles_h;
     unsigned total;        // N * tiles_h * tiles_w patches
+    int reverse;           // sweep direction (common.h)
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 32 + 4 * (chunk ^ ((row >> 1) & 7)); }
@@ -173,7 +174,7 @@ __device__ __forceinline__ void mfma_phase(const DwPwParams& p, const float (*As
 }
 
 __device__ __forceinline__ void decode_patch(const DwPwParams& p, unsigned t, int& n, int& oh0, int& ow0) {
-    const unsigned lt = xcd_remap(t, p.total);
+    const unsigned lt = xcd_remap_dir(t, p.total, p.reverse);
     ow0 = (lt % p.tiles_w) * 16;
     oh0 = ((lt / p.tiles_w) % p.tiles_h) * 8;
     n = lt / (p.tiles_w * p.tiles_h);
@@ -290,6 +291,7 @@ int launch_dwpw_fused(const float* x, const float* wd, const float* dscale, cons
     const long long total = (long long)n * p.tiles_w * p.tiles_h;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "dwpw_fused: grid too large");
     p.total = (unsigned)total;
+    p.reverse = sweep_reverse();
 #define HSEFR_DWPW(S, CC, NN, O) return launch_t<S, CC, NN, O>(p, s)
     if (stride == 1) {
         if (c == 32 && cout == 64) HSEFR_DWPW(1, 32, 64, 4);

@@ -115,6 +115,13 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
     return HSEFR_OK;
 }
 
+namespace hsefr {
+static int g_sweep_reverse = 0;
+int sweep_reverse() { return g_sweep_reverse; }
+void set_sweep_reverse(int v) { g_sweep_reverse = v; }
+}  // namespace hsefr
+static int g_sweep_alternate = 1;   // hsefr_debug_set "sweep_alternate" 0 turns the alternation off (A/B timing)
+
 extern "C" {
 
 int hsefr_version(void) { return HSEFR_VERSION; }
@@ -125,6 +132,7 @@ int hsefr_debug_set(const char* key, int value) {
     HSEFR_REQUIRE(key, HSEFR_ERR_INVALID, "debug_set: null key");
     if (!strcmp(key, "pw_tile")) { set_pw_tile(value); return HSEFR_OK; }
     if (!strcmp(key, "pws_tile")) { set_pws_tile(value); return HSEFR_OK; }
+    if (!strcmp(key, "sweep_alternate")) { g_sweep_alternate = value; return HSEFR_OK; }
     if (!strcmp(key, "clock_mode")) { set_clock_mode(value); return HSEFR_OK; }
     if (!strcmp(key, "dwpws_tw")) { set_dwpws_tw(value); return HSEFR_OK; }
     if (!strcmp(key, "dwpws_bn")) { set_dwpws_bn(value); return HSEFR_OK; }
@@ -276,6 +284,7 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
         const void* in = buf_ptr(e, o.in_buf, d_input);
         void* out = buf_ptr(e, o.out_buf, d_input);
         int rc = HSEFR_OK;
+        set_sweep_reverse(g_sweep_alternate ? (int)(i & 1) : 0);   // consecutive layers sweep in opposite directions (common.h)
         switch (o.kind) {
             case HSEFR_OP_CONV_C3:
                 rc = launch_conv_c3((const float*)in, (const float*)blob_ptr(e, o.w_off),
@@ -344,6 +353,7 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
         if (rc != HSEFR_OK) return rc;
         if (prof) HSEFR_HIP_CHECK(hipEventRecord(pev[i + 1], s));
     }
+    set_sweep_reverse(0);
     for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl) {
         if (!outs[sl]) continue;
         const int b = e->hdr.out_buffer[sl];

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(128 * WAVES_N, OCC) void pwconv_f16s_kernel(const f
                                                                const float* __restrict__ descale,
                                                                const float* __restrict__ shift, float* __restrict__ y,
                                                                long long M, int K, int Cout, float a_scale,
-                                                               unsigned tiles_n, unsigned total_tiles) {
+                                                               unsigned tiles_n, unsigned total_tiles, int reverse) {
     constexpr int NT = 128 * WAVES_N;                 // threads: 2 x WAVES_N waves
     constexpr int WM = BM / 2, WN = BN / WAVES_N;     // wave tile
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(128 * WAVES_N, OCC) void pwconv_f16s_kernel(const f
     const unsigned voff = (unsigned)srow * rowbytes + 16u * skq;     // this thread's 16 B of a staged 8-row group
 
     auto tile_origin = [&](unsigned i, long long& mm0, int& nn0) {
-        const unsigned lt = xcd_remap(blockIdx.x + (i < ntile ? i : ntile - 1) * gridDim.x, total_tiles);
+        const unsigned lt = xcd_remap_dir(blockIdx.x + (i < ntile ? i : ntile - 1) * gridDim.x, total_tiles, reverse);
         mm0 = (long long)(lt / tiles_n) * BM;
         nn0 = (lt % tiles_n) * BN;
     };
@@ -348,7 +348,7 @@ int launch_cfg(const float* x, const void* wsplit, const float* descale, const f
     dim3 grid((unsigned)g), block(128 * WAVES_N);
 #define HSEFR_PWS_LAUNCH(A)                                                                                         \
     hipLaunchKernelGGL((pwconv_f16s_kernel<BM, BN, WAVES_N, OCC, A>), grid, block, 0, s, x, (const float*)wsplit, descale, shift, \
-                       y, m, k, cout, a_scale, tiles_n, (unsigned)total)
+                       y, m, k, cout, a_scale, tiles_n, (unsigned)total, sweep_reverse())
     if (act == HSEFR_ACT_RELU6) HSEFR_PWS_LAUNCH(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_PWS_LAUNCH(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_PWS_LAUNCH(HSEFR_ACT_NONE);
