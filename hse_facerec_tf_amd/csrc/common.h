@@ -68,6 +68,23 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + idx;
 }
 
+typedef float hsefr_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hsefr_u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer resource over [p, p + bytes): loads beyond it return 0, stores beyond it are dropped -- that is how tail
+// tiles (rows >= M) are handled, with no clamping and no branches.  One VGPR byte offset per thread is constant for the
+// whole kernel; everything that changes (tile, staging pass, K-tile) is uniform and travels in the SGPR offset.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long long bytes) {
+    const unsigned n = bytes <= 0 ? 0u : (bytes > 0xffffffffll ? 0xffffffffu : (unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
+}
+__device__ __forceinline__ hsefr_f32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(hsefr_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore16(hsefr_f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hsefr_u32x4, v), r, voff, soff, 0);
+}
+
 // Sweep direction.  Every kernel walks its output (and so its input) in one address order; consecutive layers sweep in
 // OPPOSITE orders, so that a layer starts on the bytes its producer wrote last -- the ones still in the 256 MiB
 // Infinity Cache -- instead of chasing an LRU that evicts every line just before it is needed (a 302 MB activation
@@ -129,12 +146,17 @@ int launch_dwpw_f16s(const float* x, const float* wd, const float* dscale, const
                      const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride, int pad_t,
                      int pad_l, int oh, int ow, int cout, int a_log2, int act, hipStream_t s);
 bool dwpw_f16s_supported(int c, int cout, int stride);
+int launch_stem_fused(const float* x, const float* cw, const float* cshift, const float* wd, const float* dscale,
+                      const float* dshift, const void* wsplit, const float* descale, const float* pshift, float* y, int n,
+                      int h, int w, int cpad_t, int cpad_l, int oh, int ow, int a_log2, int act, hipStream_t s);
+bool stem_fused_supported(int cin, int cmid, int cout, int conv_stride, int dw_stride, int kh, int kw);
 void set_dwpws_tw(int v);
 void set_dwpws_bn(int v);
 void set_dwpw_impl(int v);
 void set_pw_tile(int v);
 void set_pws_tile(int v);
 int read_pws_stamps(void* host_out, size_t bytes);
+int read_stem_stamps(void* host_out, size_t bytes);
 void set_pw_ablate(int v);
 void set_pw_dma(int v);
 void set_dw_th(int v);

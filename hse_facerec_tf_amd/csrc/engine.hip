@@ -93,6 +93,12 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                                   o.reserved > 0 && o.reserved <= 24,
                               HSEFR_ERR_INVALID, "plan op %u: split-f16 pointwise needs split rows, descale, shift and a_log2 in (0, 24]", i);
                 break;
+            case HSEFR_OP_STEM_F16S:
+                HSEFR_REQUIRE(stem_fused_supported(o.cin, 32, o.cout, o.stride, 1, o.kh, o.kw) && o.reserved > 0 && o.reserved <= 12 &&
+                                  o.w_off != HSEFR_NO_OFFSET && o.w2_off != HSEFR_NO_OFFSET && o.shift2_off != HSEFR_NO_OFFSET &&
+                                  o.w_off + 1248 * 4 <= h.blob_bytes && o.in_buf == HSEFR_BUF_INPUT + 0 * o.in_buf,
+                              HSEFR_ERR_UNSUPPORTED, "plan op %u: fused stem cin=%d cout=%d stride=%d not covered", i, o.cin, o.cout, o.stride);
+                break;
             case HSEFR_OP_DWPW_F16S:
                 HSEFR_REQUIRE(dwpw_f16s_supported(o.cin, o.cout, o.stride) && o.reserved > 0 && o.reserved <= 12 &&
                                   o.w_off != HSEFR_NO_OFFSET && o.scale_off != HSEFR_NO_OFFSET && o.shift_off != HSEFR_NO_OFFSET &&
@@ -338,6 +344,13 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
                                        (const float*)blob_ptr(e, o.shift2_off), (float*)out, n, o.h, o.w, o.cin, o.stride,
                                        o.pad_t, o.pad_l, o.oh, o.ow, o.cout, HSEFR_ACT_RELU6, o.act, s);
                 break;
+            case HSEFR_OP_STEM_F16S: {
+                const float* pk = (const float*)blob_ptr(e, o.w_off);
+                const float* ds2 = (const float*)blob_ptr(e, o.shift2_off);
+                rc = launch_stem_fused((const float*)in, pk, pk + 864, pk + 896, pk + 1184, pk + 1216, blob_ptr(e, o.w2_off), ds2,
+                                       ds2 + o.cout, (float*)out, n, o.h, o.w, o.pad_t, o.pad_l, o.oh, o.ow, o.reserved, o.act, s);
+                break;
+            }
             case HSEFR_OP_DWPW_F16S: {
                 const float* ds2 = (const float*)blob_ptr(e, o.shift2_off);
                 rc = launch_dwpw_f16s((const float*)in, (const float*)blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
@@ -379,7 +392,10 @@ int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_
     return launch_copy(d_src, d_dst, bytes, (hipStream_t)stream);
 }
 
-int hsefr_debug_read_stamps(void* host_out, size_t bytes) { return read_pws_stamps(host_out, bytes); }
+int hsefr_debug_read_stamps(void* host_out, size_t bytes) {
+    // the split-f16 GEMM's stamps, or (bytes == 512*4*10*8) the fused stem's
+    return bytes == 512 * 4 * 10 * 8 ? read_stem_stamps(host_out, bytes) : read_pws_stamps(host_out, bytes);
+}
 
 int hsefr_debug_clock_probe(unsigned long long* d_out, int blocks, int iters, hsefr_stream_t stream) {
     return launch_clock_probe(d_out, blocks, iters, (hipStream_t)stream);
@@ -410,6 +426,15 @@ int hsefr_pwconv1x1_f16split(const float* x, const void* w_split, const float* d
                              long long m, int k, int cout, int a_log2, int act, hsefr_stream_t stream) {
     HSEFR_REQUIRE(m == 0 || (x && w_split && descale && shift && y), HSEFR_ERR_INVALID, "pwconv_f16split: null pointer");
     return launch_pwconv_f16s(x, w_split, descale, shift, y, m, k, cout, a_log2, act, (hipStream_t)stream);
+}
+
+int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd, const float* dscale,
+                     const float* dshift, const void* w_split, const float* descale, const float* pshift, float* y, int n,
+                     int h, int w, int cpad_t, int cpad_l, int oh, int ow, int a_log2, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && conv_w && conv_shift && wd && dscale && dshift && w_split && descale && pshift && y),
+                  HSEFR_ERR_INVALID, "stem_fused: null pointer");
+    return launch_stem_fused(x, conv_w, conv_shift, wd, dscale, dshift, w_split, descale, pshift, y, n, h, w, cpad_t, cpad_l,
+                             oh, ow, a_log2, act, (hipStream_t)stream);
 }
 
 int hsefr_dwpw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,

@@ -55,22 +55,6 @@ constexpr int ROWB = 128;       // LDS bytes per tile row: 32 hi halves | 32 lo 
 // byte offset of 16-B chunk `chunk` of tile row `row`
 __device__ __forceinline__ int swzb(int row, int chunk) { return row * ROWB + 16 * (chunk ^ ((row >> 1) & 7)); }
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// Raw buffer resource over [p, p + bytes): loads beyond it return 0, stores beyond it are dropped -- that is how tail
-// tiles (rows >= M) are handled, with no clamping and no branches.  One VGPR byte offset per thread is constant for the
-// whole kernel; everything that changes (tile, staging pass, K-tile) is uniform and travels in the SGPR offset.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long long bytes) {
-    const unsigned n = bytes <= 0 ? 0u : (bytes > 0xffffffffll ? 0xffffffffu : (unsigned)bytes);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
-}
-__device__ __forceinline__ f32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void bstore16(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
-}
-
 // sched_group_barrier masks
 #define SG_VALU 0x002
 #define SG_MFMA 0x008

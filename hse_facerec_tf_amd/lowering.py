@@ -30,6 +30,8 @@ ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID = 0, 1, 2, 3
 OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_GAP, OP_DENSE, OP_SOFTMAX = 1, 2, 3, 4, 5, 6
 OP_CONV_BF16, OP_MAXPOOL_BF16, OP_GAP_BF16, OP_STEM7X7_BF16, OP_DWPW_F32 = 7, 8, 9, 10, 11
 OP_PWCONV_F16S = 12      # wire kind of a pointwise Layer whose a_log2 > 0 (the IR keeps OP_PWCONV_F32 + a_log2)
+OP_DWPW_F16S = 13        # fused block with split-f16 pointwise products for any channel count (csrc/dwpw_f16s.hip)
+OP_STEM_F16S = 14        # conv1 -> depthwise -> pointwise in one kernel (csrc/stem_fused.hip)
 _BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
 BUF_INPUT, BUF_NONE = -1, -2
@@ -137,6 +139,8 @@ class Layer:
     w2: Optional[np.ndarray] = None                    # DWPW_F32: the pointwise kernel [1,1,cin,cout]
     shift2: Optional[np.ndarray] = None                # DWPW_F32: the pointwise shift
     a_log2: int = 0                                    # PWCONV: > 0 = split-f16 products, input pre-scaled by 2^a_log2
+    w0: Optional[np.ndarray] = None                    # STEM_F16S: the first conv's kernel (HWIO) ...
+    shift0: Optional[np.ndarray] = None                # ... and its shift
     out_buf: int = BUF_NONE
 
     @property
@@ -179,13 +183,23 @@ class Plan:
             elif L.kind in (OP_DWCONV3X3, OP_DWPW_F32):
                 w = w.reshape(3, 3, -1)
             w2 = None if L.w2 is None else np.ascontiguousarray(L.w2.reshape(L.w2.shape[-2], L.w2.shape[-1]).T)
+            shift2 = L.shift2
+            if L.kind == OP_STEM_F16S:
+                # one fp32 pack [conv HWIO 864 | conv shift 32 | dw 3x3x32 288 | dw scale 32 | dw shift 32], split pointwise rows
+                w = np.concatenate([L.w0.reshape(-1), L.shift0.reshape(-1), L.w.reshape(-1), L.scale.reshape(-1),
+                                    L.shift.reshape(-1)]).astype(np.float32)
+                assert w.size == 1248
+                scale = None
+                w2, descale = split_pointwise_weights(w2, L.a_log2)
+                shift2 = np.concatenate([descale, L.shift2.astype(np.float32)])
+                aux = L.a_log2
             in_buf = BUF_INPUT if L.src < 0 else self.layers[L.src].out_buf
             res_buf = BUF_NONE if L.res < 0 else self.layers[L.res].out_buf
             h, wd, cin = L.in_shape
             oh, ow, cout = L.out_shape
             ops.append(_OP.pack(kind, L.act, in_buf, L.out_buf, res_buf, h, wd, cin, oh, ow, cout,
-                                L.kh, L.kw, L.stride, L.pad_t, L.pad_l, aux, put(w), put(scale), put(L.shift),
-                                put(w2), put(L.shift2)))
+                                L.kh, L.kw, L.stride, L.pad_t, L.pad_l, aux, put(w), put(scale),
+                                put(None if L.kind == OP_STEM_F16S else L.shift), put(w2), put(shift2)))
         while len(blob) % 16:
             blob.append(0)
         out_buf = [BUF_NONE] * 3
@@ -210,7 +224,7 @@ class Plan:
         tot = 0
         for L in self.layers:
             if kinds is None or L.kind in kinds:
-                for a in (L.w, L.scale, L.shift, L.w2, L.shift2):
+                for a in (L.w, L.scale, L.shift, L.w2, L.shift2, L.w0, L.shift0):
                     if a is not None:
                         tot += 4 * a.size
         return tot
@@ -227,6 +241,8 @@ class Plan:
                 tot += 2 * oh * ow * cout * 9
             elif L.kind == OP_DWPW_F32:
                 tot += 2 * oh * ow * L.in_shape[2] * 9 + 2 * oh * ow * cout * L.in_shape[2]
+            elif L.kind == OP_STEM_F16S:
+                tot += 2 * oh * ow * 32 * 27 + 2 * oh * ow * 32 * 9 + 2 * oh * ow * cout * 32
         return tot
 
 
@@ -690,6 +706,40 @@ def fuse_dwpw(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Di
     return new_layers, remap
 
 
+def fuse_stem(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
+    """conv 3x3/2 (3 -> 32, ReLU6) whose only consumer is a fused depthwise(stride 1) -> pointwise(32 -> 64) block becomes
+    ONE layer (csrc/stem_fused.hip): the 96x96x32 map in between never reaches HBM.  Returns (layers, old -> new index)."""
+    consumers: Dict[int, List[int]] = {}
+    for i, L in enumerate(layers):
+        for s in (L.src, L.res):
+            if s >= 0:
+                consumers.setdefault(s, []).append(i)
+    remap = {i: i for i in range(len(layers))}
+    for i, L in enumerate(layers):
+        cons = consumers.get(i, [])
+        if not (L.kind == OP_CONV_C3 and i not in keep and len(cons) == 1 and L.src == -1 and L.in_shape[2] == 3 and
+                L.out_shape[2] == 32 and L.stride == 2 and L.kh == 3 and L.kw == 3 and L.act == ACT_RELU6):
+            continue
+        B = layers[cons[0]]
+        if not (B.kind == OP_DWPW_F32 and B.src == i and B.stride == 1 and B.in_shape[2] == 32 and B.out_shape[2] == 64):
+            continue
+        S = Layer(OP_STEM_F16S, B.name, -1, L.in_shape, B.out_shape, w=B.w, scale=B.scale, shift=B.shift, act=B.act, kh=3, kw=3,
+                  stride=2, pad_t=L.pad_t, pad_l=L.pad_l, sealed=True, w2=B.w2, shift2=B.shift2, a_log2=F16S_ACT_LOG2_RELU6,
+                  w0=L.w, shift0=L.shift)
+        new_layers = [x for j, x in enumerate(layers) if j != i]
+        new_layers[cons[0] - 1] = S
+        remap = {}
+        for j in range(len(layers)):
+            remap[j] = -1 if j == i else (j if j < i else j - 1)
+        for x in new_layers:
+            if x.src >= 0:
+                x.src = remap[x.src]
+            if x.res >= 0:
+                x.res = remap[x.res]
+        return new_layers, remap
+    return layers, remap
+
+
 def choose_pointwise_math(layers: List[Layer], pw_math: str) -> None:
     """Mark the pointwise layers that may form their products on the f16 MFMA (csrc/pwconv_f16s.hip): the two-term f16
     split needs a bounded input, which the graph proves when the producing layer ends in ReLU6 ([0, 6] -> a_log2 12)."""
@@ -709,8 +759,10 @@ def choose_pointwise_math(layers: List[Layer], pw_math: str) -> None:
 
 def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
                 feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32",
-                pw_math: Optional[str] = None) -> Plan:
+                pw_math: Optional[str] = None, fuse_stem_block: Optional[bool] = None) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase.
+    fuse: merge depthwise -> pointwise pairs into one kernel where a fused kernel covers the shape; fuse_stem_block
+    (default on; env HSEFR_FUSE_STEM=0 turns the default off): additionally merge conv1 into the first block.
     pw_math: 'auto' (default; env HSEFR_PW_MATH overrides the default) = split-f16 products for every pointwise layer
     whose input the graph bounds (ReLU6), fp32 MFMA otherwise; 'f32' = fp32 MFMA everywhere.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
@@ -768,6 +820,13 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
 
     if dtype == "f32":
         import os
-        choose_pointwise_math(layers, pw_math or os.environ.get("HSEFR_PW_MATH", "auto"))
+        pw_math = pw_math or os.environ.get("HSEFR_PW_MATH", "auto")
+        choose_pointwise_math(layers, pw_math)
+        if fuse_stem_block is None:
+            fuse_stem_block = os.environ.get("HSEFR_FUSE_STEM", "1") != "0"
+        if fuse and pw_math != "f32" and fuse_stem_block:
+            layers, remap = fuse_stem(layers, [li for li, _ in out_layers.values()])
+            out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
+            tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
     buffers = assign_buffers(layers, {li for li, _ in out_layers.values()})
     return Plan(layers, (input_hw[0], input_hw[1], low.in_c), buffers, out_layers, tensor_layer)

@@ -110,6 +110,25 @@ def dwpw_f16split(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1, act: 
     return y
 
 
+def stem_fused(x, conv_w, conv_shift, w_hwc, dscale, dshift, wp_t, pshift, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
+    """The MobileNet stem in one kernel (csrc/stem_fused.hip): conv 3x3/2 SAME 3->32 + shift + ReLU6 -> depthwise 3x3/1 +
+    scale + shift + ReLU6 -> pointwise 32->64 + shift + act.  conv_w TF HWIO [3,3,3,32], w_hwc [3,3,32], wp_t [64,32]."""
+    torch = _lib.require_gpu()
+    for t, nm in ((x, "x"), (conv_w, "conv_w"), (conv_shift, "conv_shift"), (w_hwc, "w"), (dscale, "dscale"), (dshift, "dshift"),
+                  (pshift, "pshift")):
+        _f32c(t, nm)
+    d_img, d_ds = prepared if prepared is not None else split_weights_device(wp_t, x.device, a_log2)
+    n, h, w, c = x.shape
+    if c != 3 or tuple(conv_w.shape) != (3, 3, 3, 32) or tuple(w_hwc.shape) != (3, 3, 32) or d_img.shape[0] != 64:
+        raise NotImplementedError("stem_fused covers 3 -> 32 -> 64 channels")
+    oh, ow, pt, pl = _same(h, w, 3, 2)
+    y = torch.empty((n, oh, ow, 64), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_stem_fused(x.data_ptr(), conv_w.data_ptr(), conv_shift.data_ptr(), w_hwc.data_ptr(), dscale.data_ptr(),
+                                           dshift.data_ptr(), d_img.data_ptr(), d_ds.data_ptr(), pshift.data_ptr(), y.data_ptr(),
+                                           n, h, w, pt, pl, oh, ow, a_log2, act, _lib.current_stream_ptr()), "hsefr_stem_fused")
+    return y
+
+
 def dwpw_fused(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1):
     """One early MobileNet block in one kernel: depthwise 3x3 SAME + scale + shift + ReLU6 -> pointwise 1x1 + shift +
     ReLU6 (graph nodes #35-#49).  c in {32, 64}, cout in {64, 128}; wp_t is the pointwise kernel transposed [cout, c]."""

@@ -106,10 +106,15 @@ typedef enum hsefr_op_kind {
     HSEFR_OP_PWCONV_F16S = 12, /* 1x1 conv + shift + act, fp32 in/out, products on the f16 MFMA from a two-term split of
                                   both operands (fp32-grade, csrc/pwconv_f16s.hip); input bounded: |x| * 2^a_log2 < 32768.
                                   w_off = split rows, scale_off = descale, shift_off = shift, `reserved` = a_log2   */
-    HSEFR_OP_DWPW_F16S = 13    /* fused depthwise 3x3 (+scale+shift+ReLU6) -> pointwise 1x1 (+shift+act) for any cin % 32,
+    HSEFR_OP_DWPW_F16S = 13,   /* fused depthwise 3x3 (+scale+shift+ReLU6) -> pointwise 1x1 (+shift+act) for any cin % 32,
                                   cout % 64, pointwise products as in PWCONV_F16S (csrc/dwpw_f16s.hip).  w_off/scale_off/
                                   shift_off = depthwise; w2_off = split rows; shift2_off = [2][cout]: descale, then shift;
                                   `reserved` = a_log2 (the depthwise result is in [0,6]: 12)                         */
+    HSEFR_OP_STEM_F16S = 14    /* the whole MobileNet stem (csrc/stem_fused.hip): conv 3x3/2 3->32 + shift + ReLU6 ->
+                                  depthwise 3x3/1 + scale + shift + ReLU6 -> pointwise 32->64 + shift + act.  h,w,cin = the
+                                  image, oh,ow,cout = the block output, pad_t/pad_l = the conv's; w_off = fp32 pack
+                                  [conv HWIO 864 | conv shift 32 | dw 3x3x32 288 | dw scale 32 | dw shift 32];
+                                  w2_off = split rows [64][64 f16]; shift2_off = [2][64] descale, shift; reserved = a_log2 */
 } hsefr_op_kind;
 
 typedef enum hsefr_output_slot {
@@ -228,6 +233,14 @@ int hsefr_pwconv1x1_f16split(const float* x, const void* w_split, const float* d
 int hsefr_dwpw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,
                         const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride,
                         int pad_t, int pad_l, int oh, int ow, int cout, int a_log2, int act, hsefr_stream_t stream);
+
+/* The MobileNet stem in one kernel (graph nodes #30-#49): conv 3x3 stride 2 SAME (3 -> 32) + shift + ReLU6 -> depthwise
+ * 3x3 stride 1 SAME + scale + shift + ReLU6 -> pointwise 1x1 (32 -> 64) + shift + act (split-f16 products).
+ * x [n,h,w,3]; conv_w TF HWIO [3,3,3,32]; wd [3,3,32]; w_split/descale as for hsefr_pwconv1x1_f16split;
+ * y [n,oh,ow,64] with oh = ceil(h/2), ow = ceil(w/2); cpad_t/cpad_l = the conv's top/left padding. */
+int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd, const float* dscale,
+                     const float* dshift, const void* w_split, const float* descale, const float* pshift, float* y, int n,
+                     int h, int w, int cpad_t, int cpad_l, int oh, int ow, int a_log2, int act, hsefr_stream_t stream);
 
 /* One whole early MobileNet block (graph nodes #35-#49) fused: depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6
  * -> pointwise 1x1 + shift + ReLU6.  x [n,h,w,c], wd [3,3,c], wp_t [cout,c] (TF kernel transposed), y [n,oh,ow,cout];

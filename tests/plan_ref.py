@@ -98,6 +98,19 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             wt = unsplit_pointwise_weights(img, np.frombuffer(data, np.float32, cout, sc_off), _r).astype(dtype)
             assert 0 < _r <= 24 and float(np.abs(src).max()) * 2.0 ** _r < 32768, "split-f16 input bound violated"
             y = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
+        elif kind == 14:     # fused stem: conv 3x3/2 (3->32) + shift + relu6 -> depthwise 3x3/1 -> pointwise 32->64 (split f16)
+            from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
+            pk = arr(w_off, 1248)
+            k0 = pk[:864].reshape(3, 3, 3, 32)
+            pb = max((oh - 1) * 2 + 3 - h - pad_t, 0)
+            pr = max((ow - 1) * 2 + 3 - w - pad_l, 0)
+            c1 = _act(tfo.conv2d(src, k0, (2, 2), "", explicit_pads=(pad_t, pb, pad_l, pr)) + pk[864:896], 2)
+            mid = _act(tfo.depthwise_conv2d(np.pad(c1, ((0, 0), (1, 1), (1, 1), (0, 0))), pk[896:1184].reshape(3, 3, 32, 1), (1, 1), "VALID")
+                       * pk[1184:1216] + pk[1216:1248], 2)
+            img = np.frombuffer(data, np.uint16, cout * 32 * 2, w2_off).reshape(cout, 1, 64)
+            ds = np.frombuffer(data, np.float32, 2 * cout, sh2_off)
+            wt = unsplit_pointwise_weights(img, ds[:cout], _r).astype(dtype)
+            y = _act(PW(mid.reshape(-1, 32), wt) + ds[cout:].astype(dtype), act).reshape(n, oh, ow, cout)
         elif kind == 4:
             y = src.mean(axis=(1, 2)).reshape(n, 1, 1, cin)
         elif kind == 5:

@@ -82,6 +82,9 @@ def test_every_layer_matches_the_oracle(torch_):
             y = ops.pwconv1x1_f16split(src, L.w.reshape(L.w.shape[2], L.w.shape[3]).T, d(L.shift), L.act, L.a_log2)
         elif L.kind == lowering.OP_PWCONV_F32:
             y = ops.pwconv1x1(src, d(L.w.reshape(L.w.shape[2], L.w.shape[3]).T), d(L.shift), L.act)
+        elif L.kind == lowering.OP_STEM_F16S:
+            y = ops.stem_fused(src, d(L.w0), d(L.shift0), d(L.w.reshape(3, 3, -1)), d(L.scale), d(L.shift),
+                               L.w2.reshape(L.w2.shape[2], L.w2.shape[3]).T, d(L.shift2), L.act, L.a_log2)
         elif L.kind == lowering.OP_DWPW_F32:
             y = ops.dwpw_fused(src, d(L.w.reshape(3, 3, -1)), d(L.scale), d(L.shift),
                                d(L.w2.reshape(L.w2.shape[2], L.w2.shape[3]).T), d(L.shift2), L.stride)

@@ -247,6 +247,66 @@ def test_fused_depthwise_pointwise_vs_oracle(env, n, h, w, c, cout, s):
     assert rel(y.cpu().numpy(), y2.cpu().numpy()) < TOL
 
 
+@pytest.mark.parametrize("n,h,w,c,cout,s", [(2, 96, 96, 32, 64, 1), (1, 96, 96, 64, 128, 2), (2, 48, 48, 128, 128, 1), (1, 48, 48, 128, 256, 2),
+                                              (3, 24, 24, 256, 256, 1), (2, 24, 24, 256, 512, 2), (5, 12, 12, 512, 512, 1),
+                                              (3, 12, 12, 512, 1024, 2), (4, 6, 6, 1024, 1024, 1), (1, 50, 50, 32, 64, 1),
+                                              (1, 51, 37, 64, 128, 2), (2, 9, 21, 96, 192, 1), (1, 3, 3, 32, 64, 2)])
+def test_fused_block_f16split_vs_oracle(env, n, h, w, c, cout, s):
+    """The any-channel-count fused block (K-chunked depthwise producer + split-f16 GEMM) vs the two-op oracle, and
+    bit-for-bit against the unfused kernels it replaces (same arithmetic per element, different schedule)."""
+    torch, ops = env
+    rs = np.random.RandomState(h * 13 + c + cout + s + 7)
+    x = rs.uniform(0, 6, (n, h, w, c)).astype(np.float32)
+    kd = (rs.randn(3, 3, c, 1) / 3).astype(np.float32)
+    sc = rs.uniform(0.2, 2, c).astype(np.float32)
+    sh = rs.randn(c).astype(np.float32)
+    kp = (rs.randn(c, cout) / np.sqrt(c)).astype(np.float32)
+    psh = rs.randn(cout).astype(np.float32)
+    mid = act6(tfo.depthwise_conv2d(x.astype(np.float64), kd, (s, s), "SAME") * sc + sh)
+    want = act6(mid.reshape(-1, c).dot(kp.astype(np.float64)) + psh).reshape(mid.shape[:3] + (cout,))
+    y = ops.dwpw_f16split(dev(torch, x), dev(torch, kd.reshape(3, 3, c)), dev(torch, sc), dev(torch, sh), kp.T, dev(torch, psh), s)
+    assert tuple(y.shape) == want.shape
+    assert rel(y.cpu().numpy(), want) < TOL * max(1.0, (c / 256.0) ** 0.5)
+    y2 = ops.pwconv1x1_f16split(ops.dwconv3x3(dev(torch, x), dev(torch, kd.reshape(3, 3, c)), dev(torch, sc), dev(torch, sh), s),
+                                kp.T, dev(torch, psh))
+    assert np.array_equal(y.cpu().numpy(), y2.cpu().numpy())
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 192, 192), (1, 224, 224), (3, 96, 96), (1, 100, 100), (2, 33, 61), (1, 7, 5), (1, 3, 3)])
+def test_fused_stem_vs_oracle(env, n, h, w):
+    """conv1 -> depthwise -> pointwise in one kernel vs the three-op oracle (odd sizes: partial patches, SAME padding on
+    both the stride-2 conv and the depthwise), and vs the unfused kernels."""
+    torch, ops = env
+    rs = np.random.RandomState(h * 7 + w)
+    x = rs.uniform(-128, 152, (n, h, w, 3)).astype(np.float32)
+    cw = (rs.randn(3, 3, 3, 32) * 0.02).astype(np.float32)
+    csh = rs.randn(32).astype(np.float32)
+    kd = (rs.randn(3, 3, 32, 1) / 3).astype(np.float32)
+    sc = rs.uniform(0.2, 2, 32).astype(np.float32)
+    sh = rs.randn(32).astype(np.float32)
+    kp = (rs.randn(32, 64) / np.sqrt(32)).astype(np.float32)
+    psh = rs.randn(64).astype(np.float32)
+    c1 = act6(tfo.conv2d(x.astype(np.float64), cw.astype(np.float64), (2, 2), "SAME") + csh)
+    mid = act6(tfo.depthwise_conv2d(c1, kd, (1, 1), "SAME") * sc + sh)
+    want = act6(mid.reshape(-1, 32).dot(kp.astype(np.float64)) + psh).reshape(mid.shape[:3] + (64,))
+    y = ops.stem_fused(dev(torch, x), dev(torch, cw), dev(torch, csh), dev(torch, kd.reshape(3, 3, 32)), dev(torch, sc), dev(torch, sh),
+                       kp.T, dev(torch, psh))
+    assert tuple(y.shape) == want.shape
+    assert rel(y.cpu().numpy(), want) < 2 * TOL
+    y1 = ops.conv3x3_c3(dev(torch, x), dev(torch, cw), dev(torch, csh), 2)
+    y2 = ops.dwpw_f16split(y1, dev(torch, kd.reshape(3, 3, 32)), dev(torch, sc), dev(torch, sh), kp.T, dev(torch, psh), 1)
+    assert rel(y.cpu().numpy(), y2.cpu().numpy()) < 2 * TOL
+
+
+def test_fused_stem_rejects_uncovered_shapes(env):
+    torch, ops = env
+    z = lambda *s: torch.zeros(s, device="cuda")
+    with pytest.raises(NotImplementedError):
+        ops.stem_fused(z(1, 8, 8, 4), z(3, 3, 3, 32), z(32), z(3, 3, 32), z(32), z(32), np.zeros((64, 32), np.float32), z(64))
+    with pytest.raises(NotImplementedError):
+        ops.stem_fused(z(1, 8, 8, 3), z(3, 3, 3, 32), z(32), z(3, 3, 32), z(32), z(32), np.zeros((128, 32), np.float32), z(128))
+
+
 def test_fused_kernel_rejects_uncovered_shapes(env):
     torch, ops = env
     z = lambda *s: torch.zeros(s, device="cuda")

@@ -77,7 +77,7 @@ def test_lowered_plan_equals_unfused_graph(graph, size, n):
 
 
 def test_fusion_pass_merges_the_early_blocks_only(graph):
-    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192))
+    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), fuse_stem_block=False)
     kinds = [L.kind for L in plan.layers]
     assert kinds[:3] == [lowering.OP_CONV_C3, lowering.OP_DWPW_F32, lowering.OP_DWPW_F32]      # C = 32 and C = 64 blocks
     assert kinds.count(lowering.OP_DWPW_F32) == 2 and kinds.count(lowering.OP_DWCONV3X3) == 11
@@ -93,11 +93,26 @@ def test_fusion_pass_merges_the_early_blocks_only(graph):
     # a depthwise tensor that is itself requested is not fused away
     keep = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "conv_dw_1_relu/clip_by_value:0"}, (64, 64))
     assert keep.layers[-1].kind == lowering.OP_DWCONV3X3
+    # default: conv1 joins the first block (one kernel for graph nodes #30-#49), another 2.36 MB per face never reach HBM
+    stem = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192))
+    ks = [L.kind for L in stem.layers]
+    assert ks[:3] == [lowering.OP_STEM_F16S, lowering.OP_DWPW_F32, lowering.OP_DWCONV3X3] and len(ks) == len(kinds) - 1
+    s0 = stem.layers[0]
+    assert s0.src == -1 and s0.in_shape == (192, 192, 3) and s0.out_shape == (96, 96, 64) and s0.stride == 2 and s0.a_log2 == 12
+    assert stem.layers[1].src == 0 and stem.flops_per_image() == unfused.flops_per_image()
+    assert plan.bytes_per_image() - stem.bytes_per_image() == 2 * 4 * 96 * 96 * 32
+    assert "conv1_relu/clip_by_value" not in stem.tensor_layer and stem.tensor_layer["conv_pw_1_relu/clip_by_value"] == 0
+    import plan_ref
+    assert plan_ref.parse(stem.serialize())["ops"][0][0] == lowering.OP_STEM_F16S
+    # conv1's own tensor requested, or the fp32-only arithmetic: no stem fusion
+    keep1 = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0", OUT_AGE: "conv1_relu/clip_by_value:0"}, (64, 64))
+    assert keep1.layers[0].kind == lowering.OP_CONV_C3
+    assert lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (64, 64), pw_math="f32").layers[0].kind == lowering.OP_CONV_C3
 
 
 def test_features_only_plan_and_intermediate_outputs(graph):
     plan = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0"}, (64, 64))
-    assert len(plan.layers) == 26 and OUT_AGE not in plan.outputs
+    assert len(plan.layers) == 25 and OUT_AGE not in plan.outputs      # stem (conv1 + block 1), block 2, 11 x (dw, pw), pool
     x = np.random.RandomState(5).uniform(-128, 128, (1, 64, 64, 3)).astype(np.float32)
     ref = tfo.GraphOracle(MODEL_PB).run("global_pooling/Mean:0", {"input_1:0": x})
     assert rel(plan_ref.run(plan.serialize(), x)["features"], ref) < 1e-6
@@ -125,6 +140,7 @@ def test_plan_struct_layout_matches_header():
                       ("HSEFR_OP_PWCONV_F32", lowering.OP_PWCONV_F32), ("HSEFR_OP_GAP", lowering.OP_GAP),
                       ("HSEFR_OP_DENSE", lowering.OP_DENSE), ("HSEFR_OP_SOFTMAX", lowering.OP_SOFTMAX),
                       ("HSEFR_OP_DWPW_F32", lowering.OP_DWPW_F32), ("HSEFR_OP_PWCONV_F16S", lowering.OP_PWCONV_F16S),
+                      ("HSEFR_OP_DWPW_F16S", lowering.OP_DWPW_F16S), ("HSEFR_OP_STEM_F16S", lowering.OP_STEM_F16S),
                       ("HSEFR_ACT_RELU6", lowering.ACT_RELU6), ("HSEFR_ACT_SIGMOID", lowering.ACT_SIGMOID)):
         assert "%s = %d" % (name, val) in hdr
 

@@ -258,6 +258,52 @@ def bench_stamps():
             print("   %-24s %6.1f %% of lifetime, %7.0f cycles per step" % (nm, 100 * (b[:, i] / tot).mean(), (b[:, i] / b[:, 7]).mean()))
 
 
+def bench_stem():
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for hw in (192, 224):
+        x = (torch.rand((B, hw, hw, 3), device="cuda", generator=g) - 0.5) * 256
+        cw = torch.randn((3, 3, 3, 32), device="cuda", generator=g) * 0.02
+        csh = torch.randn((32,), device="cuda", generator=g)
+        wd = torch.randn((3, 3, 32), device="cuda", generator=g) / 3
+        dsc = torch.rand((32,), device="cuda", generator=g) + 0.5
+        dsh = torch.randn((32,), device="cuda", generator=g) * 0.3
+        w = torch.randn((64, 32), device="cuda", generator=g) / 32 ** 0.5
+        sh = torch.randn((64,), device="cuda", generator=g)
+        t_c = timeit(lambda: ops.conv3x3_c3(x, cw, csh, 2))[0]
+        mid = ops.conv3x3_c3(x, cw, csh, 2)
+        t_b = timeit(lambda: ops.dwpw_fused(mid, wd, dsc, dsh, w, sh, 1))[0]
+        prep = ops.split_weights_device(w, x.device)
+        t_s = timeit(lambda: ops.stem_fused(x, cw, csh, wd, dsc, dsh, None, sh, prepared=prep))[0]
+        by = 4.0 * B * (hw * hw * 3 + (hw // 2) ** 2 * 64)
+        print("stem %d: conv1 %.1f + fused block %.1f = %.1f us | fused stem %.1f us  (%.0f GB/s of in+out)" %
+              (hw, t_c, t_b, t_c + t_b, t_s, by / t_s / 1e3))
+
+
+def bench_stemstamps():
+    """Diagnostic build only (-DHSEFR_STEM_STAMPS): where a fused-stem wave spends its cycles."""
+    import ctypes
+    g = torch.Generator(device="cuda").manual_seed(0)
+    hw = 192
+    x = (torch.rand((B, hw, hw, 3), device="cuda", generator=g) - 0.5) * 256
+    cw = torch.randn((3, 3, 3, 32), device="cuda", generator=g) * 0.02
+    csh = torch.randn((32,), device="cuda", generator=g)
+    wd = torch.randn((3, 3, 32), device="cuda", generator=g) / 3
+    dsc = torch.rand((32,), device="cuda", generator=g) + 0.5
+    dsh = torch.randn((32,), device="cuda", generator=g) * 0.3
+    w = torch.randn((64, 32), device="cuda", generator=g) / 32 ** 0.5
+    sh = torch.randn((64,), device="cuda", generator=g)
+    for _ in range(4):
+        ops.stem_fused(x, cw, csh, wd, dsc, dsh, w, sh)
+    torch.cuda.synchronize()
+    buf = np.zeros((512 * 4, 10), np.uint64)
+    _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+    b = buf[buf[:, 9] > 0].astype(np.float64)
+    names = ["decode + gather issue", "B conv1 mfma + Co write", "barriers", "C depthwise from LDS", "D pointwise mfma", "E epilogue", "scatter (wait gather)", "-"]
+    print("%d waves, lifetime mean %.0f cycles, patches/wave %.1f -> %.0f cycles per patch" % (len(b), b[:, 8].mean(), b[:, 9].mean(), (b[:, 8] / b[:, 9]).mean()))
+    for i, nm in enumerate(names):
+        print("   %-26s %5.1f %%  %7.0f cycles per patch" % (nm, 100 * (b[:, i] / b[:, 8]).mean(), (b[:, i] / b[:, 9]).mean()))
+
+
 def bench_pwa():
     print("GEMM ablations (timing only), 128x64 tile: us median: real / no-global-loads / no-stores / neither")
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -304,4 +350,4 @@ def bench_clock():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["pw", "dw", "c3"]
     for w in what:
-        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd, "pws": bench_pws, "blk": bench_blk, "stamps": bench_stamps}[w]()
+        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd, "pws": bench_pws, "blk": bench_blk, "stamps": bench_stamps, "stem": bench_stem, "stemstamps": bench_stemstamps}[w]()
