@@ -149,6 +149,11 @@ bool dwpw_f16s_supported(int c, int cout, int stride);
 int launch_stem_fused(const float* x, const float* cw, const float* cshift, const float* wd, const float* dscale,
                       const float* dshift, const void* wsplit, const float* descale, const float* pshift, float* y, int n,
                       int h, int w, int cpad_t, int cpad_l, int oh, int ow, int a_log2, int act, hipStream_t s);
+int launch_stem2_fused(const float* x, const float* cw, const float* cshift, const float* wd1, const float* d1scale,
+                       const float* d1shift, const void* wsplit, const float* descale, const float* pshift, const float* wd2,
+                       const float* d2scale, const float* d2shift, float* y, int n, int h, int w, int cpad_t, int cpad_l,
+                       int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int a_log2, int act, hipStream_t s);
+bool stem2_fused_supported(int cin, int c1, int c2, int conv_stride, int dw1_stride, int dw2_stride, int kh, int kw);
 bool stem_fused_supported(int cin, int cmid, int cout, int conv_stride, int dw_stride, int kh, int kw);
 void set_dwpws_tw(int v);
 void set_dwpws_bn(int v);

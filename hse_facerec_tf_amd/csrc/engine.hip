@@ -93,6 +93,12 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                                   o.reserved > 0 && o.reserved <= 24,
                               HSEFR_ERR_INVALID, "plan op %u: split-f16 pointwise needs split rows, descale, shift and a_log2 in (0, 24]", i);
                 break;
+            case HSEFR_OP_STEM2_F16S:
+                HSEFR_REQUIRE(stem2_fused_supported(o.cin, 32, o.cout, o.stride, 1, 2, o.kh, o.kw & 15) && o.reserved > 0 && o.reserved <= 12 &&
+                                  o.w_off != HSEFR_NO_OFFSET && o.w2_off != HSEFR_NO_OFFSET && o.shift2_off != HSEFR_NO_OFFSET &&
+                                  o.w_off + 1952 * 4 <= h.blob_bytes && o.in_buf == HSEFR_BUF_INPUT,
+                              HSEFR_ERR_UNSUPPORTED, "plan op %u: fused stem+dw2 cin=%d cout=%d stride=%d not covered", i, o.cin, o.cout, o.stride);
+                break;
             case HSEFR_OP_STEM_F16S:
                 HSEFR_REQUIRE(stem_fused_supported(o.cin, 32, o.cout, o.stride, 1, o.kh, o.kw) && o.reserved > 0 && o.reserved <= 12 &&
                                   o.w_off != HSEFR_NO_OFFSET && o.w2_off != HSEFR_NO_OFFSET && o.shift2_off != HSEFR_NO_OFFSET &&
@@ -344,6 +350,15 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
                                        (const float*)blob_ptr(e, o.shift2_off), (float*)out, n, o.h, o.w, o.cin, o.stride,
                                        o.pad_t, o.pad_l, o.oh, o.ow, o.cout, HSEFR_ACT_RELU6, o.act, s);
                 break;
+            case HSEFR_OP_STEM2_F16S: {
+                const float* pk = (const float*)blob_ptr(e, o.w_off);
+                const float* ds2 = (const float*)blob_ptr(e, o.shift2_off);
+                const int h1 = (o.h + 1) / 2, w1 = (o.w + 1) / 2;
+                rc = launch_stem2_fused((const float*)in, pk, pk + 864, pk + 896, pk + 1184, pk + 1216, blob_ptr(e, o.w2_off), ds2,
+                                        ds2 + 64, pk + 1248, pk + 1824, pk + 1888, (float*)out, n, o.h, o.w, o.pad_t, o.pad_l, h1, w1,
+                                        (o.kw >> 4) & 1, (o.kw >> 5) & 1, o.oh, o.ow, o.reserved, o.act, s);
+                break;
+            }
             case HSEFR_OP_STEM_F16S: {
                 const float* pk = (const float*)blob_ptr(e, o.w_off);
                 const float* ds2 = (const float*)blob_ptr(e, o.shift2_off);
@@ -426,6 +441,16 @@ int hsefr_pwconv1x1_f16split(const float* x, const void* w_split, const float* d
                              long long m, int k, int cout, int a_log2, int act, hsefr_stream_t stream) {
     HSEFR_REQUIRE(m == 0 || (x && w_split && descale && shift && y), HSEFR_ERR_INVALID, "pwconv_f16split: null pointer");
     return launch_pwconv_f16s(x, w_split, descale, shift, y, m, k, cout, a_log2, act, (hipStream_t)stream);
+}
+
+int hsefr_stem2_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd1, const float* d1scale,
+                      const float* d1shift, const void* w_split, const float* descale, const float* pshift, const float* wd2,
+                      const float* d2scale, const float* d2shift, float* y, int n, int h, int w, int cpad_t, int cpad_l,
+                      int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int a_log2, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && conv_w && conv_shift && wd1 && d1scale && d1shift && w_split && descale && pshift && wd2 &&
+                             d2scale && d2shift && y), HSEFR_ERR_INVALID, "stem2_fused: null pointer");
+    return launch_stem2_fused(x, conv_w, conv_shift, wd1, d1scale, d1shift, w_split, descale, pshift, wd2, d2scale, d2shift, y, n,
+                              h, w, cpad_t, cpad_l, h1, w1, pad_t2, pad_l2, oh2, ow2, a_log2, act, (hipStream_t)stream);
 }
 
 int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd, const float* dscale,

@@ -32,6 +32,7 @@ OP_CONV_BF16, OP_MAXPOOL_BF16, OP_GAP_BF16, OP_STEM7X7_BF16, OP_DWPW_F32 = 7, 8,
 OP_PWCONV_F16S = 12      # wire kind of a pointwise Layer whose a_log2 > 0 (the IR keeps OP_PWCONV_F32 + a_log2)
 OP_DWPW_F16S = 13        # fused block with split-f16 pointwise products for any channel count (csrc/dwpw_f16s.hip)
 OP_STEM_F16S = 14        # conv1 -> depthwise -> pointwise in one kernel (csrc/stem_fused.hip)
+OP_STEM2_F16S = 15       # ... -> pointwise -> the stride-2 depthwise of block 2 in one kernel (csrc/stem2_fused.hip)
 _BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
 BUF_INPUT, BUF_NONE = -1, -2
@@ -141,6 +142,10 @@ class Layer:
     a_log2: int = 0                                    # PWCONV: > 0 = split-f16 products, input pre-scaled by 2^a_log2
     w0: Optional[np.ndarray] = None                    # STEM_F16S: the first conv's kernel (HWIO) ...
     shift0: Optional[np.ndarray] = None                # ... and its shift
+    w3: Optional[np.ndarray] = None                    # STEM2_F16S: the second depthwise's kernel, scale, shift, top/left padding
+    scale3: Optional[np.ndarray] = None
+    shift3: Optional[np.ndarray] = None
+    pad3: Tuple[int, int] = (0, 0)
     out_buf: int = BUF_NONE
 
     @property
@@ -184,6 +189,16 @@ class Plan:
                 w = w.reshape(3, 3, -1)
             w2 = None if L.w2 is None else np.ascontiguousarray(L.w2.reshape(L.w2.shape[-2], L.w2.shape[-1]).T)
             shift2 = L.shift2
+            kw_field = L.kw
+            if L.kind == OP_STEM2_F16S:
+                w = np.concatenate([L.w0.reshape(-1), L.shift0.reshape(-1), L.w.reshape(-1), L.scale.reshape(-1), L.shift.reshape(-1),
+                                    L.w3.reshape(-1), L.scale3.reshape(-1), L.shift3.reshape(-1)]).astype(np.float32)
+                assert w.size == 1952
+                scale = None
+                w2, descale = split_pointwise_weights(w2, L.a_log2)
+                shift2 = np.concatenate([descale, L.shift2.astype(np.float32)])
+                aux = L.a_log2
+                kw_field = 3 + 16 * L.pad3[0] + 32 * L.pad3[1]
             if L.kind == OP_STEM_F16S:
                 # one fp32 pack [conv HWIO 864 | conv shift 32 | dw 3x3x32 288 | dw scale 32 | dw shift 32], split pointwise rows
                 w = np.concatenate([L.w0.reshape(-1), L.shift0.reshape(-1), L.w.reshape(-1), L.scale.reshape(-1),
@@ -198,8 +213,8 @@ class Plan:
             h, wd, cin = L.in_shape
             oh, ow, cout = L.out_shape
             ops.append(_OP.pack(kind, L.act, in_buf, L.out_buf, res_buf, h, wd, cin, oh, ow, cout,
-                                L.kh, L.kw, L.stride, L.pad_t, L.pad_l, aux, put(w), put(scale),
-                                put(None if L.kind == OP_STEM_F16S else L.shift), put(w2), put(shift2)))
+                                L.kh, kw_field, L.stride, L.pad_t, L.pad_l, aux, put(w), put(scale),
+                                put(None if L.kind in (OP_STEM_F16S, OP_STEM2_F16S) else L.shift), put(w2), put(shift2)))
         while len(blob) % 16:
             blob.append(0)
         out_buf = [BUF_NONE] * 3
@@ -224,7 +239,7 @@ class Plan:
         tot = 0
         for L in self.layers:
             if kinds is None or L.kind in kinds:
-                for a in (L.w, L.scale, L.shift, L.w2, L.shift2, L.w0, L.shift0):
+                for a in (L.w, L.scale, L.shift, L.w2, L.shift2, L.w0, L.shift0, L.w3, L.scale3, L.shift3):
                     if a is not None:
                         tot += 4 * a.size
         return tot
@@ -243,6 +258,9 @@ class Plan:
                 tot += 2 * oh * ow * L.in_shape[2] * 9 + 2 * oh * ow * cout * L.in_shape[2]
             elif L.kind == OP_STEM_F16S:
                 tot += 2 * oh * ow * 32 * 27 + 2 * oh * ow * 32 * 9 + 2 * oh * ow * cout * 32
+            elif L.kind == OP_STEM2_F16S:
+                h1, w1 = (L.in_shape[0] + 1) // 2, (L.in_shape[1] + 1) // 2
+                tot += 2 * h1 * w1 * 32 * 27 + 2 * h1 * w1 * 32 * 9 + 2 * h1 * w1 * 64 * 32 + 2 * oh * ow * 64 * 9
         return tot
 
 
@@ -740,6 +758,56 @@ def fuse_stem(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Di
     return layers, remap
 
 
+def fuse_stem2(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
+    """On the UNFUSED layer list: conv 3x3/2 (3->32, ReLU6) -> depthwise/1 (ReLU6) -> pointwise (32->64, ReLU6) ->
+    depthwise/2 (C = 64), each the only consumer of the one before and none of them a requested output, becomes ONE layer
+    (csrc/stem2_fused.hip): the three maps in between -- 96x96x64 is the network's largest tensor -- never reach HBM."""
+    consumers: Dict[int, List[int]] = {}
+    for i, L in enumerate(layers):
+        for s in (L.src, L.res):
+            if s >= 0:
+                consumers.setdefault(s, []).append(i)
+    ident = {i: i for i in range(len(layers))}
+
+    def only_consumer(i):
+        c = consumers.get(i, [])
+        return c[0] if len(c) == 1 and i not in keep and layers[c[0]].src == i else -1
+
+    for i0, L0 in enumerate(layers):
+        if not (L0.kind == OP_CONV_C3 and L0.src == -1 and L0.in_shape[2] == 3 and L0.out_shape[2] == 32 and L0.stride == 2 and
+                L0.kh == 3 and L0.kw == 3 and L0.act == ACT_RELU6):
+            continue
+        i1 = only_consumer(i0)
+        if i1 < 0 or not (layers[i1].kind == OP_DWCONV3X3 and layers[i1].stride == 1 and layers[i1].act == ACT_RELU6):
+            continue
+        i2 = only_consumer(i1)
+        if i2 < 0 or not (layers[i2].kind == OP_PWCONV_F32 and layers[i2].out_shape[2] == 64 and layers[i2].act == ACT_RELU6):
+            continue
+        i3 = only_consumer(i2)
+        if i3 < 0 or not (layers[i3].kind == OP_DWCONV3X3 and layers[i3].stride == 2 and layers[i3].in_shape[2] == 64 and
+                          layers[i3].act in (ACT_NONE, ACT_RELU, ACT_RELU6)):
+            continue
+        L1, L2, L3 = layers[i1], layers[i2], layers[i3]
+        S = Layer(OP_STEM2_F16S, L3.name, -1, L0.in_shape, L3.out_shape, w=L1.w, scale=L1.scale, shift=L1.shift, act=L3.act, kh=3, kw=3,
+                  stride=2, pad_t=L0.pad_t, pad_l=L0.pad_l, sealed=True, w2=L2.w, shift2=L2.shift, a_log2=F16S_ACT_LOG2_RELU6,
+                  w0=L0.w, shift0=L0.shift, w3=L3.w, scale3=L3.scale, shift3=L3.shift, pad3=(L3.pad_t, L3.pad_l))
+        gone = {i0, i1, i2}
+        new_layers, remap = [], {}
+        for j, x in enumerate(layers):
+            if j in gone:
+                remap[j] = -1
+                continue
+            new_layers.append(S if j == i3 else x)
+            remap[j] = len(new_layers) - 1
+        for x in new_layers:
+            if x.src >= 0:
+                x.src = remap[x.src]
+            if x.res >= 0:
+                x.res = remap[x.res]
+        return new_layers, remap
+    return layers, ident
+
+
 def choose_pointwise_math(layers: List[Layer], pw_math: str) -> None:
     """Mark the pointwise layers that may form their products on the f16 MFMA (csrc/pwconv_f16s.hip): the two-term f16
     split needs a bounded input, which the graph proves when the producing layer ends in ReLU6 ([0, 6] -> a_log2 12)."""
@@ -759,10 +827,11 @@ def choose_pointwise_math(layers: List[Layer], pw_math: str) -> None:
 
 def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
                 feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32",
-                pw_math: Optional[str] = None, fuse_stem_block: Optional[bool] = None) -> Plan:
+                pw_math: Optional[str] = None, fuse_stem_block: Optional[bool] = None, stem_fusion: Optional[str] = None) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase.
-    fuse: merge depthwise -> pointwise pairs into one kernel where a fused kernel covers the shape; fuse_stem_block
-    (default on; env HSEFR_FUSE_STEM=0 turns the default off): additionally merge conv1 into the first block.
+    fuse: merge depthwise -> pointwise pairs into one kernel where a fused kernel covers the shape.  stem_fusion:
+    'stem2' (default; env HSEFR_FUSE_STEM=0|1only|1 changes the default) = conv1 + block 1 + the depthwise of block 2 in one
+    kernel, 'stem' = conv1 + block 1, 'none'; fuse_stem_block=False is the older spelling of 'none'.
     pw_math: 'auto' (default; env HSEFR_PW_MATH overrides the default) = split-f16 products for every pointwise layer
     whose input the graph bounds (ReLU6), fp32 MFMA otherwise; 'f32' = fp32 MFMA everywhere.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
@@ -813,18 +882,26 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
             raise LoweringError("output %s is an intermediate of fused layer %s; fetch the layer's final tensor"
                                 % (tname, layers[low.where[nm]].name))
     tensor_layer = {name: li for name, li in low.where.items() if li >= 0 and low.is_final(name)}
+    import os
+    pw_math = pw_math or os.environ.get("HSEFR_PW_MATH", "auto")
+    if stem_fusion is None:
+        stem_fusion = "none" if fuse_stem_block is False else {"0": "none", "1only": "stem"}.get(os.environ.get("HSEFR_FUSE_STEM", "1"), "stem2")
+    if stem_fusion not in ("none", "stem", "stem2"):
+        raise ValueError("stem_fusion must be 'none', 'stem' or 'stem2', not %r" % (stem_fusion,))
+    want_stem = fuse and dtype == "f32" and pw_math != "f32" and stem_fusion != "none"
+    if want_stem and stem_fusion == "stem2":
+        # post-conditions (folded scales, default shifts) are in place: the stem2 pack needs them
+        layers, remap = fuse_stem2(layers, [li for li, _ in out_layers.values()])
+        out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
+        tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
     if fuse:   # early MobileNet blocks: depthwise result stays on the CU (csrc/dwpw_fused.hip)
         layers, remap = fuse_dwpw(layers, [li for li, _ in out_layers.values()])
         out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
         tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
 
     if dtype == "f32":
-        import os
-        pw_math = pw_math or os.environ.get("HSEFR_PW_MATH", "auto")
         choose_pointwise_math(layers, pw_math)
-        if fuse_stem_block is None:
-            fuse_stem_block = os.environ.get("HSEFR_FUSE_STEM", "1") != "0"
-        if fuse and pw_math != "f32" and fuse_stem_block:
+        if want_stem:
             layers, remap = fuse_stem(layers, [li for li, _ in out_layers.values()])
             out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
             tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}

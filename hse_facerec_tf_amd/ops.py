@@ -129,6 +129,29 @@ def stem_fused(x, conv_w, conv_shift, w_hwc, dscale, dshift, wp_t, pshift, act: 
     return y
 
 
+def stem2_fused(x, conv_w, conv_shift, w1_hwc, d1scale, d1shift, wp_t, pshift, w2_hwc, d2scale, d2shift, act: int = ACT_RELU6,
+                a_log2: int = 12, prepared=None):
+    """Stem + the depthwise of block 2 in one kernel (csrc/stem2_fused.hip): conv 3x3/2 3->32 -> depthwise 3x3/1 -> pointwise
+    32->64 (all + ReLU6) -> depthwise 3x3/2 + scale + shift + act.  w2_hwc [3,3,64]; output [n, ceil(h/4), ceil(w/4), 64]."""
+    torch = _lib.require_gpu()
+    for t, nm in ((x, "x"), (conv_w, "conv_w"), (conv_shift, "conv_shift"), (w1_hwc, "w1"), (d1scale, "d1scale"), (d1shift, "d1shift"),
+                  (pshift, "pshift"), (w2_hwc, "w2"), (d2scale, "d2scale"), (d2shift, "d2shift")):
+        _f32c(t, nm)
+    d_img, d_ds = prepared if prepared is not None else split_weights_device(wp_t, x.device, a_log2)
+    n, h, w, c = x.shape
+    if c != 3 or tuple(conv_w.shape) != (3, 3, 3, 32) or tuple(w1_hwc.shape) != (3, 3, 32) or d_img.shape[0] != 64 or \
+            tuple(w2_hwc.shape) != (3, 3, 64):
+        raise NotImplementedError("stem2_fused covers 3 -> 32 -> 64 channels")
+    h1, w1, pt, pl = _same(h, w, 3, 2)
+    oh2, ow2, pt2, pl2 = _same(h1, w1, 3, 2)
+    y = torch.empty((n, oh2, ow2, 64), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_stem2_fused(x.data_ptr(), conv_w.data_ptr(), conv_shift.data_ptr(), w1_hwc.data_ptr(), d1scale.data_ptr(),
+                                            d1shift.data_ptr(), d_img.data_ptr(), d_ds.data_ptr(), pshift.data_ptr(), w2_hwc.data_ptr(),
+                                            d2scale.data_ptr(), d2shift.data_ptr(), y.data_ptr(), n, h, w, pt, pl, h1, w1, pt2, pl2,
+                                            oh2, ow2, a_log2, act, _lib.current_stream_ptr()), "hsefr_stem2_fused")
+    return y
+
+
 def dwpw_fused(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1):
     """One early MobileNet block in one kernel: depthwise 3x3 SAME + scale + shift + ReLU6 -> pointwise 1x1 + shift +
     ReLU6 (graph nodes #35-#49).  c in {32, 64}, cout in {64, 128}; wp_t is the pointwise kernel transposed [cout, c]."""

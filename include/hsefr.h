@@ -110,11 +110,17 @@ typedef enum hsefr_op_kind {
                                   cout % 64, pointwise products as in PWCONV_F16S (csrc/dwpw_f16s.hip).  w_off/scale_off/
                                   shift_off = depthwise; w2_off = split rows; shift2_off = [2][cout]: descale, then shift;
                                   `reserved` = a_log2 (the depthwise result is in [0,6]: 12)                         */
-    HSEFR_OP_STEM_F16S = 14    /* the whole MobileNet stem (csrc/stem_fused.hip): conv 3x3/2 3->32 + shift + ReLU6 ->
+    HSEFR_OP_STEM_F16S = 14,   /* the whole MobileNet stem (csrc/stem_fused.hip): conv 3x3/2 3->32 + shift + ReLU6 ->
                                   depthwise 3x3/1 + scale + shift + ReLU6 -> pointwise 32->64 + shift + act.  h,w,cin = the
                                   image, oh,ow,cout = the block output, pad_t/pad_l = the conv's; w_off = fp32 pack
                                   [conv HWIO 864 | conv shift 32 | dw 3x3x32 288 | dw scale 32 | dw shift 32];
                                   w2_off = split rows [64][64 f16]; shift2_off = [2][64] descale, shift; reserved = a_log2 */
+    HSEFR_OP_STEM2_F16S = 15   /* the stem plus the depthwise of block 2 (csrc/stem2_fused.hip): ... -> pointwise 32->64 +
+                                  shift + ReLU6 -> depthwise 3x3/2 + scale + shift + act.  h,w,cin = the image, oh,ow,cout =
+                                  the stride-2 depthwise output (64 ch); pad_t/pad_l = conv1's; kh (sic) low byte = 3,
+                                  w_off = fp32 pack [conv HWIO 864 | conv shift 32 | dw1 288 | dw1 scale 32 | dw1 shift 32 |
+                                  dw2 3x3x64 576 | dw2 scale 64 | dw2 shift 64]; w2_off / shift2_off / reserved as STEM_F16S;
+                                  res_buf unused; stride = 2; `kw` = 3 + 16*pad_t2 + 32*pad_l2 (depthwise-2 padding)   */
 } hsefr_op_kind;
 
 typedef enum hsefr_output_slot {
@@ -241,6 +247,14 @@ int hsefr_dwpw_f16split(const float* x, const float* wd, const float* dscale, co
 int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd, const float* dscale,
                      const float* dshift, const void* w_split, const float* descale, const float* pshift, float* y, int n,
                      int h, int w, int cpad_t, int cpad_l, int oh, int ow, int a_log2, int act, hsefr_stream_t stream);
+
+/* The stem plus the depthwise half of block 2 (graph nodes #30-#55) in one kernel: ... -> pointwise 32->64 + shift + ReLU6
+ * -> depthwise 3x3 stride 2 SAME + scale + shift + act.  wd2 [3,3,64]; y [n,oh2,ow2,64] with h1 = ceil(h/2),
+ * oh2 = ceil(h1/2) (same for w); pad_t2/pad_l2 = the stride-2 depthwise's top/left padding (0 for even h1/w1). */
+int hsefr_stem2_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd1, const float* d1scale,
+                      const float* d1shift, const void* w_split, const float* descale, const float* pshift, const float* wd2,
+                      const float* d2scale, const float* d2shift, float* y, int n, int h, int w, int cpad_t, int cpad_l,
+                      int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int a_log2, int act, hsefr_stream_t stream);
 
 /* One whole early MobileNet block (graph nodes #35-#49) fused: depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6
  * -> pointwise 1x1 + shift + ReLU6.  x [n,h,w,c], wd [3,3,c], wp_t [cout,c] (TF kernel transposed), y [n,oh,ow,cout];

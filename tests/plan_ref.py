@@ -98,6 +98,24 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             wt = unsplit_pointwise_weights(img, np.frombuffer(data, np.float32, cout, sc_off), _r).astype(dtype)
             assert 0 < _r <= 24 and float(np.abs(src).max()) * 2.0 ** _r < 32768, "split-f16 input bound violated"
             y = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
+        elif kind == 15:     # fused stem + the stride-2 depthwise of block 2
+            from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
+            pk = arr(w_off, 1952)
+            h1, w1 = (h + 1) // 2, (w + 1) // 2
+            pb = max((h1 - 1) * 2 + 3 - h - pad_t, 0)
+            pr = max((w1 - 1) * 2 + 3 - w - pad_l, 0)
+            c1 = _act(tfo.conv2d(src, pk[:864].reshape(3, 3, 3, 32), (2, 2), "", explicit_pads=(pad_t, pb, pad_l, pr)) + pk[864:896], 2)
+            d1 = _act(tfo.depthwise_conv2d(np.pad(c1, ((0, 0), (1, 1), (1, 1), (0, 0))), pk[896:1184].reshape(3, 3, 32, 1), (1, 1), "VALID")
+                      * pk[1184:1216] + pk[1216:1248], 2)
+            img = np.frombuffer(data, np.uint16, 64 * 32 * 2, w2_off).reshape(64, 1, 64)
+            ds = np.frombuffer(data, np.float32, 128, sh2_off)
+            wt = unsplit_pointwise_weights(img, ds[:64], _r).astype(dtype)
+            p1 = _act(PW(d1.reshape(-1, 32), wt) + ds[64:].astype(dtype), 2).reshape(n, h1, w1, 64)
+            pt2, pl2 = (kw >> 4) & 1, (kw >> 5) & 1
+            pb2 = max((oh - 1) * 2 + 3 - h1 - pt2, 0)
+            pr2 = max((ow - 1) * 2 + 3 - w1 - pl2, 0)
+            y = _act(tfo.depthwise_conv2d(np.pad(p1, ((0, 0), (pt2, pb2), (pl2, pr2), (0, 0))), pk[1248:1824].reshape(3, 3, 64, 1), (2, 2), "VALID")
+                     * pk[1824:1888] + pk[1888:1952], act)
         elif kind == 14:     # fused stem: conv 3x3/2 (3->32) + shift + relu6 -> depthwise 3x3/1 -> pointwise 32->64 (split f16)
             from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
             pk = arr(w_off, 1248)

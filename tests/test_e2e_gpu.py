@@ -34,6 +34,25 @@ def test_native_library_is_the_one_loaded(torch_):
     assert "hse_facerec_tf_amd/libhsefr.so" in maps
 
 
+@pytest.mark.parametrize("stem_fusion", ["stem2", "stem", "none"])
+@pytest.mark.parametrize("size", [192, 100])
+def test_engine_matches_golden_for_every_stem_fusion(torch_, size, stem_fusion):
+    from hse_facerec_tf_amd import engine, graphdef, lowering
+    z = np.load(os.path.join(GOLDEN, "e2e_synthetic.npz"))
+    n = z["feat_%d" % size].shape[0]
+    plan = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0", {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]}, (size, size),
+                                stem_fusion=stem_fusion)
+    want_kind = {"stem2": lowering.OP_STEM2_F16S, "stem": lowering.OP_STEM_F16S, "none": lowering.OP_CONV_C3}[stem_fusion]
+    assert plan.layers[0].kind == want_kind
+    eng = engine.Engine(plan, max_batch=4)
+    x = np.random.RandomState(123).uniform(-128, 128, (n, size, size, 3)).astype(np.float32)
+    out = eng.forward(torch_.from_numpy(x).cuda(), (0, 1, 2))
+    assert rel(out["features"].cpu().numpy(), z["feat_%d" % size]) < BAR
+    assert rel(out["age_probs"].cpu().numpy(), z["age_%d" % size]) < BAR
+    assert rel(out["gender"].cpu().numpy(), z["gender_%d" % size]) < BAR
+    eng.close()
+
+
 @pytest.mark.parametrize("pw_math", ["auto", "f32"])
 @pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("size", [192, 224, 96, 100])
@@ -82,6 +101,10 @@ def test_every_layer_matches_the_oracle(torch_):
             y = ops.pwconv1x1_f16split(src, L.w.reshape(L.w.shape[2], L.w.shape[3]).T, d(L.shift), L.act, L.a_log2)
         elif L.kind == lowering.OP_PWCONV_F32:
             y = ops.pwconv1x1(src, d(L.w.reshape(L.w.shape[2], L.w.shape[3]).T), d(L.shift), L.act)
+        elif L.kind == lowering.OP_STEM2_F16S:
+            y = ops.stem2_fused(src, d(L.w0), d(L.shift0), d(L.w.reshape(3, 3, -1)), d(L.scale), d(L.shift),
+                                L.w2.reshape(L.w2.shape[2], L.w2.shape[3]).T, d(L.shift2), d(L.w3.reshape(3, 3, -1)), d(L.scale3),
+                                d(L.shift3), L.act, L.a_log2)
         elif L.kind == lowering.OP_STEM_F16S:
             y = ops.stem_fused(src, d(L.w0), d(L.shift0), d(L.w.reshape(3, 3, -1)), d(L.scale), d(L.shift),
                                L.w2.reshape(L.w2.shape[2], L.w2.shape[3]).T, d(L.shift2), L.act, L.a_log2)

@@ -298,6 +298,36 @@ def test_fused_stem_vs_oracle(env, n, h, w):
     assert rel(y.cpu().numpy(), y2.cpu().numpy()) < 2 * TOL
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 192, 192), (1, 224, 224), (3, 96, 96), (1, 100, 100), (2, 33, 61), (1, 50, 38), (1, 7, 5), (1, 3, 3)])
+def test_fused_stem2_vs_oracle(env, n, h, w):
+    """conv1 -> depthwise -> pointwise -> stride-2 depthwise in one kernel vs the four-op oracle (odd sizes: partial
+    patches, and odd intermediate maps where the stride-2 depthwise pads on top/left too), and vs the unfused kernels."""
+    torch, ops = env
+    rs = np.random.RandomState(h * 11 + w)
+    x = rs.uniform(-128, 152, (n, h, w, 3)).astype(np.float32)
+    cw = (rs.randn(3, 3, 3, 32) * 0.02).astype(np.float32)
+    csh = rs.randn(32).astype(np.float32)
+    k1 = (rs.randn(3, 3, 32, 1) / 3).astype(np.float32)
+    sc1 = rs.uniform(0.2, 2, 32).astype(np.float32)
+    sh1 = rs.randn(32).astype(np.float32)
+    kp = (rs.randn(32, 64) / np.sqrt(32)).astype(np.float32)
+    psh = rs.randn(64).astype(np.float32)
+    k2 = (rs.randn(3, 3, 64, 1) / 3).astype(np.float32)
+    sc2 = rs.uniform(0.2, 2, 64).astype(np.float32)
+    sh2 = rs.randn(64).astype(np.float32)
+    c1 = act6(tfo.conv2d(x.astype(np.float64), cw.astype(np.float64), (2, 2), "SAME") + csh)
+    d1 = act6(tfo.depthwise_conv2d(c1, k1, (1, 1), "SAME") * sc1 + sh1)
+    p1 = act6(d1.reshape(-1, 32).dot(kp.astype(np.float64)) + psh).reshape(d1.shape[:3] + (64,))
+    want = act6(tfo.depthwise_conv2d(p1, k2, (2, 2), "SAME") * sc2 + sh2)
+    d = lambda a: dev(torch, a)
+    y = ops.stem2_fused(d(x), d(cw), d(csh), d(k1.reshape(3, 3, 32)), d(sc1), d(sh1), kp.T, d(psh), d(k2.reshape(3, 3, 64)), d(sc2), d(sh2))
+    assert tuple(y.shape) == want.shape
+    assert rel(y.cpu().numpy(), want) < 2 * TOL
+    y1 = ops.stem_fused(d(x), d(cw), d(csh), d(k1.reshape(3, 3, 32)), d(sc1), d(sh1), kp.T, d(psh))
+    y2 = ops.dwconv3x3(y1, d(k2.reshape(3, 3, 64)), d(sc2), d(sh2), 2)
+    assert rel(y.cpu().numpy(), y2.cpu().numpy()) < 2 * TOL
+
+
 def test_fused_stem_rejects_uncovered_shapes(env):
     torch, ops = env
     z = lambda *s: torch.zeros(s, device="cuda")

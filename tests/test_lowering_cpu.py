@@ -94,7 +94,7 @@ def test_fusion_pass_merges_the_early_blocks_only(graph):
     keep = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "conv_dw_1_relu/clip_by_value:0"}, (64, 64))
     assert keep.layers[-1].kind == lowering.OP_DWCONV3X3
     # default: conv1 joins the first block (one kernel for graph nodes #30-#49), another 2.36 MB per face never reach HBM
-    stem = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192))
+    stem = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), stem_fusion="stem")
     ks = [L.kind for L in stem.layers]
     assert ks[:3] == [lowering.OP_STEM_F16S, lowering.OP_DWPW_F32, lowering.OP_DWCONV3X3] and len(ks) == len(kinds) - 1
     s0 = stem.layers[0]
@@ -104,6 +104,24 @@ def test_fusion_pass_merges_the_early_blocks_only(graph):
     assert "conv1_relu/clip_by_value" not in stem.tensor_layer and stem.tensor_layer["conv_pw_1_relu/clip_by_value"] == 0
     import plan_ref
     assert plan_ref.parse(stem.serialize())["ops"][0][0] == lowering.OP_STEM_F16S
+    # default: the stride-2 depthwise of block 2 joins as well (graph nodes #30-#55); block 2's pointwise is a plain GEMM then
+    s2 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192))
+    k2 = [L.kind for L in s2.layers]
+    assert k2[:4] == [lowering.OP_STEM2_F16S, lowering.OP_PWCONV_F32, lowering.OP_DWCONV3X3, lowering.OP_PWCONV_F32]
+    assert lowering.OP_DWPW_F32 not in k2 and len(k2) == len(kinds) - 1
+    L0 = s2.layers[0]
+    assert L0.in_shape == (192, 192, 3) and L0.out_shape == (48, 48, 64) and L0.pad3 == (0, 0) and L0.act == lowering.ACT_RELU6
+    assert s2.layers[1].src == 0 and s2.layers[1].a_log2 == 12 and s2.layers[1].out_shape == (48, 48, 128)
+    assert s2.flops_per_image() == unfused.flops_per_image()
+    assert unfused.bytes_per_image() - s2.bytes_per_image() == 2 * 4 * (96 * 96 * 32 * 2 + 96 * 96 * 64)
+    assert s2.tensor_layer["conv_dw_2_relu/clip_by_value"] == 0 and "conv_pw_1_relu/clip_by_value" not in s2.tensor_layer
+    assert plan_ref.parse(s2.serialize())["ops"][0][0] == lowering.OP_STEM2_F16S
+    odd = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (100, 100))          # 100 -> 50 -> 25: even map, no top/left pad
+    assert odd.layers[0].kind == lowering.OP_STEM2_F16S and odd.layers[0].pad3 == (0, 0) and odd.layers[0].out_shape == (25, 25, 64)
+    odd2 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (98, 98))           # 98 -> 49 -> 25: odd map pads one row on top/left
+    assert odd2.layers[0].pad3 == (1, 1) and odd2.layers[0].out_shape == (25, 25, 64)
+    with pytest.raises(ValueError):
+        lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (64, 64), stem_fusion="all")
     # conv1's own tensor requested, or the fp32-only arithmetic: no stem fusion
     keep1 = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0", OUT_AGE: "conv1_relu/clip_by_value:0"}, (64, 64))
     assert keep1.layers[0].kind == lowering.OP_CONV_C3
@@ -141,6 +159,7 @@ def test_plan_struct_layout_matches_header():
                       ("HSEFR_OP_DENSE", lowering.OP_DENSE), ("HSEFR_OP_SOFTMAX", lowering.OP_SOFTMAX),
                       ("HSEFR_OP_DWPW_F32", lowering.OP_DWPW_F32), ("HSEFR_OP_PWCONV_F16S", lowering.OP_PWCONV_F16S),
                       ("HSEFR_OP_DWPW_F16S", lowering.OP_DWPW_F16S), ("HSEFR_OP_STEM_F16S", lowering.OP_STEM_F16S),
+                      ("HSEFR_OP_STEM2_F16S", lowering.OP_STEM2_F16S),
                       ("HSEFR_ACT_RELU6", lowering.ACT_RELU6), ("HSEFR_ACT_SIGMOID", lowering.ACT_SIGMOID)):
         assert "%s = %d" % (name, val) in hdr
 
@@ -153,7 +172,7 @@ def test_buffers_never_alias_input_and_output(graph):
     pinned = {plan.layers[li].out_buf for li, _ in plan.outputs.values()}
     assert len(pinned) == 3
     # the two big ping-pong buffers + three small output buffers
-    assert sorted(plan.buffers, reverse=True)[:2] == [4 * 96 * 96 * 64, 4 * 96 * 96 * 32]
+    assert sorted(plan.buffers, reverse=True)[:2] == [4 * 48 * 48 * 128, 4 * 48 * 48 * 128]      # nothing at 96x96 is materialised any more
     unfused = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), fuse=False)
     assert sorted(unfused.buffers, reverse=True)[:2] == [4 * 96 * 96 * 64, 4 * 96 * 96 * 32]
 
@@ -215,9 +234,9 @@ def test_pointwise_math_selection_and_split_weight_image(graph):
     import plan_ref
     plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96))
     pws = [L for L in plan.layers if L.kind == lowering.OP_PWCONV_F32]
-    assert len(pws) == 11 and all(L.a_log2 == 12 for L in pws)
+    assert len(pws) == 12 and all(L.a_log2 == 12 for L in pws)          # pw_2 .. pw_13 (pw_1 lives in the fused stem)
     wire = [o[0] for o in plan_ref.parse(plan.serialize())["ops"]]
-    assert wire.count(lowering.OP_PWCONV_F16S) == 11 and lowering.OP_PWCONV_F32 not in wire
+    assert wire.count(lowering.OP_PWCONV_F16S) == 12 and lowering.OP_PWCONV_F32 not in wire
     plan32 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), pw_math="f32")
     assert all(L.a_log2 == 0 for L in plan32.layers)
     assert lowering.OP_PWCONV_F16S not in [o[0] for o in plan_ref.parse(plan32.serialize())["ops"]]

@@ -277,6 +277,19 @@ def bench_stem():
         by = 4.0 * B * (hw * hw * 3 + (hw // 2) ** 2 * 64)
         print("stem %d: conv1 %.1f + fused block %.1f = %.1f us | fused stem %.1f us  (%.0f GB/s of in+out)" %
               (hw, t_c, t_b, t_c + t_b, t_s, by / t_s / 1e3))
+        wd2 = torch.randn((3, 3, 64), device="cuda", generator=g) / 3
+        d2sc = torch.rand((64,), device="cuda", generator=g) + 0.5
+        d2sh = torch.randn((64,), device="cuda", generator=g) * 0.3
+        w2 = torch.randn((128, 64), device="cuda", generator=g) / 8
+        sh2 = torch.randn((128,), device="cuda", generator=g)
+        prep2 = ops.split_weights_device(w2, x.device)
+        y1 = ops.stem_fused(x, cw, csh, wd, dsc, dsh, None, sh, prepared=prep)
+        t_b2 = timeit(lambda: ops.dwpw_fused(y1, wd2, d2sc, d2sh, w2, sh2, 2))[0]
+        t_s2 = timeit(lambda: ops.stem2_fused(x, cw, csh, wd, dsc, dsh, None, sh, wd2, d2sc, d2sh, prepared=prep))[0]
+        y2 = ops.stem2_fused(x, cw, csh, wd, dsc, dsh, None, sh, wd2, d2sc, d2sh, prepared=prep)
+        t_p2 = timeit(lambda: ops.pwconv1x1_f16split(y2, None, sh2, prepared=prep2))[0]
+        print("   + block 2: stem %.1f + fused block 2 %.1f = %.1f us | stem+dw2 %.1f + pointwise 2 %.1f = %.1f us" %
+              (t_s, t_b2, t_s + t_b2, t_s2, t_p2, t_s2 + t_p2))
 
 
 def bench_stemstamps():
