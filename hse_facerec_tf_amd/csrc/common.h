@@ -162,6 +162,21 @@ void set_pw_tile(int v);
 void set_pws_tile(int v);
 int read_pws_stamps(void* host_out, size_t bytes);
 int read_stem_stamps(void* host_out, size_t bytes);
+#ifdef HSEFR_STEM_STAMPS
+// Diagnostic builds: per-wave s_memtime sums of kernel phases, [512 workgroups][4 waves][8 phases, lifetime, count].
+unsigned long long* stamp_buffer(hipStream_t s);
+#define STEM_STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); st[i] += _t - tprev; tprev = _t; } while (0)
+#define STEM_STAMP_DECL unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tprev = __builtin_amdgcn_s_memtime(); \
+    const unsigned long long tstart = tprev; unsigned npatch = 0
+#define STEM_STAMP_COUNT ++npatch
+#define STEM_STAMP_FLUSH(buf, lane, wave) do { if ((lane) == 0 && (buf) && blockIdx.x < 512) { unsigned long long* o = (buf) + (blockIdx.x * 4 + (wave)) * 10; \
+    for (int i_ = 0; i_ < 8; ++i_) o[i_] = st[i_]; o[8] = __builtin_amdgcn_s_memtime() - tstart; o[9] = npatch; } } while (0)
+#else
+#define STEM_STAMP(i) do { } while (0)
+#define STEM_STAMP_DECL do { } while (0)
+#define STEM_STAMP_COUNT do { } while (0)
+#define STEM_STAMP_FLUSH(buf, lane, wave) do { } while (0)
+#endif
 void set_pw_ablate(int v);
 void set_pw_dma(int v);
 void set_dw_th(int v);

@@ -128,6 +128,25 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
 }
 
 namespace hsefr {
+#ifdef HSEFR_STEM_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;
+unsigned long long* stamp_buffer(hipStream_t s) {
+    if (!g_stamp_buf && hipMalloc((void**)&g_stamp_buf, 512 * 4 * 10 * 8) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(g_stamp_buf, 0, 512 * 4 * 10 * 8, s);
+    return g_stamp_buf;
+}
+int read_stem_stamps(void* host_out, size_t bytes) {
+    HSEFR_REQUIRE(g_stamp_buf && bytes <= 512 * 4 * 10 * 8, HSEFR_ERR_INVALID, "read_stem_stamps: nothing recorded / too many bytes");
+    HSEFR_HIP_CHECK(hipMemcpy(host_out, g_stamp_buf, bytes, hipMemcpyDeviceToHost));
+    return HSEFR_OK;
+}
+#else
+int read_stem_stamps(void* host_out, size_t bytes) {
+    (void)host_out; (void)bytes;
+    set_error("read_stem_stamps: library built without -DHSEFR_STEM_STAMPS");
+    return HSEFR_ERR_UNSUPPORTED;
+}
+#endif
 static int g_sweep_reverse = 0;
 int sweep_reverse() { return g_sweep_reverse; }
 void set_sweep_reverse(int v) { g_sweep_reverse = v; }

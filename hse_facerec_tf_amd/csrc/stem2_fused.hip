@@ -54,6 +54,7 @@ struct Stem2Params {
     unsigned total;
     float a_scale;
     int reverse;
+    unsigned long long* stamps;   // diagnostic builds (-DHSEFR_STEM_STAMPS) only
 };
 
 constexpr int PH = 4, PW = 8;                         // output patch (of the stride-2 depthwise)
@@ -63,6 +64,8 @@ constexpr int R1ROWS = 160;                           // 10 MFMA row blocks of 1
 constexpr int R0H = R1H + 2, R0W = R1W + 2;           // conv1 region 11 x 19
 constexpr int R0PIX = R0H * R0W;                      // 209
 constexpr int R0ROWS = 224;                           // 14 MFMA row blocks of 16
+constexpr int COP = 36;                               // floats per pixel row of the conv1 region in LDS (32 + 4): taps sit at
+                                                      // compile-time offsets from one base (no per-tap swizzle arithmetic)
 constexpr int P1P = 68;                               // floats per pixel row of the 96x96x64 patch in LDS (64 + 4: rows 4 banks apart)
 
 __device__ __forceinline__ int swz32(int row, int chunk) { return row * 32 + 4 * (chunk ^ ((row >> 1) & 7)); }       // floats
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(Stem2Params p) {
     __shared__ __attribute__((aligned(16))) float4 W2[9 * 16];              // depthwise-2 weights
     __shared__ float Cv[R0ROWS];                                            // 1 = conv1 pixel inside its map
     __shared__ float Pv[R1ROWS];                                            // 1 = block-1 pixel inside its map
-    static_assert(R0ROWS * 32 <= R1PIX * P1P, "conv1 region fits in U2");
+    static_assert(R0ROWS * COP <= R1PIX * P1P, "conv1 region fits in U2");
     float* Ic = U1;
     unsigned char* As = (unsigned char*)U1;
     float* Co = U2;
@@ -202,11 +205,12 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(Stem2Params p) {
     scatter();
     __syncthreads();
 
+    STEM_STAMP_DECL;
     while (true) {
         const unsigned tn = t + gridDim.x;
         const bool more = tn < p.total;
         const Cur nxt = advance(cur);
-        if (more) gather(nxt);                                 // next patch's window loads fly during stages B-E
+        STEM_STAMP(0);
 
         // ---- stage B: conv1 on the fp32 MFMA; 14 row blocks x 2 channel blocks = 28 pairs, 7 per wave ----
         auto conv_pairs = [&](auto NP, int first) {     // NP pairs at once: independent accumulators hide the MFMA latency
@@ -237,27 +241,30 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(Stem2Params p) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = relu6(acc[i][e] + sh[e]) * valid;
-                *(f32x4*)(&Co[swz32(m, nb * 4 + q4)]) = o;
+                *(f32x4*)(&Co[m * COP + 4 * (nb * 4 + q4)]) = o;
             }
         };
         conv_pairs(std::integral_constant<int, 3>(), wave * 7);
         conv_pairs(std::integral_constant<int, 2>(), wave * 7 + 3);
         conv_pairs(std::integral_constant<int, 2>(), wave * 7 + 5);
+        STEM_STAMP(1);
         __syncthreads();     // conv1 region complete; im2col rows dead
+        STEM_STAMP(2);
 
         // ---- stage C: depthwise 1 over the 153 block-1 pixels, straight from LDS -> split-f16 A tile ----
-#pragma unroll 1
-        for (int it = 0; it < 5; ++it) {                       // not unrolled: 5 x 9 taps in flight would spill
+#pragma unroll 2
+        for (int it = 0; it < 5; ++it) {
             const int q = (tid >> 3) + 32 * it;                // block-1 region pixel
             if (q < R1ROWS) {
                 const int qq = q < R1PIX ? q : R1PIX - 1;      // rows 153..159: anything finite (their outputs are unused)
                 const int ry = qq / R1W, rx = qq % R1W;        // conv1 region pixel (ry + dy, rx + dx)
                 float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* base = &Co[(ry * R0W + rx) * COP + 4 * c4l];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx)
-                        s = fma4(ld4(&Co[swz32((ry + dy) * R0W + rx + dx, c4l)]), wk[dy * 3 + dx], s);
+                        s = fma4(ld4(base + (dy * R0W + dx) * COP), wk[dy * 3 + dx], s);
                 const float4 o = fma4(s, d1sc, d1sh);
                 f32x4 v;
                 v[0] = relu6(o.x); v[1] = relu6(o.y); v[2] = relu6(o.z); v[3] = relu6(o.w);
@@ -268,8 +275,12 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(Stem2Params p) {
                 *(f16x4*)(&As[swzb(q, 4 + (c4l >> 1)) + 8 * (c4l & 1)]) = lo;
             }
         }
+        STEM_STAMP(3);
         __syncthreads();     // A tile complete; conv1 region dead
+        STEM_STAMP(2);
 
+        if (more) gather(nxt);       // next patch's window loads fly during stages D-E (their 27 registers are free in B and C)
+        STEM_STAMP(7);
         // ---- stage D: pointwise on the f16 MFMA (K = 32 in one instruction); wave w = channels 16w..16w+15, all 10 row blocks
 #pragma unroll 2
         for (int mb = 0; mb < 10; ++mb) {
@@ -289,7 +300,9 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(Stem2Params p) {
                 *(f32x4*)(&P1[m * P1P + wave * 16 + 4 * q4]) = o;
             }
         }
+        STEM_STAMP(4);
         __syncthreads();     // 96x96x64 patch complete; A tile dead
+        STEM_STAMP(2);
 
         // ---- stage E: depthwise 2 (stride 2) from LDS -> global ----
         {
@@ -313,14 +326,19 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(Stem2Params p) {
                 bstore16(v, ry, voff, 0);
             }
         }
+        STEM_STAMP(5);
+        STEM_STAMP_COUNT;
         if (!more) break;
         // U1 (im2col rows) is free since the barrier after stage D; U2 is read by stage E of slower waves, but the next
         // writer of U2 is stage B, behind the barrier below
         scatter();
+        STEM_STAMP(6);
         __syncthreads();
+        STEM_STAMP(2);
         t = tn;
         cur = nxt;
     }
+    STEM_STAMP_FLUSH(p.stamps, lane, wave);
 }
 
 }  // namespace
@@ -351,6 +369,10 @@ int launch_stem2_fused(const float* x, const float* cw, const float* cshift, con
     p.total = (unsigned)total;
     p.a_scale = ldexpf(1.f, a_log2);
     p.reverse = sweep_reverse();
+    p.stamps = nullptr;
+#ifdef HSEFR_STEM_STAMPS
+    p.stamps = stamp_buffer(s);
+#endif
     const unsigned g = p.total < 512u ? p.total : 512u;      // 512 % 8 == 0: the kernel's incremental patch cursor relies on it
 #define HSEFR_STEM2(A) hipLaunchKernelGGL((stem2_fused_kernel<A>), dim3(g), dim3(256), 0, s, p)
     if (act == HSEFR_ACT_RELU6) HSEFR_STEM2(HSEFR_ACT_RELU6);

@@ -51,11 +51,7 @@ struct StemParams {
     unsigned long long* stamps;   // diagnostic builds (-DHSEFR_STEM_STAMPS) only
 };
 
-#ifdef HSEFR_STEM_STAMPS
-#define STEM_STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); st[i] += _t - tprev; tprev = _t; } while (0)
-#else
-#define STEM_STAMP(i) do { } while (0)
-#endif
+
 
 constexpr int TW = 16, TH = 8, RW = TW + 2, RH = TH + 2, RPIX = RW * RH;   // conv1 region 10 x 18 = 180 pixels
 constexpr int RROWS = 192;                                                   // padded to 12 MFMA row blocks of 16
@@ -182,12 +178,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemParams p) {
     if (tid < RROWS) Cv[tid] = tid < RPIX ? cv : 0.f;
     __syncthreads();
 
-#ifdef HSEFR_STEM_STAMPS
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = __builtin_amdgcn_s_memtime();
-    const unsigned long long tstart = tprev;
-    unsigned npatch = 0;
-#endif
+    STEM_STAMP_DECL;
     while (true) {
         const unsigned tn = t + gridDim.x;
         const bool more = tn < p.total;
@@ -329,9 +320,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemParams p) {
             }
         }
         STEM_STAMP(5);
-#ifdef HSEFR_STEM_STAMPS
-        ++npatch;
-#endif
+        STEM_STAMP_COUNT;
         if (!more) break;
         __syncthreads();     // every wave is done with its scratch (Ic) and with As
         STEM_STAMP(2);
@@ -343,32 +332,10 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemParams p) {
         t = tn;
         cur = nxt;
     }
-#ifdef HSEFR_STEM_STAMPS
-    if (lane == 0 && p.stamps && blockIdx.x < 512) {
-        unsigned long long* o = p.stamps + (blockIdx.x * 4 + wave) * 10;
-        for (int i = 0; i < 8; ++i) o[i] = st[i];
-        o[8] = __builtin_amdgcn_s_memtime() - tstart;
-        o[9] = npatch;
-    }
-#endif
+    STEM_STAMP_FLUSH(p.stamps, lane, wave);
 }
 
 }  // namespace
-
-#ifdef HSEFR_STEM_STAMPS
-static unsigned long long* g_stem_stamps = nullptr;
-#endif
-int read_stem_stamps(void* host_out, size_t bytes) {
-#ifdef HSEFR_STEM_STAMPS
-    HSEFR_REQUIRE(g_stem_stamps && bytes <= 512 * 4 * 10 * 8, HSEFR_ERR_INVALID, "read_stem_stamps: nothing recorded / too many bytes");
-    HSEFR_HIP_CHECK(hipMemcpy(host_out, g_stem_stamps, bytes, hipMemcpyDeviceToHost));
-    return HSEFR_OK;
-#else
-    (void)host_out; (void)bytes;
-    set_error("read_stem_stamps: library built without -DHSEFR_STEM_STAMPS");
-    return HSEFR_ERR_UNSUPPORTED;
-#endif
-}
 
 bool stem_fused_supported(int cin, int cmid, int cout, int conv_stride, int dw_stride, int kh, int kw) {
     return cin == 3 && cmid == 32 && cout == 64 && conv_stride == 2 && dw_stride == 1 && kh == 3 && kw == 3;
@@ -393,9 +360,7 @@ int launch_stem_fused(const float* x, const float* cw, const float* cshift, cons
     p.reverse = sweep_reverse();
     p.stamps = nullptr;
 #ifdef HSEFR_STEM_STAMPS
-    if (!g_stem_stamps) HSEFR_HIP_CHECK(hipMalloc((void**)&g_stem_stamps, 512 * 4 * 10 * 8));
-    HSEFR_HIP_CHECK(hipMemsetAsync(g_stem_stamps, 0, 512 * 4 * 10 * 8, s));
-    p.stamps = g_stem_stamps;
+    p.stamps = stamp_buffer(s);
 #endif
     const unsigned g = p.total < 512u ? p.total : 512u;      // 512 % 8 == 0: the kernel's incremental patch cursor relies on it
 #define HSEFR_STEM(A) hipLaunchKernelGGL((stem_fused_kernel<A>), dim3(g), dim3(256), 0, s, p)

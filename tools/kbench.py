@@ -305,13 +305,21 @@ def bench_stemstamps():
     dsh = torch.randn((32,), device="cuda", generator=g) * 0.3
     w = torch.randn((64, 32), device="cuda", generator=g) / 32 ** 0.5
     sh = torch.randn((64,), device="cuda", generator=g)
+    wd2 = torch.randn((3, 3, 64), device="cuda", generator=g) / 3
+    d2sc = torch.rand((64,), device="cuda", generator=g) + 0.5
+    d2sh = torch.randn((64,), device="cuda", generator=g) * 0.3
+    which = os.environ.get("KB_STEM", "2")
     for _ in range(4):
-        ops.stem_fused(x, cw, csh, wd, dsc, dsh, w, sh)
+        if which == "1":
+            ops.stem_fused(x, cw, csh, wd, dsc, dsh, w, sh)
+        else:
+            ops.stem2_fused(x, cw, csh, wd, dsc, dsh, w, sh, wd2, d2sc, d2sh)
     torch.cuda.synchronize()
     buf = np.zeros((512 * 4, 10), np.uint64)
     _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
     b = buf[buf[:, 9] > 0].astype(np.float64)
-    names = ["decode + gather issue", "B conv1 mfma + Co write", "barriers", "C depthwise from LDS", "D pointwise mfma", "E epilogue", "scatter (wait gather)", "-"]
+    names = ["cursor + gather issue", "B conv1 mfma + region write", "barriers", "C depthwise 1 from LDS", "D pointwise mfma (+ patch write)",
+             "E epilogue / depthwise 2 + stores", "scatter (wait gather)", "-"]
     print("%d waves, lifetime mean %.0f cycles, patches/wave %.1f -> %.0f cycles per patch" % (len(b), b[:, 8].mean(), b[:, 9].mean(), (b[:, 8] / b[:, 9]).mean()))
     for i, nm in enumerate(names):
         print("   %-26s %5.1f %%  %7.0f cycles per patch" % (nm, 100 * (b[:, i] / b[:, 8]).mean(), (b[:, i] / b[:, 9]).mean()))
