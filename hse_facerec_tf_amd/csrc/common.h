@@ -181,6 +181,8 @@ void set_pw_ablate(int v);
 void set_pw_dma(int v);
 void set_dw_th(int v);
 void set_dw_variant(int v);
+void set_dw_look(int v);
+void set_dw_look2(int v);
 void set_copy_variant(int v);
 void set_clock_mode(int v);
 int launch_clock_probe(unsigned long long* out, int blocks, int iters, hipStream_t s);

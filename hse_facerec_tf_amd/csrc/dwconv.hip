@@ -52,8 +52,10 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
 
-template <int STRIDE, int ACT, int NT>
-__global__ __launch_bounds__(256, 4) void dwconv3x3_kernel(DwParams p) {
+// LOOK = rows requested ahead of the one being consumed (stride 1): 2 at 4 workgroups per CU, or 3 at 3 (more unique bytes
+// in flight per CU: the waves of this kernel spend two thirds of their life waiting on memory).
+template <int STRIDE, int ACT, int NT, int LOOK>
+__global__ __launch_bounds__(256, LOOK == 2 ? 4 : (LOOK <= 4 ? 3 : 2)) void dwconv3x3_kernel(DwParams p) {
     const unsigned bid = xcd_remap_dir(blockIdx.x, p.nwg, p.reverse);
     const int tx = bid % p.tiles_x;
     const int th = (bid / p.tiles_x) % p.tiles_h;
@@ -128,31 +130,46 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_kernel(DwParams p) {
     if (STRIDE == 1) {
         // sliding window, rows requested TWO iterations before they are consumed
         const int ih = oh0 - p.pad_t;
-        Row r0 = load_row(ih), r1 = load_row(ih + 1), r2 = load_row(ih + 2), r3 = load_row(ih + 3);
+        Row r[LOOK + 2];     // r[0..2] = the window; r[3..] requested ahead
+#pragma unroll
+        for (int i = 0; i < LOOK + 2; ++i) r[i] = load_row(ih + i);
         for (int oh = oh0; oh < oh1; ++oh) {
-            const Row r4 = load_row(oh - p.pad_t + 4);
-            compute_store(oh, r0, r1, r2);
-            r0 = r1; r1 = r2; r2 = r3; r3 = r4;
+            const Row nx = load_row(oh - p.pad_t + LOOK + 2);
+            compute_store(oh, r[0], r[1], r[2]);
+#pragma unroll
+            for (int i = 0; i < LOOK + 1; ++i) r[i] = r[i + 1];
+            r[LOOK + 1] = nx;
         }
     } else {
-        // stride 2: two new rows per output row, requested ONE iteration ahead
+        // stride 2: two new rows per output row, requested LOOK/2 iterations ahead
+        constexpr int LA = LOOK / 2;
         const int ih = oh0 * 2 - p.pad_t;
         Row r0 = load_row(ih), r1 = load_row(ih + 1), r2 = load_row(ih + 2);
+        Row f[2 * LA];
+#pragma unroll
+        for (int i = 0; i < 2 * LA - 2; ++i) f[i] = load_row(ih + 3 + i);
         for (int oh = oh0; oh < oh1; ++oh) {
-            const Row n1 = load_row(oh * 2 - p.pad_t + 3), n2 = load_row(oh * 2 - p.pad_t + 4);
+            f[2 * LA - 2] = load_row(oh * 2 - p.pad_t + 2 * LA + 1);
+            f[2 * LA - 1] = load_row(oh * 2 - p.pad_t + 2 * LA + 2);
             compute_store(oh, r0, r1, r2);
-            r0 = r2; r1 = n1; r2 = n2;
+            r0 = r2; r1 = f[0]; r2 = f[1];
+#pragma unroll
+            for (int i = 0; i < 2 * LA - 2; ++i) f[i] = f[i + 2];
         }
     }
 }
 
 int g_dw_th = 0;
 int g_dw_variant = 0;
+int g_dw_look = 4;       // hsefr_debug_set "dw_look": 2..5 rows of load lookahead, stride-1 kernel (measured in situ: 4 is best)
+int g_dw_look2 = 2;      // hsefr_debug_set "dw_look2": 2 | 4 = one | two iterations of lookahead, stride-2 kernel
 
 }  // namespace
 
 void set_dw_th(int v) { g_dw_th = v; }
 void set_dw_variant(int v) { g_dw_variant = v; }
+void set_dw_look(int v) { g_dw_look = (v >= 2 && v <= 5) ? v : 2; }
+void set_dw_look2(int v) { g_dw_look2 = v == 4 ? 4 : 2; }
 
 int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const float* shift, float* y,
                      int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
@@ -182,11 +199,15 @@ int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const
     dim3 grid((unsigned)nwg), block(256);
 #define HSEFR_DW_LAUNCH(S, A)                                                                      \
     do {                                                                                            \
+        const int look = S == 1 ? g_dw_look : g_dw_look2;                                            \
+        if (look == 3 && S == 1) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 3>), grid, block, 0, s, p); break; } \
+        if (look == 4) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 4>), grid, block, 0, s, p); break; } \
+        if (look == 5 && S == 1) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 5>), grid, block, 0, s, p); break; } \
         switch (g_dw_variant & 3) {                                                                 \
-            case 0: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0>), grid, block, 0, s, p); break;   \
-            case 1: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 1>), grid, block, 0, s, p); break;   \
-            case 2: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 2>), grid, block, 0, s, p); break;   \
-            default: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 3>), grid, block, 0, s, p); break;  \
+            case 0: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 2>), grid, block, 0, s, p); break;   \
+            case 1: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 1, 2>), grid, block, 0, s, p); break;   \
+            case 2: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 2, 2>), grid, block, 0, s, p); break;   \
+            default: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 3, 2>), grid, block, 0, s, p); break;  \
         }                                                                                           \
     } while (0)
     if (stride == 1) {
