@@ -186,8 +186,9 @@ int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const
     p.H = h; p.W = w; p.C4 = c / 4; p.OH = oh; p.OW = ow; p.pad_t = pad_t; p.pad_l = pad_l;
     p.tiles_x = (ow * p.C4 + 255) / 256;
     // Strip height: tall strips amortise the 2-row halo, short ones balance the CUs.
-    // measured on MI355X (tools/kbench.py dw): 24-row strips for the big stride-1 maps, 12 otherwise
-    int th = (stride == 1 && oh >= 48) ? 24 : 12;
+    // measured in situ on MI355X (HSEFR_DEBUG=dw_th=N bench.py --layers): 24-row strips wherever the map has them
+    // (with the deeper load lookahead a 24-row map is best walked whole: no halo rows re-read), 12 otherwise
+    int th = oh >= 24 ? 24 : 12;
     if (th > oh) th = oh;
     while (th > 4 && (long long)n * p.tiles_x * ((oh + th - 1) / th) < 512) th = (th + 1) / 2;
     if (g_dw_th > 0) th = g_dw_th < oh ? g_dw_th : oh;  // tuning/debug only (hsefr_debug_set "dw_th")
