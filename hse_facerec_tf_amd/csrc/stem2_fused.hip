@@ -78,6 +78,10 @@ __device__ __forceinline__ float4 ld4(const float* p) {
     const f32x4 v = *(const f32x4*)p;
     return make_float4(v[0], v[1], v[2], v[3]);
 }
+// 4-wide fused multiply-add on vector types: lowers to two v_pk_fma_f32 (same rounding as fmaf, half the instructions);
+// used where no MFMA shares the issue slots (the depthwise stages).
+__device__ __forceinline__ f32x4 vfma(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x4 as_v(float4 a) { return (f32x4){a.x, a.y, a.z, a.w}; }
 
 template <int ACT>
 __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(Stem2Params p) {
@@ -258,16 +262,16 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(Stem2Params p) {
             if (q < R1ROWS) {
                 const int qq = q < R1PIX ? q : R1PIX - 1;      // rows 153..159: anything finite (their outputs are unused)
                 const int ry = qq / R1W, rx = qq % R1W;        // conv1 region pixel (ry + dy, rx + dx)
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const float* base = &Co[(ry * R0W + rx) * COP + 4 * c4l];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx)
-                        s = fma4(ld4(base + (dy * R0W + dx) * COP), wk[dy * 3 + dx], s);
-                const float4 o = fma4(s, d1sc, d1sh);
+                        s = vfma(*(const f32x4*)(base + (dy * R0W + dx) * COP), as_v(wk[dy * 3 + dx]), s);
+                const f32x4 o = vfma(s, as_v(d1sc), as_v(d1sh));
                 f32x4 v;
-                v[0] = relu6(o.x); v[1] = relu6(o.y); v[2] = relu6(o.z); v[3] = relu6(o.w);
+                v[0] = relu6(o[0]); v[1] = relu6(o[1]); v[2] = relu6(o[2]); v[3] = relu6(o[3]);
                 v = v * p.a_scale;
                 const f16x4 hi = __builtin_convertvector(v, f16x4);
                 const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
@@ -311,15 +315,15 @@ __global__ __launch_bounds__(256, 2) void stem2_fused_kernel(Stem2Params p) {
             for (int it = 0; it < 2; ++it) {
                 const int px = (tid >> 4) + 16 * it;           // 0..31: output pixel of the patch
                 const int i = px >> 3, j = px & 7;
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx)
-                        s = fma4(ld4(&P1[((2 * i + dy) * R1W + 2 * j + dx) * P1P + 4 * c4o]), W2[(dy * 3 + dx) * 16 + c4o], s);
-                const float4 o = fma4(s, d2sc, d2sh);
+                        s = vfma(*(const f32x4*)(&P1[((2 * i + dy) * R1W + 2 * j + dx) * P1P + 4 * c4o]), as_v(W2[(dy * 3 + dx) * 16 + c4o]), s);
+                const f32x4 o = vfma(s, as_v(d2sc), as_v(d2sh));
                 f32x4 v;
-                v[0] = apply_act<ACT>(o.x); v[1] = apply_act<ACT>(o.y); v[2] = apply_act<ACT>(o.z); v[3] = apply_act<ACT>(o.w);
+                v[0] = apply_act<ACT>(o[0]); v[1] = apply_act<ACT>(o[1]); v[2] = apply_act<ACT>(o[2]); v[3] = apply_act<ACT>(o[3]);
                 const int oh = cur.th * PH + i, ow = cur.tw * PW + j;
                 // a pixel outside the map gets an offset beyond the resource and the store is dropped (no branch)
                 const unsigned voff = (oh < p.OH2 && ow < p.OW2) ? (unsigned)(oh * p.OW2 + ow) * 256u + 16u * c4o : 0x80000000u;
