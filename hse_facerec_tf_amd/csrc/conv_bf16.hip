@@ -126,6 +126,21 @@ __global__ __launch_bounds__(256, OCC) void conv_bf16_kernel(ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
     gload(0);
+    // The residual tile does not depend on anything computed here: request it NOW (registers), so that its HBM round
+    // trip overlaps the whole K loop instead of sitting between the last MFMA and the first store (the 1x1 "increase"
+    // layers have one or two K-tiles and twice as many residual bytes as input bytes).
+    constexpr int CH_PER_ROW = BN / 8;                 // 16-B chunks per tile row
+    constexpr int NCH = BM * CH_PER_ROW / 256;         // chunks per thread
+    bf16x8 rres[NCH];
+    if (p.res) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int i = tid + 256 * j, r = i / CH_PER_ROW, c = i - r * CH_PER_ROW;
+            unsigned pix = m0 + r;
+            if (pix > p.P - 1) pix = p.P - 1;           // tail rows: a valid address, never stored
+            rres[j] = *(const bf16x8*)(p.res + (size_t)pix * p.Cout + n0 + c * 8);
+        }
+    }
     swrite(0);
     __syncthreads();
     const int xrow = wm * WM + li, wrow = wn * WN + li;
@@ -173,26 +188,25 @@ __global__ __launch_bounds__(256, OCC) void conv_bf16_kernel(ConvParams p) {
     }
     __syncthreads();
     // ---- epilogue 2: coalesced 16-B chunks, residual add + activation on the way out ---------------------
-    constexpr int CH_PER_ROW = BN / 8;  // 16-B chunks per tile row
-    for (int i = tid; i < BM * CH_PER_ROW; i += 256) {
-        const int r = i / CH_PER_ROW, c = i - r * CH_PER_ROW;
+    const bool full_tile = m0 + BM <= p.P;             // full tiles store unconditionally (no per-store branch / vmcnt(0))
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int i = tid + 256 * j, r = i / CH_PER_ROW, c = i - r * CH_PER_ROW;
         const unsigned pix = m0 + r;
-        if (pix >= p.P) continue;
         bf16x8 v = *(const bf16x8*)(Cs + r * CROW + c * 16);
-        const size_t off = (size_t)pix * p.Cout + n0 + c * 8;
         if (p.res || p.act != HSEFR_ACT_NONE) {
-            bf16x8 rr;
-            if (p.res) rr = *(const bf16x8*)(p.res + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float f = bf2f((u16)v[e]);
-                if (p.res) f = bf2f(f2bf(f)) + bf2f((u16)rr[e]);
+                if (p.res) f = bf2f(f2bf(f)) + bf2f((u16)rres[j][e]);
                 if (p.act == HSEFR_ACT_RELU) f = fmaxf(f, 0.f);
                 else if (p.act == HSEFR_ACT_RELU6) f = fminf(fmaxf(f, 0.f), 6.f);
                 v[e] = (short)f2bf(f);
             }
         }
-        *(bf16x8*)(p.y + off) = v;
+        const size_t off = (size_t)pix * p.Cout + n0 + c * 8;
+        if (full_tile) *(bf16x8*)(p.y + off) = v;
+        else if (pix < p.P) *(bf16x8*)(p.y + off) = v;
     }
 }
 
@@ -211,10 +225,13 @@ struct StemParams {
     unsigned P, tiles;
 };
 
+struct __attribute__((packed, aligned(4))) F3s { float a, b, c; };
+
 __global__ __launch_bounds__(256, 2) void stem7x7_bf16_kernel(StemParams p) {
     constexpr int BM = 64, KP = 256;
     __shared__ __attribute__((aligned(16))) u16 As[BM * KP];   // [pixel][k]  (32 KB)
     __shared__ __attribute__((aligned(16))) u16 Bs[64 * KP];   // [cout][k]   (32 KB)
+    __shared__ __attribute__((aligned(16))) u16 Cs[BM * 64];   // output tile [pixel][cout] for the coalesced store pass (8 KB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     // rows are 512 B = 4 x 128-B K-tiles; chunk swizzle inside each 128-B tile
@@ -224,73 +241,107 @@ __global__ __launch_bounds__(256, 2) void stem7x7_bf16_kernel(StemParams p) {
         const int r = i >> 5, c = i & 31;
         *(bf16x8*)((unsigned char*)Bs + off(r, c >> 3, c & 7)) = *(const bf16x8*)(p.wt + (size_t)r * KP + c * 8);
     }
-    for (unsigned t = blockIdx.x; t < p.tiles; t += gridDim.x) {
-        __syncthreads();   // previous tile's MFMA reads are done (and Bs is written)
-        {
-            const int pl = tid >> 2, q = tid & 3;
-            unsigned pix = t * BM + pl;
-            if (pix > p.P - 1) pix = p.P - 1;
-            const unsigned ow = pix % (unsigned)p.OW, t2 = pix / (unsigned)p.OW;
-            const unsigned oh = t2 % (unsigned)p.OH, n = t2 / (unsigned)p.OH;
-            const int ih0 = (int)oh * 2 - 3, iw0 = (int)ow * 2 - 3;
-            const float* img = p.x + (size_t)n * p.H * p.W * 3;
+    // gather: 4 threads per output pixel, kernel rows q and q+4 each (row 7 = the zero half-tile); one dwordx3 per tap
+    // pixel from a clamped address, padding applied as 0/1 factors at scatter time.  The next tile's gather is requested
+    // before the current tile's MFMAs and stores.
+    const int pl = tid >> 2, q = tid & 3;
+    F3s g[2][7];
+    int gih0 = 0, giw0 = 0;
+    auto gather = [&](unsigned t) {
+        unsigned pix = t * BM + pl;
+        if (pix > p.P - 1) pix = p.P - 1;
+        const unsigned ow = pix % (unsigned)p.OW, t2 = pix / (unsigned)p.OW;
+        const unsigned oh = t2 % (unsigned)p.OH, n = t2 / (unsigned)p.OH;
+        gih0 = (int)oh * 2 - 3; giw0 = (int)ow * 2 - 3;
+        const float* img = p.x + (size_t)n * p.H * p.W * 3;
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int dy = q + 4 * rr;          // 0..7 (7 = the zero half-tile)
-                float v[32];
-                const int ih = ih0 + dy;
-                const bool rowok = dy < 7 && ih >= 0 && ih < p.H;
-                const int ihc = min(max(ih, 0), p.H - 1);
+        for (int rr = 0; rr < 2; ++rr) {
+            const int dy = q + 4 * rr;
+            const int ihc = min(max(gih0 + (dy < 7 ? dy : 6), 0), p.H - 1);
 #pragma unroll
-                for (int dx = 0; dx < 7; ++dx) {
-                    const int iw = iw0 + dx;
-                    const bool ok = rowok && iw >= 0 && iw < p.W;
-                    const int iwc = min(max(iw, 0), p.W - 1);
-                    const float* s = img + ((size_t)ihc * p.W + iwc) * 3;
-                    v[dx * 3 + 0] = ok ? s[0] : 0.f;
-                    v[dx * 3 + 1] = ok ? s[1] : 0.f;
-                    v[dx * 3 + 2] = ok ? s[2] : 0.f;
-                }
-#pragma unroll
-                for (int e = 21; e < 32; ++e) v[e] = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {       // 32 k-values = 4 chunks of the half K-tile (dy&1)
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(v[c * 8 + e]);
-                    *(bf16x8*)((unsigned char*)As + off(pl, dy >> 1, (dy & 1) * 4 + c)) = o;
-                }
+            for (int dx = 0; dx < 7; ++dx) {
+                const int iwc = min(max(giw0 + dx, 0), p.W - 1);
+                g[rr][dx] = *(const F3s*)(img + (unsigned)(ihc * p.W + iwc) * 3u);
             }
         }
-        __syncthreads();
+    };
+    auto scatter = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int dy = q + 4 * rr;          // 0..7 (7 = the zero half-tile)
+            const int ih = gih0 + dy;
+            const bool rowok = dy < 7 && ih >= 0 && ih < p.H;
+            float v[32];
+#pragma unroll
+            for (int dx = 0; dx < 7; ++dx) {
+                const int iw = giw0 + dx;
+                const float m = (rowok && iw >= 0 && iw < p.W) ? 1.f : 0.f;
+                v[dx * 3 + 0] = g[rr][dx].a * m;
+                v[dx * 3 + 1] = g[rr][dx].b * m;
+                v[dx * 3 + 2] = g[rr][dx].c * m;
+            }
+#pragma unroll
+            for (int e = 21; e < 32; ++e) v[e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {       // 32 k-values = 4 chunks of the half K-tile (dy&1)
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(v[c * 8 + e]);
+                *(bf16x8*)((unsigned char*)As + off(pl, dy >> 1, (dy & 1) * 4 + c)) = o;
+            }
+        }
+    };
+    unsigned t = blockIdx.x;
+    if (t >= p.tiles) return;
+    gather(t);
+    scatter();
+    __syncthreads();
+    const int wm = wave >> 1, wn = wave & 1;
+    while (true) {
+        const unsigned tn = t + gridDim.x;
+        const bool more = tn < p.tiles;
+        if (more) gather(tn);
         // 64 pixels x 64 channels: wave -> (pixel half, channel half), one 32x32 block each
-        const int wm = wave >> 1, wn = wave & 1;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bf16x8 xa = *(const bf16x8*)((unsigned char*)As + off(wm * 32 + li, kt, 2 * q + lh));
-                const bf16x8 wb = *(const bf16x8*)((unsigned char*)Bs + off(wn * 32 + li, kt, 2 * q + lh));
+            for (int qq = 0; qq < 4; ++qq) {
+                const bf16x8 xa = *(const bf16x8*)((unsigned char*)As + off(wm * 32 + li, kt, 2 * qq + lh));
+                const bf16x8 wb = *(const bf16x8*)((unsigned char*)Bs + off(wn * 32 + li, kt, 2 * qq + lh));
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb, xa, acc, 0, 0, 0);
             }
-        const unsigned pix = t * BM + wm * 32 + li;
-        if (pix < p.P) {
+        // lane -> pixel wm*32 + li, registers 4g..4g+3 -> channels wn*32 + 8g + 4lh + (0..3): park as bf16, 8 B per write
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch = wn * 32 + 8 * g + 4 * lh;
-                const float4 sc = *(const float4*)(p.scale + ch);
-                const float4 sh = *(const float4*)(p.shift + ch);
-                float f[4] = {fmaf(acc[4 * g], sc.x, sh.x), fmaf(acc[4 * g + 1], sc.y, sh.y),
-                              fmaf(acc[4 * g + 2], sc.z, sh.z), fmaf(acc[4 * g + 3], sc.w, sh.w)};
-                ushort4 o;
-                if (p.act == HSEFR_ACT_RELU) { f[0] = fmaxf(f[0], 0.f); f[1] = fmaxf(f[1], 0.f); f[2] = fmaxf(f[2], 0.f); f[3] = fmaxf(f[3], 0.f); }
-                o.x = f2bf(f[0]); o.y = f2bf(f[1]); o.z = f2bf(f[2]); o.w = f2bf(f[3]);
-                *(ushort4*)(p.y + (size_t)pix * 64 + ch) = o;
-            }
+        for (int gq = 0; gq < 4; ++gq) {
+            const int ch = wn * 32 + 8 * gq + 4 * lh;
+            const float4 sc = *(const float4*)(p.scale + ch);
+            const float4 sh = *(const float4*)(p.shift + ch);
+            float f[4] = {fmaf(acc[4 * gq], sc.x, sh.x), fmaf(acc[4 * gq + 1], sc.y, sh.y),
+                          fmaf(acc[4 * gq + 2], sc.z, sh.z), fmaf(acc[4 * gq + 3], sc.w, sh.w)};
+            if (p.act == HSEFR_ACT_RELU) { f[0] = fmaxf(f[0], 0.f); f[1] = fmaxf(f[1], 0.f); f[2] = fmaxf(f[2], 0.f); f[3] = fmaxf(f[3], 0.f); }
+            ushort4 o;
+            o.x = f2bf(f[0]); o.y = f2bf(f[1]); o.z = f2bf(f[2]); o.w = f2bf(f[3]);
+            const int prow = wm * 32 + li;
+            *(ushort4*)((unsigned char*)Cs + prow * 128 + 16 * ((ch >> 3) ^ (prow & 7)) + 2 * (ch & 7)) = o;
         }
+        __syncthreads();     // tile parked; every wave is done reading As
+        // coalesced pass: 64 rows x 8 chunks of 16 B = 2 chunks per thread, whole 128-B rows
+        const bool full_tile = (unsigned long long)t * BM + BM <= (unsigned long long)p.P;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j, r = i >> 3, c = i & 7;
+            const bf16x8 v = *(const bf16x8*)((unsigned char*)Cs + r * 128 + 16 * (c ^ (r & 7)));
+            const unsigned pix = t * BM + r;
+            if (full_tile) *(bf16x8*)(p.y + (size_t)pix * 64 + c * 8) = v;
+            else if (pix < p.P) *(bf16x8*)(p.y + (size_t)pix * 64 + c * 8) = v;
+        }
+        if (!more) break;
+        scatter();
+        __syncthreads();     // next tile's rows are in As; Cs is free again
+        t = tn;
     }
 }
 
