@@ -49,6 +49,7 @@ struct ConvParams {
     int H, W, C, OH, OW, Cout, KH, KW, stride, pad_t, pad_l, act;
     unsigned P;          // N*OH*OW output pixels
     unsigned tiles_n, total_tiles;
+    int reverse;         // sweep direction (common.h)
 };
 
 template <int BM, int BN, int OCC>
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, OCC) void conv_bf16_kernel(ConvParams p) {
     const int li = lane & 31, lh = lane >> 5;
     const int srow = tid >> 3, sch = tid & 7;
 
-    const unsigned lt = xcd_remap(blockIdx.x, p.total_tiles);
+    const unsigned lt = xcd_remap_dir(blockIdx.x, p.total_tiles, p.reverse);
     const unsigned tn = lt % p.tiles_n, tm = lt / p.tiles_n;
     const unsigned m0 = tm * BM;
     const int n0 = tn * BN;
@@ -432,6 +433,7 @@ int launch_conv_cfg(ConvParams p, hipStream_t s) {
     const long long total = (long long)((p.P + BM - 1) / BM) * p.tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv_bf16: too many tiles");
     p.total_tiles = (unsigned)total;
+    p.reverse = sweep_reverse();
     hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, OCC>), dim3((unsigned)total), dim3(256), 0, s, p);
     return launch_status("conv_bf16");
 }
