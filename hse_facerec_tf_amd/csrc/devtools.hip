@@ -93,7 +93,38 @@ __global__ __launch_bounds__(256) void clock_probe_f16_kernel(unsigned long long
     }
 }
 
-int g_clock_mode = 0;    // hsefr_debug_set "clock_mode": 0 = fp32 MFMA probe, 1 = f16 MFMA probe
+// ... and with the 16x16x32 shape (same FLOPs per cycle on paper; the chip holds a different clock under it)
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void clock_probe_f16s_kernel(unsigned long long* __restrict__ out, int iters, float seed) {
+    f32x4p a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (f32x4p){seed * i, seed + i, seed - i, seed * 2 + i};
+    f16x8p x, y;
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h = h * 1664525u + 1013904223u;
+        x[j] = (_Float16)(((int)(h >> 9) & 0xffff) * (1.f / 65536.f) - 0.5f);
+        h = h * 1664525u + 1013904223u;
+        y[j] = (_Float16)(((int)(h >> 9) & 0xffff) * (1.f / 65536.f) - 0.5f);
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16((k & 1) ? x : y, (k & 2) ? x : y, a[k], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sink = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sink += a[k][0] + a[k][1] + a[k][2] + a[k][3];
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 3 + 0] = t1 - t0;
+        out[blockIdx.x * 3 + 1] = r1 - r0;
+        out[blockIdx.x * 3 + 2] = (unsigned long long)__float_as_uint(sink);
+    }
+}
+
+int g_clock_mode = 0;    // hsefr_debug_set "clock_mode": 0 = fp32 MFMA probe, 1 = f16 32x32x16 probe, 2 = f16 16x16x32 probe
 int g_copy_variant = 0;  // unroll: (v & 3) -> {1, 2, 4, 8}; nt bits: (v >> 2) & 3; grid: (v >> 4) & 3 -> {8, 4, 16, 32} WG/CU
 
 template <int U, int NT>
@@ -119,6 +150,7 @@ void set_clock_mode(int v) { g_clock_mode = v; }
 int launch_clock_probe(unsigned long long* out, int blocks, int iters, hipStream_t s) {
     HSEFR_REQUIRE(out && blocks > 0 && iters > 0, HSEFR_ERR_INVALID, "clock_probe: bad argument");
     if (g_clock_mode == 1) hipLaunchKernelGGL(clock_probe_f16_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
+    else if (g_clock_mode == 2) hipLaunchKernelGGL(clock_probe_f16s_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
     else hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
     return launch_status("clock_probe");
 }

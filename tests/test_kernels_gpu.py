@@ -146,6 +146,29 @@ def test_pointwise_f16split_vs_oracle(env, m, k, cout):
     assert err.max() < 4 * max(err32.max(), 2.0 ** -24), "split-f16 %g vs fp32 MFMA %g" % (err.max(), err32.max())
 
 
+@pytest.mark.parametrize("m,k,cout", [(36864, 512, 512), (9216, 1024, 1024), (147456, 256, 256), (36864 + 77, 256, 512)])
+def test_pointwise_f16split_full_size_every_element_and_run_to_run(env, m, k, cout):
+    """BASELINE-size GEMMs (batch 256): persistent workgroups walk several tiles each, prefetch crosses tile boundaries,
+    the epilogue borrows an LDS stage -- none of which small shapes exercise.  EVERY output element is checked against
+    fp64 (on the device), and three launches must agree bit for bit (a schedule-dependent hazard shows up as rare,
+    moving, wrong 16-byte chunks: that is how a 16x16x32-MFMA variant of this kernel was rejected)."""
+    torch, ops = env
+    g = torch.Generator(device="cuda").manual_seed(m + k)
+    x = torch.rand((m, k), device="cuda", generator=g) * 6
+    w = torch.randn((cout, k), device="cuda", generator=g) / k ** 0.5
+    sh = torch.randn((cout,), device="cuda", generator=g)
+    want = torch.clamp(x.double() @ w.double().T + sh.double(), 0, 6)
+    prep = ops.split_weights_device(w, x.device)
+    ys = [ops.pwconv1x1_f16split(x, None, sh, prepared=prep) for _ in range(3)]
+    err = float((ys[0].double() - want).abs().max() / want.abs().max())
+    assert err < TOL * max(1.0, (k / 256.0) ** 0.5), err
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    # the exact-fp32 MFMA kernel on the same data: one long fmaf chain per output, so its own round-off is LARGER
+    y32 = ops.pwconv1x1(x, w, sh)
+    err32 = float((y32.double() - want).abs().max() / want.abs().max())
+    assert err32 < 3 * TOL * max(1.0, (k / 256.0) ** 0.5) and err < 1.5 * err32
+
+
 def test_pointwise_f16split_operand_maps_with_exact_integers(env):
     """Selector rows against an asymmetric integer kernel (exact in the split: integers < 2^22 after the per-channel
     scaling): a row/column or k-slot mix-up in the f16 fragment maps or in the split-row image gives a wrong integer."""

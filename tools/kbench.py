@@ -347,7 +347,8 @@ def bench_pwa():
 def bench_clock():
     """Shader clock and fp32-MFMA rate the chip sustains with every SIMD issuing MFMAs back to back."""
     for mode, blocks, label in ((0, 256, "fp32 1 wave/SIMD"), (0, 512, "fp32 2 waves/SIMD"), (0, 768, "fp32 3 waves/SIMD"),
-                                (1, 256, "f16 1 wave/SIMD"), (1, 512, "f16 2 waves/SIMD"), (1, 768, "f16 3 waves/SIMD")):
+                                (1, 256, "f16 1 wave/SIMD"), (1, 512, "f16 2 waves/SIMD"), (1, 768, "f16 3 waves/SIMD"),
+                                (2, 256, "f16 16x16x32 1 w/SIMD"), (2, 512, "f16 16x16x32 2 w/SIMD")):
         _lib.lib().hsefr_debug_set(b"clock_mode", mode)
         iters = 200000 if mode == 0 else 400000
         out = torch.zeros((blocks * 3,), dtype=torch.int64, device="cuda")
@@ -362,7 +363,7 @@ def bench_clock():
         o = out.cpu().numpy().reshape(blocks, 3)
         clk = np.median(o[:, 0] / o[:, 1]) * 100e6
         ms = ev0.elapsed_time(ev1)
-        tf = blocks * 4 * iters * 4 * (4096.0 if mode == 0 else 32768.0) / (ms * 1e-3) / 1e12
+        tf = blocks * 4 * iters * (4 * 4096.0 if mode == 0 else (4 * 32768.0 if mode == 1 else 8 * 16384.0)) / (ms * 1e-3) / 1e12
         print("clock probe %-18s: shader clock %.3f GHz (min %.3f max %.3f), %.2f ms, %.1f TFLOP/s MFMA" %
               (label, clk / 1e9, (o[:, 0] / o[:, 1]).min() / 10, (o[:, 0] / o[:, 1]).max() / 10, ms, tf))
     _lib.lib().hsefr_debug_set(b"clock_mode", 0)
