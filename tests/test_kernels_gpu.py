@@ -351,6 +351,38 @@ def test_fused_stem2_vs_oracle(env, n, h, w):
     assert rel(y.cpu().numpy(), y2.cpu().numpy()) < 2 * TOL
 
 
+def test_fused_stems_full_size_every_element_and_run_to_run(env):
+    """Batch 256 @ 192x192 (the BASELINE workload): the fused stem kernels vs the unfused kernels on EVERY output
+    element, and three launches bit-identical (persistent workgroups, 36 patches each, LDS regions re-used across
+    stages -- hazards here would show as rare wrong chunks, not as a gross mismatch)."""
+    torch, ops = env
+    g = torch.Generator(device="cuda").manual_seed(7)
+    n, hw = 256, 192
+    x = (torch.rand((n, hw, hw, 3), device="cuda", generator=g) - 0.45) * 280
+    cw = torch.randn((3, 3, 3, 32), device="cuda", generator=g) * 0.02
+    csh = torch.randn((32,), device="cuda", generator=g)
+    k1 = torch.randn((3, 3, 32), device="cuda", generator=g) / 3
+    sc1 = torch.rand((32,), device="cuda", generator=g) + 0.5
+    sh1 = torch.randn((32,), device="cuda", generator=g) * 0.3
+    kp = (torch.randn((64, 32), device="cuda", generator=g) / 32 ** 0.5).cpu().numpy()
+    psh = torch.randn((64,), device="cuda", generator=g)
+    k2 = torch.randn((3, 3, 64), device="cuda", generator=g) / 3
+    sc2 = torch.rand((64,), device="cuda", generator=g) + 0.5
+    sh2 = torch.randn((64,), device="cuda", generator=g) * 0.3
+    prep = ops.split_weights_device(kp, x.device)
+    c1 = ops.conv3x3_c3(x, cw, csh, 2)
+    d1 = ops.dwconv3x3(c1, k1, sc1, sh1, 1)
+    p1 = ops.pwconv1x1_f16split(d1, None, psh, prepared=prep)
+    d2 = ops.dwconv3x3(p1, k2, sc2, sh2, 2)
+    s1 = [ops.stem_fused(x, cw, csh, k1, sc1, sh1, None, psh, prepared=prep) for _ in range(3)]
+    assert torch.equal(s1[0], s1[1]) and torch.equal(s1[0], s1[2])
+    assert float((s1[0] - p1).abs().max()) < 6 * 2 * TOL
+    del s1, c1, d1
+    s2 = [ops.stem2_fused(x, cw, csh, k1, sc1, sh1, None, psh, k2, sc2, sh2, prepared=prep) for _ in range(3)]
+    assert torch.equal(s2[0], s2[1]) and torch.equal(s2[0], s2[2])
+    assert float((s2[0] - d2).abs().max()) < 6 * 2 * TOL
+
+
 def test_fused_stem_rejects_uncovered_shapes(env):
     torch, ops = env
     z = lambda *s: torch.zeros(s, device="cuda")
