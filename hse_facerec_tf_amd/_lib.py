@@ -21,6 +21,8 @@ SIGNATURES = {
     "hsefr_version": (c_int, []),
     "hsefr_last_error_string": (c_char_p, []),
     "hsefr_debug_set": (c_int, [c_char_p, c_int]),
+    "hsefr_engine_set_graph_batch": (c_int, [c_void_p, c_int]),
+    "hsefr_engine_graph_launches": (c_longlong, [c_void_p]),
     "hsefr_debug_read_stamps": (c_int, [c_void_p, ctypes.c_size_t]),
     "hsefr_debug_clock_probe": (c_int, [_fp, c_int, c_int, c_void_p]),
     "hsefr_debug_copy": (c_int, [_fp, _fp, c_size_t, c_void_p]),

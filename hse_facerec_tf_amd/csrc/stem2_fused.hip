@@ -71,13 +71,6 @@ constexpr int P1P = 68;                               // floats per pixel row of
 __device__ __forceinline__ int swz32(int row, int chunk) { return row * 32 + 4 * (chunk ^ ((row >> 1) & 7)); }       // floats
 __device__ __forceinline__ int swzb(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7)); }      // bytes
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
-__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
-    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
-}
-__device__ __forceinline__ float4 ld4(const float* p) {
-    const f32x4 v = *(const f32x4*)p;
-    return make_float4(v[0], v[1], v[2], v[3]);
-}
 // 4-wide fused multiply-add on vector types: lowers to two v_pk_fma_f32 (same rounding as fmaf, half the instructions);
 // used where no MFMA shares the issue slots (the depthwise stages).
 __device__ __forceinline__ f32x4 vfma(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }

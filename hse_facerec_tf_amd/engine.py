@@ -89,6 +89,14 @@ class Engine:
                                                        _lib.current_stream_ptr()), "hsefr_engine_copy_buffer")
         return out
 
+    # -- small batches as one hipGraph launch ---------------------------------------------------
+    def set_graph_batch(self, max_n: int) -> None:
+        """Forwards of at most max_n images replay a captured hipGraph (default 0 = off: no faster on the device)."""
+        _lib.check(_lib.lib().hsefr_engine_set_graph_batch(self._h, int(max_n)))
+
+    def graph_launches(self) -> int:
+        return int(_lib.lib().hsefr_engine_graph_launches(self._h))
+
     # -- profiling -----------------------------------------------------------------------------
     def set_profiling(self, depth: int) -> None:
         """depth > 0: keep HIP-event timings of the last `depth` forwards (ring); 0: off."""

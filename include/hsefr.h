@@ -173,6 +173,14 @@ typedef struct hsefr_engine hsefr_engine;
  * be freed after the call.  Replaces tf.import_graph_def + tf.Session (facerec_test.py:41-58). */
 int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsefr_engine** out);
 
+/* Batches of at most `max_n` images (default 0 = never) run as ONE hipGraph launch: the op sequence of a (batch size,
+ * requested outputs) pair is captured once, reading an engine-owned copy of the input, and replayed.  For callers whose
+ * host thread is the bottleneck (the reference calls its session once per image, facerec_test.py:394); on the device
+ * itself a batch-1 forward is a chain of ~25 dependent kernels either way (161 us plain, 168 us replayed).
+ * hsefr_engine_graph_launches counts forwards served that way. */
+int hsefr_engine_set_graph_batch(hsefr_engine* e, int max_n);
+long long hsefr_engine_graph_launches(const hsefr_engine* e);
+
 /* Total device bytes the engine holds (weights + workspace). */
 size_t hsefr_engine_workspace_bytes(const hsefr_engine* e);
 int hsefr_engine_max_batch(const hsefr_engine* e);

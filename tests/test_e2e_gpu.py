@@ -78,6 +78,29 @@ def test_engine_matches_golden_synthetic(torch_, size, fuse, pw_math):
         eng.forward(torch_.from_numpy(x).cuda())
 
 
+def test_small_batches_replay_a_captured_graph_bit_for_bit(torch_):
+    """n <= 8 goes through hipGraph replay (engine-owned input copy): identical bits to plain launches, for every
+    combination of requested outputs, changing input pointers and interleaved batch sizes."""
+    from hse_facerec_tf_amd import engine, graphdef, lowering
+    plan = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0", {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]}, (96, 96))
+    eng = engine.Engine(plan, max_batch=16)
+    rs = np.random.RandomState(3)
+    xs = [torch_.from_numpy(rs.uniform(-128, 128, (n, 96, 96, 3)).astype(np.float32)).cuda() for n in (1, 3, 8, 1, 9, 2)]
+    eng.set_graph_batch(0)
+    ref = [eng.forward(x, (0, 1, 2)) for x in xs]
+    assert eng.graph_launches() == 0
+    eng.set_graph_batch(8)
+    for rep in range(2):
+        for x, r in zip(xs, ref):
+            out = eng.forward(x.clone(), (0, 1, 2))          # a fresh pointer every call
+            for k in ("features", "age_probs", "gender"):
+                assert torch_.equal(out[k], r[k]), (k, x.shape[0])
+            only = eng.forward(x, (0,))
+            assert torch_.equal(only["features"], r["features"])
+    assert eng.graph_launches() == 2 * 2 * 5                  # the batch of 9 takes plain launches
+    eng.close()
+
+
 def test_every_layer_matches_the_oracle(torch_):
     """Layer-by-layer: each fused layer's output vs the graph tensor it stands for (unfused fp64
     oracle), through the per-kernel entry points with the plan's own weights."""
