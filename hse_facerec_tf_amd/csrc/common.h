@@ -118,6 +118,10 @@ int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_in
 int launch_conv_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
                      int n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t,
                      int pad_l, int act, hipStream_t s);
+int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
+                        long long P, int K, int cout, int act, hipStream_t s);
+bool conv1x1_bf16_enabled(bool has_res, int k, int cout);
+void set_c11(int v);
 int launch_stem7x7_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h,
                         int w, int oh, int ow, int act, hipStream_t s);
 int launch_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int pad_t, int pad_l,

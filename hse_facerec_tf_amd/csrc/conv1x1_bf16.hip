@@ -1,0 +1,289 @@
+// 1x1 stride-1 bf16 convolution (+ BatchNorm scale/shift, optional residual add, ReLU) as a PERSISTENT bf16-MFMA GEMM,
+// NHWC bf16 in / bf16 out, gfx950: the "reduce" and "increase" layers of ResNet-50's bottlenecks (resnet50_ft,
+// vgg2_resnet.pb at facerec_test.py:213), 54 % of that model's time.
+//
+//   Y[p, n] = act( bf16( scale[n] * sum_c X[p, c] * Wt[n, c] + shift[n] ) (+ R[p, n]) )        (same rounding points as
+//                                                                                               conv_bf16.hip)
+// These layers have one to sixteen K-tiles and as many residual/output bytes as input bytes: memory-bound.  The general
+// implicit-GEMM kernel (conv_bf16.hip) runs one tile per workgroup and exposes every load latency; this one is the
+// skeleton of the split-f16 pointwise GEMM (pwconv_f16s.hip) without the split:
+//   * persistent workgroups over a flat (tile, K-tile) step sequence, raw-buffer loads TWO steps ahead (two register sets,
+//     one VGPR offset for the whole kernel, rows beyond P dropped / zero-filled by the hardware);
+//   * 128-B LDS rows (64 bf16 = one K-tile) with the (row >> 1) & 7 chunk swizzle, double-buffered stages;
+//   * v_mfma_f32_32x32x16_bf16 with the operands swapped (weights first), so a lane ends up with 4 consecutive channels;
+//   * the tile's RESIDUAL chunks are requested at the tile's first step (registers) and are long there when the epilogue
+//     needs them; the epilogue transposes through a wave-private LDS scratch (the stage just consumed) and leaves as
+//     16-byte stores of whole 128-B row segments.
+#include <type_traits>
+
+#include "common.h"
+
+namespace hsefr {
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even (inputs are finite)
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ int swzb(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7)); }
+
+__device__ __forceinline__ bf16x8 bload8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore8(bf16x8 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hsefr_u32x4, v), r, voff, soff, 0);
+}
+
+template <int BM, int BN, int OCC, bool RES, int ACT>
+__global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __restrict__ x, const u16* __restrict__ wt,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const u16* __restrict__ res, u16* __restrict__ y, long long P,
+                                                                int K, int Cout, unsigned tiles_n, unsigned total_tiles,
+                                                                int reverse) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int AP = BM / 32, BP = BN / 32;
+    static_assert(WN == 64 || WN == 32, "wave tile width");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * 128];
+    __shared__ __attribute__((aligned(16))) float Et[2][2][BN];   // [tile parity][scale | shift][n]
+    auto As = [&](int st) { return &smem[st][0]; };
+    auto Bs = [&](int st) { return &smem[st][BM * 128]; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int srow = tid >> 3, sch = tid & 7;
+    const int KT = K / 64;
+    if (blockIdx.x >= total_tiles) return;
+    const unsigned ntile = (total_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const unsigned nsteps = ntile * KT;
+    const unsigned rowbytes = (unsigned)K * 2u;
+    const unsigned voff = (unsigned)srow * rowbytes + 16u * sch;
+
+    auto tile_origin = [&](unsigned i, long long& mm0, int& nn0) {
+        const unsigned lt = xcd_remap_dir(blockIdx.x + (i < ntile ? i : ntile - 1) * gridDim.x, total_tiles, reverse);
+        mm0 = (long long)(lt / tiles_n) * BM;
+        nn0 = (lt % tiles_n) * BN;
+    };
+    __amdgpu_buffer_rsrc_t ra_rsrc, rb_rsrc;
+    unsigned pf_i = 0;
+    int pf_kt = 0;
+    auto setup_rsrc = [&](unsigned i) {
+        long long mm0;
+        int nn0;
+        tile_origin(i, mm0, nn0);
+        ra_rsrc = make_rsrc(x + mm0 * K, (P - mm0) * (long long)rowbytes);
+        rb_rsrc = make_rsrc(wt + (long long)nn0 * K, (long long)(Cout - nn0) * rowbytes);
+    };
+    bf16x8 ra[2][AP], rb[2][BP];
+    auto gload = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
+        const unsigned so = (unsigned)pf_kt * 128u;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) ra[S][p] = bload8(ra_rsrc, voff, so + (unsigned)(32 * p) * rowbytes);
+#pragma unroll
+        for (int p = 0; p < BP; ++p) rb[S][p] = bload8(rb_rsrc, voff, so + (unsigned)(32 * p) * rowbytes);
+    };
+    auto advance_prefetch = [&]() {
+        if (++pf_kt == KT) {
+            pf_kt = 0;
+            setup_rsrc(++pf_i);
+        }
+    };
+    auto swrite = [&](auto SET, int buf) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) *(bf16x8*)(As(buf) + swzb(srow + 32 * p, sch)) = ra[S][p];
+#pragma unroll
+        for (int p = 0; p < BP; ++p) *(bf16x8*)(Bs(buf) + swzb(srow + 32 * p, sch)) = rb[S][p];
+    };
+
+    f32x16 acc[NI][MI];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+    };
+    zero_acc();
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    long long m0;
+    int n0;
+    unsigned ci = 0;
+    int ckt = 0;
+    tile_origin(0, m0, n0);
+    setup_rsrc(0);
+    gload(S0());
+    advance_prefetch();
+    gload(S1());
+    advance_prefetch();
+    swrite(S0(), 0);
+    __syncthreads();
+    const int xrow = wm * WM + li, wrow = wn * WN + li;
+    // epilogue geometry (after the transpose): a wave's tile row is WN bf16 = WN*2 bytes = CPR chunks of 16 B;
+    // lane -> (row erow of a 32-row block, chunk ech); 64 / CPR rows per store instruction
+    constexpr int CPR = WN / 8;
+    constexpr int RPI = 64 / CPR;
+    const int erow = lane / CPR, ech = lane % CPR;
+    const unsigned yvoff = ((unsigned)(wm * WM + erow) * (unsigned)Cout + (unsigned)(wn * WN + 8 * ech)) * 2u;
+    bf16x8 rres[RES ? MI * (32 / RPI) : 1];
+
+    auto step = [&](auto PAR) {
+        constexpr int PB = decltype(PAR)::value;
+        const bool first = ckt == 0;
+        f32x4 ec;
+        const bool fill = first && tid < BN / 2;
+        if (fill) {
+            const int j = tid < BN / 4 ? tid : tid - BN / 4;
+            ec = *(const f32x4*)((tid < BN / 4 ? scale : shift) + n0 + 4 * j);
+        }
+        if (RES && first) {      // this tile's residual chunks, in the layout the epilogue stores in (uniform branch)
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(res + m0 * Cout + n0, ((P - m0) * Cout - n0) * 2ll);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int i = 0; i < 32 / RPI; ++i)
+                    rres[RES ? mi * (32 / RPI) + i : 0] = bload8(rr, yvoff, (unsigned)(mi * 32 + RPI * i) * (unsigned)Cout * 2u);
+        }
+        gload(PAR);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bf16x8 xa[MI], wb[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xa[mi] = *(const bf16x8*)(As(PB) + swzb(xrow + mi * 32, 2 * q + lh));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) wb[ni] = *(const bf16x8*)(Bs(PB) + swzb(wrow + ni * 32, 2 * q + lh));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        }
+        swrite(std::integral_constant<int, 1 - PB>(), 1 - PB);
+        if (fill) *(f32x4*)(&Et[ci & 1][tid < BN / 4 ? 0 : 1][4 * (tid < BN / 4 ? tid : tid - BN / 4)]) = ec;
+        __syncthreads();
+        advance_prefetch();
+        if (++ckt == KT) {
+            const float* et = &Et[ci & 1][0][0];
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + m0 * Cout + n0, ((P - m0) * Cout - n0) * 2ll);
+            unsigned char* scr = &smem[PB][wave * 4096];       // stage PB: every wave is past its last read (barrier above)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                // D[row = channel][col = pixel]: lane -> pixel li, registers 4g..4g+3 -> channels ni*32 + 8g + 4*lh + 0..3
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = ni * 32 + 8 * g + 4 * lh;          // within the wave's WN columns
+                        const f32x4 sc = *(const f32x4*)(et + wn * WN + ch), sh = *(const f32x4*)(et + BN + wn * WN + ch);
+                        ushort4 o;
+                        o.x = f2bf(fmaf(acc[ni][mi][4 * g + 0], sc[0], sh[0]));
+                        o.y = f2bf(fmaf(acc[ni][mi][4 * g + 1], sc[1], sh[1]));
+                        o.z = f2bf(fmaf(acc[ni][mi][4 * g + 2], sc[2], sh[2]));
+                        o.w = f2bf(fmaf(acc[ni][mi][4 * g + 3], sc[3], sh[3]));
+                        // scratch row li (WN*2 bytes), 16-B chunk (ch >> 3) swizzled by the row, 8-B half (ch >> 2) & 1
+                        *(ushort4*)(scr + li * (WN * 2) + 16 * ((ch >> 3) ^ (li % CPR)) + 8 * ((ch >> 2) & 1)) = o;
+                    }
+                // The reads below fetch what OTHER lanes of this wave wrote: the writes must have landed.  Neither the compiler
+                // (no dependency it can see between different lanes) nor the LDS queue (a bank-conflicted ds_write_b64 was
+                // overtaken by the ds_read_b128 behind it: rare wrong dwords in rows 9/11/13/15, caught by the batch-128
+                // permutation test) orders them.
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+#pragma unroll
+                for (int i = 0; i < 32 / RPI; ++i) {
+                    const int r = erow + RPI * i;
+                    bf16x8 v = *(const bf16x8*)(scr + r * (WN * 2) + 16 * (ech ^ (r % CPR)));
+                    if (RES || ACT != HSEFR_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float f = bf2f((u16)v[e]);
+                            if (RES) f = f + bf2f((u16)rres[RES ? mi * (32 / RPI) + i : 0][e]);
+                            f = apply_act<ACT>(f);
+                            v[e] = (short)f2bf(f);
+                        }
+                    }
+                    // rows beyond P fall outside the resource and are dropped by the hardware
+                    bstore8(v, ry, yvoff, (unsigned)(mi * 32 + RPI * i) * (unsigned)Cout * 2u);
+                }
+            }
+            __syncthreads();   // the scratch is the stage the next step refills
+            zero_acc();
+            ckt = 0;
+            ++ci;
+            tile_origin(ci, m0, n0);
+        }
+    };
+    for (unsigned g = 0; g < nsteps; g += 2) {
+        step(S0());
+        if (g + 1 >= nsteps) break;
+        step(S1());
+    }
+}
+
+template <int BM, int BN, int OCC>
+int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shift, const u16* res, u16* y, long long P, int K,
+               int cout, int act, hipStream_t s) {
+    const long long tiles_m = (P + BM - 1) / BM;
+    const unsigned tiles_n = cout / BN;
+    const long long total = tiles_m * tiles_n;
+    HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv1x1_bf16: too many tiles");
+    const long long slots = 256ll * OCC;
+    const long long g = total < slots ? total : slots;
+    dim3 grid((unsigned)g), block(256);
+    const int rev = sweep_reverse();
+#define HSEFR_C11(R, A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, R, A>), grid, block, 0, s, x, wt, scale, shift, res, y, P, K, cout, tiles_n, (unsigned)total, rev)
+    if (res) {
+        if (act == HSEFR_ACT_RELU) HSEFR_C11(true, HSEFR_ACT_RELU);
+        else if (act == HSEFR_ACT_RELU6) HSEFR_C11(true, HSEFR_ACT_RELU6);
+        else HSEFR_C11(true, HSEFR_ACT_NONE);
+    } else {
+        if (act == HSEFR_ACT_RELU) HSEFR_C11(false, HSEFR_ACT_RELU);
+        else if (act == HSEFR_ACT_RELU6) HSEFR_C11(false, HSEFR_ACT_RELU6);
+        else HSEFR_C11(false, HSEFR_ACT_NONE);
+    }
+#undef HSEFR_C11
+    return launch_status("conv1x1_bf16");
+}
+
+int g_c11 = 1;   // hsefr_debug_set "c11": 0 = route 1x1 stride-1 layers through the general conv_bf16 kernel (A/B timing)
+
+}  // namespace
+
+void set_c11(int v) { g_c11 = v; }
+bool conv1x1_bf16_enabled(bool has_res, int k, int cout) {
+    switch (g_c11) {      // values > 1: bisection aids
+        case 0: return false;
+        case 2: return has_res;
+        case 3: return !has_res;
+        case 4: return k == 64;
+        case 5: return k > 64 && cout <= 256;
+        case 6: return k > 64 && cout > 256;
+        default: return true;
+    }
+}
+
+// x [P][K] bf16, wt [cout][K] bf16, y [P][cout] bf16; K % 64 == 0, cout % 64 == 0 (checked by the caller, launch_conv_bf16)
+int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
+                        long long P, int K, int cout, int act, hipStream_t s) {
+    const u16* xx = (const u16*)x;
+    const u16* ww = (const u16*)wt;
+    const u16* rr = (const u16*)res;
+    u16* yy = (u16*)y;
+    // 128 x 128 tiles when there are enough of them to fill the machine twice over, 128 x 64 otherwise
+    const long long t128 = ((P + 127) / 128) * (cout / 128);
+    if (cout % 128 == 0 && t128 >= 768) return launch_cfg<128, 128, 2>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
+    return launch_cfg<128, 64, 3>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
+}
+
+}  // namespace hsefr

@@ -455,6 +455,9 @@ int launch_conv_bf16(const void* x, const void* wt, const float* scale, const fl
     p.x = (const u16*)x; p.wt = (const u16*)wt; p.scale = scale; p.shift = shift; p.res = (const u16*)res; p.y = (u16*)y;
     p.H = h; p.W = w; p.C = c; p.OH = oh; p.OW = ow; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride;
     p.pad_t = pad_t; p.pad_l = pad_l; p.act = act; p.P = (unsigned)P;
+    // 1x1 stride-1 layers (the bottlenecks' reduce / increase): the persistent, prefetching GEMM of conv1x1_bf16.hip
+    if (kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && oh == h && ow == w && conv1x1_bf16_enabled(res != nullptr, c, cout))
+        return launch_conv1x1_bf16(x, wt, scale, shift, res, y, P, c, cout, act, s);
     const TileCfgB cfg = choose_tile_b(p.P, cout);
     if (cfg.bm == 128 && cfg.bn == 128) return launch_conv_cfg<128, 128, 2>(p, s);
     if (cfg.bm == 128 && cfg.bn == 64) return launch_conv_cfg<128, 64, 3>(p, s);

@@ -61,6 +61,30 @@ def test_conv_bf16_vs_oracle(env, n, h, w, c, cout, k, s, res, act):
     assert ok, "max rel err %.3e" % err
 
 
+@pytest.mark.parametrize("n,hw,c,cout,res,act", [(128, 56, 64, 256, False, 0), (128, 56, 64, 64, False, 1), (128, 56, 64, 256, True, 1),
+                                                 (128, 56, 256, 64, False, 1), (128, 28, 128, 512, True, 1), (128, 14, 1024, 256, False, 1),
+                                                 (128, 7, 512, 2048, True, 1), (3, 9, 64, 192, True, 1), (1, 5, 128, 64, False, 0)])
+def test_conv1x1_persistent_kernel_bit_for_bit_and_run_to_run(env, n, hw, c, cout, res, act):
+    """The persistent 1x1 kernel (conv1x1_bf16.hip) must reproduce the general implicit-GEMM kernel BIT FOR BIT on every
+    1x1 stride-1 layer shape of ResNet-50 at batch 128, three launches in a row (a missing wait between the LDS transpose's
+    writes and reads once gave rare wrong dwords at exactly these sizes -- K = 64 without residual -- and nowhere smaller)."""
+    torch, ops, resnet50 = env
+    from hse_facerec_tf_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(hw * 31 + c + cout)
+    x = torch.randn((n, hw, hw, c), device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn((cout, c), device="cuda", generator=g) / c ** 0.5).to(torch.bfloat16)
+    sc = torch.rand((cout,), device="cuda", generator=g) + 0.5
+    sh = torch.randn((cout,), device="cuda", generator=g)
+    r = torch.randn((n, hw, hw, cout), device="cuda", generator=g).to(torch.bfloat16) if res else None
+    try:
+        _lib.check(_lib.lib().hsefr_debug_set(b"c11", 0))
+        ref = ops.conv_bf16(x, w, sc, sh, 1, 1, 1, 0, r, act)
+    finally:
+        _lib.check(_lib.lib().hsefr_debug_set(b"c11", 1))
+    for _ in range(3):
+        assert torch.equal(ops.conv_bf16(x, w, sc, sh, 1, 1, 1, 0, r, act), ref)
+
+
 def test_conv_bf16_exact_integers(env):
     """Small integers are exact in bf16 and fp32: any im2col / fragment-map / swizzle mix-up shows as an exact mismatch."""
     torch, ops, resnet50 = env
