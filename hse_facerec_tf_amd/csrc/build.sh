@@ -16,4 +16,6 @@ for s in $SRCS; do
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS
+# refuse a library with an unguarded gfx950 store-data hazard (see tools/isa_lint.py)
+python3 ../../tools/isa_lint.py "$OUT"
 echo "built $(realpath $OUT)"

@@ -305,7 +305,6 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(StemParams p) {
                     for (int e = 0; e < 4; ++e) v[e] = pacc[mi][4 * j + e];
                     *(f32x4*)(scr + li * 32 + 4 * ((2 * j + lh) ^ (li & 7))) = v;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");   // cross-lane hand-over through LDS: writes must land first
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = erow + 8 * i;

@@ -66,8 +66,8 @@ def test_conv_bf16_vs_oracle(env, n, h, w, c, cout, k, s, res, act):
                                                  (128, 7, 512, 2048, True, 1), (3, 9, 64, 192, True, 1), (1, 5, 128, 64, False, 0)])
 def test_conv1x1_persistent_kernel_bit_for_bit_and_run_to_run(env, n, hw, c, cout, res, act):
     """The persistent 1x1 kernel (conv1x1_bf16.hip) must reproduce the general implicit-GEMM kernel BIT FOR BIT on every
-    1x1 stride-1 layer shape of ResNet-50 at batch 128, three launches in a row (a missing wait between the LDS transpose's
-    writes and reads once gave rare wrong dwords at exactly these sizes -- K = 64 without residual -- and nowhere smaller)."""
+    1x1 stride-1 layer shape of ResNet-50 at batch 128, three launches in a row (an unguarded store-data hazard -- DESIGN.md
+    lesson 14 -- once gave rare wrong dwords at exactly these sizes, K = 64 without residual, and nowhere smaller)."""
     torch, ops, resnet50 = env
     from hse_facerec_tf_amd import _lib
     g = torch.Generator(device="cuda").manual_seed(hw * 31 + c + cout)
