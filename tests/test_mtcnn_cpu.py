@@ -65,3 +65,19 @@ def test_oracle_cascade_reproduces_its_fixture():
     boxes, points = det.detect(imread_rgb(TEST_IMAGE))
     assert boxes.shape == (4, 5)                                                      # 4 faces, as in the reference notebook
     assert np.abs(boxes - z["boxes"]).max() < 1e-6 and np.abs(points - z["points"]).max() < 1e-4
+
+
+def test_reference_notebook_outputs_as_a_sanity_anchor():
+    """The reference's notebook (age_gender_identity/AgeGenderIdentityDemo.ipynb, cell 7) prints TensorFlow's age / gender
+    outputs for the four faces of test_image.jpg.  They are NOT a parity pin: the notebook ran another checkpoint
+    (facial_analysis.py:45 loads age_gender_tf2_224_deep-03-0.13-0.97_new.pb; the repository ships only
+    age_gender_tf2_new-01-0.14-0.92_quantized.pb), so numbers differ at the 1e-1 level.  What must hold with either
+    checkpoint: the same four faces in the same order, the same male/female decisions (threshold 0.6,
+    facial_analysis.py:76-81), ages within a few years and the same age ranking of the adult and the older child."""
+    z = np.load(os.path.join(GOLDEN, "mtcnn_test_image.npz"))
+    nb_gender = np.array([0.06864629, 0.6463263, 0.47247198, 0.23946252])
+    nb_age = np.array([34.56404456496239, 8.960565209388733, 2.0537627935409546, 2.684981346130371])
+    ours_gender, ours_age = z["genders"][:, 0], z["ages"]
+    assert np.array_equal(ours_gender >= 0.6, nb_gender >= 0.6)
+    assert np.abs(ours_age - nb_age).max() < 2.5
+    assert list(np.argsort(-ours_age)[:2]) == list(np.argsort(-nb_age)[:2])       # adult, then the older child
