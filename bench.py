@@ -127,7 +127,7 @@ def main():
             for i, L in enumerate(plan.layers):
                 nb = 4 * B * (int(np.prod(L.in_shape)) + int(np.prod(L.out_shape)))
                 oh, ow, co = L.out_shape
-                fl = plan.flops_per_image([L.kind]) * B if L.kind in (lowering.OP_STEM_F16S, lowering.OP_STEM2_F16S, lowering.OP_DWPW_F32) else \
+                fl = plan.flops_per_image([L.kind]) * B if L.kind in (lowering.OP_STEM_F16S, lowering.OP_STEM2_F16S, lowering.OP_DWPW_F32, lowering.OP_DWPW_F16S) else \
                     2 * oh * ow * co * L.kh * L.kw * (L.in_shape[2] if L.kind != lowering.OP_DWCONV3X3 else 1) * B
                 print("layer %2d kind %d %-34s in %-16s out %-16s s%d  %8.2f us  %7.1f GB/s  %6.1f TF" %
                       (i, L.kind, L.name[:34], L.in_shape, L.out_shape, L.stride, per_op[i] * 1e3,
@@ -161,6 +161,7 @@ def main():
         "conv1_3x3x3_s2": lambda L: L.kind == lowering.OP_CONV_C3,
         "depthwise3x3": lambda L: L.kind == lowering.OP_DWCONV3X3,
         "fused_dw3x3_pw1x1": lambda L: L.kind == lowering.OP_DWPW_F32,
+        "fused_dw3x3_pw1x1_f16split": lambda L: L.kind == lowering.OP_DWPW_F16S,
         "pointwise1x1_f32mfma": lambda L: L.kind == lowering.OP_PWCONV_F32 and L.a_log2 == 0,
         "pointwise1x1_f16split": lambda L: L.kind == lowering.OP_PWCONV_F32 and L.a_log2 > 0,
         "gap": lambda L: L.kind == lowering.OP_GAP,
@@ -177,7 +178,7 @@ def main():
             prof = json.load(open(cands[-1]))["kernels"]
             prefixes = {"stem_conv1_dw_pw_dw_fused": "stem2_fused_kernel", "stem_conv1_dw_pw_fused": "stem_fused_kernel", "conv1_3x3x3_s2": "conv3x3_c3", "depthwise3x3": "dwconv3x3_kernel",
                         "pointwise1x1_f32mfma": "pwconv_f32_", "pointwise1x1_f16split": "pwconv_f16s_kernel", "gap": "hsefr::gap_kernel",
-                        "fused_dw3x3_pw1x1": "dwpw_fused_kernel"}
+                        "fused_dw3x3_pw1x1": "dwpw_fused_kernel", "fused_dw3x3_pw1x1_f16split": "dwpw2_f16s_kernel"}
             for cls, pre in prefixes.items():
                 rows = [v for k, v in prof.items() if k.startswith(pre)]
                 n = sum(r["launches"] for r in rows)
@@ -199,7 +200,7 @@ def main():
             flops = sum(plan.flops_per_image([plan.layers[i].kind]) for i in idx[:1]) * B
             # a fused block also saves writing + re-reading the depthwise result: report both byte counts
             unfused_extra = sum(2 * 4 * int(np.prod(plan.layers[i].out_shape[:2])) * plan.layers[i].in_shape[2] for i in idx
-                                if plan.layers[i].kind == lowering.OP_DWPW_F32) * B \
+                                if plan.layers[i].kind in (lowering.OP_DWPW_F32, lowering.OP_DWPW_F16S)) * B \
                 + sum(2 * 2 * 4 * int(np.prod(plan.layers[i].out_shape[:2])) * 32 for i in idx
                       if plan.layers[i].kind == lowering.OP_STEM_F16S) * B \
                 + sum(2 * 4 * ((plan.layers[i].in_shape[0] + 1) // 2) * ((plan.layers[i].in_shape[1] + 1) // 2) * (32 + 32 + 64) for i in idx

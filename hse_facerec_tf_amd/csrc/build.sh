@@ -6,15 +6,18 @@ OUT=../libhsefr.so
 SRCS="engine.hip conv_first.hip dwconv.hip pwconv_f32.hip pwconv_f16s.hip pool_dense.hip nn1.hip devtools.hip conv_bf16.hip conv1x1_bf16.hip preprocess.hip dwpw_fused.hip dwpw_f16s.hip stem_fused.hip stem2_fused.hip smallnet.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
 OBJS=""
+PIDS=""
 for s in $SRCS; do
   o="build/${s%.hip}.o"
   mkdir -p build
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/hsefr.h -nt "$o" ]; then
+    rm -f "$o"
     hipcc $FLAGS ${HSEFR_EXTRA_FLAGS:-} -c "$s" -o "$o" &
+    PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"
 done
-wait
+for pid in $PIDS; do wait "$pid"; done     # a failed compile fails the build (set -e)
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS
 # refuse a library with an unguarded gfx950 store-data hazard (see tools/isa_lint.py)
 python3 ../../tools/isa_lint.py "$OUT"

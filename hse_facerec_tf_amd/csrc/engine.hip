@@ -179,6 +179,7 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "sweep_alternate")) { g_sweep_alternate = value; return HSEFR_OK; }
     if (!strcmp(key, "clock_mode")) { set_clock_mode(value); return HSEFR_OK; }
     if (!strcmp(key, "dwpws_tw")) { set_dwpws_tw(value); return HSEFR_OK; }
+    if (!strcmp(key, "dwpws_v2")) { set_dwpws_v2(value); return HSEFR_OK; }
     if (!strcmp(key, "dwpws_bn")) { set_dwpws_bn(value); return HSEFR_OK; }
     if (!strcmp(key, "pw_ablate")) { set_pw_ablate(value); return HSEFR_OK; }
     if (!strcmp(key, "pw_dma")) { set_pw_dma(value); return HSEFR_OK; }

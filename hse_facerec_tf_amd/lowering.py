@@ -185,7 +185,7 @@ class Plan:
                 if L.a_log2 > 0:
                     kind, aux = OP_PWCONV_F16S, L.a_log2
                     w, scale = split_pointwise_weights(w, L.a_log2)
-            elif L.kind in (OP_DWCONV3X3, OP_DWPW_F32):
+            elif L.kind in (OP_DWCONV3X3, OP_DWPW_F32, OP_DWPW_F16S):
                 w = w.reshape(3, 3, -1)
             w2 = None if L.w2 is None else np.ascontiguousarray(L.w2.reshape(L.w2.shape[-2], L.w2.shape[-1]).T)
             shift2 = L.shift2
@@ -199,6 +199,10 @@ class Plan:
                 shift2 = np.concatenate([descale, L.shift2.astype(np.float32)])
                 aux = L.a_log2
                 kw_field = 3 + 16 * L.pad3[0] + 32 * L.pad3[1]
+            if L.kind == OP_DWPW_F16S:
+                w2, descale = split_pointwise_weights(w2, L.a_log2)
+                shift2 = np.concatenate([descale, L.shift2.astype(np.float32)])
+                aux = L.a_log2
             if L.kind == OP_STEM_F16S:
                 # one fp32 pack [conv HWIO 864 | conv shift 32 | dw 3x3x32 288 | dw scale 32 | dw shift 32], split pointwise rows
                 w = np.concatenate([L.w0.reshape(-1), L.shift0.reshape(-1), L.w.reshape(-1), L.scale.reshape(-1),
@@ -254,7 +258,7 @@ class Plan:
                 tot += 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
             elif L.kind == OP_DWCONV3X3:
                 tot += 2 * oh * ow * cout * 9
-            elif L.kind == OP_DWPW_F32:
+            elif L.kind in (OP_DWPW_F32, OP_DWPW_F16S):
                 tot += 2 * oh * ow * L.in_shape[2] * 9 + 2 * oh * ow * cout * L.in_shape[2]
             elif L.kind == OP_STEM_F16S:
                 tot += 2 * oh * ow * 32 * 27 + 2 * oh * ow * 32 * 9 + 2 * oh * ow * cout * 32
@@ -808,6 +812,57 @@ def fuse_stem2(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], D
     return layers, ident
 
 
+# (channels in, channels out) of the stride-1 blocks for which one fused kernel beats depthwise + GEMM on MI355X at the
+# BASELINE batch sizes (tools/kbench.py blk): the HBM-bound middle of the network.  Deeper blocks are MFMA-bound (fusing
+# only serialises the depthwise in front of the contraction), the stride-2 ones would need a 4x larger halo in LDS.
+BLOCK_F16S_AUTO = ((128, 128), (256, 256))
+
+
+def block_f16s_fusable(dw: Layer, pw: Layer, which: str) -> bool:
+    """Blocks csrc/dwpw_f16s.hip covers: depthwise 3x3 + ReLU6 feeding ONLY a split-f16 pointwise layer."""
+    c, cout = dw.in_shape[2], pw.out_shape[2]
+    if not (dw.kind == OP_DWCONV3X3 and pw.kind == OP_PWCONV_F32 and pw.a_log2 > 0 and dw.act == ACT_RELU6 and
+            pw.act in (ACT_NONE, ACT_RELU, ACT_RELU6) and dw.stride in (1, 2) and c % 32 == 0 and cout % 64 == 0):
+        return False
+    return which == "all" or (dw.stride == 1 and (c, cout) in BLOCK_F16S_AUTO)
+
+
+def fuse_block_f16s(layers: List[Layer], keep: Sequence[int], which: str) -> Tuple[List[Layer], Dict[int, int]]:
+    """Merge depthwise -> split-f16 pointwise pairs into one DWPW_F16S layer (the depthwise result never reaches HBM).
+    Bit-identical to the pair it replaces.  Returns (layers, old index -> new index; a merged depthwise maps to -1)."""
+    consumers: Dict[int, List[int]] = {}
+    for i, L in enumerate(layers):
+        for s in (L.src, L.res):
+            if s >= 0:
+                consumers.setdefault(s, []).append(i)
+    merged_into: Dict[int, int] = {}
+    for i, L in enumerate(layers):
+        cons = consumers.get(i, [])
+        if (L.kind == OP_DWCONV3X3 and i not in keep and len(cons) == 1 and layers[cons[0]].src == i and
+                block_f16s_fusable(L, layers[cons[0]], which)):
+            merged_into[i] = cons[0]
+    new_layers: List[Layer] = []
+    remap: Dict[int, int] = {}
+    for i, L in enumerate(layers):
+        if i in merged_into:
+            remap[i] = -1
+            continue
+        dws = [d for d, pwi in merged_into.items() if pwi == i]
+        if dws:
+            dw = layers[dws[0]]
+            L = Layer(OP_DWPW_F16S, L.name, dw.src, dw.in_shape, L.out_shape, w=dw.w, scale=dw.scale, shift=dw.shift,
+                      act=L.act, kh=3, kw=3, stride=dw.stride, pad_t=dw.pad_t, pad_l=dw.pad_l, sealed=True,
+                      w2=L.w, shift2=L.shift, a_log2=L.a_log2)
+        new_layers.append(L)
+        remap[i] = len(new_layers) - 1
+    for L in new_layers:
+        if L.src >= 0:
+            L.src = remap[L.src]
+        if L.res >= 0:
+            L.res = remap[L.res]
+    return new_layers, remap
+
+
 def choose_pointwise_math(layers: List[Layer], pw_math: str) -> None:
     """Mark the pointwise layers that may form their products on the f16 MFMA (csrc/pwconv_f16s.hip): the two-term f16
     split needs a bounded input, which the graph proves when the producing layer ends in ReLU6 ([0, 6] -> a_log2 12)."""
@@ -827,11 +882,15 @@ def choose_pointwise_math(layers: List[Layer], pw_math: str) -> None:
 
 def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
                 feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32",
-                pw_math: Optional[str] = None, fuse_stem_block: Optional[bool] = None, stem_fusion: Optional[str] = None) -> Plan:
+                pw_math: Optional[str] = None, fuse_stem_block: Optional[bool] = None, stem_fusion: Optional[str] = None,
+                block_fusion: Optional[str] = None) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase.
     fuse: merge depthwise -> pointwise pairs into one kernel where a fused kernel covers the shape.  stem_fusion:
     'stem2' (default; env HSEFR_FUSE_STEM=0|1only|1 changes the default) = conv1 + block 1 + the depthwise of block 2 in one
     kernel, 'stem' = conv1 + block 1, 'none'; fuse_stem_block=False is the older spelling of 'none'.
+    block_fusion: 'auto' (default; env HSEFR_FUSE_BLOCKS=auto|none|all changes the default) = the stride-1 blocks of
+    BLOCK_F16S_AUTO run as one depthwise+pointwise kernel (csrc/dwpw_f16s.hip), 'all' = every block that kernel covers,
+    'none'.
     pw_math: 'auto' (default; env HSEFR_PW_MATH overrides the default) = split-f16 products for every pointwise layer
     whose input the graph bounds (ReLU6), fp32 MFMA otherwise; 'f32' = fp32 MFMA everywhere.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
@@ -903,6 +962,13 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
         choose_pointwise_math(layers, pw_math)
         if want_stem:
             layers, remap = fuse_stem(layers, [li for li, _ in out_layers.values()])
+            out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
+            tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
+        block_fusion = block_fusion or os.environ.get("HSEFR_FUSE_BLOCKS", "auto")
+        if block_fusion not in ("auto", "none", "all"):
+            raise ValueError("block_fusion must be 'auto', 'none' or 'all', not %r" % (block_fusion,))
+        if fuse and block_fusion != "none":
+            layers, remap = fuse_block_f16s(layers, [li for li, _ in out_layers.values()], block_fusion)
             out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
             tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
     buffers = assign_buffers(layers, {li for li, _ in out_layers.values()})

@@ -144,6 +144,17 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             mid = _act(tfo.depthwise_conv2d(xp, k, (stride, stride), "VALID") * arr(sc_off, cin) + arr(sh_off, cin), 2)
             wt = arr(w2_off, cin * cout).reshape(cout, cin)
             y = _act(PW(mid.reshape(-1, cin), wt) + arr(sh2_off, cout), act).reshape(n, oh, ow, cout)
+        elif kind == 13:     # the same block with split-f16 pointwise weights (any channel count)
+            from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
+            k = arr(w_off, 9 * cin).reshape(3, 3, cin, 1)
+            pb = max((oh - 1) * stride + 3 - h - pad_t, 0)
+            pr = max((ow - 1) * stride + 3 - w - pad_l, 0)
+            xp = np.pad(src, ((0, 0), (pad_t, pb), (pad_l, pr), (0, 0)))
+            mid = _act(tfo.depthwise_conv2d(xp, k, (stride, stride), "VALID") * arr(sc_off, cin) + arr(sh_off, cin), 2)
+            img = np.frombuffer(data, np.uint16, cout * cin * 2, w2_off).reshape(cout, cin // 32, 64)
+            ds = np.frombuffer(data, np.float32, 2 * cout, sh2_off)
+            wt = unsplit_pointwise_weights(img, ds[:cout], _r).astype(dtype)
+            y = _act(PW(mid.reshape(-1, cin), wt) + ds[cout:].astype(dtype), act).reshape(n, oh, ow, cout)
         elif kind == 7:      # bf16 implicit-GEMM conv: weights [cout][kh*kw*cin] bf16, fp32 scale/shift, optional residual
             k = arr_bf16(w_off, kh * kw * cin * cout).reshape(cout, kh, kw, cin).transpose(1, 2, 3, 0)
             pb = max((oh - 1) * stride + kh - h - pad_t, 0)

@@ -53,6 +53,30 @@ def test_engine_matches_golden_for_every_stem_fusion(torch_, size, stem_fusion):
     eng.close()
 
 
+@pytest.mark.parametrize("size", [192, 100])
+def test_block_fusion_is_bit_identical_to_the_unfused_plan(torch_, size):
+    """block_fusion 'auto' (the HBM-bound stride-1 blocks) and 'all' (every block csrc/dwpw_f16s.hip covers, both
+    strides, both kernel versions) against 'none': same golden parity, and the SAME BITS -- the fused kernels keep the
+    operation order of the kernels they replace."""
+    from hse_facerec_tf_amd import engine, graphdef, lowering
+    z = np.load(os.path.join(GOLDEN, "e2e_synthetic.npz"))
+    n = z["feat_%d" % size].shape[0]
+    x = torch_.from_numpy(np.random.RandomState(123).uniform(-128, 128, (n, size, size, 3)).astype(np.float32)).cuda()
+    outs = {}
+    for mode in ("none", "auto", "all"):
+        plan = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0", {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]}, (size, size),
+                                    block_fusion=mode)
+        nfused = sum(L.kind == lowering.OP_DWPW_F16S for L in plan.layers)
+        assert nfused == {"none": 0, "auto": 2, "all": 11}[mode]
+        eng = engine.Engine(plan, max_batch=4)
+        outs[mode] = {k: v.clone() for k, v in eng.forward(x, (0, 1, 2)).items()}
+        eng.close()
+        assert rel(outs[mode]["features"].cpu().numpy(), z["feat_%d" % size]) < BAR
+    for mode in ("auto", "all"):
+        for k in outs["none"]:
+            assert torch_.equal(outs[mode][k], outs["none"][k]), (mode, k)
+
+
 @pytest.mark.parametrize("pw_math", ["auto", "f32"])
 @pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("size", [192, 224, 96, 100])
@@ -134,6 +158,9 @@ def test_every_layer_matches_the_oracle(torch_):
         elif L.kind == lowering.OP_DWPW_F32:
             y = ops.dwpw_fused(src, d(L.w.reshape(3, 3, -1)), d(L.scale), d(L.shift),
                                d(L.w2.reshape(L.w2.shape[2], L.w2.shape[3]).T), d(L.shift2), L.stride)
+        elif L.kind == lowering.OP_DWPW_F16S:
+            y = ops.dwpw_f16split(src, d(L.w.reshape(3, 3, -1)), d(L.scale), d(L.shift), L.w2.reshape(L.w2.shape[2], L.w2.shape[3]).T,
+                                  d(L.shift2), L.stride, L.act, L.a_log2)
         elif L.kind == lowering.OP_GAP:
             y = ops.gap(src)
         elif L.kind == lowering.OP_DENSE:

@@ -77,7 +77,7 @@ def test_lowered_plan_equals_unfused_graph(graph, size, n):
 
 
 def test_fusion_pass_merges_the_early_blocks_only(graph):
-    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), fuse_stem_block=False)
+    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), fuse_stem_block=False, block_fusion="none")
     kinds = [L.kind for L in plan.layers]
     assert kinds[:3] == [lowering.OP_CONV_C3, lowering.OP_DWPW_F32, lowering.OP_DWPW_F32]      # C = 32 and C = 64 blocks
     assert kinds.count(lowering.OP_DWPW_F32) == 2 and kinds.count(lowering.OP_DWCONV3X3) == 11
@@ -86,15 +86,15 @@ def test_fusion_pass_merges_the_early_blocks_only(graph):
     assert f2.in_shape == (96, 96, 64) and f2.out_shape == (48, 48, 128) and f2.stride == 2 and (f2.pad_t, f2.pad_l) == (0, 0)
     assert "conv_dw_1_relu/clip_by_value" not in plan.tensor_layer and plan.tensor_layer["conv_pw_1_relu/clip_by_value"] == 1
     # same FLOPs, 5.9 MB less HBM traffic per face (the two depthwise outputs are neither written nor re-read)
-    unfused = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), fuse=False)
+    unfused = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), fuse=False, block_fusion="none")
     assert plan.flops_per_image() == unfused.flops_per_image()
     saved = unfused.bytes_per_image() - plan.bytes_per_image()
     assert saved == 2 * 4 * (96 * 96 * 32 + 48 * 48 * 64)
     # a depthwise tensor that is itself requested is not fused away
-    keep = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "conv_dw_1_relu/clip_by_value:0"}, (64, 64))
+    keep = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "conv_dw_1_relu/clip_by_value:0"}, (64, 64), block_fusion="none")
     assert keep.layers[-1].kind == lowering.OP_DWCONV3X3
     # default: conv1 joins the first block (one kernel for graph nodes #30-#49), another 2.36 MB per face never reach HBM
-    stem = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), stem_fusion="stem")
+    stem = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), stem_fusion="stem", block_fusion="none")
     ks = [L.kind for L in stem.layers]
     assert ks[:3] == [lowering.OP_STEM_F16S, lowering.OP_DWPW_F32, lowering.OP_DWCONV3X3] and len(ks) == len(kinds) - 1
     s0 = stem.layers[0]
@@ -105,7 +105,7 @@ def test_fusion_pass_merges_the_early_blocks_only(graph):
     import plan_ref
     assert plan_ref.parse(stem.serialize())["ops"][0][0] == lowering.OP_STEM_F16S
     # default: the stride-2 depthwise of block 2 joins as well (graph nodes #30-#55); block 2's pointwise is a plain GEMM then
-    s2 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192))
+    s2 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), block_fusion="none")
     k2 = [L.kind for L in s2.layers]
     assert k2[:4] == [lowering.OP_STEM2_F16S, lowering.OP_PWCONV_F32, lowering.OP_DWCONV3X3, lowering.OP_PWCONV_F32]
     assert lowering.OP_DWPW_F32 not in k2 and len(k2) == len(kinds) - 1
@@ -116,21 +116,49 @@ def test_fusion_pass_merges_the_early_blocks_only(graph):
     assert unfused.bytes_per_image() - s2.bytes_per_image() == 2 * 4 * (96 * 96 * 32 * 2 + 96 * 96 * 64)
     assert s2.tensor_layer["conv_dw_2_relu/clip_by_value"] == 0 and "conv_pw_1_relu/clip_by_value" not in s2.tensor_layer
     assert plan_ref.parse(s2.serialize())["ops"][0][0] == lowering.OP_STEM2_F16S
-    odd = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (100, 100))          # 100 -> 50 -> 25: even map, no top/left pad
+    odd = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (100, 100), block_fusion="none")          # 100 -> 50 -> 25: even map, no top/left pad
     assert odd.layers[0].kind == lowering.OP_STEM2_F16S and odd.layers[0].pad3 == (0, 0) and odd.layers[0].out_shape == (25, 25, 64)
-    odd2 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (98, 98))           # 98 -> 49 -> 25: odd map pads one row on top/left
+    odd2 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (98, 98), block_fusion="none")           # 98 -> 49 -> 25: odd map pads one row on top/left
     assert odd2.layers[0].pad3 == (1, 1) and odd2.layers[0].out_shape == (25, 25, 64)
     with pytest.raises(ValueError):
-        lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (64, 64), stem_fusion="all")
+        lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (64, 64), stem_fusion="all", block_fusion="none")
     # conv1's own tensor requested, or the fp32-only arithmetic: no stem fusion
-    keep1 = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0", OUT_AGE: "conv1_relu/clip_by_value:0"}, (64, 64))
+    keep1 = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0", OUT_AGE: "conv1_relu/clip_by_value:0"}, (64, 64), block_fusion="none")
     assert keep1.layers[0].kind == lowering.OP_CONV_C3
-    assert lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (64, 64), pw_math="f32").layers[0].kind == lowering.OP_CONV_C3
+    assert lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (64, 64), pw_math="f32", block_fusion="none").layers[0].kind == lowering.OP_CONV_C3
+
+
+def test_block_fusion_pass(graph):
+    """The HBM-bound stride-1 blocks (128 -> 128 and 256 -> 256 channels) become ONE split-f16 fused layer each by default;
+    'all' fuses every depthwise -> pointwise pair the kernel covers; the serialised plan still evaluates to the same graph."""
+    base = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), block_fusion="none")
+    auto = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192))
+    every = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), block_fusion="all")
+    fused = [L for L in auto.layers if L.kind == lowering.OP_DWPW_F16S]
+    assert [(L.in_shape, L.out_shape, L.stride, L.a_log2) for L in fused] == [((48, 48, 128), (48, 48, 128), 1, 12), ((24, 24, 256), (24, 24, 256), 1, 12)]
+    assert len(auto.layers) == len(base.layers) - 2 and len(every.layers) == len(base.layers) - 11
+    assert sum(L.kind == lowering.OP_DWCONV3X3 for L in every.layers) == 0
+    assert auto.flops_per_image() == base.flops_per_image() == every.flops_per_image()
+    assert base.bytes_per_image() - auto.bytes_per_image() == 2 * 4 * (48 * 48 * 128 + 24 * 24 * 256)      # the two depthwise results
+    assert "conv_dw_3_relu/clip_by_value" not in auto.tensor_layer and "conv_pw_3_relu/clip_by_value" in auto.tensor_layer
+    # a requested depthwise tensor stays materialised; fp32-only arithmetic has nothing to fuse with
+    keep = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0", OUT_AGE: "conv_dw_3_relu/clip_by_value:0"}, (192, 192))
+    assert sum(L.kind == lowering.OP_DWPW_F16S for L in keep.layers) == 1
+    assert not any(L.kind == lowering.OP_DWPW_F16S for L in lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), pw_math="f32").layers)
+    with pytest.raises(ValueError):
+        lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (64, 64), block_fusion="some")
+    import plan_ref
+    z = np.load(os.path.join(GOLDEN, "e2e_synthetic.npz"))
+    x = np.random.RandomState(123).uniform(-128, 128, (3, 96, 96, 3)).astype(np.float32)
+    for mode in ("auto", "all"):
+        plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), block_fusion=mode)
+        assert lowering.OP_DWPW_F16S in [op[0] for op in plan_ref.parse(plan.serialize())["ops"]]
+        assert rel(plan_ref.run(plan.serialize(), x)["features"], z["feat_96"]) < 1e-6
 
 
 def test_features_only_plan_and_intermediate_outputs(graph):
     plan = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0"}, (64, 64))
-    assert len(plan.layers) == 25 and OUT_AGE not in plan.outputs      # stem (conv1 + block 1), block 2, 11 x (dw, pw), pool
+    assert len(plan.layers) == 23 and OUT_AGE not in plan.outputs      # stem2, pw 2, 11 blocks (two of them one fused layer each), pool
     x = np.random.RandomState(5).uniform(-128, 128, (1, 64, 64, 3)).astype(np.float32)
     ref = tfo.GraphOracle(MODEL_PB).run("global_pooling/Mean:0", {"input_1:0": x})
     assert rel(plan_ref.run(plan.serialize(), x)["features"], ref) < 1e-6
@@ -232,7 +260,7 @@ def test_pointwise_math_selection_and_split_weight_image(graph):
     """auto: every pointwise layer of the MobileNet trunk reads a ReLU6 output -> split-f16 products (wire kind 12);
     'f32' keeps the fp32 MFMA kernel; the split image reproduces the fp32 kernel to 2^-21 and inverts exactly."""
     import plan_ref
-    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96))
+    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), block_fusion="none")
     pws = [L for L in plan.layers if L.kind == lowering.OP_PWCONV_F32]
     assert len(pws) == 12 and all(L.a_log2 == 12 for L in pws)          # pw_2 .. pw_13 (pw_1 lives in the fused stem)
     wire = [o[0] for o in plan_ref.parse(plan.serialize())["ops"]]

@@ -325,6 +325,31 @@ def bench_stemstamps():
         print("   %-26s %5.1f %%  %7.0f cycles per patch" % (nm, 100 * (b[:, i] / b[:, 8]).mean(), (b[:, i] / b[:, 9]).mean()))
 
 
+def bench_blkstamps():
+    """Diagnostic build only (-DHSEFR_STEM_STAMPS): where a wave of the v2 fused block spends its cycles."""
+    import ctypes
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for hw, c, n in ((48, 128, 128), (24, 256, 256)):
+        x = torch.rand((B, hw, hw, c), device="cuda", generator=g) * 6
+        wd = torch.randn((3, 3, c), device="cuda", generator=g) / 3
+        dsc = torch.rand((c,), device="cuda", generator=g) + 0.5
+        dsh = torch.randn((c,), device="cuda", generator=g) * 0.3
+        w = torch.randn((n, c), device="cuda", generator=g) / c ** 0.5
+        sh = torch.randn((n,), device="cuda", generator=g)
+        prep = ops.split_weights_device(w, x.device)
+        for _ in range(4):
+            ops.dwpw_f16split(x, wd, dsc, dsh, None, sh, 1, prepared=prep)
+        torch.cuda.synchronize()
+        buf = np.zeros((512 * 4, 10), np.uint64)
+        _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        b = buf[buf[:, 9] > 0].astype(np.float64)
+        names = ["wait DMA + barrier 1", "DMA issue", "depthwise (LDS -> A tile)", "barrier 2", "MFMA", "epilogue"]
+        print("%d c%d->%d: %d waves, lifetime mean %.0f cycles, patches/wave %.1f -> %.0f cycles per patch" %
+              (hw, c, n, len(b), b[:, 8].mean(), b[:, 9].mean(), (b[:, 8] / b[:, 9]).mean()))
+        for i, nm in enumerate(names):
+            print("   %-26s %5.1f %%  %7.0f cycles per patch" % (nm, 100 * (b[:, i] / b[:, 8]).mean(), (b[:, i] / b[:, 9]).mean()))
+
+
 def bench_pwa():
     print("GEMM ablations (timing only), 128x64 tile: us median: real / no-global-loads / no-stores / neither")
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -372,4 +397,4 @@ def bench_clock():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["pw", "dw", "c3"]
     for w in what:
-        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd, "pws": bench_pws, "blk": bench_blk, "stamps": bench_stamps, "stem": bench_stem, "stemstamps": bench_stemstamps}[w]()
+        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd, "pws": bench_pws, "blk": bench_blk, "stamps": bench_stamps, "stem": bench_stem, "stemstamps": bench_stemstamps, "blkstamps": bench_blkstamps}[w]()
