@@ -86,6 +86,11 @@ __device__ __forceinline__ void hsefr_store_guard() { asm volatile("s_nop 0"); }
 __device__ __forceinline__ hsefr_f32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(hsefr_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// The same store with its wait state welded on (one asm statement: nothing can be scheduled in between).  hipcc does not
+// see the store, so its own vmcnt arithmetic is off by it -- only for kernels whose vector-memory waits are all explicit.
+__device__ __forceinline__ void bstore16_welded(hsefr_f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
 __device__ __forceinline__ void bstore16(hsefr_f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hsefr_u32x4, v), r, voff, soff, 0);
     hsefr_store_guard();

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void dwpw2_f16s_kernel(DwPwSParams p) {
                         f32x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(fmaf(v[e], ds[e], sh[e]));
-                        bstore16(o, ry, sv[mi][i], (unsigned)(ni * 32) * 4u);
+                        bstore16_welded(o, ry, sv[mi][i], __builtin_amdgcn_readfirstlane((unsigned)(ni * 32) * 4u));
                     }
                 }
             }
@@ -493,7 +493,293 @@ __global__ __launch_bounds__(512, 2) void dwpw2_f16s_kernel(DwPwSParams p) {
     if (wave < 4) STEM_STAMP_FLUSH(p.stamps, lane, wave);
 }
 
-int g_v2 = 1;   // tuning/debug only (hsefr_debug_set "dwpws_v2"): 0 = first version everywhere
+// ---------------------------------------------------------------------------------------------------------------------
+// v3: the same staging, with the waves SPECIALISED.  In v2 all 8 waves run the depthwise phase, meet at a barrier, run
+// the MFMA phase, meet again: the vector ALU idles during the contraction and the matrix pipe during the depthwise, and
+// in-kernel stamps put 45 % of a wave's life in barriers.  Here waves 0-3 (one per SIMD) are PRODUCERS -- halo DMA and the
+// depthwise of step g+1 into A[(g+1) & 1] -- while waves 4-7 are CONSUMERS -- weight DMA, the MFMAs of step g from
+// A[g & 1], and the epilogue.  One barrier per step; on every SIMD a producer's VALU/LDS work runs beside a consumer's
+// matrix work.  The halo ring is HS deep (3 where LDS allows: two steps of lookahead for the HBM stream; vmcnt retires
+// in order, so a producer waits with one step's pieces still in flight).  A consumer's epilogue scratch is the part of
+// the weight stage its own next DMA pieces will overwrite, so it needs no synchronisation beyond program order.
+template <int TW, int BN, int HS, int ACT>
+__global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
+    constexpr int TH = 128 / TW, HC = TW + 2;
+    constexpr int WCAP = 256;                                   // channel capacity of the resident depthwise constants
+    constexpr int B_ST = BN * ROWB;
+    constexpr int B_OFF = HS * HALO_B, A_OFF = B_OFF + 2 * B_ST, W_OFF = A_OFF + 2 * 128 * ROWB, E_OFF = W_OFF + 11 * WCAP * 4;
+    constexpr int WN = BN / 2, NI = WN / 32;                    // consumer wave tile 64 x WN (2 x 2 waves)
+    constexpr int BPW = BN / 32;                                // weight DMA pieces per consumer wave (its scratch: BPW KB >= 4)
+    constexpr int HPW = 6;                                      // halo DMA pieces per producer wave
+    static_assert(E_OFF + 2 * CMAX2 * 4 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[E_OFF + 2 * CMAX2 * 4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = p.C4 * 4, KT = p.KT;
+    {
+        float4* wl = (float4*)(smem + W_OFF);
+        for (int i = tid; i < 9 * p.C4; i += 512) wl[i] = p.wd[i];
+        for (int i = tid; i < p.C4; i += 512) { wl[9 * p.C4 + i] = p.dscale[i]; wl[10 * p.C4 + i] = p.dshift[i]; }
+        float* el = (float*)(smem + E_OFF);
+        for (int i = tid; i < p.Cout; i += 512) { el[i] = p.descale[i]; el[CMAX2 + i] = p.pshift[i]; }
+    }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long long)p.nimg * p.H * p.W * C * 4);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wsplit, (long long)p.Cout * C * 4);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, (long long)p.nimg * p.OH * p.OW * p.Cout * 4);
+    const unsigned OOB = 0xFFFFFFF0u;
+    const unsigned nitem = (p.total - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const int nsteps = (int)(nitem * KT);
+    struct Item { int n, oh0, ow0, n0; };
+    auto decode = [&](unsigned i) {
+        const unsigned lt = xcd_remap_dir(blockIdx.x + (i < nitem ? i : nitem - 1) * gridDim.x, p.total, p.reverse);
+        Item it;
+        it.n0 = (lt % p.tiles_n) * BN;
+        const unsigned pt = lt / p.tiles_n;
+        it.ow0 = (pt % p.tiles_w) * TW;
+        it.oh0 = ((pt / p.tiles_w) % p.tiles_h) * TH;
+        it.n = pt / (p.tiles_w * p.tiles_h);
+        return it;
+    };
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto piece = [&](const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
+                     "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff))
+                     : "memory");   // see v2: issued from asm so that hipcc does not drain vmcnt before every LDS read
+    };
+    // halo DMA duty: the consumers when their MFMA load is light (BN = 128), the producers otherwise
+    constexpr bool HALO_BY_CONSUMER = BN == 128;
+    const int hw = wave & 3;              // index of this wave among the four that issue the halo pieces
+    unsigned hv[HPW];
+    unsigned pf_i = 0;
+    int pf_kc = 0, pf_step = 0;
+    auto setup_halo = [&](unsigned i) {
+        const Item it = decode(i);
+#pragma unroll
+        for (int j = 0; j < HPW; ++j) {
+            const int q = (hw * HPW + j) * 8 + (lane >> 3);
+            const int hr = q / HC, hc = q - hr * HC;
+            const int ih = it.oh0 - p.pad_t + hr, iw = it.ow0 - p.pad_l + hc;
+            const bool ok = q < (TH + 2) * HC && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            hv[j] = ok ? ((unsigned)((it.n * p.H + ih) * p.W + iw) * (unsigned)C + 4u * (lane & 7)) * 4u : OOB;
+        }
+    };
+    auto halo_dma = [&]() {          // pieces of step pf_step into ring slot pf_step % HS
+        const unsigned base = lds0 + (pf_step % HS) * HALO_B;
+        const unsigned so = (unsigned)pf_kc * 128u;
+#pragma unroll
+        for (int j = 0; j < HPW; ++j) piece(rx, base + (hw * HPW + j) * 1024, hv[j], so);
+        ++pf_step;
+        if (++pf_kc == KT) {
+            pf_kc = 0;
+            setup_halo(++pf_i);
+        }
+    };
+    STEM_STAMP_DECL;
+
+    if (wave < 4) {
+        // =============================== producer: halo DMA + depthwise ===============================
+        const int quad = tid & 7, col = (tid >> 3) % TW, r0 = 4 * (tid / (8 * TW));
+        const unsigned char* hsrc0 = smem + ((r0 * HC + col) * 128 + quad * 16);
+        if (!HALO_BY_CONSUMER) {
+            setup_halo(0);
+#pragma unroll
+            for (int i = 0; i < HS - 1; ++i)
+                if (i < nsteps) halo_dma();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int dkc = 0;                      // chunk of the step the depthwise works on (step g + 1)
+        for (int g = -1; g < nsteps; ++g) {
+            const bool issued = !HALO_BY_CONSUMER && pf_step < nsteps;
+            if (issued) halo_dma();
+            STEM_STAMP(1);
+            if (g + 1 < nsteps) {
+                const float4* wl = (const float4*)(smem + W_OFF) + dkc * 8 + quad;
+                float4 wk[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) wk[i] = wl[i * p.C4];
+                const float4 dsc = wl[9 * p.C4], dsh = wl[10 * p.C4];
+                const unsigned char* hs = hsrc0 + ((g + 1) % HS) * HALO_B;
+                unsigned char* At = smem + A_OFF + ((g + 1) & 1) * (128 * ROWB);
+                float4 h[6][3];
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) h[a][b] = *(const float4*)(hs + (a * HC + b) * 128);
+                // same operation order as dwconv.hip: bit-identical to the two kernels this replaces
+                auto row_sum = [&](int a, int b) {
+                    float4 t = make_float4(h[a][0].x * wk[b].x, h[a][0].y * wk[b].y, h[a][0].z * wk[b].z, h[a][0].w * wk[b].w);
+                    t = fma4(h[a][1], wk[b + 1], t);
+                    return fma4(h[a][2], wk[b + 2], t);
+                };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 sa = row_sum(j, 0), sb = row_sum(j + 1, 3), sc = row_sum(j + 2, 6);
+                    float4 sacc = make_float4(sa.x + sb.x, sa.y + sb.y, sa.z + sb.z, sa.w + sb.w);
+                    sacc = make_float4(sacc.x + sc.x, sacc.y + sc.y, sacc.z + sc.z, sacc.w + sc.w);
+                    const float4 o = fma4(sacc, dsc, dsh);
+                    f32x4 v;
+                    v[0] = relu6(o.x); v[1] = relu6(o.y); v[2] = relu6(o.z); v[3] = relu6(o.w);
+                    v = v * p.a_scale;
+                    const f16x4 hi = __builtin_convertvector(v, f16x4);
+                    const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+                    const int R = (r0 + j) * TW + col;
+                    *(f16x4*)(At + swzb(R, quad >> 1) + 8 * (quad & 1)) = hi;
+                    *(f16x4*)(At + swzb(R, 4 + (quad >> 1)) + 8 * (quad & 1)) = lo;
+                }
+                if (++dkc == KT) { dkc = 0; STEM_STAMP_COUNT; }
+            }
+            STEM_STAMP(2);
+            // the halo of step g + 2 must have landed before the next iteration reads it; with a 3-deep ring the pieces
+            // issued in this iteration (step g + 3) stay in flight
+            if (HS >= 3 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STEM_STAMP(0);
+            __syncthreads();
+            STEM_STAMP(3);
+        }
+        STEM_STAMP_FLUSH(p.stamps, lane, wave);
+    } else {
+        // =============================== consumer: weight DMA + MFMA + epilogue ===============================
+        const int cw = wave - 4, wm = cw >> 1, wn = cw & 1;
+        const int li = lane & 31, lh = lane >> 5;
+        const int arow = wm * 64 + li, brow = wn * WN + li;
+        const int erow = lane >> 3, ech = lane & 7;
+        unsigned bv[BPW];
+        unsigned pb_i = 0;
+        int pb_kc = 0, pb_step = 0;
+        auto setup_b = [&](unsigned i) {
+            const Item it = decode(i);
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) {
+                const int r = (cw * BPW + j) * 8 + (lane >> 3);
+                bv[j] = ((unsigned)(it.n0 + r) * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7))) * 4u;
+            }
+        };
+        auto b_dma = [&]() {
+            const unsigned base = lds0 + B_OFF + (pb_step & 1) * B_ST;
+            const unsigned so = (unsigned)pb_kc * 128u;
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) piece(rw, base + (cw * BPW + j) * 1024, bv[j], so);
+            ++pb_step;
+            if (++pb_kc == KT) {
+                pb_kc = 0;
+                setup_b(++pb_i);
+            }
+        };
+        f32x16 acc[2][NI];
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        };
+        auto epilogue = [&](const Item& cur, int stage) {
+            // lane (li, lh) holds row m = li, columns 4*lh + 8*(r >> 2) + (r & 3) of each 32 x 32 block (operands swapped)
+            unsigned char* scr = smem + B_OFF + stage * B_ST + cw * (BPW * 1024);
+            const float* el = (const float*)(smem + E_OFF);
+            unsigned sv[2][4];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int R = wm * 64 + mi * 32 + erow + 8 * i;
+                    const int oh = cur.oh0 + R / TW, ow = cur.ow0 + R % TW;
+                    sv[mi][i] = (oh < p.OH && ow < p.OW)
+                                    ? ((unsigned)((cur.n * p.OH + oh) * p.OW + ow) * (unsigned)p.Cout + (unsigned)(cur.n0 + wn * WN + 4 * ech)) * 4u
+                                    : OOB;
+                }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int nl = cur.n0 + wn * WN + ni * 32 + 4 * ech;
+                const f32x4 ds = *(const f32x4*)(el + nl), sh = *(const f32x4*)(el + CMAX2 + nl);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
+                        *(f32x4*)(scr + li * 128 + 16 * ((2 * j + lh) ^ (li & 7))) = v;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = erow + 8 * i;
+                        const f32x4 v = *(const f32x4*)(scr + r * 128 + 16 * (ech ^ (r & 7)));
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(fmaf(v[e], ds[e], sh[e]));
+                        bstore16_welded(o, ry, sv[mi][i], __builtin_amdgcn_readfirstlane((unsigned)(ni * 32) * 4u));
+                    }
+                }
+            }
+        };
+        zero_acc();
+        setup_b(0);
+        Item cur = decode(0);
+        unsigned ci = 0;
+        int ckc = 0;
+        bool pending = false;             // the previous step closed a patch: its accumulators wait for their epilogue
+        if (HALO_BY_CONSUMER) {
+            setup_halo(0);
+#pragma unroll
+            for (int i = 0; i < HS - 1; ++i)
+                if (i < nsteps) halo_dma();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                  // (the producers' prologue barrier)
+        for (int g = -1; g < nsteps; ++g) {
+            if (pending) {
+                epilogue(cur, (g + 1) & 1);          // scratch: the slice of weight stage (g + 1) & 1 this wave refills next
+                zero_acc();
+                cur = decode(++ci);
+                pending = false;
+            }
+            if (pb_step < nsteps) b_dma();             // weights of step g + 1 into stage (g + 1) & 1
+            const bool halo_issued = HALO_BY_CONSUMER && pf_step < nsteps;
+            if (halo_issued) halo_dma();               // halo of step g + HS (issued AFTER the weights: vmcnt retires in order)
+            if (g >= 0) {
+                const unsigned char* As = smem + A_OFF + (g & 1) * (128 * ROWB);
+                const unsigned char* Bs = smem + B_OFF + (g & 1) * B_ST;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f16x8 ah[2], al[2], bh[NI], bl[NI];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        ah[mi] = *(const f16x8*)(As + swzb(arow + mi * 32, 2 * s + lh));
+                        al[mi] = *(const f16x8*)(As + swzb(arow + mi * 32, 4 + 2 * s + lh));
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        bh[ni] = *(const f16x8*)(Bs + swzb(brow + ni * 32, 2 * s + lh));
+                        bl[ni] = *(const f16x8*)(Bs + swzb(brow + ni * 32, 4 + 2 * s + lh));
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ni], al[mi], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ni], ah[mi], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ni], ah[mi], acc[mi][ni], 0, 0, 0);
+                        }
+                }
+                if (++ckc == KT) { ckc = 0; pending = true; }
+            }
+            // the next step's weights, the halo of step g + 2 (and this patch's stores) have landed; with a 3-deep ring
+            // the halo pieces issued in this iteration stay in flight
+            if (HS >= 3 && halo_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (pending) epilogue(cur, (nsteps - 1) & 1);
+    }
+}
+
+int g_v2 = 2;   // tuning/debug only (hsefr_debug_set "dwpws_v2"): 0 = first version everywhere, 1 = v2, 2 = v3 where it applies
 int g_tw = 0;   // tuning/debug only (hsefr_debug_set "dwpws_tw"): 0 = auto, 8 | 16 = forced patch width
 int g_bn = 0;   // tuning/debug only (hsefr_debug_set "dwpws_bn"): 0 = auto, 64 | 128 | 256 = forced N tile
 
@@ -543,6 +829,25 @@ int launch_v2(DwPwSParams& p, int n, int act, hipStream_t s) {
     return launch_status("dwpw_f16split");
 }
 
+template <int TW, int BN, int HS>
+int launch_v3(DwPwSParams& p, int n, int act, hipStream_t s) {
+    constexpr int TH = 128 / TW;
+    p.tiles_w = (p.OW + TW - 1) / TW;
+    p.tiles_h = (p.OH + TH - 1) / TH;
+    p.tiles_n = p.Cout / BN;
+    const long long total = (long long)n * p.tiles_w * p.tiles_h * p.tiles_n;
+    HSEFR_REQUIRE(total < (1ll << 31) / 16, HSEFR_ERR_UNSUPPORTED, "dwpw_f16split: grid too large");
+    p.total = (unsigned)total;
+    const unsigned g = p.total < 256u ? p.total : 256u;
+#define HSEFR_DWPW3(A) hipLaunchKernelGGL((dwpw3_f16s_kernel<TW, BN, HS, A>), dim3(g), dim3(512), 0, s, p)
+    if (act == HSEFR_ACT_RELU6) HSEFR_DWPW3(HSEFR_ACT_RELU6);
+    else if (act == HSEFR_ACT_RELU) HSEFR_DWPW3(HSEFR_ACT_RELU);
+    else if (act == HSEFR_ACT_NONE) HSEFR_DWPW3(HSEFR_ACT_NONE);
+    else { set_error("dwpw_f16split: act %d", act); return HSEFR_ERR_UNSUPPORTED; }
+#undef HSEFR_DWPW3
+    return launch_status("dwpw_f16split");
+}
+
 }  // namespace
 
 void set_dwpws_v2(int v) { g_v2 = v; }
@@ -580,6 +885,10 @@ int launch_dwpw_f16s(const float* x, const float* wd, const float* dscale, const
         if (g_tw == 8 || g_tw == 16) tw = g_tw;
         int bn = cout % 256 == 0 ? 256 : 128;
         if ((g_bn == 128 || g_bn == 256) && cout % g_bn == 0) bn = g_bn;
+        if (g_v2 >= 2 && c <= 256) {      // wave-specialised form (resident depthwise constants for up to 256 channels)
+            if (bn == 256) return tw == 16 ? launch_v3<16, 256, 2>(p, n, act, s) : launch_v3<8, 256, 2>(p, n, act, s);
+            return tw == 16 ? launch_v3<16, 128, 3>(p, n, act, s) : launch_v3<8, 128, 3>(p, n, act, s);
+        }
         if (bn == 256) return tw == 16 ? launch_v2<16, 256>(p, n, act, s) : launch_v2<8, 256>(p, n, act, s);
         return tw == 16 ? launch_v2<16, 128>(p, n, act, s) : launch_v2<8, 128>(p, n, act, s);
     }
