@@ -178,9 +178,9 @@ def main():
             prof = json.load(open(cands[-1]))["kernels"]
             prefixes = {"stem_conv1_dw_pw_dw_fused": "stem2_fused_kernel", "stem_conv1_dw_pw_fused": "stem_fused_kernel", "conv1_3x3x3_s2": "conv3x3_c3", "depthwise3x3": "dwconv3x3_kernel",
                         "pointwise1x1_f32mfma": "pwconv_f32_", "pointwise1x1_f16split": "pwconv_f16s_kernel", "gap": "hsefr::gap_kernel",
-                        "fused_dw3x3_pw1x1": "dwpw_fused_kernel", "fused_dw3x3_pw1x1_f16split": "dwpw2_f16s_kernel"}
+                        "fused_dw3x3_pw1x1": "dwpw_fused_kernel", "fused_dw3x3_pw1x1_f16split": ("dwpw3_f16s_kernel", "dwpw2_f16s_kernel", "dwpw_f16s_kernel")}
             for cls, pre in prefixes.items():
-                rows = [v for k, v in prof.items() if k.startswith(pre)]
+                rows = [v for k, v in prof.items() if k.startswith(pre)]      # str.startswith takes a tuple of prefixes too
                 n = sum(r["launches"] for r in rows)
                 if n:
                     traffic_by_class[cls] = sum(r["launches"] * r["hbm_bytes_per_launch"] for r in rows) / n
