@@ -383,6 +383,35 @@ def test_fused_stems_full_size_every_element_and_run_to_run(env):
     assert float((s2[0] - d2).abs().max()) < 6 * 2 * TOL
 
 
+@pytest.mark.parametrize("hw,c,cout,n", [(48, 128, 128, 256), (24, 256, 256, 256), (56, 128, 128, 64), (28, 256, 256, 130), (12, 512, 512, 256)])
+def test_fused_blocks_full_size_bit_identical_and_run_to_run(env, hw, c, cout, n):
+    """The LDS-DMA fused block at the BASELINE sizes (and at the 224-pixel configuration's 56 / 28-pixel maps, whose patches
+    are partial; and a 512-channel block, which takes the unspecialised kernel): EVERY output element equal, bit for bit, to
+    depthwise kernel + split-f16 GEMM, three launches in a row -- 18 patches per persistent workgroup, LDS stages re-used
+    every chunk, DMA pieces in flight across patch boundaries: a hazard would show as rare wrong chunks only at this size."""
+    torch, ops = env
+    from hse_facerec_tf_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(hw + c)
+    x = torch.rand((n, hw, hw, c), device="cuda", generator=g) * 6
+    x[torch.rand((n, hw, hw, c), device="cuda", generator=g) < 0.3] = 0.0
+    kd = torch.randn((3, 3, c), device="cuda", generator=g) / 3
+    sc = torch.rand((c,), device="cuda", generator=g) + 0.5
+    sh = torch.randn((c,), device="cuda", generator=g) * 0.3
+    kp = (torch.randn((cout, c), device="cuda", generator=g) / c ** 0.5).cpu().numpy()
+    psh = torch.randn((cout,), device="cuda", generator=g)
+    prep = ops.split_weights_device(kp, x.device)
+    ref = ops.pwconv1x1_f16split(ops.dwconv3x3(x, kd, sc, sh, 1), None, psh, prepared=prep)
+    for _ in range(3):
+        assert torch.equal(ops.dwpw_f16split(x, kd, sc, sh, None, psh, 1, prepared=prep), ref)
+    if c <= 256:                                   # the unspecialised LDS-DMA kernel and the first register-staged version too
+        for v in (1, 0):
+            try:
+                _lib.check(_lib.lib().hsefr_debug_set(b"dwpws_v2", v))
+                assert torch.equal(ops.dwpw_f16split(x, kd, sc, sh, None, psh, 1, prepared=prep), ref)
+            finally:
+                _lib.check(_lib.lib().hsefr_debug_set(b"dwpws_v2", 2))
+
+
 def test_fused_stem_rejects_uncovered_shapes(env):
     torch, ops = env
     z = lambda *s: torch.zeros(s, device="cuda")
