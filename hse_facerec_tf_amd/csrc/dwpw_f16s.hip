@@ -548,8 +548,10 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
                      "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff))
                      : "memory");   // see v2: issued from asm so that hipcc does not drain vmcnt before every LDS read
     };
-    // halo DMA duty: the consumers when their MFMA load is light (BN = 128), the producers otherwise
-    constexpr bool HALO_BY_CONSUMER = BN == 128;
+    // halo DMA duty: producers.  (Measured both ways with in-kernel stamps: the patch time does not change -- 224 (BN = 128) or
+    // 576 (BN = 256) one-KB vector-memory instructions per patch, DMA pieces and stores alike, take ~70 cycles each CU-wide,
+    // whichever wave issues them: the kernel is bound by the CU's vector-memory instruction rate, ~15 B/clk.)
+    constexpr bool HALO_BY_CONSUMER = false;
     const int hw = wave & 3;              // index of this wave among the four that issue the halo pieces
     unsigned hv[HPW];
     unsigned pf_i = 0;
@@ -596,32 +598,34 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
             if (issued) halo_dma();
             STEM_STAMP(1);
             if (g + 1 < nsteps) {
-                const float4* wl = (const float4*)(smem + W_OFF) + dkc * 8 + quad;
-                float4 wk[9];
+                // f32x4 vector arithmetic: each operation becomes two v_pk_*_f32 on the register pairs the ds_read_b128
+                // delivered (written on float4 structs the SLP vectoriser paired lanes of DIFFERENT rows: four v_mov per
+                // packed op).  Same IEEE operations per element, same order as dwconv.hip: bit-identical to it.
+                const f32x4* wl = (const f32x4*)(smem + W_OFF) + dkc * 8 + quad;
+                f32x4 wk[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) wk[i] = wl[i * p.C4];
-                const float4 dsc = wl[9 * p.C4], dsh = wl[10 * p.C4];
+                const f32x4 dsc = wl[9 * p.C4], dsh = wl[10 * p.C4];
                 const unsigned char* hs = hsrc0 + ((g + 1) % HS) * HALO_B;
                 unsigned char* At = smem + A_OFF + ((g + 1) & 1) * (128 * ROWB);
-                float4 h[6][3];
+                f32x4 h[6][3];
 #pragma unroll
                 for (int a = 0; a < 6; ++a)
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) h[a][b] = *(const float4*)(hs + (a * HC + b) * 128);
-                // same operation order as dwconv.hip: bit-identical to the two kernels this replaces
+                    for (int b = 0; b < 3; ++b) h[a][b] = *(const f32x4*)(hs + (a * HC + b) * 128);
                 auto row_sum = [&](int a, int b) {
-                    float4 t = make_float4(h[a][0].x * wk[b].x, h[a][0].y * wk[b].y, h[a][0].z * wk[b].z, h[a][0].w * wk[b].w);
-                    t = fma4(h[a][1], wk[b + 1], t);
-                    return fma4(h[a][2], wk[b + 2], t);
+                    f32x4 t = h[a][0] * wk[b];
+                    t = __builtin_elementwise_fma(h[a][1], wk[b + 1], t);
+                    return __builtin_elementwise_fma(h[a][2], wk[b + 2], t);
                 };
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float4 sa = row_sum(j, 0), sb = row_sum(j + 1, 3), sc = row_sum(j + 2, 6);
-                    float4 sacc = make_float4(sa.x + sb.x, sa.y + sb.y, sa.z + sb.z, sa.w + sb.w);
-                    sacc = make_float4(sacc.x + sc.x, sacc.y + sc.y, sacc.z + sc.z, sacc.w + sc.w);
-                    const float4 o = fma4(sacc, dsc, dsh);
+                    const f32x4 sa = row_sum(j, 0), sb = row_sum(j + 1, 3), sc = row_sum(j + 2, 6);
+                    const f32x4 sacc = (sa + sb) + sc;
+                    const f32x4 o = __builtin_elementwise_fma(sacc, dsc, dsh);
                     f32x4 v;
-                    v[0] = relu6(o.x); v[1] = relu6(o.y); v[2] = relu6(o.z); v[3] = relu6(o.w);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = relu6(o[e]);
                     v = v * p.a_scale;
                     const f16x4 hi = __builtin_convertvector(v, f16x4);
                     const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
@@ -738,10 +742,13 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
                 zero_acc();
                 cur = decode(++ci);
                 pending = false;
+                STEM_STAMP_COUNT;
             }
+            STEM_STAMP(5);
             if (pb_step < nsteps) b_dma();             // weights of step g + 1 into stage (g + 1) & 1
             const bool halo_issued = HALO_BY_CONSUMER && pf_step < nsteps;
             if (halo_issued) halo_dma();               // halo of step g + HS (issued AFTER the weights: vmcnt retires in order)
+            STEM_STAMP(1);
             if (g >= 0) {
                 const unsigned char* As = smem + A_OFF + (g & 1) * (128 * ROWB);
                 const unsigned char* Bs = smem + B_OFF + (g & 1) * B_ST;
@@ -769,13 +776,24 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
                 }
                 if (++ckc == KT) { ckc = 0; pending = true; }
             }
+            STEM_STAMP(4);
             // the next step's weights, the halo of step g + 2 (and this patch's stores) have landed; with a 3-deep ring
             // the halo pieces issued in this iteration stay in flight
             if (HS >= 3 && halo_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STEM_STAMP(0);
             __syncthreads();
+            STEM_STAMP(3);
         }
-        if (pending) epilogue(cur, (nsteps - 1) & 1);
+        if (pending) { epilogue(cur, (nsteps - 1) & 1); STEM_STAMP_COUNT; }
+#ifdef HSEFR_STEM_STAMPS
+        if (lane == 0 && p.stamps && blockIdx.x < 256) {      // consumer waves report in the upper half of the stamp table
+            unsigned long long* o = p.stamps + ((blockIdx.x + 256) * 4 + cw) * 10;
+            for (int i_ = 0; i_ < 8; ++i_) o[i_] = st[i_];
+            o[8] = __builtin_amdgcn_s_memtime() - tstart;
+            o[9] = npatch;
+        }
+#endif
     }
 }
 

@@ -342,12 +342,15 @@ def bench_blkstamps():
         torch.cuda.synchronize()
         buf = np.zeros((512 * 4, 10), np.uint64)
         _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
-        b = buf[buf[:, 9] > 0].astype(np.float64)
-        names = ["wait DMA + barrier 1", "DMA issue", "depthwise (LDS -> A tile)", "barrier 2", "MFMA", "epilogue"]
-        print("%d c%d->%d: %d waves, lifetime mean %.0f cycles, patches/wave %.1f -> %.0f cycles per patch" %
-              (hw, c, n, len(b), b[:, 8].mean(), b[:, 9].mean(), (b[:, 8] / b[:, 9]).mean()))
-        for i, nm in enumerate(names):
-            print("   %-26s %5.1f %%  %7.0f cycles per patch" % (nm, 100 * (b[:, i] / b[:, 8]).mean(), (b[:, i] / b[:, 9]).mean()))
+        names = ["wait vmcnt", "DMA issue", "depthwise (LDS -> A tile)", "barrier", "MFMA", "epilogue"]
+        for role, rows in (("producers (v3) / all waves (v2)", buf[:1024]), ("consumers (v3)", buf[1024:])):
+            b = rows[rows[:, 9] > 0].astype(np.float64)
+            if not len(b):
+                continue
+            print("%d c%d->%d %s: %d waves, lifetime mean %.0f cycles, patches/wave %.1f -> %.0f cycles per patch" %
+                  (hw, c, n, role, len(b), b[:, 8].mean(), b[:, 9].mean(), (b[:, 8] / b[:, 9]).mean()))
+            for i, nm in enumerate(names):
+                print("   %-26s %5.1f %%  %7.0f cycles per patch" % (nm, 100 * (b[:, i] / b[:, 8]).mean(), (b[:, i] / b[:, 9]).mean()))
 
 
 def bench_pwa():
