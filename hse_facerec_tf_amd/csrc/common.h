@@ -161,6 +161,11 @@ int launch_dwpw_f16s(const float* x, const float* wd, const float* dscale, const
                      const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride, int pad_t,
                      int pad_l, int oh, int ow, int cout, int a_log2, int act, hipStream_t s);
 bool dwpw_f16s_supported(int c, int cout, int stride);
+bool dwpwdw_f16s_supported(int c, int cout, int act2);
+int launch_dwpwdw_f16s(const float* x, const float* wd, const float* dscale, const float* dshift, const void* wsplit,
+                       const float* descale, const float* pshift, const float* wd2, const float* d2scale, const float* d2shift,
+                       float* y, int n, int h, int w, int c, int cout, int pad_t2, int pad_l2, int oh2, int ow2, int a_log2,
+                       int act, int act2, hipStream_t s);
 void set_dwpws_v2(int v);
 int launch_stem_fused(const float* x, const float* cw, const float* cshift, const float* wd, const float* dscale,
                       const float* dshift, const void* wsplit, const float* descale, const float* pshift, float* y, int n,

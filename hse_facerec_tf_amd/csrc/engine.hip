@@ -551,6 +551,16 @@ int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shif
                              oh, ow, a_log2, act, (hipStream_t)stream);
 }
 
+int hsefr_dwpwdw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,
+                          const float* descale, const float* pshift, const float* wd2, const float* d2scale,
+                          const float* d2shift, float* y, int n, int h, int w, int c, int cout, int pad_t2, int pad_l2, int oh2,
+                          int ow2, int a_log2, int act, int act2, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(x && wd && dscale && dshift && w_split && descale && pshift && wd2 && d2scale && d2shift && y, HSEFR_ERR_INVALID,
+                  "dwpwdw_f16split: null pointer");
+    return launch_dwpwdw_f16s(x, wd, dscale, dshift, w_split, descale, pshift, wd2, d2scale, d2shift, y, n, h, w, c, cout, pad_t2, pad_l2,
+                              oh2, ow2, a_log2, act, act2, (hipStream_t)stream);
+}
+
 int hsefr_dwpw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,
                         const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride,
                         int pad_t, int pad_l, int oh, int ow, int cout, int a_log2, int act, hsefr_stream_t stream) {

@@ -264,6 +264,17 @@ int hsefr_stem2_fused(const float* x, const float* conv_w, const float* conv_shi
                       const float* d2scale, const float* d2shift, float* y, int n, int h, int w, int cpad_t, int cpad_l,
                       int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int a_log2, int act, hsefr_stream_t stream);
 
+/* One stride-1 block and the depthwise half of the stride-2 block behind it in one kernel (e.g. conv_dw_3 ... conv_dw_4_relu):
+ * depthwise 3x3/1 SAME + scale + shift + ReLU6 -> pointwise c -> 128 + shift + act (split-f16 products) -> depthwise 3x3/2
+ * SAME + scale + shift + act2 (ReLU6).  x [n,h,w,c] with c in {64, 96, 128}; wd [3,3,c]; w_split / descale as for
+ * hsefr_pwconv1x1_f16split; wd2 [3,3,128]; y [n,oh2,ow2,128] with oh2 = ceil(h/2); pad_t2/pad_l2 = the stride-2
+ * depthwise's top/left padding (0 for even h/w).  Bit-identical to the three kernels it replaces.  Not used by the engine:
+ * LDS capacity limits its patch to 18 output pixels and it measures 10 % slower than fused block + depthwise. */
+int hsefr_dwpwdw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,
+                          const float* descale, const float* pshift, const float* wd2, const float* d2scale,
+                          const float* d2shift, float* y, int n, int h, int w, int c, int cout, int pad_t2, int pad_l2, int oh2,
+                          int ow2, int a_log2, int act, int act2, hsefr_stream_t stream);
+
 /* One whole early MobileNet block (graph nodes #35-#49) fused: depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6
  * -> pointwise 1x1 + shift + ReLU6.  x [n,h,w,c], wd [3,3,c], wp_t [cout,c] (TF kernel transposed), y [n,oh,ow,cout];
  * c in {32,64}, cout in {64,128}; HSEFR_ERR_UNSUPPORTED otherwise (callers fall back to the two separate kernels). */
