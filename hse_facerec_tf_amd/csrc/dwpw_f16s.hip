@@ -51,7 +51,7 @@ struct DwPwSParams {
 };
 
 constexpr int ROWB = 128;
-__device__ __forceinline__ int swzb(int row, int chunk) { return row * ROWB + 16 * (chunk ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ int swzb(int row, int chunk) { return row * ROWB + 16 * (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)); }
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void dwpw2_f16s_kernel(DwPwSParams p) {
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
             const int r = (wave * BI + j) * 8 + (lane >> 3);
-            bv[j] = ((unsigned)(it.n0 + r) * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7))) * 4u;
+            bv[j] = ((unsigned)(it.n0 + r) * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7) ^ ((r & 1) << 2))) * 4u;
         }
     };
     // The DMA pieces are issued from inline asm: hipcc tracks LDS-DMA issued through the builtin and, unable to tell
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
 #pragma unroll
             for (int j = 0; j < BPW; ++j) {
                 const int r = (cw * BPW + j) * 8 + (lane >> 3);
-                bv[j] = ((unsigned)(it.n0 + r) * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7))) * 4u;
+                bv[j] = ((unsigned)(it.n0 + r) * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7) ^ ((r & 1) << 2))) * 4u;
             }
         };
         auto b_dma = [&]() {

@@ -60,7 +60,7 @@ constexpr int B_OFF = 2 * HSLOT, A_OFF = B_OFF + 2 * B_ST, P_OFF = A_OFF + 2 * M
 constexpr int W_OFF = P_OFF + ((R1PIX * PP * 4 + 1023) / 1024) * 1024, E_OFF = W_OFF + 11 * 128 * 4, SMEM = E_OFF + 2 * COUT * 4;
 static_assert(SMEM <= 160 * 1024, "LDS budget");
 
-__device__ __forceinline__ int swzb(int row, int chunk) { return row * ROWB + 16 * (chunk ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ int swzb(int row, int chunk) { return row * ROWB + 16 * (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)); }
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 
 template <int ACT>
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void dwpwdw_f16s_kernel(B3Params p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = (cw * 4 + j) * 8 + (lane >> 3);
-            bv[j] = ((unsigned)r * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7))) * 4u;
+            bv[j] = ((unsigned)r * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7) ^ ((r & 1) << 2))) * 4u;
         }
         int pb_kc = 0, pb_step = 0;
         auto b_dma = [&]() {

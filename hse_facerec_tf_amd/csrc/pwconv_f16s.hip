@@ -53,7 +53,7 @@ constexpr int BK = 32;          // input channels per K-tile
 constexpr int ROWB = 128;       // LDS bytes per tile row: 32 hi halves | 32 lo halves
 
 // byte offset of 16-B chunk `chunk` of tile row `row`
-__device__ __forceinline__ int swzb(int row, int chunk) { return row * ROWB + 16 * (chunk ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ int swzb(int row, int chunk) { return row * ROWB + 16 * (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)); }
 
 // sched_group_barrier masks
 #define SG_VALU 0x002
