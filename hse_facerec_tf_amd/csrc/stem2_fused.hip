@@ -68,7 +68,7 @@ constexpr int COP = 36;                               // floats per pixel row of
                                                       // compile-time offsets from one base (no per-tap swizzle arithmetic)
 constexpr int P1P = 68;                               // floats per pixel row of the 96x96x64 patch in LDS (64 + 4: rows 4 banks apart)
 
-__device__ __forceinline__ int swz32(int row, int chunk) { return row * 32 + 4 * (chunk ^ ((row >> 1) & 7)); }       // floats
+__device__ __forceinline__ int swz32(int row, int chunk) { return row * 32 + 4 * (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)); }       // floats
 __device__ __forceinline__ int swzb(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)); }      // bytes; b64 writes of adjacent rows land in different halves of the 128-B bank window
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 // 4-wide fused multiply-add on vector types: lowers to two v_pk_fma_f32 (same rounding as fmaf, half the instructions);

@@ -56,7 +56,7 @@ struct StemParams {
 constexpr int TW = 16, TH = 8, RW = TW + 2, RH = TH + 2, RPIX = RW * RH;   // conv1 region 10 x 18 = 180 pixels
 constexpr int RROWS = 192;                                                   // padded to 12 MFMA row blocks of 16
 
-__device__ __forceinline__ int swz32(int row, int chunk) { return row * 32 + 4 * (chunk ^ ((row >> 1) & 7)); }       // floats
+__device__ __forceinline__ int swz32(int row, int chunk) { return row * 32 + 4 * (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)); }       // floats
 __device__ __forceinline__ int swzb(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)); }      // bytes; b64 writes of adjacent rows land in different halves of the 128-B bank window
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
