@@ -169,7 +169,7 @@ def main():
     # HBM traffic per launch measured with rocprofv3 PMC counters (separate --pmc FETCH_SIZE / WRITE_SIZE
     # passes, FETCH_SIZE doubled per the gfx950 correction) and committed under profiles/ -- counters cannot
     # be read from inside this process, so the latest committed profile is what is reported.
-    traffic_by_class, traffic_src = {}, None
+    traffic_by_class, mfma_by_class, traffic_src = {}, {}, None
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
@@ -184,8 +184,13 @@ def main():
                 n = sum(r["launches"] for r in rows)
                 if n:
                     traffic_by_class[cls] = sum(r["launches"] * r["hbm_bytes_per_launch"] for r in rows) / n
+                    # share of the matrix pipes' cycles in use, time-weighted over the class (PMC: SQ_VALU_MFMA_BUSY_CYCLES /
+                    # (1024 SIMDs x kernel cycles); tools/make_profile_summary.py)
+                    tw = sum(r["launches"] * r["avg_us"] for r in rows if "mfma_util" in r)
+                    if tw:
+                        mfma_by_class[cls] = sum(r["launches"] * r["avg_us"] * r["mfma_util"] for r in rows if "mfma_util" in r) / tw
     except Exception:
-        traffic_by_class = {}
+        traffic_by_class, mfma_by_class = {}, {}
     kernels = []
     if per_op is not None:
         for name, pred in classes.items():
@@ -230,6 +235,7 @@ def main():
                             "unfused_equivalent_gbs": round((nbytes + unfused_extra) / (ms * 1e-3) / 1e9, 1) if unfused_extra else None,
                             "traffic": None if name not in traffic_by_class else int(traffic_by_class[name]),
                             "traffic_unit": "HBM bytes per launch (class average)", "traffic_source": traffic_src,
+                            "mfma_util_pmc": None if not mfma_by_class.get(name) else round(mfma_by_class[name], 4),
                             "note": note})
     dominant = max(kernels, key=lambda k: k["ms_per_step"]) if kernels else None
     dw = next((k for k in kernels if k["kernel"] == "depthwise3x3"), None)
@@ -239,7 +245,7 @@ def main():
             return None
         return {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
                 "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_launch_us": k["avg_launch_us"],
-                "launches_per_step": k["launches_per_step"]}
+                "launches_per_step": k["launches_per_step"], "mfma_util_pmc": k.get("mfma_util_pmc")}
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:

@@ -34,10 +34,24 @@ for line in open(os.path.join(src, "summary.txt")):
                 traffic[cur]["fetch_bytes_x2_corrected"] = kib * 1024 * 2
             else:
                 traffic[cur]["write_bytes"] = kib * 1024
+        m = re.match(r"\s+(SQ_VALU_MFMA_BUSY_CYCLES|GRBM_GUI_ACTIVE|SQ_INSTS_MFMA|SQ_LDS_BANK_CONFLICT|SQ_LDS_IDX_ACTIVE)\s+n=\d+\s+avg=\s*([\d.]+)", line)
+        if m and cur:
+            traffic[cur][m.group(1)] = float(m.group(2))
 for k, v in traffic.items():
     if "fetch_bytes_x2_corrected" in v and "write_bytes" in v:
         v["hbm_bytes_per_launch"] = v["fetch_bytes_x2_corrected"] + v["write_bytes"]
+    if v.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (= MFMA instructions x their
+        # pipe cycles): busy / (1024 x kernel cycles) = share of the matrix pipes' cycles in use = fraction of the dense peak
+        # at the clock the kernel actually ran at
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        v["mfma_util"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 4)
+        if v.get("avg_us") and v["avg_us"] >= 50:          # (short kernels: the counter window is longer than the kernel)
+            v["gfx_clock_ghz"] = round(cyc / (v["avg_us"] * 1e3), 3)
+    if v.get("SQ_LDS_IDX_ACTIVE"):
+        v["lds_conflict_share"] = round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"], 4)
 traffic = {k: v for k, v in traffic.items() if "hbm_bytes_per_launch" in v and not k.startswith("void at::") and not k.startswith("__amd")}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request)",
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); "
+                     "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
            "kernels": traffic}, open(os.path.join(out, "%s_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
