@@ -98,10 +98,14 @@ __global__ __launch_bounds__(128 * WAVES_N, OCC) void pwconv_f16s_kernel(const f
     const unsigned rowbytes = (unsigned)K * 4u;
     const unsigned voff = (unsigned)srow * rowbytes + 16u * skq;     // this thread's 16 B of a staged 8-row group
 
+    const bool tn_pow2 = (tiles_n & (tiles_n - 1u)) == 0u;
+    const int tn_shift = __builtin_ctz(tiles_n);
     auto tile_origin = [&](unsigned i, long long& mm0, int& nn0) {
         const unsigned lt = xcd_remap_dir(blockIdx.x + (i < ntile ? i : ntile - 1) * gridDim.x, total_tiles, reverse);
-        mm0 = (long long)(lt / tiles_n) * BM;
-        nn0 = (lt % tiles_n) * BN;
+        // tiles_n is a power of two for every MobileNet / ResNet layer: two shifts instead of two 32-bit divisions, four times per tile
+        const unsigned tm = tn_pow2 ? lt >> tn_shift : lt / tiles_n;
+        mm0 = (long long)tm * BM;
+        nn0 = (lt - tm * tiles_n) * BN;
     };
     __amdgpu_buffer_rsrc_t ra_rsrc, rb_rsrc;
     unsigned pf_i = 0;   // prefetch cursor: tile ordinal, K-tile
