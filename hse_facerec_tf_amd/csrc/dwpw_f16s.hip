@@ -47,6 +47,7 @@ struct DwPwSParams {
     float a_scale;         // 2^a_log2
     int reverse;           // sweep direction (common.h)
     int nimg;              // batch (v2: buffer resource sizes)
+    unsigned m_n, m_w, m_h;   // v3: ceil(2^32 / d) for d = tiles_n, tiles_w, tiles_h (exact quotients for x * d < 2^32; 0 for d = 1)
     unsigned long long* stamps;   // diagnostic builds (-DHSEFR_STEM_STAMPS) only
 };
 
@@ -56,6 +57,8 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+// x / d by multiplication with m = ceil(2^32 / d) (m = 0 stands for d = 1): exact while x * d < 2^32
+__device__ __forceinline__ unsigned fastdiv(unsigned x, unsigned m) { return m ? __umulhi(x, m) : x; }
 
 template <int STRIDE, int TW, int BN, int OCC, int ACT>
 __global__ __launch_bounds__(256, OCC) void dwpw_f16s_kernel(DwPwSParams p) {
@@ -534,12 +537,13 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
     struct Item { int n, oh0, ow0, n0; };
     auto decode = [&](unsigned i) {
         const unsigned lt = xcd_remap_dir(blockIdx.x + (i < nitem ? i : nitem - 1) * gridDim.x, p.total, p.reverse);
-        Item it;
-        it.n0 = (lt % p.tiles_n) * BN;
-        const unsigned pt = lt / p.tiles_n;
-        it.ow0 = (pt % p.tiles_w) * TW;
-        it.oh0 = ((pt / p.tiles_w) % p.tiles_h) * TH;
-        it.n = pt / (p.tiles_w * p.tiles_h);
+        Item it;                                       // three multiply-high quotients instead of five 32-bit divisions
+        const unsigned pt = fastdiv(lt, p.m_n);
+        it.n0 = (lt - pt * p.tiles_n) * BN;
+        const unsigned pr = fastdiv(pt, p.m_w);         // patch row index over all images
+        it.ow0 = (pt - pr * p.tiles_w) * TW;
+        it.n = fastdiv(pr, p.m_h);
+        it.oh0 = (pr - it.n * p.tiles_h) * TH;
         return it;
     };
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -857,6 +861,10 @@ int launch_v3(DwPwSParams& p, int n, int act, hipStream_t s) {
     const long long total = (long long)n * p.tiles_w * p.tiles_h * p.tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31) / 16, HSEFR_ERR_UNSUPPORTED, "dwpw_f16split: grid too large");
     p.total = (unsigned)total;
+    auto magic = [](unsigned d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); };
+    p.m_n = magic(p.tiles_n); p.m_w = magic(p.tiles_w); p.m_h = magic(p.tiles_h);
+    HSEFR_REQUIRE(total * (long long)(p.tiles_n > p.tiles_w ? (p.tiles_n > p.tiles_h ? p.tiles_n : p.tiles_h) : (p.tiles_w > p.tiles_h ? p.tiles_w : p.tiles_h)) < (1ll << 32),
+                  HSEFR_ERR_UNSUPPORTED, "dwpw_f16split: grid too large for the quotient multipliers");
     const unsigned g = p.total < 256u ? p.total : 256u;
 #define HSEFR_DWPW3(A) hipLaunchKernelGGL((dwpw3_f16s_kernel<TW, BN, HS, A>), dim3(g), dim3(512), 0, s, p)
     if (act == HSEFR_ACT_RELU6) HSEFR_DWPW3(HSEFR_ACT_RELU6);
