@@ -58,6 +58,16 @@ def test_argument_validation_needs_no_gpu():
     with pytest.raises(ValueError):
         _lib.check(rc, "hsefr_engine_create")
     assert L.hsefr_engine_destroy(None) == 0
+    # shape checks of the fused-block entry points come before any device work too
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.POINTER(ctypes.c_float))
+    vp = ctypes.cast(buf, ctypes.c_void_p)
+    rc = L.hsefr_dwpwdw_f16split(p, p, p, p, vp, p, p, p, p, p, p, 1, 8, 8, 32, 128, 0, 0, 4, 4, 12, 2, 2, None)      # c = 32: not covered
+    assert rc == _lib.ERR_UNSUPPORTED and "not covered" in _lib.last_error()
+    rc = L.hsefr_dwpwdw_f16split(p, p, p, p, vp, p, p, p, p, p, p, 1, 8, 8, 128, 128, 0, 0, 4, 4, 13, 2, 2, None)     # a_log2 out of range
+    assert rc == _lib.ERR_INVALID and "a_log2" in _lib.last_error()
+    rc = L.hsefr_dwpw_f16split(p, p, p, p, vp, p, p, p, 1, 8, 8, 48, 1, 1, 1, 8, 8, 64, 12, 2, None)                   # c % 32 != 0
+    assert rc == _lib.ERR_UNSUPPORTED
 
 
 def test_no_unguarded_store_data_hazard_in_the_device_code():
