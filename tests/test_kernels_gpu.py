@@ -273,7 +273,10 @@ def test_fused_depthwise_pointwise_vs_oracle(env, n, h, w, c, cout, s):
 @pytest.mark.parametrize("n,h,w,c,cout,s", [(2, 96, 96, 32, 64, 1), (1, 96, 96, 64, 128, 2), (2, 48, 48, 128, 128, 1), (1, 48, 48, 128, 256, 2),
                                               (3, 24, 24, 256, 256, 1), (2, 24, 24, 256, 512, 2), (5, 12, 12, 512, 512, 1),
                                               (3, 12, 12, 512, 1024, 2), (4, 6, 6, 1024, 1024, 1), (1, 50, 50, 32, 64, 1),
-                                              (1, 51, 37, 64, 128, 2), (2, 9, 21, 96, 192, 1), (1, 3, 3, 32, 64, 2)])
+                                              (1, 51, 37, 64, 128, 2), (2, 9, 21, 96, 192, 1), (1, 3, 3, 32, 64, 2),
+                                              # the LDS-DMA kernels at every chunk count their rings have to cope with (1, 2, 3, 5, 7 chunks)
+                                              (1, 16, 16, 32, 128, 1), (2, 20, 13, 64, 256, 1), (1, 20, 20, 96, 128, 1), (1, 17, 9, 160, 256, 1),
+                                              (1, 11, 30, 224, 128, 1), (3, 5, 5, 512, 512, 1)])
 def test_fused_block_f16split_vs_oracle(env, n, h, w, c, cout, s):
     """The any-channel-count fused block (K-chunked depthwise producer + split-f16 GEMM) vs the two-op oracle, and
     bit-for-bit against the unfused kernels it replaces (same arithmetic per element, different schedule)."""
