@@ -2,24 +2,33 @@
 """Headline benchmark: faces/sec of embedding extraction, MobileNet-192, batch 256, fp32 --
 BASELINE.json configs[1] -- on N MI355X GPUs of one node (one process per GPU).
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W]          # N > 1: starts its own N ranks (before any GPU call)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # or pre-launched
 
 A "step" is one pass of the hot path (conv1 -> 13 x (depthwise + pointwise) -> GAP) over one
 batch of 256 synthetic preprocessed images already resident in HBM.  Prints ONE JSON line on
-rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel class by device time, priced against its bound
-                (fp32-MFMA 157.3 TFLOP/s for the pointwise GEMM, HBM 8 TB/s for the others),
-                durations from HIP events recorded on the forward's own stream during the timed
-                steps; `kernels` lists every class, `roofline_depthwise` is the class the
-                north-star target (>= 60 % of HBM roofline) is stated against.
-  cpu_baseline  the reference's batch-1 extract loop (facerec_test.py:394) on the host cores:
-                the same frozen graph executed op-by-op by torch-CPU/oneDNN (oracle/torch_cpu.py),
-                kind "port" -- TensorFlow itself cannot be installed on this image.
+rank 0 (contract in the task statement) with these extra objects:
+  roofline       the dominant kernel class by device time, priced against its bound; durations from HIP
+                 events recorded on the forward's own stream over the same K steps; `kernels` lists every
+                 class; `roofline_depthwise` is the class the north-star target (>= 60 % of the HBM roofline)
+                 is stated against, split into the standalone layers and the ones inside fused kernels.
+  cpu_baseline   the reference's batch-1 extract loop (facerec_test.py:394) on the host cores: the same frozen
+                 graph executed op-by-op by torch-CPU/oneDNN (oracle/torch_cpu.py), kind "port" -- TensorFlow
+                 itself cannot be installed on this image; plus the CPU's best case (batch 256).
+  config5        BASELINE configs[4] end to end: 9164 synthetic 250x250 photos of 1680 persons, sharded
+                 S = ceil(N/P) per rank -> device preprocessing + extract -> ONE all-gather -> L2-normalise ->
+                 stratified 50/50 split -> 1-NN (4582 x 4582 x 1024), wall time per phase
+                 (facerec_test.py:377-432).
+  other_configs  (N = 1) the other BASELINE configs measured in the same process: ResNet-50 batch 128 bf16,
+                 age/gender MobileNet-224 batch 512 with three outputs, MobileNet-192 with strict-fp32 pointwise
+                 products.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,7 +42,7 @@ MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = 157.3 TFLO
 MFMA_F16_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA ~2.5 PFLOP/s
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -41,10 +50,264 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--size", type=int, default=192)
     ap.add_argument("--no-op-events", action="store_true", help="skip the instrumented second pass (no roofline objects)")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--config5-images", type=int, default=9164)
+    ap.add_argument("--config5-classes", type=int, default=1680)
     ap.add_argument("--layers", action="store_true", help="also print per-layer times to stderr")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher + process-group plumbing only (no GPU, no measurement): every rank joins the group, one "
+                         "all-gather of rank ids, rank 0 prints {\"dry_run\": true, ...}; used by the CPU test of the self-launch path")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo lets several ranks share one GPU (launcher/plumbing tests only)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` typed as is: start N ranks with torch.distributed.run as a CHILD process.  Nothing in
+    this (parent) process has touched the GPU -- not even torch.cuda.is_available() -- and it never exec()s."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env["HSEFR_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def csrc_hash() -> str:
+    """sha256 over the kernel sources: lets the line say whether the committed PMC profile is of THIS code."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hse_facerec_tf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# synthetic LFW-shaped photos for config 5, generated on the device (data generation only: torch ops, not the path)
+# ----------------------------------------------------------------------------------------------------------------
+def synth_photos_u8(idx, labels, hw=250, grid=10, class_w=0.5, inst_w=0.5, noise_amp=24.0):
+    """uint8 RGB [n, hw, hw, 3]: a smooth colour pattern per PERSON + a smooth pattern per PHOTO + pixel noise.
+    Every pixel is a pure function of (global photo index, label), so any sharding generates the same gallery."""
+    import torch
+    import torch.nn.functional as F
+    dev = idx.device
+    n = idx.numel()
+    A, C = 6364136223846793005, 1442695040888963407
+
+    def smooth(keys, salt):
+        cell = torch.arange(grid * grid * 3, device=dev, dtype=torch.int64)
+        h = (keys[:, None] * 1000003 + cell[None, :] * 7919 + salt) * A + C
+        h = (h ^ (h >> 29)) * A + C
+        p = ((h >> 33) & 255).to(torch.float32).reshape(n, grid, grid, 3).permute(0, 3, 1, 2)
+        return F.interpolate(p, size=(hw, hw), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+
+    pix = torch.arange(hw * hw * 3, device=dev, dtype=torch.int64)
+    hn = (idx[:, None] * 2654435761 + pix[None, :] * 40503 + 977) * A + C
+    hn = (hn ^ (hn >> 31)) * A + C
+    noise = (((hn >> 35) & 255).to(torch.float32) - 127.5) * (noise_amp / 127.5)
+    img = class_w * smooth(labels, 12345) + inst_w * smooth(idx, 54321) + noise.reshape(n, hw, hw, 3)
+    return img.clamp_(0, 255).round_().to(torch.uint8).contiguous()
+
+
+def run_config5(args, tfi, dev, world, rank, backend, dist):
+    """BASELINE configs[4]: shard -> extract -> ONE all-gather -> normalise -> 1-NN (facerec_test.py:377-432)."""
+    import torch
+    from hse_facerec_tf_amd import gallery, identification
+    N, C = args.config5_images, args.config5_classes
+    y = gallery.lfw_like_labels(N, C)                       # directory-walk order: identical on every rank
+    lo, hi = gallery.shard_range(N, rank, world)
+    y_dev = torch.from_numpy(y).to(dev)
+    # this rank's photos, resident in HBM as decoded 250x250 RGB uint8 (LFW's size, facerec_test.py:82)
+    photos = torch.empty((hi - lo, 250, 250, 3), dtype=torch.uint8, device=dev)
+    for i in range(lo, hi, 128):
+        j = min(i + 128, hi)
+        ids = torch.arange(i, j, device=dev, dtype=torch.int64)
+        photos[i - lo:j - lo] = synth_photos_u8(ids, y_dev[i:j])
+
+    def extract(ids):                                       # ids: contiguous global indices of one batch
+        return tfi.extract_images(photos[ids[0] - lo:ids[-1] + 1 - lo])
+
+    B = args.batch
+    tfi.extract_images(photos[:min(B, hi - lo)])            # warm-up (tap tables, kernels)
+    timings = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    X = gallery.extract_sharded(extract, list(range(N)), tfi.feature_dim, dev, batch=B, timings=timings)
+    t_gathered = time.perf_counter()
+    ident = {}
+    res = identification.one_nn_identification(X, y, timings=ident)
+    torch.cuda.synchronize()
+    t_end = time.perf_counter()
+    # per-rank phase times -> rank 0 (host-side bookkeeping, after the timed pipeline)
+    mine = torch.tensor([timings["extract_s"], timings["allgather_s"], ident["normalize_s"], ident["host_split_s"],
+                         ident["select_s"], ident["nn1_s"], t_end - t0, float(hi - lo)], dtype=torch.float64)
+    if world > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if backend == "nccl":
+            allr_d = [t.to(dev) for t in allr]
+            dist.all_gather(allr_d, mine.to(dev))
+            allr = [t.cpu() for t in allr_d]
+        else:
+            dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).numpy()
+    else:
+        per_rank = mine.numpy()[None]
+    if rank != 0:
+        return None
+    # ---- verification, outside the timed pipeline: fp64 brute force + scikit-learn's own classifier (:422) on the
+    # gathered embeddings; the shard of rank 0 inside the gathered matrix must be its local result bit for bit
+    Xh = X.cpu().numpy().astype(np.float64)
+    Xn = Xh / np.maximum(np.linalg.norm(Xh, axis=1, keepdims=True), 1e-300)
+    tr, te = res["train"], res["test"]
+    d2 = 2.0 - 2.0 * (Xn[res["indices"]][te] @ Xn[res["indices"]][tr].T)
+    best = d2.min(axis=1)
+    chosen = d2[np.arange(len(te)), res["nn_index"]]
+    near_ties = int((chosen > best + 1e-6).sum())              # picks that are not a nearest row within fp32 round-off
+    mismatch = int((res["nn_index"] != d2.argmin(axis=1)).sum())
+    acc64 = float((res["y"][tr][d2.argmin(axis=1)] == res["y"][te]).mean())
+    acc_sk = None
+    try:
+        from sklearn.neighbors import KNeighborsClassifier
+        from sklearn.preprocessing import normalize
+        Xs = normalize(X.cpu().numpy(), norm="l2")[res["indices"]]
+        clf = KNeighborsClassifier(n_neighbors=1, p=2).fit(Xs[tr], res["y"][tr])
+        acc_sk = float((clf.predict(Xs[te]) == res["y"][te]).mean())
+    except ImportError:
+        pass
+    local_again = torch.cat([extract(list(range(i, min(i + B, hi)))) for i in range(lo, hi, B)])
+    shard_ok = bool(torch.equal(local_again, X[lo:hi]))
+    ext = per_rank[:, 0]
+    nq, ng, d = ident["nn1_shape"]
+    return {
+        "workload": "BASELINE configs[4]: %d synthetic 250x250 RGB photos of %d persons (LFW totals after the >1-photo filter, "
+                    "long-tailed class sizes), device-resident uint8 -> PIL-bilinear resize + BGR + mean on the GPU -> MobileNet-192 "
+                    "-> ONE all-gather -> L2-normalise -> StratifiedShuffleSplit(0.5, seed 0) -> 1-NN" % (N, C),
+        "n_gpus": world, "shard_rows": gallery.shard_size(N, world), "pad_rows": gallery.shard_size(N, world) * world - N,
+        "extract_ms_per_rank": [round(float(v) * 1e3, 3) for v in ext],
+        "extract_faces_per_s_per_rank": [round(float(per_rank[r, 7] / ext[r]), 1) for r in range(world)],
+        "extract_faces_per_s": round(float(N / ext.max()), 1),
+        "allgather_ms": round(float(per_rank[:, 1].max()) * 1e3, 4),
+        "allgather_bytes_per_rank": timings.get("allgather_bytes_per_rank", 0),
+        "normalize_ms": round(float(per_rank[0, 2]) * 1e3, 4),
+        "host_split_ms": round(float(per_rank[0, 3]) * 1e3, 3),
+        "select_ms": round(float(per_rank[0, 4]) * 1e3, 4),
+        "nn1_ms": round(float(per_rank[0, 5]) * 1e3, 4), "nn1_shape": [nq, ng, d],
+        "nn1_tflops": round(2.0 * nq * ng * d / float(per_rank[0, 5]) / 1e12, 2),
+        "total_ms": round(float(per_rank[:, 6].max()) * 1e3, 3),
+        "accuracy": res["accuracy"], "accuracy_fp64_bruteforce": acc64, "accuracy_sklearn": acc_sk,
+        "nn_index_mismatches_vs_fp64": mismatch, "picks_not_nearest_within_1e-6": near_ties,
+        "num_classes": res["num_classes"], "gathered_shard_equals_local": shard_ok,
+    }
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the other BASELINE configs, same process (N = 1)
+# ----------------------------------------------------------------------------------------------------------------
+def time_engine(eng, x, want, steps, warm):
+    import torch
+    for _ in range(warm):
+        eng.forward(x, want)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = eng.forward(x, want)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert all(bool(torch.isfinite(v).all()) for v in out.values())
+    return dt
+
+
+def run_other_configs(args, dev):
+    import torch
+    from hse_facerec_tf_amd import lowering, resnet50
+    from hse_facerec_tf_amd.engine import Engine
+    from hse_facerec_tf_amd.graphdef import read_graph
+    from hse_facerec_tf_amd.tf_inference import AGE_GENDER_PB
+    out = []
+    steps, warm = max(5, min(args.steps, 20)), 3
+    rs = np.random.RandomState(123)
+
+    def gen(n, s):
+        g = torch.Generator(device=dev)
+        g.manual_seed(123)
+        return (torch.rand((n, s, s, 3), device=dev, generator=g) * 256.0 - 128.0).contiguous()
+
+    # -- configs[2]: ResNet-50 (resnet50_ft topology, synthetic He weights: vgg2_resnet.pb is a missing blob), bf16 MFMA
+    try:
+        B = 128
+        plan = resnet50.build_plan(resnet50.synthetic_weights(123), (224, 224), "caffe")
+        eng = Engine(plan, max_batch=B, device=dev.index)
+        dt = time_engine(eng, gen(B, 224), (0,), steps, warm)
+        fl, by = resnet50.flops_per_image(plan), resnet50.activation_bytes_per_image(plan)
+        wb = sum(int(np.asarray(L.w).size) * 2 for L in plan.layers if L.w is not None)
+        t_hbm, t_mfma = (by * B + wb) / (HBM_PEAK_GBS * 1e9), fl * B / (MFMA_F16_PEAK_TF * 1e12)
+        out.append({"config": "BASELINE configs[2]: ResNet-50 embeddings (2048-D), batch 128, 224x224x3, bf16 storage + bf16 MFMA, fp32 accumulate",
+                    "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "dtype": "bf16",
+                    "weights": "synthetic (seed 123)", "tflops": round(fl * B / dt / 1e12, 1),
+                    "roofline": {"bound": "hbm", "achieved": round((by * B + wb) / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(t_hbm / dt, 4), "traffic": None,
+                                 "note": "layer-wise HBM floor %.3f ms vs bf16 MFMA floor %.3f ms per batch: the net is HBM-bound unless layers are fused"
+                                         % (t_hbm * 1e3, t_mfma * 1e3)}})
+        eng.close()
+    except Exception as e:      # a failing side config must not take the headline line down
+        out.append({"config": "BASELINE configs[2]: ResNet-50", "error": repr(e)})
+    # -- configs[3]: age/gender multi-head MobileNet-224, batch 512, three outputs
+    try:
+        B = 512
+        g = read_graph(AGE_GENDER_PB)
+        fetch = {0: "global_pooling/Mean:0", 1: "age_pred/Softmax:0", 2: "gender_pred/Sigmoid:0"}
+        plan = lowering.lower_graph(g, "input_1:0", fetch)
+        eng = Engine(plan, max_batch=B, device=dev.index)
+        dt = time_engine(eng, gen(B, 224), (0, 1, 2), steps, warm)
+        by = 40.948e6 * B + 12.74e6          # SURVEY 8d: unfused layer-wise bytes per face @224 + weights per batch
+        out.append({"config": "BASELINE configs[3]: age_gender_tf2 MobileNet-224 multi-head (features + age softmax + gender sigmoid), batch 512, fp32",
+                    "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "dtype": "f32",
+                    "weights": "age_gender_tf2_new-01-0.14-0.92_quantized.pb",
+                    "roofline": {"bound": "hbm", "achieved": round(by / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(by / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                 "note": "unfused layer-wise algorithmic bytes (40.948 MB/face, SURVEY 8d) / time"}})
+        eng.close()
+    except Exception as e:
+        out.append({"config": "BASELINE configs[3]: age/gender MobileNet-224", "error": repr(e)})
+    # -- configs[1] again with every pointwise product on the fp32 MFMA (no f16 split anywhere)
+    try:
+        B, S = args.batch, args.size
+        g = read_graph(AGE_GENDER_PB)
+        plan = lowering.lower_graph(g, "input_1:0", {0: "global_pooling/Mean:0"}, (S, S), pw_math="f32")
+        eng = Engine(plan, max_batch=B, device=dev.index)
+        dt = time_engine(eng, gen(B, S), (0,), steps, warm)
+        fl = plan.flops_per_image([lowering.OP_PWCONV_F32])
+        out.append({"config": "BASELINE configs[1] with pw_math='f32': MobileNet-192 batch %d, every product on the fp32 pipes "
+                              "(v_mfma_f32_32x32x2_f32 / fp32 FMA), no f16 split" % B,
+                    "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "dtype": "f32",
+                    "roofline": {"bound": "mfma", "achieved": round(plan.flops_per_image() * B / dt / 1e12, 1), "peak": MFMA_F32_PEAK_TF,
+                                 "unit": "TFLOP/s", "frac": round(plan.flops_per_image() * B / dt / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                                 "note": "whole-net flops (%.0f %% pointwise) over the fp32-MFMA peak" % (100.0 * fl / plan.flops_per_image())}})
+        eng.close()
+    except Exception as e:
+        out.append({"config": "BASELINE configs[1] pw_math=f32", "error": repr(e)})
+    del rs
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, argv))
 
     import torch
     import torch.distributed as dist
@@ -53,29 +316,42 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        from hse_facerec_tf_amd import gallery
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            got = gallery.all_gather_rows(torch.full((2, 3), float(rank))).tolist()
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            got = [[0.0] * 3] * 2
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "gathered_first_column": [r[0] for r in got],
+                              "self_launched": os.environ.get("HSEFR_BENCH_SELF_LAUNCHED") == "1"}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > n_dev:
+        raise SystemExit("--gpus %d but only %d GPU(s) visible (RCCL needs one GPU per rank)" % (world, n_dev))
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from hse_facerec_tf_amd import lowering
     from hse_facerec_tf_amd.tf_inference import AGE_GENDER_PB, TensorFlowInference
 
-    # tuning/debug knobs (never needed for correct results), e.g. HSEFR_DEBUG="dw_variant=3,pw_tile=1"
-    if os.environ.get("HSEFR_DEBUG"):
-        from hse_facerec_tf_amd import _lib
-        for kv in os.environ["HSEFR_DEBUG"].split(","):
-            k, v = kv.split("=")
-            _lib.check(_lib.lib().hsefr_debug_set(k.strip().encode(), int(v)), "hsefr_debug_set")
-
     B, S = args.batch, args.size
     tfi = TensorFlowInference(AGE_GENDER_PB, input_tensor="input_1:0", output_tensor="global_pooling/Mean:0",
-                              convert2BGR=True, imageNetUtilsMean=True, input_size=(S, S), max_batch=B, device=local_rank)
+                              convert2BGR=True, imageNetUtilsMean=True, input_size=(S, S), max_batch=B, device=dev_index)
     eng, plan = tfi.engine, tfi.plan
     # synthetic preprocessed batch: U(-128,128) fp32 NHWC, seed 123 (+rank)
     x_host = np.random.RandomState(123 + rank).uniform(-128, 128, (B, S, S, 3)).astype(np.float32)
@@ -97,11 +373,15 @@ def main():
     for _ in range(args.steps):
         out = step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    per_rank_fps = [B * args.steps / elapsed_local]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        per_rank_fps = [B * args.steps / float(v.item()) for v in ts]
+        elapsed = max(float(v.item()) for v in ts)             # MAX over ranks
     assert bool(torch.isfinite(out).all())
 
     # ---- the same `steps` forwards again with HIP events around every launch, recorded on the
@@ -126,29 +406,37 @@ def main():
         if args.layers and rank == 0:
             for i, L in enumerate(plan.layers):
                 nb = 4 * B * (int(np.prod(L.in_shape)) + int(np.prod(L.out_shape)))
-                oh, ow, co = L.out_shape
-                fl = plan.flops_per_image([L.kind]) * B if L.kind in (lowering.OP_STEM_F16S, lowering.OP_STEM2_F16S, lowering.OP_DWPW_F32, lowering.OP_DWPW_F16S) else \
-                    2 * oh * ow * co * L.kh * L.kw * (L.in_shape[2] if L.kind != lowering.OP_DWCONV3X3 else 1) * B
+                fl = plan.layer_flops(L) * B
                 print("layer %2d kind %d %-34s in %-16s out %-16s s%d  %8.2f us  %7.1f GB/s  %6.1f TF" %
                       (i, L.kind, L.name[:34], L.in_shape, L.out_shape, L.stride, per_op[i] * 1e3,
                        nb / (per_op[i] * 1e-3) / 1e9 if per_op[i] > 0 else 0, fl / (per_op[i] * 1e-3) / 1e12 if per_op[i] > 0 else 0),
                       file=sys.stderr)
 
-    # the exchange of config 5 (one all-gather of the embeddings), outside the timed region
+    # the exchange of config 5 (one all-gather of one batch of embeddings per rank), outside the timed region
     allgather_ms = None
     if world > 1:
-        full = torch.empty((world * B, out.shape[1]), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(full, out)
+        from hse_facerec_tf_amd import gallery
+        full = gallery.all_gather_rows(out)
         barrier()
         t1 = time.perf_counter()
         for _ in range(10):
-            dist.all_gather_into_tensor(full, out)
+            full = gallery.all_gather_rows(out)
         barrier()
         allgather_ms = (time.perf_counter() - t1) / 10 * 1e3
         assert torch.equal(full[rank * B:(rank + 1) * B], out)
 
+    config5 = None
+    if not args.no_config5:
+        try:
+            config5 = run_config5(args, tfi, dev, world, rank, args.backend, dist)
+        except Exception as e:
+            if world > 1:
+                raise
+            config5 = {"error": repr(e)}
+
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -168,16 +456,20 @@ def main():
     }
     # HBM traffic per launch measured with rocprofv3 PMC counters (separate --pmc FETCH_SIZE / WRITE_SIZE
     # passes, FETCH_SIZE doubled per the gfx950 correction) and committed under profiles/ -- counters cannot
-    # be read from inside this process, so the latest committed profile is what is reported.
-    traffic_by_class, mfma_by_class, traffic_src = {}, {}, None
+    # be read from inside this process, so the latest committed profile is what is reported; `traffic_stale`
+    # says whether the kernel sources changed since that profile was taken.
+    traffic_by_class, mfma_by_class, traffic_src, traffic_stale = {}, {}, None, None
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
         if cands:
             traffic_src = os.path.relpath(cands[-1], ROOT)
-            prof = json.load(open(cands[-1]))["kernels"]
-            prefixes = {"stem_conv1_dw_pw_dw_fused": "stem2_fused_kernel", "stem_conv1_dw_pw_fused": "stem_fused_kernel", "conv1_3x3x3_s2": "conv3x3_c3", "depthwise3x3": "dwconv3x3_kernel",
-                        "pointwise1x1_f32mfma": "pwconv_f32_", "pointwise1x1_f16split": "pwconv_f16s_kernel", "gap": "hsefr::gap_kernel",
+            pj = json.load(open(cands[-1]))
+            prof = pj["kernels"]
+            traffic_stale = pj.get("csrc_hash") != csrc_hash()
+            prefixes = {"stem_conv1_dw_pw_dw_fused": ("stem2_fused_kernel", "stem3_"), "stem_conv1_dw_pw_fused": "stem_fused_kernel", "conv1_3x3x3_s2": "conv3x3_c3",
+                        "depthwise3x3": "dwconv3x3_kernel",
+                        "pointwise1x1_f32mfma": "pwconv_f32_", "pointwise1x1_f16split": ("pwconv_f16s_kernel", "pwconv_ps_"), "gap": "hsefr::gap_kernel",
                         "fused_dw3x3_pw1x1": "dwpw_fused_kernel", "fused_dw3x3_pw1x1_f16split": ("dwpw3_f16s_kernel", "dwpw2_f16s_kernel", "dwpw_f16s_kernel")}
             for cls, pre in prefixes.items():
                 rows = [v for k, v in prof.items() if k.startswith(pre)]      # str.startswith takes a tuple of prefixes too
@@ -191,6 +483,10 @@ def main():
                         mfma_by_class[cls] = sum(r["launches"] * r["avg_us"] * r["mfma_util"] for r in rows if "mfma_util" in r) / tw
     except Exception:
         traffic_by_class, mfma_by_class = {}, {}
+
+    def layer_weight_bytes(L):
+        return 4 * sum(a.size for a in (L.w, L.scale, L.shift, L.w2, L.shift2, L.w0, L.shift0, L.w3, L.scale3, L.shift3) if a is not None)
+
     kernels = []
     if per_op is not None:
         for name, pred in classes.items():
@@ -199,10 +495,8 @@ def main():
                 continue
             ms = float(per_op[idx].sum())
             nbytes = sum(4 * (int(np.prod(plan.layers[i].in_shape)) + int(np.prod(plan.layers[i].out_shape))) for i in idx) * B \
-                + sum(4 * sum(a.size for a in (plan.layers[i].w, plan.layers[i].scale, plan.layers[i].shift, plan.layers[i].w2,
-                                               plan.layers[i].shift2, plan.layers[i].w0, plan.layers[i].shift0, plan.layers[i].w3,
-                                               plan.layers[i].scale3, plan.layers[i].shift3) if a is not None) for i in idx)
-            flops = sum(plan.flops_per_image([plan.layers[i].kind]) for i in idx[:1]) * B
+                + sum(layer_weight_bytes(plan.layers[i]) for i in idx)
+            flops = sum(plan.layer_flops(plan.layers[i]) for i in idx) * B          # the class's OWN layers
             # a fused block also saves writing + re-reading the depthwise result: report both byte counts
             unfused_extra = sum(2 * 4 * int(np.prod(plan.layers[i].out_shape[:2])) * plan.layers[i].in_shape[2] for i in idx
                                 if plan.layers[i].kind in (lowering.OP_DWPW_F32, lowering.OP_DWPW_F16S)) * B \
@@ -235,6 +529,7 @@ def main():
                             "unfused_equivalent_gbs": round((nbytes + unfused_extra) / (ms * 1e-3) / 1e9, 1) if unfused_extra else None,
                             "traffic": None if name not in traffic_by_class else int(traffic_by_class[name]),
                             "traffic_unit": "HBM bytes per launch (class average)", "traffic_source": traffic_src,
+                            "traffic_stale": traffic_stale,
                             "mfma_util_pmc": None if not mfma_by_class.get(name) else round(mfma_by_class[name], 4),
                             "note": note})
     dominant = max(kernels, key=lambda k: k["ms_per_step"]) if kernels else None
@@ -244,8 +539,35 @@ def main():
         if k is None:
             return None
         return {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
-                "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "avg_launch_us": k["avg_launch_us"],
+                "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "traffic_stale": k["traffic_stale"],
+                "avg_launch_us": k["avg_launch_us"],
                 "launches_per_step": k["launches_per_step"], "mfma_util_pmc": k.get("mfma_util_pmc")}
+
+    # the depthwise class, honestly split: the layers that run as their own kernel vs the ones inside fused kernels
+    roofline_dw = roof(dw)
+    if roofline_dw is not None:
+        standalone = [L for L in plan.layers if L.kind == lowering.OP_DWCONV3X3]
+        roofline_dw["covers"] = "the %d STANDALONE depthwise layers only: %s" % (
+            len(standalone), ", ".join("%dx%dx%d/s%d" % (L.in_shape[0], L.in_shape[1], L.in_shape[2], L.stride) for L in standalone))
+        inside = []
+        for k in kernels:
+            if k["kernel"] in ("stem_conv1_dw_pw_dw_fused", "stem_conv1_dw_pw_fused", "fused_dw3x3_pw1x1", "fused_dw3x3_pw1x1_f16split"):
+                Ls = [L for L in plan.layers if classes[k["kernel"]](L)]
+                dws = []
+                for L in Ls:
+                    if L.kind == lowering.OP_STEM2_F16S:
+                        h1 = (L.in_shape[0] + 1) // 2
+                        dws += ["%dx%dx32/s1" % (h1, h1), "%dx%dx64/s2" % (h1, h1)]
+                    elif L.kind == lowering.OP_STEM_F16S:
+                        dws += ["%dx%dx32/s1" % (L.out_shape[0], L.out_shape[1])]
+                    else:
+                        dws += ["%dx%dx%d/s%d" % (L.in_shape[0], L.in_shape[1], L.in_shape[2], L.stride)]
+                inside.append({"kernel": k["kernel"], "depthwise_layers": dws, "frac_of_hbm_roofline": k["frac"],
+                               "unfused_equivalent_frac": None if not k["unfused_equivalent_gbs"] else round(k["unfused_equivalent_gbs"] / HBM_PEAK_GBS, 4),
+                               "ms_per_step": k["ms_per_step"]})
+        roofline_dw["inside_fused_kernels"] = inside
+        roofline_dw["note"] = ("`frac` is the standalone class; the largest depthwise layers (96x96, 48x48, 24x24x256) run inside the fused "
+                               "kernels listed under inside_fused_kernels, whose own fractions are the honest figure for them")
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
@@ -259,10 +581,18 @@ def main():
         cores = max(1, min(avail, 32))
         fps, n_img = time_reference_loop(AGE_GENDER_PB, "global_pooling/Mean:0", x_host[:32], cores,
                                          budget_s=args.cpu_baseline_seconds, batch=1)
+        fps256, n256 = time_reference_loop(AGE_GENDER_PB, "global_pooling/Mean:0", x_host, cores,
+                                           budget_s=args.cpu_baseline_seconds, batch=B)
         cpu_baseline = {"value": round(fps, 2), "unit": "faces/s", "cores": cores, "kind": "port",
                         "sample": "%d images of the same synthetic %dx%dx3 batch through the reference's batch-1 loop "
                                   "(facerec_test.py:394): same frozen graph, op-by-op fp32 on torch-CPU/oneDNN; not TensorFlow"
-                                  % (n_img, S, S)}
+                                  % (n_img, S, S),
+                        "batch%d" % B: {"value": round(fps256, 2), "unit": "faces/s", "cores": cores,
+                                        "sample": "%d images as batches of %d through the same graph: the CPU's best case (BASELINE.md 4)" % (n256, B)}}
+
+    other = None
+    if world == 1 and not args.no_other_configs:
+        other = run_other_configs(args, dev)
 
     line = {
         "metric": "faces/sec embedding-extract (MobileNet-192, bs=256)",
@@ -277,16 +607,26 @@ def main():
                                     if any(L.a_log2 for L in plan.layers) else "on the fp32 MFMA"),
                    "weights": "trunk of age_gender_tf2_new-01-0.14-0.92_quantized.pb (the reference's only shipped graph)",
                    "parallelism": "%d independent replicas, gallery sharded by image, one all-gather of embeddings" % world,
+                   "backend": None if world == 1 else ("RCCL (torch 'nccl')" if args.backend == "nccl" else "gloo"),
+                   # the knobs that change WHAT is benchmarked: effective values, env overrides included
+                   "pw_math": "f16split" if any(L.a_log2 for L in plan.layers) else "f32",
+                   "plan_kinds": [int(L.kind) for L in plan.layers],
+                   "env_overrides": {k: os.environ[k] for k in ("HSEFR_PW_MATH", "HSEFR_FUSE_STEM", "HSEFR_FUSE_BLOCKS") if k in os.environ},
                    "op_events": "second pass of the same %d steps, HIP events on the forward stream" % args.steps if use_events else None},
+        "per_rank_faces_per_s": [round(v, 1) for v in per_rank_fps],
         "ms_per_step_instrumented": None if instrumented_ms is None else round(instrumented_ms, 4),
-        "roofline": roof(dominant), "roofline_depthwise": roof(dw), "kernels": kernels,
+        "roofline": roof(dominant), "roofline_depthwise": roofline_dw, "kernels": kernels,
         "cpu_baseline": cpu_baseline,
         "allgather_ms": None if allgather_ms is None else round(allgather_ms, 4),
+        "config5": config5,
+        "other_configs": other,
         "device_bytes": eng.device_bytes,
+        "csrc_hash": csrc_hash(),
     }
     print(json.dumps(line))
     sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

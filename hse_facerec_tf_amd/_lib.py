@@ -114,5 +114,26 @@ def require_gpu():
 
 
 def current_stream_ptr() -> int:
+    """The current torch stream OF THE CURRENT DEVICE: callers launch under ``on_device(tensor)`` so that the
+    current device is the one that owns the pointers they pass."""
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def cuda_device(device=None):
+    """None -> the current device; an index, 'cuda:1' or torch.device -> torch.device('cuda', index)."""
+    torch = require_gpu()
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    d = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    if d.type != "cuda":
+        raise ValueError("hse_facerec_tf_amd runs on a ROCm GPU, not on %r" % (device,))
+    return torch.device("cuda", torch.cuda.current_device() if d.index is None else d.index)
+
+
+def on_device(t):
+    """Context manager: make the device that owns tensor ``t`` (or the given torch.device) current, so that the
+    stream handed to libhsefr and the HIP launch target match the pointers (a launch under device 0
+    on device-1 pointers is a memory fault, not an exception)."""
+    import torch
+    return torch.cuda.device(t.device if hasattr(t, "device") else t)

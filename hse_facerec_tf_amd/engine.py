@@ -19,7 +19,7 @@ class Engine:
         torch = _lib.require_gpu()
         self._torch = torch
         self.plan = plan
-        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.device = _lib.cuda_device(device)
         self.max_batch = int(max_batch)
         blob = plan.serialize()
         handle = ctypes.c_void_p()
@@ -60,6 +60,8 @@ class Engine:
                              % (tuple(x.shape), h, w, c))
         if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
             raise ValueError("engine input must be a contiguous float32 CUDA tensor")
+        if x.device != self.device:      # weights and activation buffers live on self.device: never launch across devices
+            raise ValueError("engine input is on %s but the engine was created on %s" % (x.device, self.device))
         n = int(x.shape[0])
         outs = {}
         ptrs = [None, None, None]
@@ -69,15 +71,18 @@ class Engine:
             t = torch.empty((n, self.out_elems[slot]), dtype=torch.float32, device=x.device)
             outs[_SLOT_NAMES[slot]] = t
             ptrs[slot] = t.data_ptr()
-        with torch.cuda.device(x.device):
+        with torch.cuda.device(self.device):
             _lib.check(_lib.lib().hsefr_engine_forward(self._h, x.data_ptr(), n, ptrs[0], ptrs[1], ptrs[2],
                                                        _lib.current_stream_ptr()), "hsefr_engine_forward")
         return outs
 
     def forward_all_layers(self, x) -> None:
         """Run every op (no fetch pruning); intermediate buffers can then be read with layer_output."""
-        _lib.check(_lib.lib().hsefr_engine_forward(self._h, x.data_ptr(), int(x.shape[0]), None, None, None,
-                                                   _lib.current_stream_ptr()), "hsefr_engine_forward")
+        if x.device != self.device:
+            raise ValueError("engine input is on %s but the engine was created on %s" % (x.device, self.device))
+        with self._torch.cuda.device(self.device):
+            _lib.check(_lib.lib().hsefr_engine_forward(self._h, x.data_ptr(), int(x.shape[0]), None, None, None,
+                                                       _lib.current_stream_ptr()), "hsefr_engine_forward")
 
     def layer_output(self, layer_index: int, n: int):
         """Copy of a layer's activation buffer as a CUDA tensor [n, oh, ow, c].  Only meaningful
@@ -85,8 +90,9 @@ class Engine:
         torch = self._torch
         L = self.plan.layers[layer_index]
         out = torch.empty((n,) + tuple(L.out_shape), dtype=torch.float32, device=self.device)
-        _lib.check(_lib.lib().hsefr_engine_copy_buffer(self._h, L.out_buf, out.data_ptr(), out.numel() * 4,
-                                                       _lib.current_stream_ptr()), "hsefr_engine_copy_buffer")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().hsefr_engine_copy_buffer(self._h, L.out_buf, out.data_ptr(), out.numel() * 4,
+                                                           _lib.current_stream_ptr()), "hsefr_engine_copy_buffer")
         return out
 
     # -- small batches as one hipGraph launch ---------------------------------------------------

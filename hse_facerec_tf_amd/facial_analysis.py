@@ -47,7 +47,7 @@ class FacialImageProcessing:
         self.detector = detector
         if detector is None and mtcnn_detector:        # facial_analysis.py:59-61: the MTCNN cascade of mtcnn.pb
             from .mtcnn import MTCNNDetector
-            self.detector = MTCNNDetector(minsize=minsize)
+            self.detector = MTCNNDetector(minsize=minsize, device=device)
         # facial_analysis.py:45 loads a sibling .pb; the one that ships with the reference checkout is
         # the quantised age_gender_tf2_new-01-0.14-0.92 model.
         self.model_file = model_file or AGE_GENDER_PB
@@ -95,7 +95,7 @@ class FacialImageProcessing:
             chunk = faces_rgb_u8[i:i + mb]
             if self.device_preprocess:      # cv2.resize + BGR + mean on the GPU (integer resize: same bits)
                 from . import preprocess_device
-                xd = preprocess_device.preprocess_faces_cv(chunk, (self.h, self.w))
+                xd = preprocess_device.preprocess_faces_cv(chunk, (self.h, self.w), device=self.sess.device)
             else:
                 x = np.stack([self.preprocess_face(f) for f in chunk])
                 xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.sess.device)

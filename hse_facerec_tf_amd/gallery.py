@@ -25,9 +25,20 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(lo + s, n)
 
 
-def extract_sharded(extract_fn: Callable, items: Sequence, dim: int, device, group=None, batch: int = 256):
+def _sync(device) -> float:
+    import time
+    import torch
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    return time.perf_counter()
+
+
+def extract_sharded(extract_fn: Callable, items: Sequence, dim: int, device, group=None, batch: int = 256,
+                    timings: Optional[dict] = None):
     """extract_fn(list_of_items) -> float32 tensor [len, dim] on ``device``.  Returns the full
-    [N, dim] tensor (on ``device``) on every rank.  Works un-initialised (world = 1) too."""
+    [N, dim] tensor (on ``device``) on every rank.  Works un-initialised (world = 1) too.
+    ``timings`` (optional dict) receives wall seconds of the two phases, device-synchronised:
+    'extract_s' (this rank's shard) and 'allgather_s' (the one collective)."""
     import torch
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
@@ -37,20 +48,66 @@ def extract_sharded(extract_fn: Callable, items: Sequence, dim: int, device, gro
     s = shard_size(n, world)
     lo, hi = shard_range(n, rank, world)
     local = torch.zeros((s, dim), dtype=torch.float32, device=device)      # tail rows stay zero (pad)
+    t0 = _sync(device) if timings is not None else 0.0
     for i in range(lo, hi, batch):
         j = min(i + batch, hi)
         out = extract_fn(items[i:j])
         if tuple(out.shape) != (j - i, dim):
             raise ValueError("extract_fn returned %r for %d items of dim %d" % (tuple(out.shape), j - i, dim))
         local[i - lo:j - lo] = out
+    if timings is not None:
+        t1 = _sync(device)
+        timings["extract_s"] = t1 - t0
+        timings["shard"] = (lo, hi)
     if world == 1:
+        if timings is not None:
+            timings["allgather_s"] = 0.0
         return local[:n]
-    full = torch.empty((world * s, dim), dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(full, local, group=group)
+    full = all_gather_rows(local, group)
+    if timings is not None:
+        timings["allgather_s"] = _sync(device) - t1
+        timings["allgather_bytes_per_rank"] = int(local.numel() * 4)
     return full[:n]
 
 
-def gather_labels(labels: np.ndarray) -> np.ndarray:
-    """Labels come from the directory names of the (identical, sorted) file list on every rank
-    (facerec_test.py:386-389) -- nothing to exchange."""
-    return np.asarray(labels)
+def all_gather_rows(local, group=None):
+    """THE collective of the path: every rank contributes [S, D] and receives [P*S, D] in rank order
+    (ncclAllGather on RCCL over xGMI with backend "nccl").  On a gloo group (CPU tests, or several ranks
+    sharing one GPU in the launcher test) device tensors are staged through the host."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(full.shape, dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous(), group=group)
+        full.copy_(host)
+    else:
+        dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+    return full
+
+
+def lfw_like_class_sizes(n_images: int = 9164, n_classes: int = 1680) -> np.ndarray:
+    """A deterministic long-tailed class-size histogram with LFW's totals after the >1-image filter of
+    facerec_test.py:407-412 (9164 photos of 1680 persons, README.md:14): Zipf-like, largest class 530
+    (LFW's own maximum), every class >= 2.  The real per-person counts need the dataset; only the totals
+    and the shape of the tail matter for the synthetic config-5 workload."""
+    r = np.arange(1, n_classes + 1, dtype=np.float64)
+    top = min(530, max(2, n_images - 2 * (n_classes - 1)))
+    lo, hi = 0.0, 8.0
+    for _ in range(80):
+        p = 0.5 * (lo + hi)
+        if np.maximum(2, np.floor(top / r ** p)).sum() > n_images:
+            lo = p
+        else:
+            hi = p
+    sizes = np.maximum(2, np.floor(top / r ** hi)).astype(np.int64)
+    sizes[0] += n_images - int(sizes.sum())               # whatever the floor left over goes to the largest class
+    if sizes.min() < 2 or sizes.sum() != n_images:
+        raise ValueError("no histogram with %d images in %d classes of >= 2" % (n_images, n_classes))
+    return sizes
+
+
+def lfw_like_labels(n_images: int = 9164, n_classes: int = 1680) -> np.ndarray:
+    """Labels in directory-walk order (get_files: images of one person are consecutive, persons sorted)."""
+    return np.repeat(np.arange(n_classes), lfw_like_class_sizes(n_images, n_classes))

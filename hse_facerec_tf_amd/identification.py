@@ -32,23 +32,38 @@ def stratified_half_split(y: np.ndarray, random_state: int = 0) -> Tuple[np.ndar
 
 
 def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np.ndarray]] = None,
-                          pca_components: Optional[int] = None) -> Dict:
+                          pca_components: Optional[int] = None, timings: Optional[dict] = None) -> Dict:
     """The protocol of facerec_test.py:401-432: 'k-NN' (pca_components=None) or 'k-NN+PCA'
     (pca_components=128, the Pipeline of :421 -- PCA is fitted on the gallery half by scikit-learn on
     the host, exactly as the reference does, and the projected vectors go back to the device for the search).
 
     X: [N, D] float32 embeddings, CUDA tensor or NumPy array (uploaded); y: [N] labels.
-    Returns accuracy, the split, predictions and nearest-gallery indices."""
+    Returns accuracy, the split, predictions and nearest-gallery indices.  ``timings`` (optional dict) receives the
+    device-synchronised wall seconds of each phase: normalize_s, host_split_s, select_s, nn1_s."""
+    import time
     from . import _lib, ops
     torch = _lib.require_gpu()
     if isinstance(X, np.ndarray):
         X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).cuda()
+
+    def lap(key, t_prev):
+        if timings is None:
+            return 0.0
+        torch.cuda.synchronize(X.device)
+        t = time.perf_counter()
+        timings[key] = t - t_prev
+        return t
+
+    t = lap("_start", 0.0)
     Xn = ops.l2_normalize(X.contiguous())                       # :401
+    t = lap("normalize_s", t)
     indices, y_enc = filter_classes(y)                          # :407-412
-    Xn = Xn[torch.from_numpy(indices).to(Xn.device)].contiguous()   # :413
     train, test = split if split is not None else stratified_half_split(y_enc)
+    t = lap("host_split_s", t)
+    Xn = Xn[torch.from_numpy(indices).to(Xn.device)].contiguous()   # :413
     gal = Xn[torch.from_numpy(train).to(Xn.device)].contiguous()
     qry = Xn[torch.from_numpy(test).to(Xn.device)].contiguous()
+    t = lap("select_s", t)
     if pca_components:
         from sklearn.decomposition import PCA
         pca = PCA(n_components=pca_components).fit(gal.cpu().numpy())
@@ -59,6 +74,10 @@ def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np
             return torch.from_numpy(np.pad(z, ((0, 0), (0, pad)))).to(Xn.device).contiguous()
         gal, qry = proj(gal), proj(qry)
     nn_idx, nn_d2 = ops.nn1(qry, gal)
+    t = lap("nn1_s", t)
+    if timings is not None:
+        timings.pop("_start", None)
+        timings["nn1_shape"] = (int(qry.shape[0]), int(gal.shape[0]), int(qry.shape[1]))
     nn_idx_h = nn_idx.cpu().numpy()
     y_pred = y_enc[train][nn_idx_h]
     acc = float((y_pred == y_enc[test]).mean()) if len(test) else float("nan")
@@ -73,7 +92,8 @@ def feature_distance_matrix(features, born_years=None, photo_years=None) -> np.n
     clustering code (facial_clustering.get_facial_clusters) expects."""
     from . import _lib, ops
     torch = _lib.require_gpu()
-    f = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).cuda()
+    f = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).cuda() if isinstance(features, np.ndarray) \
+        else features.float().contiguous()
     dist = ops.pairwise_distances(f).cpu().numpy().astype(np.float64)
     if born_years is not None:
         by = np.asarray(born_years, dtype=np.float64)

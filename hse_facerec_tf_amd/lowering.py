@@ -248,24 +248,25 @@ class Plan:
                         tot += 4 * a.size
         return tot
 
+    @staticmethod
+    def layer_flops(L: "Layer") -> int:
+        """Algorithmic multiply-add flops of ONE layer per image (fused layers: the sum of what they replace)."""
+        oh, ow, cout = L.out_shape
+        if L.kind in (OP_CONV_C3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16):
+            return 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
+        if L.kind == OP_DWCONV3X3:
+            return 2 * oh * ow * cout * 9
+        if L.kind in (OP_DWPW_F32, OP_DWPW_F16S):
+            return 2 * oh * ow * L.in_shape[2] * 9 + 2 * oh * ow * cout * L.in_shape[2]
+        if L.kind == OP_STEM_F16S:
+            return 2 * oh * ow * 32 * 27 + 2 * oh * ow * 32 * 9 + 2 * oh * ow * cout * 32
+        if L.kind == OP_STEM2_F16S:
+            h1, w1 = (L.in_shape[0] + 1) // 2, (L.in_shape[1] + 1) // 2
+            return 2 * h1 * w1 * 32 * 27 + 2 * h1 * w1 * 32 * 9 + 2 * h1 * w1 * 64 * 32 + 2 * oh * ow * 64 * 9
+        return 0
+
     def flops_per_image(self, kinds: Optional[Sequence[int]] = None) -> int:
-        tot = 0
-        for L in self.layers:
-            if kinds is not None and L.kind not in kinds:
-                continue
-            oh, ow, cout = L.out_shape
-            if L.kind in (OP_CONV_C3, OP_PWCONV_F32, OP_DENSE):
-                tot += 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
-            elif L.kind == OP_DWCONV3X3:
-                tot += 2 * oh * ow * cout * 9
-            elif L.kind in (OP_DWPW_F32, OP_DWPW_F16S):
-                tot += 2 * oh * ow * L.in_shape[2] * 9 + 2 * oh * ow * cout * L.in_shape[2]
-            elif L.kind == OP_STEM_F16S:
-                tot += 2 * oh * ow * 32 * 27 + 2 * oh * ow * 32 * 9 + 2 * oh * ow * cout * 32
-            elif L.kind == OP_STEM2_F16S:
-                h1, w1 = (L.in_shape[0] + 1) // 2, (L.in_shape[1] + 1) // 2
-                tot += 2 * h1 * w1 * 32 * 27 + 2 * h1 * w1 * 32 * 9 + 2 * h1 * w1 * 64 * 32 + 2 * oh * ow * 64 * 9
-        return tot
+        return sum(self.layer_flops(L) for L in self.layers if kinds is None or L.kind in kinds)
 
 
 # --------------------------------------------------------------------------------------

@@ -30,10 +30,11 @@ MTCNN_PB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 class _DeviceNet:
     """Evaluate tensors of a small frozen CNN on the GPU, fusing bias / PReLU / softmax sub-graphs."""
 
-    def __init__(self, graph: Graph):
+    def __init__(self, graph: Graph, device=None):
         torch = _lib.require_gpu()
         self.g = graph
         self._torch = torch
+        self.device = _lib.cuda_device(device)
         self._const: Dict[str, object] = {}
 
     def _dev(self, node: GraphNode, reshape=None):
@@ -43,7 +44,7 @@ class _DeviceNet:
             a = np.ascontiguousarray(self._const_np(node), dtype=np.float32)
             if reshape is not None:
                 a = a.reshape(reshape)
-            t = self._torch.from_numpy(a).cuda()
+            t = self._torch.from_numpy(a).to(self.device)
             self._const[key] = t
         return t
 
@@ -228,11 +229,12 @@ class MTCNNDetector:
     THRESHOLDS = (0.6, 0.7, 0.9)       # facial_analysis.py:481
     FACTOR = 0.709                     # :483
 
-    def __init__(self, mtcnn_pb: Optional[str] = None, minsize: int = 32):
+    def __init__(self, mtcnn_pb: Optional[str] = None, minsize: int = 32, device=None):
         torch = _lib.require_gpu()
         self._torch = torch
         self.minsize = minsize
-        self.net = _DeviceNet(read_graph(mtcnn_pb or MTCNN_PB))
+        self.device = _lib.cuda_device(device)
+        self.net = _DeviceNet(read_graph(mtcnn_pb or MTCNN_PB), self.device)
 
     # the three sess.run lambdas of load_mtcnn (:347-349)
     def pnet(self, img):
@@ -255,7 +257,7 @@ class MTCNNDetector:
         return scales
 
     def _to_device(self, a: np.ndarray):
-        return self._torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+        return self._torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
     def _stage1(self, img: np.ndarray) -> np.ndarray:
         h, w = img.shape[:2]

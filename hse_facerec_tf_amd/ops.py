@@ -11,6 +11,23 @@ from . import _lib
 from .lowering import ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SIGMOID, tf_same_padding  # noqa: F401
 
 
+def _device_guarded(fn):
+    """Run the launch with the device of the first CUDA tensor argument current (stream + launch target = the
+    device that owns the pointers); mixing devices in one call is an error, not a memory fault."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        devs = [a.device for a in list(args) + list(kw.values()) if hasattr(a, "is_cuda") and a.is_cuda]
+        if not devs:
+            return fn(*args, **kw)
+        if any(d != devs[0] for d in devs):
+            raise ValueError("%s: tensors live on different devices: %s" % (fn.__name__, sorted({str(d) for d in devs})))
+        with _lib.on_device(devs[0]):
+            return fn(*args, **kw)
+    return wrapper
+
+
 def _f32c(t, name):
     torch = _lib.require_gpu()
     if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
@@ -24,6 +41,7 @@ def _same(h: int, w: int, k: int, stride: int) -> Tuple[int, int, int, int]:
     return oh, ow, pt, pl
 
 
+@_device_guarded
 def conv3x3_c3(x, w_hwio, shift, stride: int = 2, act: int = ACT_RELU6):
     """Conv2D 3x3 SAME over a 3-channel NHWC image + shift + act (graph nodes #30-34)."""
     torch = _lib.require_gpu()
@@ -40,6 +58,7 @@ def conv3x3_c3(x, w_hwio, shift, stride: int = 2, act: int = ACT_RELU6):
     return y
 
 
+@_device_guarded
 def dwconv3x3(x, w_hwc, scale, shift, stride: int = 1, act: int = ACT_RELU6):
     """DepthwiseConv2dNative 3x3 SAME + scale + shift + act (graph nodes #35-39,#44)."""
     torch = _lib.require_gpu()
@@ -53,6 +72,7 @@ def dwconv3x3(x, w_hwc, scale, shift, stride: int = 1, act: int = ACT_RELU6):
     return y
 
 
+@_device_guarded
 def pwconv1x1(x, w_t, shift, act: int = ACT_RELU6):
     """1x1 conv + shift + act on NHWC x [..., k]; w_t is the TF kernel transposed: [cout, k]."""
     torch = _lib.require_gpu()
@@ -76,6 +96,7 @@ def split_weights_device(w_t, device, a_log2: int = 12):
     return torch.from_numpy(img.view(np.int16)).to(device), torch.from_numpy(descale).to(device)
 
 
+@_device_guarded
 def pwconv1x1_f16split(x, w_t, shift, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
     """1x1 conv + shift + act with split-f16 products (fp32-grade, csrc/pwconv_f16s.hip).  PRECONDITION:
     |x| * 2^a_log2 < 32768 (a ReLU6 producer with the default 12).  w_t [cout, k] fp32 is split on the host
@@ -93,6 +114,7 @@ def pwconv1x1_f16split(x, w_t, shift, act: int = ACT_RELU6, a_log2: int = 12, pr
     return y
 
 
+@_device_guarded
 def dwpw_f16split(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
     """One MobileNet block in one kernel, any c % 32 == 0 / cout % 64 == 0: depthwise 3x3 SAME + scale + shift + ReLU6 ->
     pointwise 1x1 + shift + act with split-f16 products (csrc/dwpw_f16s.hip).  wp_t [cout, c] fp32 is split on the host."""
@@ -110,6 +132,7 @@ def dwpw_f16split(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1, act: 
     return y
 
 
+@_device_guarded
 def dwpwdw_f16split(x, w_hwc, dscale, dshift, wp_t, pshift, w2_hwc, d2scale, d2shift, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
     """A stride-1 block and the stride-2 depthwise behind it in one kernel (csrc/dwpwdw_f16s.hip): depthwise 3x3/1 -> pointwise
     c -> 128 (split-f16 products) -> depthwise 3x3/2 + scale + shift + ReLU6.  wp_t [128, c] fp32 is split on the host."""
@@ -129,6 +152,7 @@ def dwpwdw_f16split(x, w_hwc, dscale, dshift, wp_t, pshift, w2_hwc, d2scale, d2s
     return y
 
 
+@_device_guarded
 def stem_fused(x, conv_w, conv_shift, w_hwc, dscale, dshift, wp_t, pshift, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
     """The MobileNet stem in one kernel (csrc/stem_fused.hip): conv 3x3/2 SAME 3->32 + shift + ReLU6 -> depthwise 3x3/1 +
     scale + shift + ReLU6 -> pointwise 32->64 + shift + act.  conv_w TF HWIO [3,3,3,32], w_hwc [3,3,32], wp_t [64,32]."""
@@ -148,6 +172,7 @@ def stem_fused(x, conv_w, conv_shift, w_hwc, dscale, dshift, wp_t, pshift, act: 
     return y
 
 
+@_device_guarded
 def stem2_fused(x, conv_w, conv_shift, w1_hwc, d1scale, d1shift, wp_t, pshift, w2_hwc, d2scale, d2shift, act: int = ACT_RELU6,
                 a_log2: int = 12, prepared=None):
     """Stem + the depthwise of block 2 in one kernel (csrc/stem2_fused.hip): conv 3x3/2 3->32 -> depthwise 3x3/1 -> pointwise
@@ -171,6 +196,7 @@ def stem2_fused(x, conv_w, conv_shift, w1_hwc, d1scale, d1shift, wp_t, pshift, w
     return y
 
 
+@_device_guarded
 def dwpw_fused(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1):
     """One early MobileNet block in one kernel: depthwise 3x3 SAME + scale + shift + ReLU6 -> pointwise 1x1 + shift +
     ReLU6 (graph nodes #35-#49).  c in {32, 64}, cout in {64, 128}; wp_t is the pointwise kernel transposed [cout, c]."""
@@ -187,6 +213,7 @@ def dwpw_fused(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1):
     return y
 
 
+@_device_guarded
 def gap(x):
     torch = _lib.require_gpu()
     _f32c(x, "x")
@@ -196,6 +223,7 @@ def gap(x):
     return y
 
 
+@_device_guarded
 def dense(x, w, bias=None, act: int = ACT_NONE):
     torch = _lib.require_gpu()
     _f32c(x, "x"), _f32c(w, "w")
@@ -207,6 +235,7 @@ def dense(x, w, bias=None, act: int = ACT_NONE):
     return y
 
 
+@_device_guarded
 def softmax(x):
     torch = _lib.require_gpu()
     _f32c(x, "x")
@@ -216,6 +245,7 @@ def softmax(x):
     return y
 
 
+@_device_guarded
 def l2_normalize(x):
     """preprocessing.normalize(X, norm='l2') (facerec_test.py:401)."""
     torch = _lib.require_gpu()
@@ -227,6 +257,7 @@ def l2_normalize(x):
     return y
 
 
+@_device_guarded
 def nn1(queries, gallery):
     """Index (int32) and squared L2 distance of each query's nearest gallery row."""
     torch = _lib.require_gpu()
@@ -242,6 +273,7 @@ def nn1(queries, gallery):
     return idx, dist
 
 
+@_device_guarded
 def conv2d_direct(x, w_hwio, bias=None, alpha=None, stride: int = 1, padding: str = "VALID"):
     """Generic Conv2D + BiasAdd + optional PReLU (MTCNN nets).  padding: 'VALID' | 'SAME' (TensorFlow rule)."""
     torch = _lib.require_gpu()
@@ -263,6 +295,7 @@ def conv2d_direct(x, w_hwio, bias=None, alpha=None, stride: int = 1, padding: st
     return y
 
 
+@_device_guarded
 def maxpool(x, k: int, stride: int, padding: str = "SAME"):
     torch = _lib.require_gpu()
     _f32c(x, "x")
@@ -279,6 +312,7 @@ def maxpool(x, k: int, stride: int, padding: str = "SAME"):
     return y
 
 
+@_device_guarded
 def pairwise_distances(x, y=None):
     """sklearn pairwise_distances(X[, Y]) (euclidean) -> CUDA float32 [n, m] (facial_clustering_test.py:396)."""
     torch = _lib.require_gpu()
@@ -300,13 +334,14 @@ def _bf16c(t, name):
     return t
 
 
-def bf16_from_bits(bits_u16):
+def bf16_from_bits(bits_u16, device=None):
     """NumPy uint16 bf16 bit patterns -> CUDA bfloat16 tensor (a container; no arithmetic)."""
     torch = _lib.require_gpu()
     import numpy as np
-    return torch.from_numpy(np.ascontiguousarray(bits_u16).view(np.int16)).cuda().view(torch.bfloat16)
+    return torch.from_numpy(np.ascontiguousarray(bits_u16).view(np.int16)).to(_lib.cuda_device(device)).view(torch.bfloat16)
 
 
+@_device_guarded
 def conv_bf16(x, w_packed, scale, shift, kh: int, kw: int, stride: int = 1, pad: int = 0, res=None, act: int = ACT_RELU):
     """x [n,h,w,c] bf16; w_packed [cout, kh*kw*c] bf16 (resnet50.pack_conv_weight); -> [n,oh,ow,cout] bf16."""
     torch = _lib.require_gpu()
@@ -322,6 +357,7 @@ def conv_bf16(x, w_packed, scale, shift, kh: int, kw: int, stride: int = 1, pad:
     return y
 
 
+@_device_guarded
 def stem7x7_bf16(x, w_packed, scale, shift, act: int = ACT_RELU):
     torch = _lib.require_gpu()
     _f32c(x, "x"), _bf16c(w_packed, "w")
@@ -334,6 +370,7 @@ def stem7x7_bf16(x, w_packed, scale, shift, act: int = ACT_RELU):
     return y
 
 
+@_device_guarded
 def maxpool3x3s2_bf16(x, ceil_mode: bool = True):
     torch = _lib.require_gpu()
     _bf16c(x, "x")
@@ -348,6 +385,7 @@ def maxpool3x3s2_bf16(x, ceil_mode: bool = True):
     return y
 
 
+@_device_guarded
 def gap_bf16(x):
     torch = _lib.require_gpu()
     _bf16c(x, "x")

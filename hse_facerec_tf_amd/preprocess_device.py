@@ -88,36 +88,40 @@ def _mean_array(imageNetUtilsMean: bool):
     return (ctypes.c_double * 3)(float(m[0]), float(m[1]), float(m[2]))
 
 
-def _as_u8_cuda(imgs):
+def _as_u8_cuda(imgs, device=None):
     torch = _lib.require_gpu()
     if isinstance(imgs, np.ndarray):
-        imgs = torch.from_numpy(np.ascontiguousarray(imgs, dtype=np.uint8)).cuda()
+        imgs = torch.from_numpy(np.ascontiguousarray(imgs, dtype=np.uint8)).to(_lib.cuda_device(device))
+    elif device is not None and imgs.is_cuda and imgs.device != _lib.cuda_device(device):
+        raise ValueError("images are on %s, expected %s" % (imgs.device, _lib.cuda_device(device)))
     if imgs.dtype != torch.uint8 or imgs.dim() != 4 or imgs.shape[3] != 3 or not imgs.is_cuda:
         raise ValueError("images must be a uint8 [n,H,W,3] RGB batch")
     return imgs.contiguous()
 
 
-def preprocess_pil(imgs, out_hw: Tuple[int, int], convert2BGR: bool = True, imageNetUtilsMean: bool = True):
-    """facerec_test.py:93-110 for a batch of same-size decoded RGB images -> CUDA float32 [n,oh,ow,3]."""
+def preprocess_pil(imgs, out_hw: Tuple[int, int], convert2BGR: bool = True, imageNetUtilsMean: bool = True, device=None):
+    """facerec_test.py:93-110 for a batch of same-size decoded RGB images -> CUDA float32 [n,oh,ow,3].
+    A NumPy batch is uploaded to ``device`` (default: the current one); a CUDA batch stays where it is."""
     torch = _lib.require_gpu()
-    x = _as_u8_cuda(imgs)
+    x = _as_u8_cuda(imgs, device)
     n, H, W, _ = x.shape
     oh, ow = int(out_hw[0]), int(out_hw[1])
     xm, xc, xk, xks, ym, yc, yk, yks = _pil_tables_dev(H, W, oh, ow, x.device.index or 0)
     tmp = torch.empty((n, H, ow, 3), dtype=torch.uint8, device=x.device)
     out = torch.empty((n, oh, ow, 3), dtype=torch.float32, device=x.device)
     mode = COLOR_BGR_MEAN_F64 if convert2BGR else COLOR_RGB_UNIT
-    _lib.check(_lib.lib().hsefr_preprocess_pil_u8(x.data_ptr(), tmp.data_ptr(), out.data_ptr(), n, H, W, oh, ow, xm.data_ptr(),
-                                                  xc.data_ptr(), xk.data_ptr(), xks, ym.data_ptr(), yc.data_ptr(), yk.data_ptr(),
-                                                  yks, mode, _mean_array(imageNetUtilsMean), _lib.current_stream_ptr()),
-               "hsefr_preprocess_pil_u8")
+    with _lib.on_device(x):
+        _lib.check(_lib.lib().hsefr_preprocess_pil_u8(x.data_ptr(), tmp.data_ptr(), out.data_ptr(), n, H, W, oh, ow, xm.data_ptr(),
+                                                      xc.data_ptr(), xk.data_ptr(), xks, ym.data_ptr(), yc.data_ptr(), yk.data_ptr(),
+                                                      yks, mode, _mean_array(imageNetUtilsMean), _lib.current_stream_ptr()),
+                   "hsefr_preprocess_pil_u8")
     return out
 
 
-def preprocess_cv(imgs, out_hw: Tuple[int, int]):
+def preprocess_cv(imgs, out_hw: Tuple[int, int], device=None):
     """facial_analysis.py:95-107 (cv2.resize -> float32 -> BGR -> ImageNet-Caffe mean) for a same-size batch."""
     torch = _lib.require_gpu()
-    x = _as_u8_cuda(imgs)
+    x = _as_u8_cuda(imgs, device)
     n, H, W, _ = x.shape
     oh, ow = int(out_hw[0]), int(out_hw[1])
     out = torch.empty((n, oh, ow, 3), dtype=torch.float32, device=x.device)
@@ -125,21 +129,23 @@ def preprocess_cv(imgs, out_hw: Tuple[int, int]):
         tabs = [None] * 6
     else:
         tabs = [t.data_ptr() for t in _cv_tables_dev(H, W, oh, ow, x.device.index or 0)]
-    _lib.check(_lib.lib().hsefr_preprocess_cv_u8(x.data_ptr(), out.data_ptr(), n, H, W, oh, ow, *tabs, COLOR_BGR_MEAN_F32,
-                                                 _mean_array(True), _lib.current_stream_ptr()), "hsefr_preprocess_cv_u8")
+    with _lib.on_device(x):
+        _lib.check(_lib.lib().hsefr_preprocess_cv_u8(x.data_ptr(), out.data_ptr(), n, H, W, oh, ow, *tabs, COLOR_BGR_MEAN_F32,
+                                                     _mean_array(True), _lib.current_stream_ptr()), "hsefr_preprocess_cv_u8")
     return out
 
 
-def preprocess_faces_cv(crops: Sequence[np.ndarray], out_hw: Tuple[int, int]):
+def preprocess_faces_cv(crops: Sequence[np.ndarray], out_hw: Tuple[int, int], device=None):
     """Variable-size face crops (process_image's per-box crops): grouped by size, one launch per group,
-    results returned in input order as one CUDA float32 [n,oh,ow,3] tensor."""
+    results returned in input order as one CUDA float32 [n,oh,ow,3] tensor on ``device``."""
     torch = _lib.require_gpu()
     oh, ow = out_hw
-    out = torch.empty((len(crops), oh, ow, 3), dtype=torch.float32, device="cuda")
+    dev = _lib.cuda_device(device)
+    out = torch.empty((len(crops), oh, ow, 3), dtype=torch.float32, device=dev)
     groups = {}
     for i, c in enumerate(crops):
         groups.setdefault(c.shape[:2], []).append(i)
     for (h, w), idx in groups.items():
         batch = np.stack([np.ascontiguousarray(crops[i], dtype=np.uint8) for i in idx])
-        out[torch.tensor(idx, device="cuda")] = preprocess_cv(batch, out_hw)
+        out[torch.tensor(idx, device=dev)] = preprocess_cv(batch, out_hw, dev)
     return out

@@ -123,7 +123,8 @@ class TensorFlowInference:
         """Decoded RGB uint8 images [n,H,W,3] (same size; NumPy or CUDA) -> CUDA features [n,D]: the resize +
         BGR + mean of preprocess_image run on the device (bit-exact with the PIL path), then one forward."""
         from . import preprocess_device
-        x = preprocess_device.preprocess_pil(imgs_u8, (self.w, self.h), self.convert2BGR, self.imageNetUtilsMean)
+        x = preprocess_device.preprocess_pil(imgs_u8, (self.w, self.h), self.convert2BGR, self.imageNetUtilsMean,
+                                             device=self.engine.device)
         return self.engine.forward(x, (OUT_FEATURES,))["features"]
 
     def extract_files(self, paths: Sequence[str], batch: int = 256, crop_center: bool = False,

@@ -66,3 +66,18 @@ def synthetic_gallery(n_classes: int = 200, dim: int = 1024, seed: int = 123, no
     y = np.asarray(y)
     perm = rs.permutation(len(y))
     return X[perm], y[perm]
+
+
+def embeddings_for_labels(y: np.ndarray, dim: int = 1024, seed: int = 123, noise: float = 1.0) -> np.ndarray:
+    """Config-5-sized synthetic embeddings for a GIVEN label vector (directory-walk order): Gaussian class
+    centroids + isotropic noise, clipped at zero like post-ReLU6 GAP features.  Deterministic in (y, dim, seed,
+    noise); drawn class by class so that it does not depend on NumPy's block sizes."""
+    rs = np.random.RandomState(seed)
+    y = np.asarray(y)
+    n_classes = int(y.max()) + 1
+    cent = rs.randn(n_classes, dim).astype(np.float32)
+    X = np.empty((len(y), dim), np.float32)
+    for c in range(n_classes):
+        rows = np.nonzero(y == c)[0]
+        X[rows] = np.maximum(cent[c] + noise * rs.randn(len(rows), dim).astype(np.float32), 0)
+    return X

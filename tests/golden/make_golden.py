@@ -134,6 +134,25 @@ def nn1():
     print("nn1: N=%d kept=%d classes=%d acc=%.4f" % (len(y), len(y2), y2.max() + 1, acc))
 
 
+def nn1_lfw():
+    """BASELINE configs[4] at full size: 9164 embeddings of 1680 classes (the product's LFW-shaped label vector) ->
+    scikit-learn's own normalize / StratifiedShuffleSplit / KNeighborsClassifier(1) -> 4582 x 4582 x 1024."""
+    from hse_facerec_tf_amd import gallery
+    y = gallery.lfw_like_labels(9164, 1680)
+    noise = 2.0
+    X = oid.embeddings_for_labels(y, 1024, 123, noise)
+    Xn, y2, kept = oid.filter_and_encode(X, y)
+    acc, train, test, y_pred, nn_idx, nn_dist = oid.one_nn(Xn, y2)
+    # margin between the nearest and the second-nearest gallery row of every probe (fp64): the fixture must not hinge on ties
+    d2 = 2.0 - 2.0 * (Xn[test].astype(np.float64) @ Xn[train].astype(np.float64).T)
+    part = np.partition(d2, 1, axis=1)
+    margin = float((part[:, 1] - part[:, 0]).min())
+    np.savez_compressed(os.path.join(HERE, "nn1_lfw.npz"), n=9164, n_classes=1680, dim=1024, seed=123, noise=noise,
+                        train=train.astype(np.int32), test=test.astype(np.int32), nn_index=nn_idx.astype(np.int32),
+                        y_pred=y_pred.astype(np.int32), accuracy=acc, min_margin=margin, kept_all=bool(len(kept) == 9164))
+    print("nn1_lfw: kept=%d acc=%.6f min d2 margin=%.3e" % (len(kept), acc, margin))
+
+
 def mtcnn():
     """Oracle MTCNN cascade (fp32 graph interpreter + restated INTER_AREA) on the reference's demo image, then the
     oracle age/gender model on the detected faces exactly as process_image crops them (facial_analysis.py:233-271)."""
@@ -166,6 +185,6 @@ def mtcnn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["e2e_image", "e2e_synthetic", "kernels", "nn1", "mtcnn"]
+    which = sys.argv[1:] or ["e2e_image", "e2e_synthetic", "kernels", "nn1", "nn1_lfw", "mtcnn"]
     for w in which:
         globals()[w]()

@@ -1,0 +1,63 @@
+"""bench.py on the GPU box: the JSON contract, config 5 end to end, and the N > 1 path (self-launched ranks, the
+product's all-gather, per-rank figures) -- with two ranks SHARING the one GPU of the test box over gloo, since RCCL
+wants one GPU per rank; the collective call sites and the sharding are the ones the 8-GPU run uses."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, BENCH] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def _check_config5(c5, n, world):
+    assert "error" not in c5, c5
+    assert c5["n_gpus"] == world and c5["shard_rows"] == -(-n // world)
+    assert c5["gathered_shard_equals_local"] is True
+    assert c5["picks_not_nearest_within_1e-6"] == 0
+    assert abs(c5["accuracy"] - c5["accuracy_fp64_bruteforce"]) <= (c5["nn_index_mismatches_vs_fp64"] + 0.5) / (n // 2)
+    if c5["accuracy_sklearn"] is not None:
+        assert abs(c5["accuracy"] - c5["accuracy_sklearn"]) <= (c5["nn_index_mismatches_vs_fp64"] + 0.5) / (n // 2)
+    assert len(c5["extract_ms_per_rank"]) == world and all(v > 0 for v in c5["extract_ms_per_rank"])
+    for k in ("allgather_ms", "normalize_ms", "select_ms", "nn1_ms", "total_ms", "extract_faces_per_s"):
+        assert c5[k] >= 0
+
+
+def test_bench_line_contract_and_small_config5():
+    line = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
+                 "--config5-images", "700", "--config5-classes", "120"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "config5"):
+        assert k in line
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["unit"] == "faces/s" and line["scaling"] == "weak"
+    assert line["value"] == pytest.approx(256 * 1e3 / line["ms_per_step"], rel=1e-3)
+    rf = line["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3)
+    assert "workload" in line["config"] and "model" not in line["config"]
+    dw = line["roofline_depthwise"]
+    assert "STANDALONE" in dw["covers"] and len(dw["inside_fused_kernels"]) >= 1
+    _check_config5(line["config5"], 700, 1)
+
+
+def test_bench_two_self_launched_ranks_share_the_gpu_over_gloo():
+    line = _run(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--no-op-events",
+                 "--config5-images", "701", "--config5-classes", "120"])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512
+    assert len(line["per_rank_faces_per_s"]) == 2 and line["allgather_ms"] > 0
+    assert line["value"] == pytest.approx(2 * 256 * 1e3 / line["ms_per_step"], rel=1e-3)
+    c5 = line["config5"]
+    _check_config5(c5, 701, 2)
+    assert c5["pad_rows"] == 1 and c5["allgather_bytes_per_rank"] == 351 * 1024 * 4

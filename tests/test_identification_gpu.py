@@ -161,3 +161,32 @@ def test_feature_distance_matrix_matches_reference_loop(torch_):
     want = np.clip(np.sum(pair, axis=2), a_min=0, a_max=None)
     got = identification.feature_distance_matrix(feats, born, years)
     assert np.abs(got - want).max() < 2e-4
+
+
+def test_nn1_at_full_lfw_size_vs_sklearn_fixture_and_fp64(torch_):
+    """BASELINE configs[4]'s identification stage at its real size -- 9164 embeddings of 1680 persons -> 4582 probes x
+    4582 gallery rows x 1024-D (facerec_test.py:401-432) -- against scikit-learn's own split / predictions
+    (tests/golden/nn1_lfw.npz) and against an fp64 brute force of every distance."""
+    from hse_facerec_tf_amd import gallery, identification
+    z = np.load(os.path.join(GOLDEN, "nn1_lfw.npz"))
+    y = gallery.lfw_like_labels(int(z["n"]), int(z["n_classes"]))
+    X = oid.embeddings_for_labels(y, int(z["dim"]), int(z["seed"]), float(z["noise"]))
+    tm = {}
+    r = identification.one_nn_identification(X, y, timings=tm)
+    assert tm["nn1_shape"] == (4582, 4582, 1024) and r["num_classes"] == 1680 and len(r["indices"]) == 9164
+    assert np.array_equal(r["train"], z["train"]) and np.array_equal(r["test"], z["test"])        # same split as scikit-learn
+    # fp64 brute force of all 21 M distances
+    Xn = X.astype(np.float64)
+    Xn /= np.linalg.norm(Xn, axis=1, keepdims=True)
+    d2 = ((Xn[r["test"]] ** 2).sum(1)[:, None] + (Xn[r["train"]] ** 2).sum(1)[None, :] - 2.0 * Xn[r["test"]] @ Xn[r["train"]].T)
+    best = d2.min(axis=1)
+    part = np.partition(d2, 1, axis=1)
+    clear = (part[:, 1] - part[:, 0]) > 2e-6                 # probes whose nearest neighbour is not an fp32-level tie
+    assert clear.mean() > 0.995
+    assert np.array_equal(r["nn_index"][clear], d2.argmin(axis=1)[clear])
+    assert np.array_equal(r["nn_index"][clear], z["nn_index"][clear])                               # == KNeighborsClassifier
+    assert np.all(d2[np.arange(4582), r["nn_index"]] <= best + 2e-6)                                # a tie pick is still a nearest row
+    assert np.abs(r["nn_dist"] - np.sqrt(np.maximum(best, 0))).max() < 1e-4
+    assert abs(r["accuracy"] - float(z["accuracy"])) <= (~clear).sum() / 4582.0 + 1e-12
+    if clear.all():
+        assert r["accuracy"] == pytest.approx(float(z["accuracy"]), abs=1e-12)
