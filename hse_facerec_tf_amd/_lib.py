@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhsefr.so")
+# HSEFR_LIB selects another build of the library (e.g. libhsefr_dev.so for tools/kbench.py); the product is libhsefr.so
+LIB_PATH = os.path.join(_HERE, os.environ.get("HSEFR_LIB", "libhsefr.so"))
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_SHAPE = 0, -1, -2, -3, -4, -5
 
@@ -20,12 +21,8 @@ _fp = c_void_p   # device pointers travel as integers (tensor.data_ptr())
 SIGNATURES = {
     "hsefr_version": (c_int, []),
     "hsefr_last_error_string": (c_char_p, []),
-    "hsefr_debug_set": (c_int, [c_char_p, c_int]),
     "hsefr_engine_set_graph_batch": (c_int, [c_void_p, c_int]),
     "hsefr_engine_graph_launches": (c_longlong, [c_void_p]),
-    "hsefr_debug_read_stamps": (c_int, [c_void_p, ctypes.c_size_t]),
-    "hsefr_debug_clock_probe": (c_int, [_fp, c_int, c_int, c_void_p]),
-    "hsefr_debug_copy": (c_int, [_fp, _fp, c_size_t, c_void_p]),
     "hsefr_engine_create": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
     "hsefr_engine_workspace_bytes": (c_size_t, [c_void_p]),
     "hsefr_engine_max_batch": (c_int, [c_void_p]),
@@ -41,7 +38,6 @@ SIGNATURES = {
     "hsefr_pwconv1x1_bias_relu6": (c_int, [_fp, _fp, _fp, _fp, c_longlong, c_int, c_int, c_int, c_void_p]),
     "hsefr_stem2_fused": (c_int, [_fp] * 6 + [c_void_p] + [_fp] * 6 + [c_int] * 13 + [c_void_p]),
     "hsefr_stem_fused": (c_int, [_fp] * 6 + [c_void_p, _fp, _fp, _fp] + [c_int] * 9 + [c_void_p]),
-    "hsefr_dwpwdw_f16split": (c_int, [_fp, _fp, _fp, _fp, c_void_p, _fp, _fp, _fp, _fp, _fp, _fp] + [c_int] * 12 + [c_void_p]),
     "hsefr_dwpw_f16split": (c_int, [_fp, _fp, _fp, _fp, c_void_p, _fp, _fp, _fp] + [c_int] * 12 + [c_void_p]),
     "hsefr_pwconv1x1_f16split": (c_int, [_fp, c_void_p, _fp, _fp, _fp, c_longlong, c_int, c_int, c_int, c_int, c_void_p]),
     "hsefr_dwpw_fused": (c_int, [_fp] * 7 + [c_int] * 10 + [c_void_p]),
@@ -60,6 +56,14 @@ SIGNATURES = {
     "hsefr_maxpool_f32": (c_int, [_fp, _fp] + [c_int] * 10 + [c_void_p]),
     "hsefr_pairwise_dist": (c_int, [_fp, _fp, c_int, c_int, c_int, _fp, c_void_p]),
     "hsefr_nn1": (c_int, [_fp, _fp, c_int, c_int, c_int, _fp, _fp, c_void_p]),
+}
+
+# development builds only (csrc/hsefr_dev.h; build.sh with HSEFR_DEV=1): bound when the loaded library has them
+DEV_SIGNATURES = {
+    "hsefr_debug_set": (c_int, [c_char_p, c_int]),
+    "hsefr_debug_read_stamps": (c_int, [c_void_p, ctypes.c_size_t]),
+    "hsefr_debug_clock_probe": (c_int, [_fp, c_int, c_int, c_void_p]),
+    "hsefr_debug_copy": (c_int, [_fp, _fp, c_size_t, c_void_p]),
 }
 
 
@@ -82,6 +86,11 @@ def lib() -> ctypes.CDLL:
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in DEV_SIGNATURES.items():
+            if hasattr(L, name):
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
         _lib = L
     return _lib
 

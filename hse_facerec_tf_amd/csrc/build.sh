@@ -1,16 +1,22 @@
 #!/bin/bash
 # Builds libhsefr.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+#   HSEFR_DEV=1 build.sh   builds libhsefr_dev.so instead: the same sources with -DHSEFR_DEV (tuning knobs as run-time
+#                          variables, hsefr_debug_*, the calibration kernels of devtools.hip) -- for tools/kbench.py only.
 set -euo pipefail
 cd "$(dirname "$0")"
-OUT=../libhsefr.so
-SRCS="engine.hip conv_first.hip dwconv.hip pwconv_f32.hip pwconv_f16s.hip pool_dense.hip nn1.hip devtools.hip conv_bf16.hip conv1x1_bf16.hip preprocess.hip dwpw_fused.hip dwpw_f16s.hip dwpwdw_f16s.hip stem_fused.hip stem2_fused.hip smallnet.hip"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
+SRCS="engine.hip conv_first.hip dwconv.hip pwconv_f32.hip pwconv_f16s.hip pool_dense.hip nn1.hip conv_bf16.hip conv1x1_bf16.hip preprocess.hip dwpw_fused.hip dwpw_f16s.hip stem_fused.hip stem2_fused.hip smallnet.hip"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-result"
+if [ "${HSEFR_DEV:-0}" = "1" ]; then
+  OUT=../libhsefr_dev.so; BUILD=build_dev; SRCS="$SRCS devtools.hip"; FLAGS="$FLAGS -DHSEFR_DEV"
+else
+  OUT=../libhsefr.so; BUILD=build
+fi
 OBJS=""
 PIDS=""
+mkdir -p "$BUILD"
 for s in $SRCS; do
-  o="build/${s%.hip}.o"
-  mkdir -p build
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/hsefr.h -nt "$o" ]; then
+  o="$BUILD/${s%.hip}.o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ hsefr_dev.h -nt "$o" ] || [ ../../include/hsefr.h -nt "$o" ] || [ build.sh -nt "$o" ]; then
     rm -f "$o"
     hipcc $FLAGS ${HSEFR_EXTRA_FLAGS:-} -c "$s" -o "$o" &
     PIDS="$PIDS $!"

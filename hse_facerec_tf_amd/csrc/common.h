@@ -5,6 +5,9 @@
 #include <stdio.h>
 
 #include "../../include/hsefr.h"
+#ifdef HSEFR_DEV
+#include "hsefr_dev.h"
+#endif
 
 namespace hsefr {
 
@@ -104,8 +107,17 @@ __device__ __forceinline__ unsigned xcd_remap_dir(unsigned bid, unsigned nwg, in
     const unsigned lt = xcd_remap(bid, nwg);
     return reverse ? nwg - 1u - lt : lt;
 }
-int sweep_reverse();
+int sweep_reverse();          // per host thread (thread_local in engine.hip): engines on different threads do not interfere
 void set_sweep_reverse(int v);
+
+// Tuning knobs exist in DEVELOPMENT builds only (build.sh with HSEFR_DEV=1 -> -DHSEFR_DEV: hsefr_debug_set, devtools.hip,
+// tools/kbench.py).  In the product library every knob is a compile-time constant: the measured-best value, no
+// process-global mutable state, and the variants behind the other values are not even compiled.
+#ifdef HSEFR_DEV
+#define HSEFR_KNOB(name, value) int name = value
+#else
+#define HSEFR_KNOB(name, value) constexpr int name = value
+#endif
 
 // --- launchers implemented in the .hip files (same ones the engine calls) -------------
 int launch_conv_c3(const float* x, const float* wgt, const float* shift, float* y, int n, int h, int w,
@@ -132,7 +144,6 @@ int launch_conv_bf16(const void* x, const void* wt, const float* scale, const fl
 int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
                         long long P, int K, int cout, int act, hipStream_t s);
 bool conv1x1_bf16_enabled(bool has_res, int k, int cout);
-void set_c11(int v);
 int launch_stem7x7_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h,
                         int w, int oh, int ow, int act, hipStream_t s);
 int launch_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int pad_t, int pad_l,
@@ -161,12 +172,6 @@ int launch_dwpw_f16s(const float* x, const float* wd, const float* dscale, const
                      const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride, int pad_t,
                      int pad_l, int oh, int ow, int cout, int a_log2, int act, hipStream_t s);
 bool dwpw_f16s_supported(int c, int cout, int stride);
-bool dwpwdw_f16s_supported(int c, int cout, int act2);
-int launch_dwpwdw_f16s(const float* x, const float* wd, const float* dscale, const float* dshift, const void* wsplit,
-                       const float* descale, const float* pshift, const float* wd2, const float* d2scale, const float* d2shift,
-                       float* y, int n, int h, int w, int c, int cout, int pad_t2, int pad_l2, int oh2, int ow2, int a_log2,
-                       int act, int act2, hipStream_t s);
-void set_dwpws_v2(int v);
 int launch_stem_fused(const float* x, const float* cw, const float* cshift, const float* wd, const float* dscale,
                       const float* dshift, const void* wsplit, const float* descale, const float* pshift, float* y, int n,
                       int h, int w, int cpad_t, int cpad_l, int oh, int ow, int a_log2, int act, hipStream_t s);
@@ -176,11 +181,6 @@ int launch_stem2_fused(const float* x, const float* cw, const float* cshift, con
                        int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int a_log2, int act, hipStream_t s);
 bool stem2_fused_supported(int cin, int c1, int c2, int conv_stride, int dw1_stride, int dw2_stride, int kh, int kw);
 bool stem_fused_supported(int cin, int cmid, int cout, int conv_stride, int dw_stride, int kh, int kw);
-void set_dwpws_tw(int v);
-void set_dwpws_bn(int v);
-void set_dwpw_impl(int v);
-void set_pw_tile(int v);
-void set_pws_tile(int v);
 int read_pws_stamps(void* host_out, size_t bytes);
 int read_stem_stamps(void* host_out, size_t bytes);
 #ifdef HSEFR_STEM_STAMPS
@@ -198,6 +198,12 @@ unsigned long long* stamp_buffer(hipStream_t s);
 #define STEM_STAMP_COUNT do { } while (0)
 #define STEM_STAMP_FLUSH(buf, lane, wave) do { } while (0)
 #endif
+#ifdef HSEFR_DEV
+void set_c11(int v);
+void set_dwpws_tw(int v);
+void set_dwpws_bn(int v);
+void set_pw_tile(int v);
+void set_pws_tile(int v);
 void set_pw_ablate(int v);
 void set_pw_dma(int v);
 void set_dw_th(int v);
@@ -206,8 +212,9 @@ void set_dw_look(int v);
 void set_dw_look2(int v);
 void set_copy_variant(int v);
 void set_clock_mode(int v);
+void set_c3_impl(int v);
 int launch_clock_probe(unsigned long long* out, int blocks, int iters, hipStream_t s);
 int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
-void set_c3_impl(int v);
+#endif
 
 }  // namespace hsefr

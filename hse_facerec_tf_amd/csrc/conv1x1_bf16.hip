@@ -252,11 +252,13 @@ int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shi
     return launch_status("conv1x1_bf16");
 }
 
-int g_c11 = 1;   // hsefr_debug_set "c11": 0 = route 1x1 stride-1 layers through the general conv_bf16 kernel (A/B timing)
+HSEFR_KNOB(g_c11, 1);   // dev builds: 0 = route 1x1 stride-1 layers through the general conv_bf16 kernel (A/B timing)
 
 }  // namespace
 
+#ifdef HSEFR_DEV
 void set_c11(int v) { g_c11 = v; }
+#endif
 bool conv1x1_bf16_enabled(bool has_res, int k, int cout) {
     switch (g_c11) {      // values > 1: bisection aids
         case 0: return false;

@@ -267,11 +267,13 @@ int launch_mfma(const C3MParams& p, int act, hipStream_t s) {
     return launch_status("conv_c3_mfma");
 }
 
-int g_c3_impl = 0;  // tuning/debug only (hsefr_debug_set "c3_impl"): 0 = auto, 1 = VALU kernel, 2 = MFMA kernel
+HSEFR_KNOB(g_c3_impl, 0);  // dev builds: 0 = auto, 1 = VALU kernel, 2 = MFMA kernel
 
 }  // namespace
 
+#ifdef HSEFR_DEV
 void set_c3_impl(int v) { g_c3_impl = v; }
+#endif
 
 int launch_conv_c3(const float* x, const float* wgt, const float* shift, float* y, int n, int h, int w,
                    int kh, int kw, int stride, int pad_t, int pad_l, int oh, int ow, int cout, int act,

@@ -21,8 +21,11 @@ namespace hsefr {
 
 namespace {
 
-extern int g_dw_th;
-extern int g_dw_variant;
+// knobs (constants in the product build; see HSEFR_KNOB in common.h)
+HSEFR_KNOB(g_dw_th, 0);         // forced strip height
+HSEFR_KNOB(g_dw_variant, 0);    // load-policy / grid variants
+HSEFR_KNOB(g_dw_look, 4);       // 2..5 rows of load lookahead, stride-1 kernel (measured in situ: 4 is best)
+HSEFR_KNOB(g_dw_look2, 2);      // 2 | 4 = one | two iterations of lookahead, stride-2 kernel
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -159,17 +162,14 @@ __global__ __launch_bounds__(256, LOOK == 2 ? 4 : (LOOK <= 4 ? 3 : 2)) void dwco
     }
 }
 
-int g_dw_th = 0;
-int g_dw_variant = 0;
-int g_dw_look = 4;       // hsefr_debug_set "dw_look": 2..5 rows of load lookahead, stride-1 kernel (measured in situ: 4 is best)
-int g_dw_look2 = 2;      // hsefr_debug_set "dw_look2": 2 | 4 = one | two iterations of lookahead, stride-2 kernel
-
 }  // namespace
 
+#ifdef HSEFR_DEV
 void set_dw_th(int v) { g_dw_th = v; }
 void set_dw_variant(int v) { g_dw_variant = v; }
 void set_dw_look(int v) { g_dw_look = (v >= 2 && v <= 5) ? v : 2; }
 void set_dw_look2(int v) { g_dw_look2 = v == 4 ? 4 : 2; }
+#endif
 
 int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const float* shift, float* y,
                      int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,

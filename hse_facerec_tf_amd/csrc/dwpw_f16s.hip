@@ -46,7 +46,7 @@ struct DwPwSParams {
     unsigned total;        // N * tiles_h * tiles_w * tiles_n work items
     float a_scale;         // 2^a_log2
     int reverse;           // sweep direction (common.h)
-    int nimg;              // batch (v2: buffer resource sizes)
+    int nimg;              // batch (LDS-DMA form: buffer resource sizes)
     unsigned m_n, m_w, m_h;   // v3: ceil(2^32 / d) for d = tiles_n, tiles_w, tiles_h (exact quotients for x * d < 2^32; 0 for d = 1)
     unsigned long long* stamps;   // diagnostic builds (-DHSEFR_STEM_STAMPS) only
 };
@@ -232,11 +232,13 @@ __global__ __launch_bounds__(256, OCC) void dwpw_f16s_kernel(DwPwSParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// v2 (stride 1): ONE persistent workgroup of 8 waves per CU, everything the block needs staged by LDS-DMA.
+// LDS-DMA form (stride 1, up to 256 channels): ONE persistent workgroup of 8 waves per CU, everything the block needs
+// staged by LDS-DMA.
 //
-// The first version above keeps each chunk's 18 input float4 per thread in registers and consumes them at once: every
+// The general kernel above keeps each chunk's 18 input float4 per thread in registers and consumes them at once: every
 // chunk pays a memory round trip, and it lost to the two-kernel form for C >= 128.  Here nothing the depthwise reads
-// passes through a VGPR on its way in:
+// passes through a VGPR on its way in (an earlier generation with all 8 waves alternating depthwise and MFMA phases --
+// "v2", two barriers per chunk -- was retired in round 2; git history has it):
 //   * per 32-channel chunk the (TH+2) x (TW+2) halo patch (180 pixels x 128 B) and the chunk's slice of the split weight
 //     rows (BN x 128 B) go global -> LDS with `buffer_load_dwordx4 ... lds`, ONE CHUNK AHEAD of their use (two stages);
 //     the only thing that changes from chunk to chunk is the SGPR offset.  Pixels outside the image are given an
@@ -249,256 +251,14 @@ __global__ __launch_bounds__(256, OCC) void dwpw_f16s_kernel(DwPwSParams p) {
 //   * contraction as in pwconv_f16s.hip (operands swapped, 32x32x16 f16 MFMA, 3 products), waves as 2 (M) x 4 (N);
 //   * epilogue through a wave-private 4 KB scratch in the stage the last chunk has just released: 128-B-line stores whose
 //     per-lane offsets are out of range for pixels beyond the map (partial patches cost no branches).
-// Two barriers per chunk; the (patch, chunk) steps of a workgroup form one flat sequence, so the first chunk of the next
-// patch streams in under the last MFMAs and the stores of the current one.
+// The (patch, chunk) steps of a workgroup form one flat sequence, so the first chunk of the next patch streams in under
+// the last MFMAs and the stores of the current one.
 constexpr int HALO_B = 192 * 128;   // 180 pixels used, 24 wave-instructions of 8 pixels
 constexpr int CMAX2 = 512;          // channel bound of the resident depthwise constants (11 floats per channel)
 
-template <int TW, int BN, int ACT>
-__global__ __launch_bounds__(512, 2) void dwpw2_f16s_kernel(DwPwSParams p) {
-    constexpr int TH = 128 / TW, HC = TW + 2;
-    constexpr int STAGE = HALO_B + BN * ROWB;
-    constexpr int A_OFF = 2 * STAGE, W_OFF = A_OFF + 128 * ROWB, E_OFF = W_OFF + 11 * CMAX2 * 4;
-    constexpr int WN = BN / 4, NI = WN / 32, BI = BN / 64;     // wave tile 64 x WN; weight DMA instructions per wave
-    constexpr int NSTORE = 2 * NI * 4;                          // global stores per wave and patch
-    static_assert(2 * 4096 * 4 <= STAGE, "epilogue scratch: 4 KB per wave inside one stage");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[E_OFF + 2 * CMAX2 * 4];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int li = lane & 31, lh = lane >> 5;
-    const int C = p.C4 * 4, KT = p.KT;
-
-    // ---- resident constants: depthwise taps [9][C], scale [C], shift [C]; pointwise descale [Cout], shift [Cout] ----
-    {
-        float4* wl = (float4*)(smem + W_OFF);
-        for (int i = tid; i < 9 * p.C4; i += 512) wl[i] = p.wd[i];
-        for (int i = tid; i < p.C4; i += 512) { wl[9 * p.C4 + i] = p.dscale[i]; wl[10 * p.C4 + i] = p.dshift[i]; }
-        float* el = (float*)(smem + E_OFF);
-        for (int i = tid; i < p.Cout; i += 512) { el[i] = p.descale[i]; el[CMAX2 + i] = p.pshift[i]; }
-    }
-
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long long)p.nimg * p.H * p.W * C * 4);
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wsplit, (long long)p.Cout * C * 4);
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, (long long)p.nimg * p.OH * p.OW * p.Cout * 4);
-    const unsigned OOB = 0xFFFFFFF0u;
-
-    // work items of this workgroup: t = blockIdx.x + i * gridDim.x
-    const unsigned nitem = (p.total - blockIdx.x + gridDim.x - 1) / gridDim.x;
-    const unsigned nsteps = nitem * KT;
-    struct Item { int n, oh0, ow0, n0; };
-    auto decode = [&](unsigned i) {
-        const unsigned lt = xcd_remap_dir(blockIdx.x + (i < nitem ? i : nitem - 1) * gridDim.x, p.total, p.reverse);
-        Item it;
-        it.n0 = (lt % p.tiles_n) * BN;
-        const unsigned pt = lt / p.tiles_n;
-        it.ow0 = (pt % p.tiles_w) * TW;
-        it.oh0 = ((pt / p.tiles_w) % p.tiles_h) * TH;
-        it.n = pt / (p.tiles_w * p.tiles_h);
-        return it;
-    };
-
-    // ---- LDS-DMA prefetch cursor ----
-    unsigned hv[3], bv[BI];          // per-lane byte offsets of this wave's DMA pieces (halo: per patch; weights: per N tile)
-    unsigned pf_i = 0;
-    int pf_kc = 0;
-    auto setup_dma = [&](unsigned i) {
-        const Item it = decode(i);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int q = (wave * 3 + j) * 8 + (lane >> 3);
-            const int hr = q / HC, hc = q - hr * HC;
-            const int ih = it.oh0 - p.pad_t + hr, iw = it.ow0 - p.pad_l + hc;
-            const bool ok = q < (TH + 2) * HC && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            hv[j] = ok ? ((unsigned)((it.n * p.H + ih) * p.W + iw) * (unsigned)C + 4u * (lane & 7)) * 4u : OOB;
-        }
-#pragma unroll
-        for (int j = 0; j < BI; ++j) {
-            const int r = (wave * BI + j) * 8 + (lane >> 3);
-            bv[j] = ((unsigned)(it.n0 + r) * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7) ^ ((r & 1) << 2))) * 4u;
-        }
-    };
-    // The DMA pieces are issued from inline asm: hipcc tracks LDS-DMA issued through the builtin and, unable to tell
-    // the two stages apart, puts `s_waitcnt vmcnt(0)` in front of every later LDS read -- which is exactly the
-    // latency the second stage exists to hide.  Ordering is explicit instead: the counted vmcnt wait + barrier at the
-    // top of each step.  (M0 = LDS byte address of the piece; one wait state between the M0 write and the load.)
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-    auto piece = [&](const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(soff)
-                     : "memory");   // M0 is written: nothing else in this kernel uses it (hipcc sets M0 right before each use)
-    };
-    auto dma = [&](int stg) {
-        const unsigned base = lds0 + stg * STAGE;
-        const unsigned so = (unsigned)pf_kc * 128u;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) piece(rx, base + (wave * 3 + j) * 1024, hv[j], so);
-#pragma unroll
-        for (int j = 0; j < BI; ++j) piece(rw, base + HALO_B + (wave * BI + j) * 1024, bv[j], so);
-        if (++pf_kc == KT) {
-            pf_kc = 0;
-            setup_dma(++pf_i);
-        }
-    };
-
-    // ---- depthwise coordinates ----
-    const int quad = tid & 7, col = (tid >> 3) % TW, r0 = 2 * (tid / (8 * TW));
-    const unsigned char* hsrc0 = smem + ((r0 * HC + col) * 128 + quad * 16);
-    // ---- MFMA / epilogue coordinates ----
-    const int arow = wm * 64 + li, brow = wn * WN + li;
-    const int erow = lane >> 3, ech = lane & 7;
-
-    f32x16 acc[2][NI];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    };
-    zero_acc();
-
-    setup_dma(0);
-    dma(0);
-    STEM_STAMP_DECL;
-    Item cur = decode(0);
-    unsigned ci = 0;
-    int ckc = 0;
-    bool stores_pending = false;
-    for (unsigned g = 0; g < nsteps; ++g) {
-        const int sg = g & 1;
-        // this step's DMA pieces have landed (the stores of a patch that has just ended were issued after them and may
-        // still be in flight: vmcnt retires in order)
-        if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stores_pending = false;
-        __syncthreads();                       // ... for every wave; and every wave is past the previous step's LDS reads
-        STEM_STAMP(0);
-        if (g + 1 < nsteps) dma((g + 1) & 1);  // next step's halo + weights into the other stage (none in flight at exit)
-        STEM_STAMP(1);
-        // ---- depthwise of chunk ckc from the halo in LDS ----
-        {
-            const float4* wl = (const float4*)(smem + W_OFF) + ckc * 8 + quad;
-            float4 wk[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) wk[i] = wl[i * p.C4];
-            const float4 dsc = wl[9 * p.C4], dsh = wl[10 * p.C4];
-            const unsigned char* hs = hsrc0 + sg * STAGE;
-            float4 h[4][3];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) h[a][b] = *(const float4*)(hs + (a * HC + b) * 128);
-            // same operation order as dwconv.hip (row sums left to right, rows top to bottom): the fused block is
-            // bit-identical to the two kernels it replaces
-            auto row_sum = [&](int a, int b) {
-                float4 t = make_float4(h[a][0].x * wk[b].x, h[a][0].y * wk[b].y, h[a][0].z * wk[b].z, h[a][0].w * wk[b].w);
-                t = fma4(h[a][1], wk[b + 1], t);
-                return fma4(h[a][2], wk[b + 2], t);
-            };
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float4 sa = row_sum(j, 0), sb = row_sum(j + 1, 3), sc = row_sum(j + 2, 6);
-                float4 sacc = make_float4(sa.x + sb.x, sa.y + sb.y, sa.z + sb.z, sa.w + sb.w);
-                sacc = make_float4(sacc.x + sc.x, sacc.y + sc.y, sacc.z + sc.z, sacc.w + sc.w);
-                const float4 o = fma4(sacc, dsc, dsh);
-                f32x4 v;
-                v[0] = relu6(o.x); v[1] = relu6(o.y); v[2] = relu6(o.z); v[3] = relu6(o.w);
-                v = v * p.a_scale;
-                const f16x4 hi = __builtin_convertvector(v, f16x4);
-                const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
-                const int R = (r0 + j) * TW + col;
-                *(f16x4*)(smem + A_OFF + swzb(R, quad >> 1) + 8 * (quad & 1)) = hi;
-                *(f16x4*)(smem + A_OFF + swzb(R, 4 + (quad >> 1)) + 8 * (quad & 1)) = lo;
-            }
-        }
-        STEM_STAMP(2);
-        __syncthreads();
-        STEM_STAMP(3);
-        // ---- contraction of chunk ckc ----
-        {
-            const unsigned char* As = smem + A_OFF;
-            const unsigned char* Bs = smem + sg * STAGE + HALO_B;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f16x8 ah[2], al[2], bh[NI], bl[NI];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    ah[mi] = *(const f16x8*)(As + swzb(arow + mi * 32, 2 * s + lh));
-                    al[mi] = *(const f16x8*)(As + swzb(arow + mi * 32, 4 + 2 * s + lh));
-                }
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    bh[ni] = *(const f16x8*)(Bs + swzb(brow + ni * 32, 2 * s + lh));
-                    bl[ni] = *(const f16x8*)(Bs + swzb(brow + ni * 32, 4 + 2 * s + lh));
-                }
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ni], al[mi], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ni], ah[mi], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ni], ah[mi], acc[mi][ni], 0, 0, 0);
-                    }
-            }
-        }
-        STEM_STAMP(4);
-        if (++ckc == KT) {
-            STEM_STAMP_COUNT;
-            // ---- epilogue of the patch: lane (li, lh) holds row m = li, columns 4*lh + 8*(r >> 2) + (r & 3) of each block ----
-            __syncthreads();                                   // every wave is done with this stage's weight rows
-            unsigned char* scr = smem + sg * STAGE + wave * 4096;
-            const float* el = (const float*)(smem + E_OFF);
-            unsigned sv[2][4];                                  // store offsets; pixels beyond the map fall out of range
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int R = wm * 64 + mi * 32 + erow + 8 * i;
-                    const int oh = cur.oh0 + R / TW, ow = cur.ow0 + R % TW;
-                    sv[mi][i] = (oh < p.OH && ow < p.OW)
-                                    ? ((unsigned)((cur.n * p.OH + oh) * p.OW + ow) * (unsigned)p.Cout + (unsigned)(cur.n0 + wn * WN + 4 * ech)) * 4u
-                                    : OOB;
-                }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int nl = cur.n0 + wn * WN + ni * 32 + 4 * ech;
-                const f32x4 ds = *(const f32x4*)(el + nl), sh = *(const f32x4*)(el + CMAX2 + nl);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
-                        *(f32x4*)(scr + li * 128 + 16 * ((2 * j + lh) ^ (li & 7))) = v;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = erow + 8 * i;
-                        const f32x4 v = *(const f32x4*)(scr + r * 128 + 16 * (ech ^ (r & 7)));
-                        f32x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(fmaf(v[e], ds[e], sh[e]));
-                        bstore16_welded(o, ry, sv[mi][i], __builtin_amdgcn_readfirstlane((unsigned)(ni * 32) * 4u));
-                    }
-                }
-            }
-            stores_pending = true;
-            zero_acc();
-            ckc = 0;
-            cur = decode(++ci);
-            STEM_STAMP(5);
-        }
-    }
-    if (wave < 4) STEM_STAMP_FLUSH(p.stamps, lane, wave);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// v3: the same staging, with the waves SPECIALISED.  In v2 all 8 waves run the depthwise phase, meet at a barrier, run
-// the MFMA phase, meet again: the vector ALU idles during the contraction and the matrix pipe during the depthwise, and
+// The waves are SPECIALISED.  With all 8 waves running the depthwise phase, meeting at a barrier, running the MFMA phase
+// and meeting again, the vector ALU idles during the contraction and the matrix pipe during the depthwise, and
 // in-kernel stamps put 45 % of a wave's life in barriers.  Here waves 0-3 (one per SIMD) are PRODUCERS -- halo DMA and the
 // depthwise of step g+1 into A[(g+1) & 1] -- while waves 4-7 are CONSUMERS -- weight DMA, the MFMAs of step g from
 // A[g & 1], and the epilogue.  One barrier per step; on every SIMD a producer's VALU/LDS work runs beside a consumer's
@@ -550,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
     auto piece = [&](const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
                      "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff))
-                     : "memory");   // see v2: issued from asm so that hipcc does not drain vmcnt before every LDS read
+                     : "memory");   // issued from asm so that hipcc does not drain vmcnt before every LDS read
     };
     // halo DMA duty: producers.  (Measured both ways with in-kernel stamps: the patch time does not change, the waiting moves to
     // whichever waves issue the vector-memory instructions.  Neither did keeping all the weight rows of the 128-channel block
@@ -802,9 +562,8 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
     }
 }
 
-int g_v2 = 2;   // tuning/debug only (hsefr_debug_set "dwpws_v2"): 0 = first version everywhere, 1 = v2, 2 = v3 where it applies
-int g_tw = 0;   // tuning/debug only (hsefr_debug_set "dwpws_tw"): 0 = auto, 8 | 16 = forced patch width
-int g_bn = 0;   // tuning/debug only (hsefr_debug_set "dwpws_bn"): 0 = auto, 64 | 128 | 256 = forced N tile
+HSEFR_KNOB(g_tw, 0);   // dev builds: 0 = auto, 8 | 16 = forced patch width
+HSEFR_KNOB(g_bn, 0);   // dev builds: 0 = auto, 64 | 128 | 256 = forced N tile
 
 template <int STRIDE, int TW, int BN, int OCC>
 int launch_t(DwPwSParams& p, int n, int act, hipStream_t s) {
@@ -833,25 +592,6 @@ int launch_bn(DwPwSParams& p, int n, int bn, int act, hipStream_t s) {
     return launch_t<STRIDE, TW, 256, 2>(p, n, act, s);
 }
 
-template <int TW, int BN>
-int launch_v2(DwPwSParams& p, int n, int act, hipStream_t s) {
-    constexpr int TH = 128 / TW;
-    p.tiles_w = (p.OW + TW - 1) / TW;
-    p.tiles_h = (p.OH + TH - 1) / TH;
-    p.tiles_n = p.Cout / BN;
-    const long long total = (long long)n * p.tiles_w * p.tiles_h * p.tiles_n;
-    HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "dwpw_f16split: grid too large");
-    p.total = (unsigned)total;
-    const unsigned g = p.total < 256u ? p.total : 256u;    // one workgroup (8 waves, ~125-158 KB of LDS) per CU
-#define HSEFR_DWPW2(A) hipLaunchKernelGGL((dwpw2_f16s_kernel<TW, BN, A>), dim3(g), dim3(512), 0, s, p)
-    if (act == HSEFR_ACT_RELU6) HSEFR_DWPW2(HSEFR_ACT_RELU6);
-    else if (act == HSEFR_ACT_RELU) HSEFR_DWPW2(HSEFR_ACT_RELU);
-    else if (act == HSEFR_ACT_NONE) HSEFR_DWPW2(HSEFR_ACT_NONE);
-    else { set_error("dwpw_f16split: act %d", act); return HSEFR_ERR_UNSUPPORTED; }
-#undef HSEFR_DWPW2
-    return launch_status("dwpw_f16split");
-}
-
 template <int TW, int BN, int HS>
 int launch_v3(DwPwSParams& p, int n, int act, hipStream_t s) {
     constexpr int TH = 128 / TW;
@@ -877,9 +617,10 @@ int launch_v3(DwPwSParams& p, int n, int act, hipStream_t s) {
 
 }  // namespace
 
-void set_dwpws_v2(int v) { g_v2 = v; }
+#ifdef HSEFR_DEV
 void set_dwpws_tw(int v) { g_tw = v; }
 void set_dwpws_bn(int v) { g_bn = v; }
+#endif
 
 bool dwpw_f16s_supported(int c, int cout, int stride) {
     return c > 0 && c % 32 == 0 && cout > 0 && cout % 64 == 0 && (stride == 1 || stride == 2);
@@ -905,19 +646,17 @@ int launch_dwpw_f16s(const float* x, const float* wd, const float* dscale, const
     p.stamps = stamp_buffer(s);
 #endif
     const long long in_bytes = (long long)n * h * w * c * 4, out_bytes = (long long)n * oh * ow * cout * 4;
-    if (g_v2 && stride == 1 && c <= CMAX2 && cout <= CMAX2 && cout % 128 == 0 && in_bytes < (1ll << 32) - 16 && out_bytes < (1ll << 32) - 16) {
+    // wave-specialised LDS-DMA form (resident depthwise constants for up to 256 channels); everything else -- stride 2,
+    // more than 256 channels, cout % 128 != 0, tensors beyond 4 GB -- takes the general K-chunked kernel below
+    if (stride == 1 && c <= 256 && cout <= CMAX2 && cout % 128 == 0 && in_bytes < (1ll << 32) - 16 && out_bytes < (1ll << 32) - 16) {
         // patch shape: 8 x 16 or 16 x 8 output pixels, whichever wastes fewer (partial patches cost compute, not bytes)
         auto padded = [&](int tw) { const int th = 128 / tw; return (long long)((ow + tw - 1) / tw * tw) * ((oh + th - 1) / th * th); };
         int tw = padded(16) <= padded(8) ? 16 : 8;
         if (g_tw == 8 || g_tw == 16) tw = g_tw;
         int bn = cout % 256 == 0 ? 256 : 128;
         if ((g_bn == 128 || g_bn == 256) && cout % g_bn == 0) bn = g_bn;
-        if (g_v2 >= 2 && c <= 256) {      // wave-specialised form (resident depthwise constants for up to 256 channels)
-            if (bn == 256) return tw == 16 ? launch_v3<16, 256, 2>(p, n, act, s) : launch_v3<8, 256, 2>(p, n, act, s);
-            return tw == 16 ? launch_v3<16, 128, 3>(p, n, act, s) : launch_v3<8, 128, 3>(p, n, act, s);
-        }
-        if (bn == 256) return tw == 16 ? launch_v2<16, 256>(p, n, act, s) : launch_v2<8, 256>(p, n, act, s);
-        return tw == 16 ? launch_v2<16, 128>(p, n, act, s) : launch_v2<8, 128>(p, n, act, s);
+        if (bn == 256) return tw == 16 ? launch_v3<16, 256, 2>(p, n, act, s) : launch_v3<8, 256, 2>(p, n, act, s);
+        return tw == 16 ? launch_v3<16, 128, 3>(p, n, act, s) : launch_v3<8, 128, 3>(p, n, act, s);
     }
     // N tile: 128 output channels (64 accumulator registers; the 256 variant spills); wider layers redo the depthwise
     // work once per N tile, the tiles of one patch running side by side on one XCD so that the re-read hits its L2

@@ -207,68 +207,18 @@ __global__ __launch_bounds__(256, OCC) void dwpw_fused_kernel(DwPwParams p) {
     }
 }
 
-// Variant B: 512 threads = 4 producer waves (depthwise of patch i+1 into the other A buffer) + 4 consumer waves (MFMA +
-// store of patch i), one workgroup barrier per patch: inside ONE workgroup the HBM reads, the MFMAs and the HBM writes
-// of consecutive patches overlap, instead of relying on neighbours being out of phase.
-template <int STRIDE, int C, int BN, int OCC>
-__global__ __launch_bounds__(512, OCC) void dwpw_fused_ws_kernel(DwPwParams p) {
-    constexpr int KT = C / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][KT][128 * 32];
-    __shared__ __attribute__((aligned(16))) float Bs[KT][BN * 32];
-    const int tid = threadIdx.x;
-    const bool producer = tid < 256;            // waves 0-3; provably wave-uniform
-    const int ptid = tid & 255;
-    load_pw_weights<C, BN>(p, Bs, tid, 512);
-    unsigned t = blockIdx.x;
-    if (t >= p.total) return;
-    int n, oh0, ow0;
-    decode_patch(p, t, n, oh0, ow0);
-    if (producer) dw_phase<STRIDE, C>(p, As[0], ptid, n, oh0, ow0);
-    __syncthreads();
-    int buf = 0;
-    while (true) {
-        const unsigned tn = t + gridDim.x;
-        const bool more = tn < p.total;
-        if (producer) {
-            if (more) {
-                int n2, oh2, ow2;
-                decode_patch(p, tn, n2, oh2, ow2);
-                dw_phase<STRIDE, C>(p, As[buf ^ 1], ptid, n2, oh2, ow2);
-            }
-        } else {
-            mfma_phase<C, BN>(p, As[buf], Bs, (tid >> 6) & 3, tid & 63, n, oh0, ow0);
-        }
-        if (!more) break;
-        __syncthreads();
-        buf ^= 1;
-        t = tn;
-        decode_patch(p, t, n, oh0, ow0);
-    }
-}
-
-int g_dwpw_impl = 0;  // tuning/debug only (hsefr_debug_set "dwpw_impl"): 0 = auto, 1 = alternating phases, 2 = producer/consumer waves
-
 template <int STRIDE, int C, int BN, int OCC>
 int launch_t(const DwPwParams& p, hipStream_t s) {
-    constexpr int KT = C / 32;
-    constexpr int ws_lds = (2 * KT * 128 * 32 + KT * BN * 32) * 4;
-    constexpr int ws_blocks = (160 * 1024 / ws_lds) < 2 ? (160 * 1024 / ws_lds) : 2;     // 512-thread groups per CU
-    const bool use_ws = g_dwpw_impl == 2;   // measured: the alternating-phase kernel at 4 WG/CU is as fast or faster
-    if (use_ws) {
-        const unsigned cap = 256u * ws_blocks;
-        const unsigned g = p.total < cap ? p.total : cap;
-        hipLaunchKernelGGL((dwpw_fused_ws_kernel<STRIDE, C, BN, 2 * ws_blocks>), dim3(g), dim3(512), 0, s, p);
-    } else {
-        const unsigned cap = 256u * OCC;
-        const unsigned g = p.total < cap ? p.total : cap;
-        hipLaunchKernelGGL((dwpw_fused_kernel<STRIDE, C, BN, OCC>), dim3(g), dim3(256), 0, s, p);
-    }
+    // (a producer/consumer-wave form of this kernel -- 512 threads, double-buffered A tile -- was no faster than the
+    // alternating phases at 4 WG/CU and was retired in round 2; git history has it)
+    const unsigned cap = 256u * OCC;
+    const unsigned g = p.total < cap ? p.total : cap;
+    hipLaunchKernelGGL((dwpw_fused_kernel<STRIDE, C, BN, OCC>), dim3(g), dim3(256), 0, s, p);
     return launch_status("dwpw_fused");
 }
 
 }  // namespace
 
-void set_dwpw_impl(int v) { g_dwpw_impl = v; }
 
 bool dwpw_fused_supported(int c, int cout, int stride, int act_dw, int act_pw) {
     return (c == 32 || c == 64) && (cout == 64 || cout == 128) && (stride == 1 || stride == 2) &&

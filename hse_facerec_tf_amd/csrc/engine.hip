@@ -62,10 +62,13 @@ static const void* blob_ptr(const hsefr_engine* e, uint64_t off) {
     return off == HSEFR_NO_OFFSET ? nullptr : (const void*)(e->d_blob + off);
 }
 
-static void* buf_ptr(hsefr_engine* e, int id, const void* d_input) {
+// Buffer table of ONE forward: the engine's activation buffers, with the buffers of the requested outputs replaced by
+// the caller's pointers -- the producing kernel writes its result where the caller wants it (and any later op that
+// reads that tensor, e.g. the dense heads behind the pooled features, reads it from there): no copy-out.
+static void* buf_ptr(const std::vector<void*>& tab, int id, const void* d_input) {
     if (id == HSEFR_BUF_INPUT) return const_cast<void*>(d_input);
-    if (id < 0 || id >= (int)e->d_bufs.size()) return nullptr;
-    return e->d_bufs[id];
+    if (id < 0 || id >= (int)tab.size()) return nullptr;
+    return tab[id];
 }
 
 static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bufs, const hsefr_plan_op* ops) {
@@ -93,12 +96,43 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                           "plan op %u: input exceeds buffer %d", i, o.in_buf);
         }
         HSEFR_REQUIRE(o.res_buf != o.out_buf, HSEFR_ERR_INVALID, "plan op %u: residual aliases the output", i);
+        // every operand a kind reads must be present and fit the blob with its whole extent (a truncated or hand-made
+        // plan is HSEFR_ERR_INVALID, never an out-of-bounds device read)
+        auto need = [&](uint64_t off, uint64_t bytes, const char* what) {
+            if (off != HSEFR_NO_OFFSET && off + bytes <= h.blob_bytes) return true;
+            set_error("plan op %u (kind %u): operand %s missing or %llu bytes beyond the %llu-byte blob", i, o.kind, what,
+                      (unsigned long long)bytes, (unsigned long long)h.blob_bytes);
+            return false;
+        };
+        const uint64_t co = o.cout, ci = o.cin, kk = (uint64_t)o.kh * o.kw;
         switch (o.kind) {
-            case HSEFR_OP_CONV_C3: case HSEFR_OP_DWCONV3X3: case HSEFR_OP_PWCONV_F32: case HSEFR_OP_GAP:
-            case HSEFR_OP_DENSE: case HSEFR_OP_SOFTMAX: case HSEFR_OP_CONV_BF16: case HSEFR_OP_MAXPOOL_BF16:
-            case HSEFR_OP_GAP_BF16: case HSEFR_OP_STEM7X7_BF16:
+            case HSEFR_OP_GAP: case HSEFR_OP_SOFTMAX: case HSEFR_OP_MAXPOOL_BF16: case HSEFR_OP_GAP_BF16:
+                break;
+            case HSEFR_OP_CONV_C3:
+                if (!need(o.w_off, kk * ci * co * 4, "kernel") || !need(o.shift_off, co * 4, "shift")) return HSEFR_ERR_INVALID;
+                break;
+            case HSEFR_OP_DWCONV3X3:
+                if (!need(o.w_off, 9 * ci * 4, "kernel") || !need(o.scale_off, ci * 4, "scale") || !need(o.shift_off, ci * 4, "shift"))
+                    return HSEFR_ERR_INVALID;
+                break;
+            case HSEFR_OP_PWCONV_F32:
+                if (!need(o.w_off, ci * co * 4, "kernel") || !need(o.shift_off, co * 4, "shift")) return HSEFR_ERR_INVALID;
+                break;
+            case HSEFR_OP_DENSE:
+                if (!need(o.w_off, ci * co * 4, "kernel")) return HSEFR_ERR_INVALID;
+                if (o.shift_off != HSEFR_NO_OFFSET && !need(o.shift_off, co * 4, "bias")) return HSEFR_ERR_INVALID;
+                break;
+            case HSEFR_OP_CONV_BF16:
+                if (!need(o.w_off, kk * ci * co * 2, "kernel") || !need(o.scale_off, co * 4, "scale") || !need(o.shift_off, co * 4, "shift"))
+                    return HSEFR_ERR_INVALID;
+                break;
+            case HSEFR_OP_STEM7X7_BF16:
+                if (!need(o.w_off, 64 * 256 * 2, "kernel") || !need(o.scale_off, co * 4, "scale") || !need(o.shift_off, co * 4, "shift"))
+                    return HSEFR_ERR_INVALID;
                 break;
             case HSEFR_OP_PWCONV_F16S:
+                if (!need(o.w_off, ci * co * 4, "split rows") || !need(o.scale_off, co * 4, "descale") || !need(o.shift_off, co * 4, "shift"))
+                    return HSEFR_ERR_INVALID;
                 HSEFR_REQUIRE(o.w_off != HSEFR_NO_OFFSET && o.scale_off != HSEFR_NO_OFFSET && o.shift_off != HSEFR_NO_OFFSET &&
                                   o.reserved > 0 && o.reserved <= 24,
                               HSEFR_ERR_INVALID, "plan op %u: split-f16 pointwise needs split rows, descale, shift and a_log2 in (0, 24]", i);
@@ -112,10 +146,13 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
             case HSEFR_OP_STEM_F16S:
                 HSEFR_REQUIRE(stem_fused_supported(o.cin, 32, o.cout, o.stride, 1, o.kh, o.kw) && o.reserved > 0 && o.reserved <= 12 &&
                                   o.w_off != HSEFR_NO_OFFSET && o.w2_off != HSEFR_NO_OFFSET && o.shift2_off != HSEFR_NO_OFFSET &&
-                                  o.w_off + 1248 * 4 <= h.blob_bytes && o.in_buf == HSEFR_BUF_INPUT + 0 * o.in_buf,
+                                  o.w_off + 1248 * 4 <= h.blob_bytes && o.in_buf == HSEFR_BUF_INPUT,
                               HSEFR_ERR_UNSUPPORTED, "plan op %u: fused stem cin=%d cout=%d stride=%d not covered", i, o.cin, o.cout, o.stride);
                 break;
             case HSEFR_OP_DWPW_F16S:
+                if (!need(o.w_off, 9 * ci * 4, "depthwise kernel") || !need(o.scale_off, ci * 4, "scale") || !need(o.shift_off, ci * 4, "shift") ||
+                    !need(o.w2_off, ci * co * 4, "split rows") || !need(o.shift2_off, 2 * co * 4, "descale | shift"))
+                    return HSEFR_ERR_INVALID;
                 HSEFR_REQUIRE(dwpw_f16s_supported(o.cin, o.cout, o.stride) && o.reserved > 0 && o.reserved <= 12 &&
                                   o.w_off != HSEFR_NO_OFFSET && o.scale_off != HSEFR_NO_OFFSET && o.shift_off != HSEFR_NO_OFFSET &&
                                   o.w2_off != HSEFR_NO_OFFSET && o.shift2_off != HSEFR_NO_OFFSET,
@@ -123,6 +160,9 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                               i, o.cin, o.cout, o.stride, o.reserved);
                 break;
             case HSEFR_OP_DWPW_F32:
+                if (!need(o.w_off, 9 * ci * 4, "depthwise kernel") || !need(o.scale_off, ci * 4, "scale") || !need(o.shift_off, ci * 4, "shift") ||
+                    !need(o.w2_off, ci * co * 4, "pointwise kernel") || !need(o.shift2_off, co * 4, "pointwise shift"))
+                    return HSEFR_ERR_INVALID;
                 HSEFR_REQUIRE(dwpw_fused_supported(o.cin, o.cout, o.stride, HSEFR_ACT_RELU6, (int)o.act), HSEFR_ERR_UNSUPPORTED,
                               "plan op %u: fused depthwise-pointwise block cin=%d cout=%d not covered", i, o.cin, o.cout);
                 break;
@@ -157,18 +197,20 @@ int read_stem_stamps(void* host_out, size_t bytes) {
     return HSEFR_ERR_UNSUPPORTED;
 }
 #endif
-static int g_sweep_reverse = 0;
+static thread_local int g_sweep_reverse = 0;    // set per op by the forward running on THIS host thread, read by its launchers
 int sweep_reverse() { return g_sweep_reverse; }
 void set_sweep_reverse(int v) { g_sweep_reverse = v; }
 }  // namespace hsefr
-static int g_sweep_alternate = 1;   // hsefr_debug_set "sweep_alternate" 0 turns the alternation off (A/B timing)
+HSEFR_KNOB(g_sweep_alternate, 1);   // dev builds: 0 turns the alternation off (A/B timing)
 
+#pragma GCC visibility push(default)   // the library is built with -fvisibility=hidden: the C ABI below is ALL it exports
 extern "C" {
 
 int hsefr_version(void) { return HSEFR_VERSION; }
 
 const char* hsefr_last_error_string(void) { return g_err; }
 
+#ifdef HSEFR_DEV
 int hsefr_debug_set(const char* key, int value) {
     HSEFR_REQUIRE(key, HSEFR_ERR_INVALID, "debug_set: null key");
     if (!strcmp(key, "pw_tile")) { set_pw_tile(value); return HSEFR_OK; }
@@ -179,18 +221,31 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "sweep_alternate")) { g_sweep_alternate = value; return HSEFR_OK; }
     if (!strcmp(key, "clock_mode")) { set_clock_mode(value); return HSEFR_OK; }
     if (!strcmp(key, "dwpws_tw")) { set_dwpws_tw(value); return HSEFR_OK; }
-    if (!strcmp(key, "dwpws_v2")) { set_dwpws_v2(value); return HSEFR_OK; }
     if (!strcmp(key, "dwpws_bn")) { set_dwpws_bn(value); return HSEFR_OK; }
     if (!strcmp(key, "pw_ablate")) { set_pw_ablate(value); return HSEFR_OK; }
     if (!strcmp(key, "pw_dma")) { set_pw_dma(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_th")) { set_dw_th(value); return HSEFR_OK; }
-    if (!strcmp(key, "dwpw_impl")) { set_dwpw_impl(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_variant")) { set_dw_variant(value); return HSEFR_OK; }
     if (!strcmp(key, "copy_variant")) { set_copy_variant(value); return HSEFR_OK; }
     if (!strcmp(key, "c3_impl")) { set_c3_impl(value); return HSEFR_OK; }
     set_error("debug_set: unknown key %s", key);
     return HSEFR_ERR_INVALID;
 }
+
+int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(bytes == 0 || (d_src && d_dst), HSEFR_ERR_INVALID, "debug_copy: null pointer");
+    return launch_copy(d_src, d_dst, bytes, (hipStream_t)stream);
+}
+
+int hsefr_debug_read_stamps(void* host_out, size_t bytes) {
+    // the split-f16 GEMM's stamps, or (bytes == 512*4*10*8) the fused stem's
+    return bytes == 512 * 4 * 10 * 8 ? read_stem_stamps(host_out, bytes) : read_pws_stamps(host_out, bytes);
+}
+
+int hsefr_debug_clock_probe(unsigned long long* d_out, int blocks, int iters, hsefr_stream_t stream) {
+    return launch_clock_probe(d_out, blocks, iters, (hipStream_t)stream);
+}
+#endif  // HSEFR_DEV
 
 int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsefr_engine** out) {
     HSEFR_REQUIRE(plan && out, HSEFR_ERR_INVALID, "engine_create: null argument");
@@ -290,7 +345,8 @@ int hsefr_engine_op_times_ms(hsefr_engine* e, int slot, float* ms, int n_ops) {
 }
 
 // Launch the needed ops of the plan for a batch of n on stream s (plain launches: also what a graph capture records).
-static int run_ops(hsefr_engine* e, const void* d_input, int n, const std::vector<char>& needed, hipStream_t s, hipEvent_t* pev) {
+static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d_input, int n, const std::vector<char>& needed,
+                   hipStream_t s, hipEvent_t* pev) {
     const bool prof = pev != nullptr;
     if (prof) HSEFR_HIP_CHECK(hipEventRecord(pev[0], s));
     for (size_t i = 0; i < e->ops.size(); ++i) {
@@ -299,8 +355,8 @@ static int run_ops(hsefr_engine* e, const void* d_input, int n, const std::vecto
             if (prof) HSEFR_HIP_CHECK(hipEventRecord(pev[i + 1], s));
             continue;
         }
-        const void* in = buf_ptr(e, o.in_buf, d_input);
-        void* out = buf_ptr(e, o.out_buf, d_input);
+        const void* in = buf_ptr(tab, o.in_buf, d_input);
+        void* out = buf_ptr(tab, o.out_buf, d_input);
         int rc = HSEFR_OK;
         set_sweep_reverse(g_sweep_alternate ? (int)(i & 1) : 0);   // consecutive layers sweep in opposite directions (common.h)
         switch (o.kind) {
@@ -337,7 +393,7 @@ static int run_ops(hsefr_engine* e, const void* d_input, int n, const std::vecto
             case HSEFR_OP_CONV_BF16:
                 rc = launch_conv_bf16(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
                                       (const float*)blob_ptr(e, o.shift_off),
-                                      o.res_buf >= 0 ? e->d_bufs[o.res_buf] : nullptr, out, n, o.h, o.w, o.cin, o.oh,
+                                      o.res_buf >= 0 ? tab[o.res_buf] : nullptr, out, n, o.h, o.w, o.cin, o.oh,
                                       o.ow, o.cout, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.act, s);
                 break;
             case HSEFR_OP_STEM7X7_BF16:
@@ -436,7 +492,7 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
         if (!exec) {
             hipGraph_t graph = nullptr;
             HSEFR_HIP_CHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-            const int rc = run_ops(e, e->d_in_stage, n, needed, e->cap_stream, nullptr);
+            const int rc = run_ops(e, e->d_bufs, e->d_in_stage, n, needed, e->cap_stream, nullptr);   // captured pointers must not change
             const hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
             if (rc != HSEFR_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             HSEFR_HIP_CHECK(ce);
@@ -447,15 +503,29 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
         HSEFR_HIP_CHECK(hipMemcpyAsync(e->d_in_stage, d_input, in_bytes * n, hipMemcpyDeviceToDevice, s));
         HSEFR_HIP_CHECK(hipGraphLaunch(exec, s));
         e->graph_launches++;
+        for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl) {      // a replayed graph writes the engine's own buffers
+            if (!outs[sl]) continue;
+            const size_t bytes = (size_t)e->hdr.out_elems[sl] * sizeof(float) * n;
+            HSEFR_HIP_CHECK(hipMemcpyAsync(outs[sl], e->d_bufs[e->hdr.out_buffer[sl]], bytes, hipMemcpyDeviceToDevice, s));
+        }
     } else {
-        const int rc = run_ops(e, d_input, n, needed, s, prof ? pev : nullptr);
+        // Output buffers are pinned by the lowering (one producer, never recycled, distinct per slot), so the caller's
+        // pointer can stand in for the whole forward.  A buffer serving two slots is written once and copied once.
+        std::vector<void*> tab(e->d_bufs);
+        int first_slot_of[HSEFR_N_OUTPUT_SLOTS];
+        for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl) {
+            first_slot_of[sl] = sl;
+            if (!outs[sl]) continue;
+            for (int t = 0; t < sl; ++t)
+                if (outs[t] && e->hdr.out_buffer[t] == e->hdr.out_buffer[sl]) { first_slot_of[sl] = t; break; }
+            if (first_slot_of[sl] == sl) tab[e->hdr.out_buffer[sl]] = outs[sl];
+        }
+        const int rc = run_ops(e, tab, d_input, n, needed, s, prof ? pev : nullptr);
         if (rc != HSEFR_OK) return rc;
-    }
-    for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl) {
-        if (!outs[sl]) continue;
-        const int b = e->hdr.out_buffer[sl];
-        const size_t bytes = (size_t)e->hdr.out_elems[sl] * sizeof(float) * n;
-        HSEFR_HIP_CHECK(hipMemcpyAsync(outs[sl], e->d_bufs[b], bytes, hipMemcpyDeviceToDevice, s));
+        for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl)
+            if (outs[sl] && first_slot_of[sl] != sl)
+                HSEFR_HIP_CHECK(hipMemcpyAsync(outs[sl], outs[first_slot_of[sl]], (size_t)e->hdr.out_elems[sl] * sizeof(float) * n,
+                                               hipMemcpyDeviceToDevice, s));
     }
     if (prof) e->prof_calls++;
     return HSEFR_OK;
@@ -489,20 +559,6 @@ int hsefr_engine_destroy(hsefr_engine* e) {
     if (e->d_in_stage) (void)hipFree(e->d_in_stage);
     delete e;
     return HSEFR_OK;
-}
-
-int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_t stream) {
-    HSEFR_REQUIRE(bytes == 0 || (d_src && d_dst), HSEFR_ERR_INVALID, "debug_copy: null pointer");
-    return launch_copy(d_src, d_dst, bytes, (hipStream_t)stream);
-}
-
-int hsefr_debug_read_stamps(void* host_out, size_t bytes) {
-    // the split-f16 GEMM's stamps, or (bytes == 512*4*10*8) the fused stem's
-    return bytes == 512 * 4 * 10 * 8 ? read_stem_stamps(host_out, bytes) : read_pws_stamps(host_out, bytes);
-}
-
-int hsefr_debug_clock_probe(unsigned long long* d_out, int blocks, int iters, hsefr_stream_t stream) {
-    return launch_clock_probe(d_out, blocks, iters, (hipStream_t)stream);
 }
 
 // ---- per-kernel entry points ---------------------------------------------------------------
@@ -549,16 +605,6 @@ int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shif
                   HSEFR_ERR_INVALID, "stem_fused: null pointer");
     return launch_stem_fused(x, conv_w, conv_shift, wd, dscale, dshift, w_split, descale, pshift, y, n, h, w, cpad_t, cpad_l,
                              oh, ow, a_log2, act, (hipStream_t)stream);
-}
-
-int hsefr_dwpwdw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,
-                          const float* descale, const float* pshift, const float* wd2, const float* d2scale,
-                          const float* d2shift, float* y, int n, int h, int w, int c, int cout, int pad_t2, int pad_l2, int oh2,
-                          int ow2, int a_log2, int act, int act2, hsefr_stream_t stream) {
-    HSEFR_REQUIRE(x && wd && dscale && dshift && w_split && descale && pshift && wd2 && d2scale && d2shift && y, HSEFR_ERR_INVALID,
-                  "dwpwdw_f16split: null pointer");
-    return launch_dwpwdw_f16s(x, wd, dscale, dshift, w_split, descale, pshift, wd2, d2scale, d2shift, y, n, h, w, c, cout, pad_t2, pad_l2,
-                              oh2, ow2, a_log2, act, act2, (hipStream_t)stream);
 }
 
 int hsefr_dwpw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,
@@ -668,3 +714,4 @@ int hsefr_pairwise_dist(const float* x, const float* y, int n, int m, int d, flo
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

@@ -323,7 +323,7 @@ int choose_tile(long long m, int cout, int forced) {
     return best;
 }
 
-int g_forced_tile = -1;  // tuning/debug only (hsefr_debug_set "pws_tile"): 0 = 128x128, 1 = 128x64, 2 = 64x64
+HSEFR_KNOB(g_forced_tile, -1);  // dev builds: 0 = 128x128, 1 = 128x64, 2 = 64x64
 
 template <int BM, int BN, int WAVES_N, int OCC>
 int launch_cfg(const float* x, const void* wsplit, const float* descale, const float* shift, float* y, long long m, int k,
@@ -347,7 +347,9 @@ int launch_cfg(const float* x, const void* wsplit, const float* descale, const f
 
 }  // namespace
 
+#ifdef HSEFR_DEV
 void set_pws_tile(int v) { g_forced_tile = v; }
+#endif
 
 int read_pws_stamps(void* host_out, size_t bytes) {
 #ifdef HSEFR_PWS_STAMPS

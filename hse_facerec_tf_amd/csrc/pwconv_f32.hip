@@ -379,9 +379,9 @@ TileCfg choose_tile(long long m, int cout, int forced) {
     return cands[best];
 }
 
-int g_pw_dma = 1;       // 1 = LDS-DMA staging (default), 0 = register staging
-int g_pw_ablate = 0;    // timing-only ablations (results WRONG): 1 = no global loads after the first tile, 2 = no stores
-int g_forced_tile = -1;  // tuning/debug only (hsefr_debug_set "pw_tile"): 0 = 128x128, 1 = 128x64, 2 = 64x64
+HSEFR_KNOB(g_pw_dma, 1);       // 1 = LDS-DMA staging (default), 0 = register staging
+HSEFR_KNOB(g_pw_ablate, 0);    // timing-only ablations (results WRONG): 1 = no global loads after the first tile, 2 = no stores
+HSEFR_KNOB(g_forced_tile, -1);  // dev builds: 0 = 128x128, 1 = 128x64, 2 = 64x64
 
 template <int BM, int BN, int OCC>
 int launch_cfg(const float* x, const float* wt, const float* shift, float* y, long long m, int k, int cout,
@@ -412,9 +412,11 @@ int launch_cfg(const float* x, const float* wt, const float* shift, float* y, lo
 
 }  // namespace
 
+#ifdef HSEFR_DEV
 void set_pw_tile(int v) { g_forced_tile = v; }
 void set_pw_ablate(int v) { g_pw_ablate = v; }
 void set_pw_dma(int v) { g_pw_dma = v; }
+#endif
 
 int launch_pwconv_f32(const float* x, const float* wgt_t, const float* shift, float* y, long long m, int k,
                       int cout, int act, hipStream_t s) {

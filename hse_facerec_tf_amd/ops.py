@@ -133,26 +133,6 @@ def dwpw_f16split(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1, act: 
 
 
 @_device_guarded
-def dwpwdw_f16split(x, w_hwc, dscale, dshift, wp_t, pshift, w2_hwc, d2scale, d2shift, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
-    """A stride-1 block and the stride-2 depthwise behind it in one kernel (csrc/dwpwdw_f16s.hip): depthwise 3x3/1 -> pointwise
-    c -> 128 (split-f16 products) -> depthwise 3x3/2 + scale + shift + ReLU6.  wp_t [128, c] fp32 is split on the host."""
-    torch = _lib.require_gpu()
-    for t, nm in ((x, "x"), (w_hwc, "w"), (dscale, "dscale"), (dshift, "dshift"), (pshift, "pshift"), (w2_hwc, "w2"), (d2scale, "d2scale"),
-                  (d2shift, "d2shift")):
-        _f32c(t, nm)
-    d_img, d_ds = prepared if prepared is not None else split_weights_device(wp_t, x.device, a_log2)
-    n, h, w, c = x.shape
-    cout = d_img.shape[0]
-    oh2, ow2, pt2, pl2 = _same(h, w, 3, 2)
-    y = torch.empty((n, oh2, ow2, cout), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().hsefr_dwpwdw_f16split(x.data_ptr(), w_hwc.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), d_img.data_ptr(),
-                                                d_ds.data_ptr(), pshift.data_ptr(), w2_hwc.data_ptr(), d2scale.data_ptr(), d2shift.data_ptr(),
-                                                y.data_ptr(), n, h, w, c, cout, pt2, pl2, oh2, ow2, a_log2, act, ACT_RELU6,
-                                                _lib.current_stream_ptr()), "hsefr_dwpwdw_f16split")
-    return y
-
-
-@_device_guarded
 def stem_fused(x, conv_w, conv_shift, w_hwc, dscale, dshift, wp_t, pshift, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
     """The MobileNet stem in one kernel (csrc/stem_fused.hip): conv 3x3/2 SAME 3->32 + shift + ReLU6 -> depthwise 3x3/1 +
     scale + shift + ReLU6 -> pointwise 32->64 + shift + act.  conv_w TF HWIO [3,3,3,32], w_hwc [3,3,32], wp_t [64,32]."""

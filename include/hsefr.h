@@ -59,25 +59,8 @@ typedef void* hsefr_stream_t; /* hipStream_t */
 
 int hsefr_version(void);
 const char* hsefr_last_error_string(void);
-/* Tuning/debug knobs, process-wide, never needed for correct results.
- * "pw_tile": -1 = choose per layer (default), 0 = 128x128, 1 = 128x64, 2 = 64x64 GEMM tile.
- * "pw_dma":  1 = GEMM tiles staged by LDS-DMA (global_load_lds, default), 0 = through registers.
- * "pw_ablate": timing-only ablations of the GEMM (results are WRONG): bit 0 = no global loads after the first
- *            K-tile, bit 1 = no epilogue stores.  0 = the real kernel (default).
- * "dw_th":   0 = choose per layer (default), >0 = output rows per depthwise strip.
- * "dw_variant": cache policy of the depthwise kernel: bit 0 = nontemporal loads, bit 1 = nontemporal stores.
- * "copy_variant": shape of the hsefr_debug_copy calibration kernel (unroll / nontemporal / grid bits).
- * "dwpw_impl": 0 = auto (default), 1 = alternating-phase fused block kernel, 2 = producer/consumer-wave kernel.
- * "c3_impl": 0 = auto (default), 1 = VALU first-conv kernel, 2 = im2col fp32-MFMA first-conv kernel. */
-int hsefr_debug_set(const char* key, int value);
-/* Calibration: plain float4 device-to-device copy kernel (the practical HBM ceiling on this GPU). */
-int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_t stream);
-/* Calibration: dense fp32-MFMA loop on `blocks` workgroups; d_out[3*b] = shader-clock ticks, d_out[3*b+1] = 100 MHz
- * ticks of workgroup b (clock under fp32-matrix load = ratio * 100 MHz; 4*iters MFMAs of 4096 FLOP per wave). */
-/* Diagnostic builds only (-DHSEFR_PWS_STAMPS): per-wave phase cycle sums of the last split-f16 GEMM launch;
- * HSEFR_ERR_UNSUPPORTED in the shipped library. */
-int hsefr_debug_read_stamps(void* host_out, size_t bytes);
-int hsefr_debug_clock_probe(unsigned long long* d_out, int blocks, int iters, hsefr_stream_t stream);
+/* Tuning knobs and calibration kernels (hsefr_debug_*) are NOT part of this ABI: they exist only in development builds
+ * of the library (hse_facerec_tf_amd/csrc/hsefr_dev.h, build.sh with HSEFR_DEV=1). */
 
 /* ------------------------------------------------------------------------------------ */
 /* Plan: the lowered frozen graph handed to hsefr_engine_create (host memory).           */
@@ -263,17 +246,6 @@ int hsefr_stem2_fused(const float* x, const float* conv_w, const float* conv_shi
                       const float* d1shift, const void* w_split, const float* descale, const float* pshift, const float* wd2,
                       const float* d2scale, const float* d2shift, float* y, int n, int h, int w, int cpad_t, int cpad_l,
                       int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int a_log2, int act, hsefr_stream_t stream);
-
-/* One stride-1 block and the depthwise half of the stride-2 block behind it in one kernel (e.g. conv_dw_3 ... conv_dw_4_relu):
- * depthwise 3x3/1 SAME + scale + shift + ReLU6 -> pointwise c -> 128 + shift + act (split-f16 products) -> depthwise 3x3/2
- * SAME + scale + shift + act2 (ReLU6).  x [n,h,w,c] with c in {64, 96, 128}; wd [3,3,c]; w_split / descale as for
- * hsefr_pwconv1x1_f16split; wd2 [3,3,128]; y [n,oh2,ow2,128] with oh2 = ceil(h/2); pad_t2/pad_l2 = the stride-2
- * depthwise's top/left padding (0 for even h/w).  Bit-identical to the three kernels it replaces.  Not used by the engine:
- * LDS capacity limits its patch to 18 output pixels and it measures 10 % slower than fused block + depthwise. */
-int hsefr_dwpwdw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,
-                          const float* descale, const float* pshift, const float* wd2, const float* d2scale,
-                          const float* d2shift, float* y, int n, int h, int w, int c, int cout, int pad_t2, int pad_l2, int oh2,
-                          int ow2, int a_log2, int act, int act2, hsefr_stream_t stream);
 
 /* One whole early MobileNet block (graph nodes #35-#49) fused: depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6
  * -> pointwise 1x1 + shift + ReLU6.  x [n,h,w,c], wd [3,3,c], wp_t [cout,c] (TF kernel transposed), y [n,oh,ow,cout];

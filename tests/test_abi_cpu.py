@@ -62,9 +62,7 @@ def test_argument_validation_needs_no_gpu():
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.POINTER(ctypes.c_float))
     vp = ctypes.cast(buf, ctypes.c_void_p)
-    rc = L.hsefr_dwpwdw_f16split(p, p, p, p, vp, p, p, p, p, p, p, 1, 8, 8, 32, 128, 0, 0, 4, 4, 12, 2, 2, None)      # c = 32: not covered
-    assert rc == _lib.ERR_UNSUPPORTED and "not covered" in _lib.last_error()
-    rc = L.hsefr_dwpwdw_f16split(p, p, p, p, vp, p, p, p, p, p, p, 1, 8, 8, 128, 128, 0, 0, 4, 4, 13, 2, 2, None)     # a_log2 out of range
+    rc = L.hsefr_dwpw_f16split(p, p, p, p, vp, p, p, p, 1, 8, 8, 128, 1, 1, 1, 8, 8, 128, 13, 2, None)                 # a_log2 out of range
     assert rc == _lib.ERR_INVALID and "a_log2" in _lib.last_error()
     rc = L.hsefr_dwpw_f16split(p, p, p, p, vp, p, p, p, 1, 8, 8, 48, 1, 1, 1, 8, 8, 64, 12, 2, None)                   # c % 32 != 0
     assert rc == _lib.ERR_UNSUPPORTED
@@ -98,3 +96,34 @@ def test_no_unguarded_store_data_hazard_in_the_device_code():
 """
     found = lint.scan_listing(listing)
     assert len(found) == 1 and found[0][3] == [("v", 2), ("v", 3)] and found[0][4] == 1
+    # a wide store followed by a TAKEN branch is checked against the first instructions of the branch target
+    branchy = """
+0000000000002000 <kernel_b>:
+	buffer_store_dwordx4 v[0:3], v112, s[4:7], 0 offen        // 0000
+	s_cbranch_scc1 L42                                         // 0008
+	s_nop 1                                                    // 000C
+	v_mov_b32_e32 v9, 0                                        // 0010
+0000000000002014 <L42>:
+	v_pk_mul_f32 v[0:1], v[10:11], v[34:35]                    // 0014
+	s_endpgm                                                   // 001C
+"""
+    found = lint.scan_listing(branchy)
+    assert len(found) == 1 and found[0][3] == [("v", 0), ("v", 1)]
+    # and a library in which nothing could be scanned does not pass vacuously
+    import subprocess, sys, tempfile
+    with tempfile.NamedTemporaryFile(suffix=".so") as f:
+        f.write(b"\x7fELF" + b"\0" * 60)
+        f.flush()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint.py"), f.name], capture_output=True, text=True)
+    assert r.returncode != 0
+
+
+def test_product_library_exports_the_documented_surface_only():
+    """No tuning knobs, calibration kernels or C++ internals in the product ABI: the dynamic symbol
+    table holds exactly the functions include/hsefr.h declares."""
+    from hse_facerec_tf_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    syms = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert [x for x in syms if "debug" in x] == []
+    extra = [x for x in syms if x not in declared_functions() and not x.startswith(("_init", "_fini"))]
+    assert extra == [], extra

@@ -389,11 +389,10 @@ def test_fused_stems_full_size_every_element_and_run_to_run(env):
 @pytest.mark.parametrize("hw,c,cout,n", [(48, 128, 128, 256), (24, 256, 256, 256), (56, 128, 128, 64), (28, 256, 256, 130), (12, 512, 512, 256)])
 def test_fused_blocks_full_size_bit_identical_and_run_to_run(env, hw, c, cout, n):
     """The LDS-DMA fused block at the BASELINE sizes (and at the 224-pixel configuration's 56 / 28-pixel maps, whose patches
-    are partial; and a 512-channel block, which takes the unspecialised kernel): EVERY output element equal, bit for bit, to
+    are partial; and a 512-channel block, which takes the general K-chunked kernel): EVERY output element equal, bit for bit, to
     depthwise kernel + split-f16 GEMM, three launches in a row -- 18 patches per persistent workgroup, LDS stages re-used
     every chunk, DMA pieces in flight across patch boundaries: a hazard would show as rare wrong chunks only at this size."""
     torch, ops = env
-    from hse_facerec_tf_amd import _lib
     g = torch.Generator(device="cuda").manual_seed(hw + c)
     x = torch.rand((n, hw, hw, c), device="cuda", generator=g) * 6
     x[torch.rand((n, hw, hw, c), device="cuda", generator=g) < 0.3] = 0.0
@@ -406,46 +405,6 @@ def test_fused_blocks_full_size_bit_identical_and_run_to_run(env, hw, c, cout, n
     ref = ops.pwconv1x1_f16split(ops.dwconv3x3(x, kd, sc, sh, 1), None, psh, prepared=prep)
     for _ in range(3):
         assert torch.equal(ops.dwpw_f16split(x, kd, sc, sh, None, psh, 1, prepared=prep), ref)
-    if c <= 256:                                   # the unspecialised LDS-DMA kernel and the first register-staged version too
-        for v in (1, 0):
-            try:
-                _lib.check(_lib.lib().hsefr_debug_set(b"dwpws_v2", v))
-                assert torch.equal(ops.dwpw_f16split(x, kd, sc, sh, None, psh, 1, prepared=prep), ref)
-            finally:
-                _lib.check(_lib.lib().hsefr_debug_set(b"dwpws_v2", 2))
-
-
-@pytest.mark.parametrize("n,h,w,c", [(2, 48, 48, 128), (3, 24, 24, 128), (1, 56, 56, 128), (2, 13, 21, 128), (1, 7, 5, 64), (2, 48, 48, 64),
-                                     (1, 30, 30, 96), (1, 1, 1, 128), (256, 48, 48, 128)])
-def test_fused_block_plus_stride2_depthwise_bit_identical(env, n, h, w, c):
-    """depthwise 3x3/1 -> pointwise c -> 128 -> depthwise 3x3/2 in one kernel (csrc/dwpwdw_f16s.hip) vs the three kernels it
-    replaces, bit for bit (odd sizes: partial patches, both paddings of the stride-2 depthwise; the BASELINE size last:
-    32 patches per persistent workgroup, every element, three launches), and vs the fp64 oracle on the small cases."""
-    torch, ops = env
-    g = torch.Generator(device="cuda").manual_seed(h * 7 + w + c + n)
-    x = torch.rand((n, h, w, c), device="cuda", generator=g) * 6
-    x[torch.rand((n, h, w, c), device="cuda", generator=g) < 0.25] = 0.0
-    kd = torch.randn((3, 3, c), device="cuda", generator=g) / 3
-    sc = torch.rand((c,), device="cuda", generator=g) + 0.5
-    sh = torch.randn((c,), device="cuda", generator=g) * 0.3
-    kp = (torch.randn((128, c), device="cuda", generator=g) / c ** 0.5).cpu().numpy()
-    psh = torch.randn((128,), device="cuda", generator=g)
-    kd2 = torch.randn((3, 3, 128), device="cuda", generator=g) / 3
-    sc2 = torch.rand((128,), device="cuda", generator=g) + 0.5
-    sh2 = torch.randn((128,), device="cuda", generator=g) * 0.3
-    prep = ops.split_weights_device(kp, x.device)
-    mid = ops.pwconv1x1_f16split(ops.dwconv3x3(x, kd, sc, sh, 1), None, psh, prepared=prep)
-    ref = ops.dwconv3x3(mid, kd2, sc2, sh2, 2)
-    for _ in range(3 if n > 8 else 1):
-        y = ops.dwpwdw_f16split(x, kd, sc, sh, None, psh, kd2, sc2, sh2, prepared=prep)
-        assert tuple(y.shape) == tuple(ref.shape)
-        assert torch.equal(y, ref)
-    if n <= 3:
-        xn = x.cpu().numpy().astype(np.float64)
-        m1 = act6(tfo.depthwise_conv2d(xn, kd.cpu().numpy()[..., None], (1, 1), "SAME") * sc.cpu().numpy() + sh.cpu().numpy())
-        m2 = act6(m1.reshape(-1, c).dot(kp.T.astype(np.float64)) + psh.cpu().numpy()).reshape(m1.shape[:3] + (128,))
-        want = act6(tfo.depthwise_conv2d(m2, kd2.cpu().numpy()[..., None], (2, 2), "SAME") * sc2.cpu().numpy() + sh2.cpu().numpy())
-        assert rel(y.cpu().numpy(), want) < 2 * TOL
 
 
 def test_fused_stem_rejects_uncovered_shapes(env):

@@ -72,6 +72,9 @@ def store_data_regs(mnemonic, operands):
     return regs(ops[0] if mnemonic.startswith("buffer_") else ops[1])
 
 
+LOAD_RE = re.compile(r"^\s*((?:buffer|global|flat|scratch)_load_\w+|ds_read\w*|ds_load\w*|ds_bpermute\w*|ds_permute\w*)\s+(.*)$")
+
+
 def vector_dest_regs(line):
     """Registers written by a vector ALU instruction (first operand of v_* except compares and stores)."""
     m = re.match(r"^\s*(v_\w+)\s+(.*)$", line)
@@ -80,45 +83,87 @@ def vector_dest_regs(line):
     return regs(m.group(2).split(",")[0])
 
 
+def load_dest_regs(line):
+    """Destination of a VMEM / DS load.  NOT a hazard: a load's data returns tens to hundreds of cycles after issue, long
+    after the store has read its data registers; the compiler re-uses a store's registers for the next load all the
+    time (282 places in the round-2 library, whose full-size every-element tests are bit-exact).  Counted and reported
+    so that the claim stays visible; it does not fail the build."""
+    m = LOAD_RE.match(line)
+    if m and " lds" not in line:                  # LDS-DMA loads have no VGPR destination
+        return regs(m.group(2).split(",")[0])
+    return set()
+
+
+BRANCH_RE = re.compile(r"^\s*s_c?branch\w*\s+(\S+)")
+
+
 def scan_listing(dis, counts=None):
-    """Findings in one llvm-objdump listing: (symbol, store, writer, registers hit, wait states in between)."""
-    findings = []
-    kernel, pending = None, []          # pending: [store text, data registers, wait states still needed]
+    """Findings in one llvm-objdump listing: (symbol, store, writer, registers hit, wait states in between).
+    The scan is linear (fall-through), and at every branch the pending window is ALSO carried to the first
+    instructions of the branch target (a wide store followed by a taken branch is checked against what it lands on)."""
+    # pass 1: instruction lines per symbol, and the instruction index every label (global or local) points at
+    symbols = []          # [name, [lines], {label: index}]
     for raw in dis.splitlines():
         lab = re.match(r"^[0-9a-f]+ <([^>]+)>:", raw)
         if lab:
-            if not lab.group(1).startswith("L"):      # local labels are basic blocks: fall-through keeps the window
-                kernel, pending = lab.group(1), []
+            if not lab.group(1).startswith("L") or not symbols:
+                symbols.append([lab.group(1), [], {}])
                 if counts is not None:
                     counts[0] += 1
+            symbols[-1][2][lab.group(1)] = len(symbols[-1][1])
             continue
         line = raw.split("//")[0].strip()
-        if not line:
-            continue
+        if line and symbols:
+            symbols[-1][1].append(line)
+
+    def advance(pending, line, kernel, findings):
         dest = vector_dest_regs(line)
+        ldest = load_dest_regs(line)
         for st in pending:
             hit = st[1] & dest
             if hit:
                 findings.append((kernel, st[0], line, sorted(hit), WAIT_STATES - st[2]))
+            if counts is not None and len(counts) > 2 and st[1] & ldest:
+                counts[2] += 1
         nop = re.match(r"^s_nop\s+(\d+)", line)
         used = int(nop.group(1)) + 1 if nop else 1
-        pending = [[t, r, w - used] for t, r, w in pending if w - used > 0]
-        m = STORE_RE.match(line)
-        if m:
-            if counts is not None:
-                counts[1] += 1
-            pending.append([line, store_data_regs(m.group(1), m.group(2)), WAIT_STATES])
+        return [[t, r, w - used] for t, r, w in pending if w - used > 0]
+
+    findings = []
+    for kernel, lines, labels in symbols:
+        pending = []          # [store text, data registers, wait states still needed]
+        for i, line in enumerate(lines):
+            pending = advance(pending, line, kernel, findings)
+            m = STORE_RE.match(line)
+            if m:
+                if counts is not None:
+                    counts[1] += 1
+                pending.append([line, store_data_regs(m.group(1), m.group(2)), WAIT_STATES])
+            b = BRANCH_RE.match(line)
+            if b and pending:
+                tgt = re.sub(r"^<|>$", "", b.group(1))
+                j = labels.get(tgt)
+                if j is None:
+                    # unknown target (should not happen inside one function): flag conservatively
+                    findings.append((kernel, pending[0][0], line + "   <- branch to an unresolved label with a store window open",
+                                     sorted(pending[0][1]), WAIT_STATES - pending[0][2]))
+                    continue
+                carried = [list(p) for p in pending]
+                while carried and j < len(lines):
+                    carried = advance(carried, lines[j], kernel, findings)
+                    j += 1
     return findings
 
 
 def lint(lib):
-    findings, counts = [], [0, 0]
+    findings, counts = [], [0, 0, 0]
     for idx, elf in code_objects(lib):
         with tempfile.NamedTemporaryFile(suffix=".elf") as f:
             f.write(elf)
             f.flush()
             dis = subprocess.check_output([OBJDUMP, "-d", "--no-show-raw-insn", f.name], text=True)
         findings += scan_listing(dis, counts)
+    lint.load_reuse = counts[2]
     return findings, counts[0], counts[1]
 
 
@@ -129,7 +174,11 @@ def main():
     for kernel, store, nxt, hit, gap in findings:
         print(f"HAZARD in {kernel}:\n    {store}\n    ... {gap} wait state(s) ...\n    {nxt}\n    overwrites {''.join(f'{c}{i} ' for c, i in hit)}",
               file=sys.stderr)
-    print(f"isa_lint: {nk} symbols, {ns} wide stores, {len(findings)} store-data hazards")
+    print(f"isa_lint: {nk} symbols, {ns} wide stores, {len(findings)} store-data hazards "
+          f"({getattr(lint, 'load_reuse', 0)} loads re-use a store's data registers inside the window: benign, see load_dest_regs)")
+    if nk == 0 or ns == 0:
+        print("isa_lint: nothing was scanned (no gfx950 code object / no wide store found): refusing to pass vacuously", file=sys.stderr)
+        return 2
     return 1 if findings else 0
 
 

@@ -2,12 +2,15 @@
 """Kernel micro-benchmarks on one MI355X: every layer shape of MobileNet-192 @ batch 256 through
 the per-kernel C-ABI entry points, interleaved variants in ONE process (cdna guide rule 24).
     python tools/kbench.py [pw] [dw] [c3]
+Needs the DEVELOPMENT build of the library (tuning knobs, calibration kernels):
+    HSEFR_DEV=1 bash hse_facerec_tf_amd/csrc/build.sh      -> hse_facerec_tf_amd/libhsefr_dev.so (selected below)
 """
 import os
 import sys
 
 import numpy as np
 
+os.environ.setdefault("HSEFR_LIB", "libhsefr_dev.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
