@@ -101,8 +101,9 @@ def scan_listing(dis, counts=None):
     """Findings in one llvm-objdump listing: (symbol, store, writer, registers hit, wait states in between).
     The scan is linear (fall-through), and at every branch the pending window is ALSO carried to the first
     instructions of the branch target (a wide store followed by a taken branch is checked against what it lands on)."""
-    # pass 1: instruction lines per symbol, and the instruction index every label (global or local) points at
-    symbols = []          # [name, [lines], {label: index}]
+    # pass 1: instruction lines per symbol with their addresses (llvm-objdump prints "// ADDRESS: raw words" behind every
+    # instruction and numeric branch offsets), and the instruction index every label / address points at
+    symbols = []          # [name, [lines], {label or address: index}]
     for raw in dis.splitlines():
         lab = re.match(r"^[0-9a-f]+ <([^>]+)>:", raw)
         if lab:
@@ -114,7 +115,11 @@ def scan_listing(dis, counts=None):
             continue
         line = raw.split("//")[0].strip()
         if line and symbols:
+            am = re.search(r"//\s*([0-9A-Fa-f]{6,}):", raw)
+            if am:
+                symbols[-1][2][int(am.group(1), 16)] = len(symbols[-1][1])
             symbols[-1][1].append(line)
+    addr_of = [{i: a for a, i in labels.items() if isinstance(a, int)} for _, _, labels in symbols]
 
     def advance(pending, line, kernel, findings):
         dest = vector_dest_regs(line)
@@ -130,7 +135,7 @@ def scan_listing(dis, counts=None):
         return [[t, r, w - used] for t, r, w in pending if w - used > 0]
 
     findings = []
-    for kernel, lines, labels in symbols:
+    for si, (kernel, lines, labels) in enumerate(symbols):
         pending = []          # [store text, data registers, wait states still needed]
         for i, line in enumerate(lines):
             pending = advance(pending, line, kernel, findings)
@@ -143,6 +148,10 @@ def scan_listing(dis, counts=None):
             if b and pending:
                 tgt = re.sub(r"^<|>$", "", b.group(1))
                 j = labels.get(tgt)
+                if j is None and re.fullmatch(r"\d+", tgt) and i in addr_of[si]:
+                    off = int(tgt)                      # simm16, in dwords, relative to the next instruction
+                    off = off - 65536 if off >= 32768 else off
+                    j = labels.get(addr_of[si][i] + 4 + 4 * off)
                 if j is None:
                     # unknown target (should not happen inside one function): flag conservatively
                     findings.append((kernel, pending[0][0], line + "   <- branch to an unresolved label with a store window open",
