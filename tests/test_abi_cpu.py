@@ -115,7 +115,7 @@ def test_no_unguarded_store_data_hazard_in_the_device_code():
 	v_pk_mul_f32 v[2:3], v[10:11], v[34:35]                    // 000000003000: D3B10002 1802450A
 	s_nop 0                                                    // 000000003008: BF800000
 	global_store_dwordx4 v[8:9], v[0:3], off                   // 00000000300C: DC7C8000 007F0008
-	s_cbranch_scc1 65531                                       // 000000003014: BF85FFFB <kernel_c+0x0>
+	s_cbranch_scc1 65530                                       // 000000003014: BF85FFFA <kernel_c+0x0>
 	s_endpgm                                                   // 000000003018: BF810000
 """
     found = lint.scan_listing(numeric)
