@@ -126,10 +126,17 @@ int launch_conv_c3(const float* x, const float* wgt, const float* shift, float* 
 int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const float* shift, float* y,
                      int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
                      hipStream_t s);
+int launch_dwconv3x3_split(const float* x, const float* wgt, const float* scale, const float* shift, void* y_split,
+                           int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
+                           int a_log2, hipStream_t s);
 int launch_pwconv_f32(const float* x, const float* wgt_t, const float* shift, float* y, long long m, int k,
                       int cout, int act, hipStream_t s);
 int launch_pwconv_f16s(const float* x, const void* wsplit, const float* descale, const float* shift, float* y,
                        long long m, int k, int cout, int a_log2, int act, hipStream_t s);
+// pre-split activations (csrc/pwconv_ps.hip): xs = split rows [m][k/32][hi 32 x f16 | lo 32 x f16], scaled by 2^a_log2 (folded in descale)
+bool pwconv_ps_supported(long long m, int k, int cout);
+int launch_pwconv_ps(const void* xs, const void* wsplit, const float* descale, const float* shift, float* y, long long m, int k,
+                     int cout, int act, hipStream_t s);
 int launch_gap(const float* x, float* y, int n, int hw, int c, hipStream_t s);
 int launch_dense(const float* x, const float* wgt, const float* bias, float* y, int n, int k, int cout,
                  int act, hipStream_t s);
@@ -204,6 +211,7 @@ void set_dwpws_tw(int v);
 void set_dwpws_bn(int v);
 void set_pw_tile(int v);
 void set_pws_tile(int v);
+void set_ps_mb(int v);
 void set_pw_ablate(int v);
 void set_pw_dma(int v);
 void set_dw_th(int v);

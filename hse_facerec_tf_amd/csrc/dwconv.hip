@@ -39,7 +39,12 @@ struct DwParams {
     unsigned nwg;
     int reverse;  // sweep direction (common.h)
     int variant;  // 0 = real kernel; timing-only ablations: 1 = one load per row, 2 = no stores
+    float a_scale;  // SPLIT kernels: 2^a_log2
 };
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 ntload(const float4* p) {
     const f4 v = __builtin_nontemporal_load((const f4*)p);
@@ -57,7 +62,13 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 
 // LOOK = rows requested ahead of the one being consumed (stride 1): 2 at 4 workgroups per CU, or 3 at 3 (more unique bytes
 // in flight per CU: the waves of this kernel spend two thirds of their life waiting on memory).
-template <int STRIDE, int ACT, int NT, int LOOK>
+// SPLIT = 1: the result is stored PRE-SPLIT for the split-f16 GEMM that consumes it (pwconv_ps.hip): per pixel and
+// 32-channel group one 128-byte "split row" [hi(32 x f16) | lo(32 x f16)], hi = f16(v * 2^a_log2), lo = f16(v * 2^a_log2 - hi)
+// -- the very operations pwconv_f16s.hip applies on its way into LDS, so the GEMM sees the same bits either way.  The
+// tensor keeps its size (4 B per element).  A thread owns 4 channels = 8 B of the hi half and 8 B of the lo half; lane
+// pairs (the quads 2j, 2j+1 of a group) swap one 8-byte half by DPP, so that every lane still issues ONE 16-byte store
+// and a wave still writes whole 128-byte lines: even quad -> [hi(2j) | hi(2j+1)], odd quad -> [lo(2j) | lo(2j+1)].
+template <int STRIDE, int ACT, int NT, int LOOK, int SPLIT = 0>
 __global__ __launch_bounds__(256, LOOK == 2 ? 4 : (LOOK <= 4 ? 3 : 2)) void dwconv3x3_kernel(DwParams p) {
     const unsigned bid = xcd_remap_dir(blockIdx.x, p.nwg, p.reverse);
     const int tx = bid % p.tiles_x;
@@ -114,7 +125,11 @@ __global__ __launch_bounds__(256, LOOK == 2 ? 4 : (LOOK <= 4 ? 3 : 2)) void dwco
 
     const int oh0 = th * p.TH;
     const int oh1 = min(oh0 + p.TH, p.OH);
-    float4* yout = p.y + ((size_t)n * p.OH * p.OW + ow) * p.C4 + c4;
+    // 16-B unit of this lane's store inside the pixel: fp32 layout = its channel quad; split rows = quad q of group gq goes
+    // to unit q/2 of the hi half (even q) or 4 + q/2, the lo half (odd q)
+    const int qg = c4 & 7;
+    const int c4s = SPLIT ? (c4 & ~7) + ((qg & 1) ? 4 + (qg >> 1) : (qg >> 1)) : c4;
+    float4* yout = p.y + ((size_t)n * p.OH * p.OW + ow) * p.C4 + c4s;
 
     auto compute_store = [&](int oh, const Row& a, const Row& b, const Row& c) {
         const float4 sa = row_sum(a, 0), sb = row_sum(b, 3), sc2 = row_sum(c, 6);
@@ -126,6 +141,21 @@ __global__ __launch_bounds__(256, LOOK == 2 ? 4 : (LOOK <= 4 ? 3 : 2)) void dwco
         o.y = apply_act<ACT>(o.y);
         o.z = apply_act<ACT>(o.z);
         o.w = apply_act<ACT>(o.w);
+        if (SPLIT) {
+            const f4 v = f4{o.x, o.y, o.z, o.w} * p.a_scale;
+            const f16x4 hi = __builtin_convertvector(v, f16x4);
+            const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f4), f16x4);
+            const u32x2 hb = __builtin_bit_cast(u32x2, hi), lb = __builtin_bit_cast(u32x2, lo);
+            const bool odd = qg & 1;
+            const u32x2 send = odd ? hb : lb;          // the even quad gives away its lo half, the odd quad its hi half
+            u32x2 recv;                                // quad_perm [1,0,3,2]: swap with the neighbouring lane
+            recv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);
+            recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
+            const u32x4 out = odd ? u32x4{recv.x, recv.y, lb.x, lb.y} : u32x4{hb.x, hb.y, recv.x, recv.y};
+            const f4 ov = __builtin_bit_cast(f4, out);
+            yout[(size_t)oh * p.OW * p.C4] = make_float4(ov.x, ov.y, ov.z, ov.w);
+            return;
+        }
         if (NT & 2) ntstore(o, yout + (size_t)oh * p.OW * p.C4);
         else yout[(size_t)oh * p.OW * p.C4] = o;
     };
@@ -171,10 +201,16 @@ void set_dw_look(int v) { g_dw_look = (v >= 2 && v <= 5) ? v : 2; }
 void set_dw_look2(int v) { g_dw_look2 = v == 4 ? 4 : 2; }
 #endif
 
-int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const float* shift, float* y,
-                     int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
-                     hipStream_t s) {
+static int launch_dwconv3x3_impl(const float* x, const float* wgt, const float* scale, const float* shift, float* y,
+                                 int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
+                                 int a_log2, hipStream_t s) {
     HSEFR_REQUIRE(c % 4 == 0, HSEFR_ERR_UNSUPPORTED, "dwconv3x3: c=%d must be a multiple of 4", c);
+    if (a_log2) {
+        HSEFR_REQUIRE(c % 32 == 0, HSEFR_ERR_UNSUPPORTED, "dwconv3x3 (split output): c=%d must be a multiple of 32", c);
+        HSEFR_REQUIRE(act == HSEFR_ACT_RELU6 && a_log2 > 0 && a_log2 <= 12, HSEFR_ERR_INVALID,
+                      "dwconv3x3 (split output): needs the ReLU6 bound and a_log2 in [1, 12] (6 * 2^a_log2 < 32768), got act %d a_log2 %d",
+                      act, a_log2);
+    }
     HSEFR_REQUIRE(stride == 1 || stride == 2, HSEFR_ERR_UNSUPPORTED, "dwconv3x3: stride %d", stride);
     HSEFR_REQUIRE(n >= 0 && h > 0 && w > 0 && oh > 0 && ow > 0, HSEFR_ERR_INVALID, "dwconv3x3: bad shape");
     if (n == 0) return HSEFR_OK;
@@ -183,6 +219,7 @@ int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const
     p.shift = (const float4*)shift; p.y = (float4*)y;
     p.variant = g_dw_variant;
     p.reverse = sweep_reverse();
+    p.a_scale = ldexpf(1.f, a_log2);
     p.H = h; p.W = w; p.C4 = c / 4; p.OH = oh; p.OW = ow; p.pad_t = pad_t; p.pad_l = pad_l;
     p.tiles_x = (ow * p.C4 + 255) / 256;
     // Strip height: tall strips amortise the 2-row halo, short ones balance the CUs.
@@ -201,6 +238,13 @@ int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const
 #define HSEFR_DW_LAUNCH(S, A)                                                                      \
     do {                                                                                            \
         const int look = S == 1 ? g_dw_look : g_dw_look2;                                            \
+        if (a_log2) {   /* split rows for the GEMM behind (ReLU6 only: checked above) */           \
+            if (A == HSEFR_ACT_RELU6) {                                                             \
+                if (S == 1) hipLaunchKernelGGL((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 0, 4, 1>), grid, block, 0, s, p); \
+                else hipLaunchKernelGGL((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 0, 2, 1>), grid, block, 0, s, p);      \
+            }                                                                                       \
+            break;                                                                                  \
+        }                                                                                           \
         if (look == 3 && S == 1) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 3>), grid, block, 0, s, p); break; } \
         if (look == 4) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 4>), grid, block, 0, s, p); break; } \
         if (look == 5 && S == 1) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 5>), grid, block, 0, s, p); break; } \
@@ -224,6 +268,19 @@ int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const
     }
 #undef HSEFR_DW_LAUNCH
     return launch_status("dwconv3x3");
+}
+
+int launch_dwconv3x3(const float* x, const float* wgt, const float* scale, const float* shift, float* y,
+                     int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
+                     hipStream_t s) {
+    return launch_dwconv3x3_impl(x, wgt, scale, shift, y, n, h, w, c, stride, pad_t, pad_l, oh, ow, act, 0, s);
+}
+
+int launch_dwconv3x3_split(const float* x, const float* wgt, const float* scale, const float* shift, void* y_split,
+                           int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
+                           int a_log2, hipStream_t s) {
+    HSEFR_REQUIRE(a_log2 > 0, HSEFR_ERR_INVALID, "dwconv3x3 (split output): a_log2=%d", a_log2);
+    return launch_dwconv3x3_impl(x, wgt, scale, shift, (float*)y_split, n, h, w, c, stride, pad_t, pad_l, oh, ow, act, a_log2, s);
 }
 
 }  // namespace hsefr

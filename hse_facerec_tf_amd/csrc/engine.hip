@@ -114,6 +114,8 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
             case HSEFR_OP_DWCONV3X3:
                 if (!need(o.w_off, 9 * ci * 4, "kernel") || !need(o.scale_off, ci * 4, "scale") || !need(o.shift_off, ci * 4, "shift"))
                     return HSEFR_ERR_INVALID;
+                HSEFR_REQUIRE(o.reserved == 0 || (o.reserved > 0 && o.reserved <= 12 && o.act == HSEFR_ACT_RELU6 && o.cin % 32 == 0),
+                              HSEFR_ERR_INVALID, "plan op %u: split-row depthwise output needs ReLU6, c %% 32 == 0 and a_log2 in [1, 12]", i);
                 break;
             case HSEFR_OP_PWCONV_F32:
                 if (!need(o.w_off, ci * co * 4, "kernel") || !need(o.shift_off, co * 4, "shift")) return HSEFR_ERR_INVALID;
@@ -130,6 +132,10 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                 if (!need(o.w_off, 64 * 256 * 2, "kernel") || !need(o.scale_off, co * 4, "scale") || !need(o.shift_off, co * 4, "shift"))
                     return HSEFR_ERR_INVALID;
                 break;
+            case HSEFR_OP_PWCONV_PS:
+                HSEFR_REQUIRE(pwconv_ps_supported(0, o.cin, o.cout), HSEFR_ERR_UNSUPPORTED,
+                              "plan op %u: pre-split pointwise cin=%d cout=%d not covered", i, o.cin, o.cout);
+                [[fallthrough]];
             case HSEFR_OP_PWCONV_F16S:
                 if (!need(o.w_off, ci * co * 4, "split rows") || !need(o.scale_off, co * 4, "descale") || !need(o.shift_off, co * 4, "shift"))
                     return HSEFR_ERR_INVALID;
@@ -366,9 +372,19 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                     o.stride, o.pad_t, o.pad_l, o.oh, o.ow, o.cout, o.act, s);
                 break;
             case HSEFR_OP_DWCONV3X3:
-                rc = launch_dwconv3x3((const float*)in, (const float*)blob_ptr(e, o.w_off),
-                                      (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
-                                      (float*)out, n, o.h, o.w, o.cin, o.stride, o.pad_t, o.pad_l, o.oh, o.ow, o.act, s);
+                if (o.reserved > 0)
+                    rc = launch_dwconv3x3_split((const float*)in, (const float*)blob_ptr(e, o.w_off),
+                                                (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
+                                                out, n, o.h, o.w, o.cin, o.stride, o.pad_t, o.pad_l, o.oh, o.ow, o.act, o.reserved, s);
+                else
+                    rc = launch_dwconv3x3((const float*)in, (const float*)blob_ptr(e, o.w_off),
+                                          (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
+                                          (float*)out, n, o.h, o.w, o.cin, o.stride, o.pad_t, o.pad_l, o.oh, o.ow, o.act, s);
+                break;
+            case HSEFR_OP_PWCONV_PS:
+                rc = launch_pwconv_ps(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
+                                      (const float*)blob_ptr(e, o.shift_off), (float*)out, (long long)n * o.h * o.w, o.cin, o.cout,
+                                      o.act, s);
                 break;
             case HSEFR_OP_PWCONV_F32:
                 rc = launch_pwconv_f32((const float*)in, (const float*)blob_ptr(e, o.w_off),
@@ -574,6 +590,19 @@ int hsefr_dwconv3x3_bn_relu6(const float* x, const float* wgt, const float* scal
                              hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || (x && wgt && scale && shift && y), HSEFR_ERR_INVALID, "dwconv3x3: null pointer");
     return launch_dwconv3x3(x, wgt, scale, shift, y, n, h, w, c, stride, pad_t, pad_l, oh, ow, act, (hipStream_t)stream);
+}
+
+int hsefr_dwconv3x3_bn_relu6_split(const float* x, const float* wgt, const float* scale, const float* shift, void* y_split,
+                                   int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
+                                   int a_log2, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wgt && scale && shift && y_split), HSEFR_ERR_INVALID, "dwconv3x3_split: null pointer");
+    return launch_dwconv3x3_split(x, wgt, scale, shift, y_split, n, h, w, c, stride, pad_t, pad_l, oh, ow, act, a_log2, (hipStream_t)stream);
+}
+
+int hsefr_pwconv1x1_presplit(const void* x_split, const void* w_split, const float* descale, const float* shift, float* y,
+                             long long m, int k, int cout, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(m == 0 || (x_split && w_split && descale && shift && y), HSEFR_ERR_INVALID, "pwconv_presplit: null pointer");
+    return launch_pwconv_ps(x_split, w_split, descale, shift, y, m, k, cout, act, (hipStream_t)stream);
 }
 
 int hsefr_pwconv1x1_bias_relu6(const float* x, const float* wgt_t, const float* shift, float* y, long long m, int k,

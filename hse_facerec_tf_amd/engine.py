@@ -86,13 +86,19 @@ class Engine:
 
     def layer_output(self, layer_index: int, n: int):
         """Copy of a layer's activation buffer as a CUDA tensor [n, oh, ow, c].  Only meaningful
-        right after the op ran and before a later op recycled the buffer."""
+        right after the op ran and before a later op recycled the buffer.  A layer whose result is stored as split
+        rows for the GEMM behind it (Layer.out_split) is decoded back to fp32 values."""
         torch = self._torch
         L = self.plan.layers[layer_index]
         out = torch.empty((n,) + tuple(L.out_shape), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().hsefr_engine_copy_buffer(self._h, L.out_buf, out.data_ptr(), out.numel() * 4,
                                                            _lib.current_stream_ptr()), "hsefr_engine_copy_buffer")
+        if getattr(L, "out_split", 0):
+            from . import ops
+            c = L.out_shape[2]
+            rows = out.view(torch.float16).reshape((n,) + tuple(L.out_shape[:2]) + (c // 32, 2, 32))
+            return ops.split_rows_decode(rows, L.out_split)
         return out
 
     # -- small batches as one hipGraph launch ---------------------------------------------------

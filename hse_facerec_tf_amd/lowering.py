@@ -33,6 +33,7 @@ OP_PWCONV_F16S = 12      # wire kind of a pointwise Layer whose a_log2 > 0 (the 
 OP_DWPW_F16S = 13        # fused block with split-f16 pointwise products for any channel count (csrc/dwpw_f16s.hip)
 OP_STEM_F16S = 14        # conv1 -> depthwise -> pointwise in one kernel (csrc/stem_fused.hip)
 OP_STEM2_F16S = 15       # ... -> pointwise -> the stride-2 depthwise of block 2 in one kernel (csrc/stem2_fused.hip)
+OP_PWCONV_PS = 16        # wire kind of a split-f16 pointwise Layer whose input is stored PRE-SPLIT by its producer (csrc/pwconv_ps.hip)
 _BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
 BUF_INPUT, BUF_NONE = -1, -2
@@ -146,6 +147,8 @@ class Layer:
     scale3: Optional[np.ndarray] = None
     shift3: Optional[np.ndarray] = None
     pad3: Tuple[int, int] = (0, 0)
+    out_split: int = 0                                 # DWCONV3X3: > 0 = output stored as split rows scaled by 2^out_split
+    in_split: bool = False                             # PWCONV: the input buffer holds split rows (wire kind OP_PWCONV_PS)
     out_buf: int = BUF_NONE
 
     @property
@@ -183,10 +186,12 @@ class Plan:
             if L.kind == OP_PWCONV_F32:
                 w = np.ascontiguousarray(w.reshape(w.shape[-2], w.shape[-1]).T)      # [1,1,K,Cout] -> [Cout,K]
                 if L.a_log2 > 0:
-                    kind, aux = OP_PWCONV_F16S, L.a_log2
+                    kind, aux = (OP_PWCONV_PS if L.in_split else OP_PWCONV_F16S), L.a_log2
                     w, scale = split_pointwise_weights(w, L.a_log2)
             elif L.kind in (OP_DWCONV3X3, OP_DWPW_F32, OP_DWPW_F16S):
                 w = w.reshape(3, 3, -1)
+                if L.kind == OP_DWCONV3X3:
+                    aux = L.out_split
             w2 = None if L.w2 is None else np.ascontiguousarray(L.w2.reshape(L.w2.shape[-2], L.w2.shape[-1]).T)
             shift2 = L.shift2
             kw_field = L.kw
@@ -881,10 +886,34 @@ def choose_pointwise_math(layers: List[Layer], pw_math: str) -> None:
             raise LoweringError("%s: split-f16 pointwise needs a ReLU6-bounded input, k %% 32 == 0 and cout %% 64 == 0" % L.name)
 
 
+def presplit_activations(layers: List[Layer], keep: Sequence[int]) -> int:
+    """Storage-format pass: a standalone depthwise layer (ReLU6, c % 32 == 0) whose ONLY consumer is a split-f16 pointwise
+    layer that csrc/pwconv_ps.hip covers (cout % 128 == 0) stores its result already split -- the 128-byte "split rows"
+    the weight image uses -- and the GEMM takes both operands by LDS-DMA.  Same values, same 4 bytes per element; the
+    tensor simply never exists as fp32.  Returns the number of tensors converted."""
+    consumers: Dict[int, List[int]] = {}
+    for i, L in enumerate(layers):
+        for s in (L.src, L.res):
+            if s >= 0:
+                consumers.setdefault(s, []).append(i)
+    n = 0
+    for i, L in enumerate(layers):
+        if not (L.kind == OP_PWCONV_F32 and L.a_log2 > 0 and L.src >= 0):
+            continue
+        P = layers[L.src]
+        k, cout = L.in_shape[2], L.out_shape[2]
+        if (P.kind == OP_DWCONV3X3 and P.act == ACT_RELU6 and L.src not in keep and consumers.get(L.src, []) == [i] and
+                k % 32 == 0 and cout % 128 == 0 and 0 < L.a_log2 <= 12):
+            P.out_split = L.a_log2
+            L.in_split = True
+            n += 1
+    return n
+
+
 def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
                 feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32",
                 pw_math: Optional[str] = None, fuse_stem_block: Optional[bool] = None, stem_fusion: Optional[str] = None,
-                block_fusion: Optional[str] = None) -> Plan:
+                block_fusion: Optional[str] = None, presplit: Optional[str] = None) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase.
     fuse: merge depthwise -> pointwise pairs into one kernel where a fused kernel covers the shape.  stem_fusion:
     'stem2' (default; env HSEFR_FUSE_STEM=0|1only|1 changes the default) = conv1 + block 1 + the depthwise of block 2 in one
@@ -894,6 +923,8 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
     'none'.
     pw_math: 'auto' (default; env HSEFR_PW_MATH overrides the default) = split-f16 products for every pointwise layer
     whose input the graph bounds (ReLU6), fp32 MFMA otherwise; 'f32' = fp32 MFMA everywhere.
+    presplit: 'auto' (default; env HSEFR_PRESPLIT=auto|none) = depthwise layers feeding a split-f16 pointwise layer store
+    their result pre-split and the GEMM stages both operands by LDS-DMA (presplit_activations); 'none' = fp32 tensors.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
     (general KxK Conv2D, Pad, FusedBatchNorm / Mul+Add, residual Add, MaxPool 3x3/2, global AvgPool / Mean)."""
     in_node, _ = g.get_tensor_by_name(input_tensor)
@@ -972,5 +1003,10 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
             layers, remap = fuse_block_f16s(layers, [li for li, _ in out_layers.values()], block_fusion)
             out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
             tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
+        presplit = presplit or os.environ.get("HSEFR_PRESPLIT", "auto")
+        if presplit not in ("auto", "none"):
+            raise ValueError("presplit must be 'auto' or 'none', not %r" % (presplit,))
+        if presplit == "auto":
+            presplit_activations(layers, [li for li, _ in out_layers.values()])
     buffers = assign_buffers(layers, {li for li, _ in out_layers.values()})
     return Plan(layers, (input_hw[0], input_hw[1], low.in_c), buffers, out_layers, tensor_layer)

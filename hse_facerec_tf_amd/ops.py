@@ -72,6 +72,58 @@ def dwconv3x3(x, w_hwc, scale, shift, stride: int = 1, act: int = ACT_RELU6):
     return y
 
 
+def split_rows_encode(x, a_log2: int = 12):
+    """fp32 [..., c] (c % 32 == 0) -> the split-row image of it as a float16 tensor [..., c/32, 2, 32] ([..., 0, :] = hi,
+    [..., 1, :] = lo), computed with torch ops exactly as the kernels do: v = x * 2^a_log2, hi = f16(v), lo = f16(v - hi).
+    A reference / container helper for tests; the product path writes this format in dwconv.hip."""
+    torch = _lib.require_gpu()
+    c = x.shape[-1]
+    v = (x.float() * float(2 ** a_log2)).reshape(tuple(x.shape[:-1]) + (c // 32, 32))
+    hi = v.to(torch.float16)
+    lo = (v - hi.float()).to(torch.float16)
+    return torch.stack([hi, lo], dim=-2).contiguous()
+
+
+def split_rows_decode(xs, a_log2: int = 12):
+    """Inverse view of split rows: float16 [..., c/32, 2, 32] -> fp32 [..., c] = (hi + lo) / 2^a_log2 (exact in fp32
+    for values the split represents exactly; otherwise within 2^-22 relative)."""
+    v = xs[..., 0, :].float() + xs[..., 1, :].float()
+    return (v / float(2 ** a_log2)).reshape(tuple(xs.shape[:-3]) + (xs.shape[-3] * 32,))
+
+
+@_device_guarded
+def dwconv3x3_split(x, w_hwc, scale, shift, stride: int = 1, act: int = ACT_RELU6, a_log2: int = 12):
+    """dwconv3x3 with its result stored PRE-SPLIT for the GEMM behind it (csrc/dwconv.hip SPLIT): float16 tensor
+    [n, oh, ow, c/32, 2, 32] (same bytes as the fp32 tensor)."""
+    torch = _lib.require_gpu()
+    _f32c(x, "x"), _f32c(w_hwc, "w"), _f32c(scale, "scale"), _f32c(shift, "shift")
+    n, h, w, c = x.shape
+    oh, ow, pt, pl = _same(h, w, 3, stride)
+    y = torch.empty((n, oh, ow, max(c // 32, 0), 2, 32), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.lib().hsefr_dwconv3x3_bn_relu6_split(x.data_ptr(), w_hwc.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                         y.data_ptr(), n, h, w, c, stride, pt, pl, oh, ow, act, a_log2,
+                                                         _lib.current_stream_ptr()), "hsefr_dwconv3x3_bn_relu6_split")
+    return y
+
+
+@_device_guarded
+def pwconv1x1_presplit(xs, w_t, shift, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
+    """1x1 conv + shift + act on PRE-SPLIT activations xs = float16 [..., k/32, 2, 32] (csrc/pwconv_ps.hip); weights as for
+    pwconv1x1_f16split (a_log2 must be the exponent xs was split with)."""
+    torch = _lib.require_gpu()
+    _f32c(shift, "shift")
+    if not (xs.is_cuda and xs.dtype == torch.float16 and xs.is_contiguous() and xs.dim() >= 3 and tuple(xs.shape[-2:]) == (2, 32)):
+        raise ValueError("xs must be a contiguous float16 CUDA tensor [..., k/32, 2, 32]")
+    d_img, d_ds = prepared if prepared is not None else split_weights_device(w_t, xs.device, a_log2)
+    k = xs.shape[-3] * 32
+    cout = d_img.shape[0]
+    m = xs.numel() // (2 * k)
+    y = torch.empty(tuple(xs.shape[:-3]) + (cout,), dtype=torch.float32, device=xs.device)
+    _lib.check(_lib.lib().hsefr_pwconv1x1_presplit(xs.data_ptr(), d_img.data_ptr(), d_ds.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                                   m, k, cout, act, _lib.current_stream_ptr()), "hsefr_pwconv1x1_presplit")
+    return y
+
+
 @_device_guarded
 def pwconv1x1(x, w_t, shift, act: int = ACT_RELU6):
     """1x1 conv + shift + act on NHWC x [..., k]; w_t is the TF kernel transposed: [cout, k]."""

@@ -98,6 +98,9 @@ typedef enum hsefr_op_kind {
                                   image, oh,ow,cout = the block output, pad_t/pad_l = the conv's; w_off = fp32 pack
                                   [conv HWIO 864 | conv shift 32 | dw 3x3x32 288 | dw scale 32 | dw shift 32];
                                   w2_off = split rows [64][64 f16]; shift2_off = [2][64] descale, shift; reserved = a_log2 */
+    HSEFR_OP_PWCONV_PS = 16,   /* PWCONV_F16S whose INPUT buffer holds pre-split activations ("split rows", written by a
+                                  DWCONV3X3 op with `reserved` = a_log2 > 0): both GEMM operands go to LDS by DMA
+                                  (csrc/pwconv_ps.hip); operands as PWCONV_F16S; k % 32 == 0, cout % 128 == 0            */
     HSEFR_OP_STEM2_F16S = 15   /* the stem plus the depthwise of block 2 (csrc/stem2_fused.hip): ... -> pointwise 32->64 +
                                   shift + ReLU6 -> depthwise 3x3/2 + scale + shift + act.  h,w,cin = the image, oh,ow,cout =
                                   the stride-2 depthwise output (64 ch); pad_t/pad_l = conv1's; kh (sic) low byte = 3,
@@ -138,7 +141,9 @@ typedef struct hsefr_plan_op {
     int32_t oh, ow, cout; /* output                                                    */
     int32_t kh, kw, stride;
     int32_t pad_t, pad_l; /* TF SAME: pad_total//2 on top/left (0 for even input, k=3, s=2) */
-    int32_t reserved;   /* PWCONV_F16S: a_log2 (activation pre-scale exponent); 0 otherwise      */
+    int32_t reserved;   /* PWCONV_F16S / PWCONV_PS / fused kinds: a_log2 (activation pre-scale exponent);
+                           DWCONV3X3: 0 = fp32 output, a_log2 > 0 = output stored as split rows scaled by 2^a_log2
+                           (act must be ReLU6, c % 32 == 0); 0 otherwise */
     uint64_t w_off;     /* weights; layout depends on kind (see the per-kernel entry points) */
     uint64_t scale_off; /* per-channel scale (DWCONV), descale (PWCONV_F16S)                 */
     uint64_t shift_off; /* per-channel shift / bias                                          */
@@ -208,6 +213,14 @@ int hsefr_dwconv3x3_bn_relu6(const float* x, const float* wgt, const float* scal
                              float* y, int n, int h, int w, int c, int stride, int pad_t, int pad_l,
                              int oh, int ow, int act, hsefr_stream_t stream);
 
+/* The same depthwise layer with its result stored PRE-SPLIT for the split-f16 GEMM behind it: y_split holds, per pixel
+ * and 32-channel group, one 128-byte "split row" [hi(32 x f16) | lo(32 x f16)] with hi = f16(v * 2^a_log2),
+ * lo = f16(v * 2^a_log2 - hi) (same byte size as the fp32 tensor).  act must be HSEFR_ACT_RELU6 (the bound the split
+ * needs), a_log2 in 1..12, c multiple of 32. */
+int hsefr_dwconv3x3_bn_relu6_split(const float* x, const float* wgt, const float* scale, const float* shift, void* y_split,
+                                   int n, int h, int w, int c, int stride, int pad_t, int pad_l, int oh, int ow, int act,
+                                   int a_log2, hsefr_stream_t stream);
+
 /* Conv2D 1x1 (+ Add shift + ReLU6; graph nodes #45-49) as an fp32-MFMA GEMM:
  * x [m,k] (m = n*h*w pixels, NHWC), wgt_t [cout,k] = the TF kernel [1,1,k,cout] TRANSPOSED,
  * y [m,cout].  k multiple of 32, cout multiple of 64. */
@@ -222,6 +235,13 @@ int hsefr_pwconv1x1_bias_relu6(const float* x, const float* wgt_t, const float* 
  * descale[n] = 2^-(e_n + a_log2).  y = act(acc * descale + shift).  k multiple of 32, cout multiple of 64. */
 int hsefr_pwconv1x1_f16split(const float* x, const void* w_split, const float* descale, const float* shift, float* y,
                              long long m, int k, int cout, int a_log2, int act, hsefr_stream_t stream);
+
+/* The same layer on PRE-SPLIT activations (x_split = [m][k/32] split rows as hsefr_dwconv3x3_bn_relu6_split writes them,
+ * scaled by the 2^a_log2 that descale already undoes): both operands travel global -> LDS by DMA, the K loop carries no
+ * VALU (csrc/pwconv_ps.hip).  k multiple of 32, cout multiple of 128; HSEFR_ERR_UNSUPPORTED otherwise.  Same error bound
+ * as hsefr_pwconv1x1_f16split (not bit-identical to it: a different MFMA shape sums the products in another order). */
+int hsefr_pwconv1x1_presplit(const void* x_split, const void* w_split, const float* descale, const float* shift, float* y,
+                             long long m, int k, int cout, int act, hsefr_stream_t stream);
 
 /* One whole MobileNet block (graph nodes #35-#49 and their later twins) fused, for any c % 32 == 0 and cout % 64 == 0:
  * depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6 -> pointwise 1x1 + shift + act with split-f16 products.

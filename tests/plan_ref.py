@@ -65,6 +65,7 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
 
     mem = {}
     owner = {}
+    split_fmt = {}          # buffer -> a_log2 of the split rows it holds (0 = plain fp32): the storage-format contract
     x = x.astype(dtype)
     for i, o in enumerate(p["ops"]):
         (kind, act, in_buf, out_buf, res_buf, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l, _r,
@@ -89,10 +90,14 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             xp = np.pad(src, ((0, 0), (pad_t, pb), (pad_l, pr), (0, 0)))
             y = tfo.depthwise_conv2d(xp, k, (stride, stride), "VALID")
             y = _act(y * arr(sc_off, cin) + arr(sh_off, cin), act)
+            if _r:      # result stored as split rows for the GEMM behind it: same values, another storage format
+                assert act == 2 and cin % 32 == 0 and 0 < _r <= 12, "split-row depthwise output needs ReLU6, c % 32 == 0"
         elif kind == 3:
             wt = arr(w_off, cin * cout).reshape(cout, cin)
             y = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
-        elif kind == 12:     # split-f16 pointwise: the fp64 weights the two f16 planes stand for
+        elif kind in (12, 16):     # split-f16 pointwise (16: on pre-split input): the fp64 weights the two f16 planes stand for
+            assert split_fmt.get(in_buf, 0) == (_r if kind == 16 else 0), "op %d reads buffer %d in the wrong storage format" % (i, in_buf)
+            assert kind == 12 or (cin % 32 == 0 and cout % 128 == 0)
             from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
             img = np.frombuffer(data, np.uint16, cout * cin * 2, w_off).reshape(cout, cin // 32, 64)
             wt = unsplit_pointwise_weights(img, np.frombuffer(data, np.float32, cout, sc_off), _r).astype(dtype)
@@ -185,7 +190,10 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
         else:
             raise AssertionError("unknown op kind %d" % kind)
         assert y.shape[1:] == (oh, ow, cout), (i, y.shape, (oh, ow, cout))
+        if kind not in (12, 16):
+            assert split_fmt.get(in_buf, 0) == 0 or in_buf == -1, "op %d (kind %d) reads split rows it cannot decode" % (i, kind)
         mem[out_buf] = y
+        split_fmt[out_buf] = _r if kind == 2 else 0
     outs = {}
     for slot, name in enumerate(("features", "age_probs", "gender")):
         if p["out_buf"][slot] >= 0:
