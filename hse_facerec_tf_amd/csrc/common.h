@@ -212,6 +212,8 @@ void set_dwpws_bn(int v);
 void set_pw_tile(int v);
 void set_pws_tile(int v);
 void set_ps_mb(int v);
+void set_ps_grid(int v);
+int read_ps_stamps(void* host_out, size_t bytes);
 void set_pw_ablate(int v);
 void set_pw_dma(int v);
 void set_dw_th(int v);

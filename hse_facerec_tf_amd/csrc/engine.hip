@@ -221,6 +221,8 @@ int hsefr_debug_set(const char* key, int value) {
     HSEFR_REQUIRE(key, HSEFR_ERR_INVALID, "debug_set: null key");
     if (!strcmp(key, "pw_tile")) { set_pw_tile(value); return HSEFR_OK; }
     if (!strcmp(key, "pws_tile")) { set_pws_tile(value); return HSEFR_OK; }
+    if (!strcmp(key, "ps_mb")) { set_ps_mb(value); return HSEFR_OK; }
+    if (!strcmp(key, "ps_grid")) { set_ps_grid(value); return HSEFR_OK; }
     if (!strcmp(key, "c11")) { set_c11(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_look")) { set_dw_look(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_look2")) { set_dw_look2(value); return HSEFR_OK; }
@@ -244,7 +246,8 @@ int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_
 }
 
 int hsefr_debug_read_stamps(void* host_out, size_t bytes) {
-    // the split-f16 GEMM's stamps, or (bytes == 512*4*10*8) the fused stem's
+    // the split-f16 GEMM's stamps, (bytes == 512*4*10*8) the fused stem's, or (bytes == 256*12*8*8) the pre-split GEMM's
+    if (bytes == 256 * 12 * 8 * 8) return read_ps_stamps(host_out, bytes);
     return bytes == 512 * 4 * 10 * 8 ? read_stem_stamps(host_out, bytes) : read_pws_stamps(host_out, bytes);
 }
 

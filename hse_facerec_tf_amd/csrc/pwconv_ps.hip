@@ -18,15 +18,19 @@
 // no ds_write in the loop.  The K loop is: DMA issue for the step after next, ds_read_b128 fragments, MFMAs, one barrier.
 //
 // Shape of the kernel
-//   * ONE persistent workgroup of 8 waves per CU, tile (32 * MB) x 128 with MB = 8 or 9 (256 or 288 rows): every layer
+//   * ONE persistent workgroup of 12 waves per CU -- 8 MFMA waves and 4 loader waves that issue every DMA piece (a piece
+//     costs its wave 100+ cycles of issue stall with the queues busy; in a first version where the MFMA waves issued their
+//     own pieces right behind the step barrier both waves of a SIMD stalled together: 58 us per 36864 x 512 x 512 layer,
+//     half the matrix rate) -- tile (32 * MB) x 128 with MB = 8 or 9 (256 or 288 rows): every layer
 //     of MobileNet-192 at batch 256 has M = 9 * 2^k rows, so 288-row tiles fill whole rounds of 256 workgroups
 //     (36864 x 512 -> 512 tiles = 2.0 rounds, where 128 x 128 tiles gave 2.25 rounds that cost 3); 224-pixel inputs
 //     (M = 49 * 2^k) take whichever of the two needs fewer tile-rounds;
 //   * three LDS stages of (BM + 128) x 128 B (156 KB for MB = 9): the DMA runs TWO K-steps ahead of the MFMAs;
-//   * waves as 2 (M) x 4 (N), wave tile (16 * MB) x 32 on v_mfma_f32_16x16x32_f16 (one instruction per 32-deep K-step and
+//   * MFMA waves as 2 (M) x 4 (N), wave tile (16 * MB) x 32 on v_mfma_f32_16x16x32_f16 (one instruction per 32-deep K-step and
 //     product; it sustains a higher clock than 32x32x16 on this chip -- DESIGN.md lesson 10), operands swapped so a lane
 //     owns 4 consecutive output channels, 72 accumulator registers;
-//   * epilogue through a wave-private 4 KB scratch inside the stage the tile's last step has released: 128-B-line stores.
+//   * epilogue straight from the accumulators: a lane's 4 consecutive channels are one 16-byte store, an instruction covers
+//     16 rows x 64 B and the neighbouring channel block completes the lines (no LDS round trip, no barrier between tiles).
 //
 // Every output element is accumulated over K in ONE fixed order by ONE wave: results are bit-identical run to run and
 // independent of the grid.  (They are NOT bit-identical to pwconv_f16s.hip: a 16x16x32 MFMA sums its 32 products in a
@@ -40,6 +44,19 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef HSEFR_PS_STAMPS
+// Diagnostic build only (HSEFR_DEV=1 HSEFR_EXTRA_FLAGS=-DHSEFR_PS_STAMPS build.sh): per-wave s_memtime sums of the step phases.
+__device__ unsigned long long g_ps_stamps[256 * 12 * 8];
+#define PS_STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); st[i] += _t - tprev; tprev = _t; } while (0)
+#define PS_STAMP_DECL unsigned long long st[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tprev = __builtin_amdgcn_s_memtime(); const unsigned long long tstart = tprev
+#define PS_STAMP_FLUSH do { if (lane == 0 && blockIdx.x < 256) { unsigned long long* o = g_ps_stamps + (blockIdx.x * 12 + wave) * 8; \
+    for (int i_ = 0; i_ < 6; ++i_) o[i_] = st[i_]; o[6] = __builtin_amdgcn_s_memtime() - tstart; o[7] = nsteps; } } while (0)
+#else
+#define PS_STAMP(i) do { } while (0)
+#define PS_STAMP_DECL do { } while (0)
+#define PS_STAMP_FLUSH do { } while (0)
+#endif
+
 constexpr int ROWB = 128;       // bytes per split row: 32 hi halves | 32 lo halves
 constexpr int BN = 128;
 
@@ -47,24 +64,22 @@ constexpr int BN = 128;
 __device__ __forceinline__ int swz_key(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
 template <int MB, int ACT>
-__global__ __launch_bounds__(512, 1) void pwconv_ps_kernel(const void* __restrict__ xs, const void* __restrict__ wsplit,
+__global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restrict__ xs, const void* __restrict__ wsplit,
                                                            const float* __restrict__ descale, const float* __restrict__ shift,
                                                            float* __restrict__ y, long long M, int K, int Cout, unsigned tiles_n,
                                                            unsigned total_tiles, int reverse) {
     constexpr int BM = 32 * MB;
     constexpr int STAGE = (BM + BN) * ROWB;
-    constexpr int NPIECE = (BM + BN) / 8;          // 1-KiB DMA pieces per K-step (8 rows each)
-    constexpr int PPW_HI = (NPIECE + 7) / 8;       // pieces issued by waves 0 .. NPIECE % 8 - 1 (all of them if NPIECE % 8 == 0)
-    constexpr int N_HI = NPIECE % 8 == 0 ? 8 : NPIECE % 8;
-    constexpr int PPW_LO = NPIECE / 8;
-    constexpr int E_OFF = 3 * STAGE;               // epilogue constants of the current tile: [descale piece 1 KiB | shift piece 1 KiB]
-    static_assert(E_OFF + 2048 <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[E_OFF + 2048];
+    constexpr int NPIECE = (BM + BN) / 8;          // 1-KiB DMA pieces per K-step (8 rows each): 52 | 48
+    constexpr int PPW = NPIECE / 4;                // per loader wave: 13 | 12
+    static_assert(NPIECE % 4 == 0, "pieces divide over the four loader waves");
+    constexpr int E_OFF = 3 * STAGE;               // epilogue constants, by tile parity: [descale piece 1 KiB | shift piece 1 KiB] x 2
+    static_assert(E_OFF + 4096 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[E_OFF + 4096];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
     const int KT = K / 32;
     if (blockIdx.x >= total_tiles) return;
     const unsigned ntile = (total_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
@@ -79,59 +94,90 @@ __global__ __launch_bounds__(512, 1) void pwconv_ps_kernel(const void* __restric
         mm0 = (long long)tm * BM;
         nn0 = (lt - tm * tiles_n) * BN;
     };
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
 
-    // ---- DMA duty of this wave: pieces p = first_piece .. first_piece + npieces - 1 of every step ----------------------
-    const int npieces = wave < N_HI ? PPW_HI : PPW_LO;
-    const int first_piece = wave < N_HI ? wave * PPW_HI : N_HI * PPW_HI + (wave - N_HI) * PPW_LO;
-    unsigned pv[PPW_HI];          // per-lane byte offset of the piece's 16 B inside the A (or B) tile, K-step 0
-    {
+    if (wave >= 8) {
+        // =================================== loader waves 8..11: all the vector-memory reads ===================================
+        // (their issue stalls -- 100+ cycles per piece with the queues busy -- never hold up an MFMA wave's instruction stream)
+        const int lw = wave - 8;
+        unsigned pv[PPW];          // per-lane byte offset of the piece's 16 B inside the A (or B) tile, K-step 0
 #pragma unroll
-        for (int j = 0; j < PPW_HI; ++j) {
-            const int p = first_piece + (j < npieces ? j : 0);
+        for (int j = 0; j < PPW; ++j) {
+            const int p = lw * PPW + j;
             const int r = (p < BM / 8 ? p * 8 : (p - BM / 8) * 8) + (lane >> 3);     // row inside its own tile (A or B)
             pv[j] = (unsigned)r * rowbytes + 16u * (unsigned)((lane & 7) ^ swz_key(r));
         }
-    }
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-    auto piece = [&](const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
-        // issued from asm: hipcc serialises builtin LDS-DMA against every later ds_read (DESIGN.md lesson 15b)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
-                     "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff))
-                     : "memory");
-    };
-    __amdgpu_buffer_rsrc_t ra_rsrc, rb_rsrc;
-    unsigned pf_i = 0, pf_step = 0;
-    int pf_kt = 0;
-    auto setup_rsrc = [&](unsigned i) {
-        long long mm0;
-        int nn0;
-        tile_origin(i, mm0, nn0);
-        // rows beyond M / Cout fall outside the resource: the DMA writes ZEROS for them (tail tiles cost no branches)
-        ra_rsrc = make_rsrc((const char*)xs + mm0 * (long long)rowbytes, (M - mm0) * (long long)rowbytes);
-        rb_rsrc = make_rsrc((const char*)wsplit + (long long)nn0 * rowbytes, (long long)(Cout - nn0) * rowbytes);
-    };
-    auto issue_step = [&]() {      // DMA of the prefetch cursor's step into ring slot pf_step % 3; past the end it re-reads the last tile
-        const unsigned base = lds0 + (pf_step % 3u) * STAGE;
-        const unsigned so = (unsigned)pf_kt * 128u;
+        auto piece = [&](const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
+            // issued from asm: hipcc serialises builtin LDS-DMA against every later ds_read (DESIGN.md lesson 15b)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
+                         "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff))
+                         : "memory");
+        };
+        __amdgpu_buffer_rsrc_t ra_rsrc, rb_rsrc;
+        unsigned pf_i = 0, pf_step = 0;
+        int pf_kt = 0, pf_n0 = 0;
+        auto setup_rsrc = [&](unsigned i) {
+            long long mm0;
+            tile_origin(i, mm0, pf_n0);
+            // rows beyond M / Cout fall outside the resource: the DMA writes ZEROS for them (tail tiles cost no branches)
+            ra_rsrc = make_rsrc((const char*)xs + mm0 * (long long)rowbytes, (M - mm0) * (long long)rowbytes);
+            rb_rsrc = make_rsrc((const char*)wsplit + (long long)pf_n0 * rowbytes, (long long)(Cout - pf_n0) * rowbytes);
+        };
+        auto issue_step = [&]() {      // DMA of the prefetch cursor's step into ring slot pf_step % 3; past the end it re-reads the last tile
+            const unsigned base = lds0 + (pf_step % 3u) * STAGE;
+            const unsigned so = (unsigned)pf_kt * 128u;
 #pragma unroll
-        for (int j = 0; j < PPW_HI; ++j) {
-            if (j < npieces) {
-                const int p = first_piece + j;       // wave-uniform: the resource is picked with scalar selects
+            for (int j = 0; j < PPW; ++j) {
+                const int p = lw * PPW + j;       // wave-uniform: the resource is picked with scalar selects
                 piece(p < BM / 8 ? ra_rsrc : rb_rsrc, base + p * 1024, pv[j], so);
             }
+            ++pf_step;
+            if (++pf_kt == KT) {
+                pf_kt = 0;
+                setup_rsrc(++pf_i);
+            }
+        };
+        setup_rsrc(0);
+        int e_n0 = pf_n0;          // output-channel origin of the tile the MFMA waves are on
+        unsigned ci = 0;
+        int ckt = 0;
+        issue_step();
+        issue_step();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        __syncthreads();
+        PS_STAMP_DECL;
+        for (unsigned g = 0; g < nsteps; ++g) {
+            if (ckt == 0 && lw == 3) {
+                // The tile's epilogue constants travel by LDS-DMA too: descale[n0 .. n0+127] as lanes 0-31 of one piece,
+                // shift[..] as lanes 32-63 of a second one; the other half of each piece is out of range (zeros, unused).
+                // Issued AHEAD of this step's pieces, so the counted wait below covers them.  Two copies by tile parity: the
+                // MFMA waves may still be in the previous tile's epilogue (there is no barrier between tiles).
+                const __amdgpu_buffer_rsrc_t rd = make_rsrc(descale + e_n0, 512), rs = make_rsrc(shift + e_n0, 512);
+                const unsigned eb = lds0 + E_OFF + (ci & 1u) * 2048u;
+                piece(rd, eb, 16u * lane, 0u);
+                piece(rs, eb + 1024, 16u * (unsigned)(lane - 32), 0u);      // lanes 0-31 wrap to ~4 G: out of range
+            }
+            issue_step();                                   // step g + 2 into slot (g + 2) % 3 (released at the last barrier)
+            PS_STAMP(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // step g + 1 (and the constants) have landed: vmcnt retires in order
+            PS_STAMP(1);
+            __syncthreads();
+            PS_STAMP(2);
+            if (++ckt == KT) {
+                ckt = 0;
+                long long mm0;
+                tile_origin(++ci, mm0, e_n0);
+                __syncthreads();                            // pause while the MFMA waves store the tile (shared path to L2)
+                PS_STAMP(3);
+            }
         }
-        ++pf_step;
-        if (++pf_kt == KT) {
-            pf_kt = 0;
-            setup_rsrc(++pf_i);
-        }
-    };
-    auto wait_all_but_last_step = [&]() {      // everything older than the step issued last has landed (vmcnt retires in order)
-        if (wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW_HI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW_LO) : "memory");
-    };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the run-ahead pieces must not outlive the workgroup's LDS
+        PS_STAMP_FLUSH;
+        return;
+    }
 
-    // ---- MFMA duty: wave tile rows [wm * 16 MB, +16 MB) x columns [wn * 32, +32) --------------------------------------
+    // =================================== MFMA waves 0..7: wave tile rows [wm * 16 MB, +16 MB) x columns [wn * 32, +32) ===================================
+    const int wm = wave >> 2, wn = wave & 3;
     const int l16 = lane & 15, lq = lane >> 4;
     // fragment byte offsets inside a stage: row (base + l16), logical chunk lq (hi) / 4 + lq (lo); + 16-row block strides
     const int arow = wm * 16 * MB + l16, brow = BM + wn * 32 + l16;
@@ -147,116 +193,106 @@ __global__ __launch_bounds__(512, 1) void pwconv_ps_kernel(const void* __restric
     };
     zero_acc();
 
-    // epilogue geometry: lane reads back row (lane >> 3) + 8 i of a 32-row scratch, 16-B chunk (lane & 7) = 4 channels
-    const int erow = lane >> 3, ech = lane & 7;
-    const unsigned yvoff = ((unsigned)(wm * 16 * MB + erow) * (unsigned)Cout + (unsigned)(wn * 32 + 4 * ech)) * 4u;
+    // epilogue geometry: row l16 of each 16-row block, channels 4 lq .. 4 lq + 3 of each 16-channel block
+    const unsigned yvoff = ((unsigned)(wm * 16 * MB + l16) * (unsigned)Cout + (unsigned)(wn * 32 + 4 * lq)) * 4u;
 
     long long m0;
     int n0;
     unsigned ci = 0;
     int ckt = 0;
     tile_origin(0, m0, n0);
-    setup_rsrc(0);
-    issue_step();
-    issue_step();
-    wait_all_but_last_step();
-    __syncthreads();
+    __syncthreads();                                        // (the loaders' prologue barrier: step 0 has landed)
+    PS_STAMP_DECL;
+
+    // The MFMAs of a step's LAST HB row blocks are held back until after the step barrier: their fragments are already in
+    // registers, so the matrix pipe has work while the barrier resolves and the next step's first fragments come out of LDS
+    // (stamps of the first version: 14 % of the K loop with both waves of a SIMD waiting).  A tile's first step finds
+    // zero fragments there (adding +0 changes nothing); its last step runs its own held-back blocks before the epilogue.
+    // Per accumulator the products are still added in step order: same bits as without the hold-back.
+    constexpr int HB = 2;
+    const f16x8 fzero = {0, 0, 0, 0, 0, 0, 0, 0};
+    f16x8 h_ah[HB], h_al[HB], h_bh0 = fzero, h_bl0 = fzero, h_bh1 = fzero, h_bl1 = fzero;
+#pragma unroll
+    for (int i = 0; i < HB; ++i) h_ah[i] = h_al[i] = fzero;
+    auto mfma_block = [&](int mb, const f16x8& xh, const f16x8& xl, const f16x8& wh0, const f16x8& wl0, const f16x8& wh1, const f16x8& wl1) {
+        // per accumulator the products keep the order (wh*al, wl*ah, wh*ah) of pwconv_f16s.hip
+        acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xl, acc[mb][0], 0, 0, 0);
+        acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xl, acc[mb][1], 0, 0, 0);
+        acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl0, xh, acc[mb][0], 0, 0, 0);
+        acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl1, xh, acc[mb][1], 0, 0, 0);
+        acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xh, acc[mb][0], 0, 0, 0);
+        acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xh, acc[mb][1], 0, 0, 0);
+    };
 
     for (unsigned g = 0; g < nsteps; ++g) {
-        const bool last = ckt == KT - 1;
-        if (ckt == 0 && wave == 7) {
-            // The tile's epilogue constants travel by LDS-DMA too (no VGPR, no compiler-side wait): descale[n0 .. n0+127] as
-            // lanes 0-31 of one piece, shift[..] as lanes 32-63 of a second one; the other half of each piece is out of range
-            // (zeros, unused).  Issued AHEAD of this step's pieces, so the counted wait below covers them; the previous
-            // tile's epilogue is behind a barrier.
-            const __amdgpu_buffer_rsrc_t rd = make_rsrc(descale + n0, 512), rs = make_rsrc(shift + n0, 512);
-            piece(rd, lds0 + E_OFF, 16u * lane, 0u);
-            piece(rs, lds0 + E_OFF + 1024, 16u * (unsigned)(lane - 32), 0u);      // lanes 0-31 wrap to ~4 G: out of range
-        }
-        issue_step();                                   // step g + 2 into slot (g + 2) % 3 (released at the last barrier)
-        const unsigned char* st = smem + (g % 3u) * STAGE;
-        const f16x8 bh0 = *(const f16x8*)(st + b_hi), bl0 = *(const f16x8*)(st + b_lo);
-        const f16x8 bh1 = *(const f16x8*)(st + b_hi + 16 * ROWB), bl1 = *(const f16x8*)(st + b_lo + 16 * ROWB);
+        const unsigned char* stg = smem + (g % 3u) * STAGE;
+        const f16x8 bh0 = *(const f16x8*)(stg + b_hi), bl0 = *(const f16x8*)(stg + b_lo);
+        const f16x8 bh1 = *(const f16x8*)(stg + b_hi + 16 * ROWB), bl1 = *(const f16x8*)(stg + b_lo + 16 * ROWB);
         f16x8 ah[MB], al[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-            ah[mb] = *(const f16x8*)(st + a_hi + mb * 16 * ROWB);
-            al[mb] = *(const f16x8*)(st + a_lo + mb * 16 * ROWB);
+            ah[mb] = *(const f16x8*)(stg + a_hi + mb * 16 * ROWB);
+            al[mb] = *(const f16x8*)(stg + a_lo + mb * 16 * ROWB);
         }
-        // two row blocks at a time: four independent accumulators between two MFMAs on the same one; per accumulator the
-        // products keep the order (wh*al, wl*ah, wh*ah) of pwconv_f16s.hip
+        // (1) the previous step's held-back blocks, (2) this step's blocks 0 .. MB - HB - 1
 #pragma unroll
-        for (int mb = 0; mb < MB; mb += 2) {
+        for (int i = 0; i < HB; ++i) mfma_block(MB - HB + i, h_ah[i], h_al[i], h_bh0, h_bl0, h_bh1, h_bl1);
 #pragma unroll
-            for (int pdt = 0; pdt < 3; ++pdt)
+        for (int mb = 0; mb < MB - HB; ++mb) mfma_block(mb, ah[mb], al[mb], bh0, bl0, bh1, bl1);
+        // schedule: weight fragments + PRE row blocks of activation fragments up front, then per group of six MFMAs the two
+        // reads of one more row block in their shadow; the first HB groups need none of this step's reads
+        constexpr int PRE = 2;
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * PRE, 0);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (mb + h < MB) {
-                        const f16x8 a = pdt == 0 ? al[mb + h] : ah[mb + h];
-                        acc[mb + h][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pdt == 1 ? bl0 : bh0, a, acc[mb + h][0], 0, 0, 0);
-                        acc[mb + h][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pdt == 1 ? bl1 : bh1, a, acc[mb + h][1], 0, 0, 0);
-                    }
-                }
-        }
-        // schedule: the weight fragments and PRE row blocks of activation fragments up front, then per row block its six
-        // MFMAs with the two reads of the block PRE further down in their shadow (LDS latency never exposed, ~40 fragment
-        // registers live)
-        constexpr int PRE = 4;
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * (PRE < MB ? PRE : MB), 0);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
+        for (int grp = 0; grp < MB; ++grp) {
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-            if (mb + PRE < MB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (grp + PRE < MB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
-        wait_all_but_last_step();                       // step g + 1 (and this tile's constants) have landed
-        __syncthreads();                                // ... for every wave; slot g % 3 is released
-        if (last) {
-            // lane (l16, lq) holds, per 16 x 16 block, channels 4 lq .. 4 lq + 3 of row l16 (operands swapped).  Two row
-            // blocks at a time go through a wave-private 32-row x 128 B scratch in the released slot and leave as
-            // stores of 8 rows x 128 B: whole lines.
-            unsigned char* scr = smem + (g % 3u) * STAGE + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < HB; ++i) { h_ah[i] = ah[MB - HB + i]; h_al[i] = al[MB - HB + i]; }
+        h_bh0 = bh0; h_bl0 = bl0; h_bh1 = bh1; h_bl1 = bl1;
+        PS_STAMP(0);
+        __syncthreads();                                // step g + 1 has landed (the loaders waited for it); slot g % 3 is released
+        PS_STAMP(1);
+        if (++ckt == KT) {
+#pragma unroll
+            for (int i = 0; i < HB; ++i) mfma_block(MB - HB + i, h_ah[i], h_al[i], h_bh0, h_bl0, h_bh1, h_bl1);
+#pragma unroll
+            for (int i = 0; i < HB; ++i) h_ah[i] = h_al[i] = fzero;
+            h_bh0 = h_bl0 = h_bh1 = h_bl1 = fzero;
+            // lane (l16, lq) holds, per 16 x 16 block, channels 4 lq .. 4 lq + 3 of row l16 (operands swapped): 16 bytes.
+            // Stored as they are: one instruction covers 16 rows x 64 contiguous bytes, the block of the other 16 channels
+            // completes the 128-byte lines right behind it (L2 merges the halves).  The store path of a CU (64 B/clk to L2)
+            // is shared with the loaders' DMA: they pause at the barrier below until the tile is out (stamps: 2300 cycles
+            // of stores alone became 6500-7200 when both ran together, all of it MFMA-wave stall).
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + m0 * Cout + n0, ((M - m0) * Cout - n0) * 4ll);
-            const f32x4 e_ds = *(const f32x4*)(smem + E_OFF + (wn * 32 + 4 * ech) * 4);
-            const f32x4 e_sh = *(const f32x4*)(smem + E_OFF + 1024 + 512 + (wn * 32 + 4 * ech) * 4);
+            f32x4 e_ds[2], e_sh[2];
 #pragma unroll
-            for (int pr = 0; pr < (MB + 1) / 2; ++pr) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int mb = 2 * pr + h;
-                    if (mb < MB) {
-                        const int r = 16 * h + l16;
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) *(f32x4*)(scr + r * 128 + 16 * ((4 * nb + lq) ^ (r & 7))) = acc[mb][nb];
-                    }
-                }
-                f32x4 rb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = erow + 8 * i;
-                    if (2 * pr * 16 + 8 * i < 16 * MB) rb[i] = *(const f32x4*)(scr + r * 128 + 16 * (ech ^ (r & 7)));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (2 * pr * 16 + 8 * i < 16 * MB) {          // the odd last block of MB = 9 fills only half the scratch
-                        f32x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(fmaf(rb[i][e], e_ds[e], e_sh[e]));
-                        // rows beyond M fall outside the resource and are dropped by the hardware
-                        // (asm store with its wait state welded on: every vector-memory wait in this kernel is explicit)
-                        bstore16_welded(o, ry, yvoff, __builtin_amdgcn_readfirstlane((unsigned)(32 * pr + 8 * i) * (unsigned)Cout * 4u));
-                    }
-                }
+            for (int nb = 0; nb < 2; ++nb) {
+                e_ds[nb] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * 2048 + (wn * 32 + 16 * nb + 4 * lq) * 4);
+                e_sh[nb] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * 2048 + 1024 + 512 + (wn * 32 + 16 * nb + 4 * lq) * 4);
             }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(fmaf(acc[mb][nb][e], e_ds[nb][e], e_sh[nb][e]));
+                    // rows beyond M fall outside the resource and are dropped by the hardware
+                    // (asm store with its wait state welded on: every vector-memory wait in this kernel is explicit)
+                    bstore16_welded(o, ry, yvoff + 64u * nb, __builtin_amdgcn_readfirstlane((unsigned)(16 * mb) * (unsigned)Cout * 4u));
+                }
             zero_acc();
             ckt = 0;
-            ++ci;
-            tile_origin(ci, m0, n0);
-            __syncthreads();                            // the scratch is the slot the next iteration's DMA refills
-        } else {
-            ++ckt;
+            tile_origin(++ci, m0, n0);
+            PS_STAMP(2);
+            __syncthreads();                            // lets the loaders go on
+            PS_STAMP(3);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the run-ahead DMA pieces must not outlive the workgroup's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stores issued from asm: drained before the wave ends
+    PS_STAMP_FLUSH;
 }
 
 // Tile height: 32 * MB rows with MB = 9 or 8, whichever costs fewer (rounds of 256 workgroups) x (rows per tile).
@@ -273,6 +309,7 @@ int choose_mb(long long m, int cout, int forced) {
 }
 
 HSEFR_KNOB(g_ps_mb, 0);   // dev builds: 8 | 9 = forced tile height / 32
+HSEFR_KNOB(g_ps_grid, 0); // dev builds: > 0 = forced number of persistent workgroups (contention experiments)
 
 template <int MB>
 int launch_mb(const void* xs, const void* wsplit, const float* descale, const float* shift, float* y, long long m, int k, int cout,
@@ -281,9 +318,10 @@ int launch_mb(const void* xs, const void* wsplit, const float* descale, const fl
     const unsigned tiles_n = cout / BN;
     const long long total = tiles_m * tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit: too many tiles");
-    const unsigned g = (unsigned)(total < 256 ? total : 256);
+    unsigned g = (unsigned)(total < 256 ? total : 256);
+    if (g_ps_grid > 0 && (unsigned)g_ps_grid < g) g = (unsigned)g_ps_grid;
 #define HSEFR_PS_LAUNCH(A)                                                                                                 \
-    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A>), dim3(g), dim3(512), 0, s, xs, wsplit, descale, shift, y, m, k, cout, tiles_n, \
+    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, y, m, k, cout, tiles_n, \
                        (unsigned)total, sweep_reverse())
     if (act == HSEFR_ACT_RELU6) HSEFR_PS_LAUNCH(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_PS_LAUNCH(HSEFR_ACT_RELU);
@@ -297,6 +335,18 @@ int launch_mb(const void* xs, const void* wsplit, const float* descale, const fl
 
 #ifdef HSEFR_DEV
 void set_ps_mb(int v) { g_ps_mb = v; }
+void set_ps_grid(int v) { g_ps_grid = v; }
+int read_ps_stamps(void* host_out, size_t bytes) {
+#ifdef HSEFR_PS_STAMPS
+    HSEFR_REQUIRE(bytes <= sizeof(unsigned long long) * 256 * 12 * 8, HSEFR_ERR_INVALID, "read_ps_stamps: too many bytes");
+    HSEFR_HIP_CHECK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ps_stamps), bytes));
+    return HSEFR_OK;
+#else
+    (void)host_out; (void)bytes;
+    set_error("read_ps_stamps: library built without -DHSEFR_PS_STAMPS");
+    return HSEFR_ERR_UNSUPPORTED;
+#endif
+}
 #endif
 
 bool pwconv_ps_supported(long long m, int k, int cout) {
