@@ -886,6 +886,12 @@ def choose_pointwise_math(layers: List[Layer], pw_math: str) -> None:
             raise LoweringError("%s: split-f16 pointwise needs a ReLU6-bounded input, k %% 32 == 0 and cout %% 64 == 0" % L.name)
 
 
+# Measured on MI355X at the BASELINE batch sizes (tools/kbench_ps.py, bench.py --layers): the LDS-DMA GEMM wins where the
+# contraction is deep enough for its 288-row tiles to pay for their long epilogue -- 37 vs 41 us at K = 256, 53 vs 64 us at
+# K = 512, 50 vs 62-78 us at K = 1024 -- and loses on the HBM-bound K = 64 / 128 layers (61 vs 54 us), which keep fp32 tensors.
+PRESPLIT_MIN_K = 256
+
+
 def presplit_activations(layers: List[Layer], keep: Sequence[int]) -> int:
     """Storage-format pass: a standalone depthwise layer (ReLU6, c % 32 == 0) whose ONLY consumer is a split-f16 pointwise
     layer that csrc/pwconv_ps.hip covers (cout % 128 == 0) stores its result already split -- the 128-byte "split rows"
@@ -903,7 +909,7 @@ def presplit_activations(layers: List[Layer], keep: Sequence[int]) -> int:
         P = layers[L.src]
         k, cout = L.in_shape[2], L.out_shape[2]
         if (P.kind == OP_DWCONV3X3 and P.act == ACT_RELU6 and L.src not in keep and consumers.get(L.src, []) == [i] and
-                k % 32 == 0 and cout % 128 == 0 and 0 < L.a_log2 <= 12):
+                k % 32 == 0 and k >= PRESPLIT_MIN_K and cout % 128 == 0 and 0 < L.a_log2 <= 12):
             P.out_split = L.a_log2
             L.in_split = True
             n += 1

@@ -264,11 +264,12 @@ def test_pointwise_math_selection_and_split_weight_image(graph):
     pws = [L for L in plan.layers if L.kind == lowering.OP_PWCONV_F32]
     assert len(pws) == 12 and all(L.a_log2 == 12 for L in pws)          # pw_2 .. pw_13 (pw_1 lives in the fused stem)
     wire = [o[0] for o in plan_ref.parse(plan.serialize())["ops"]]
-    # pw_2 reads the fused stem's fp32 output (wire kind 12); the other eleven read a depthwise layer that stores its
-    # result pre-split for them (wire kind 16, round 2) -- and that depthwise op carries the split exponent
-    assert wire.count(lowering.OP_PWCONV_F16S) == 1 and wire.count(lowering.OP_PWCONV_PS) == 11 and lowering.OP_PWCONV_F32 not in wire
+    # pw_2 reads the fused stem's fp32 output, pw_3 / pw_4 are shallow (K = 128): wire kind 12; the nine layers with
+    # K >= 256 read a depthwise layer that stores its result pre-split for them (wire kind 16, round 2) -- and that
+    # depthwise op carries the split exponent
+    assert wire.count(lowering.OP_PWCONV_F16S) == 3 and wire.count(lowering.OP_PWCONV_PS) == 9 and lowering.OP_PWCONV_F32 not in wire
     ops_ = plan_ref.parse(plan.serialize())["ops"]
-    assert sum(1 for o in ops_ if o[0] == lowering.OP_DWCONV3X3 and o[16] == 12) == 11
+    assert sum(1 for o in ops_ if o[0] == lowering.OP_DWCONV3X3 and o[16] == 12) == 9
     plain = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), block_fusion="none", presplit="none")
     wire0 = [o[0] for o in plan_ref.parse(plain.serialize())["ops"]]
     assert wire0.count(lowering.OP_PWCONV_F16S) == 12 and lowering.OP_PWCONV_PS not in wire0

@@ -141,7 +141,8 @@ def test_presplit_gemm_rejects_uncovered_shapes(env):
 
 def test_whole_network_presplit_vs_fp32_tensors(env):
     """The engine with pre-split activations (default) against the same plan with fp32 tensors and the register-staged
-    GEMM: embeddings agree to round-off, and the lowering really converted the nine depthwise -> pointwise tensors."""
+    GEMM: embeddings agree to round-off, and the lowering really converted the eight deep (K >= 256) depthwise -> pointwise
+    tensors."""
     torch, ops = env
     from hse_facerec_tf_amd import graphdef, lowering
     from hse_facerec_tf_amd.engine import Engine
@@ -150,7 +151,7 @@ def test_whole_network_presplit_vs_fp32_tensors(env):
     fetch = {0: "global_pooling/Mean:0", 1: "age_pred/Softmax:0", 2: "gender_pred/Sigmoid:0"}
     pa = lowering.lower_graph(g, "input_1:0", fetch, (192, 192))
     pb = lowering.lower_graph(g, "input_1:0", fetch, (192, 192), presplit="none")
-    assert sum(1 for L in pa.layers if L.in_split) == 9 and sum(1 for L in pa.layers if L.out_split) == 9
+    assert sum(1 for L in pa.layers if L.in_split) == 8 and sum(1 for L in pa.layers if L.out_split) == 8
     assert not any(L.in_split or L.out_split for L in pb.layers)
     x = torch.from_numpy(np.random.RandomState(5).uniform(-128, 128, (5, 192, 192, 3)).astype(np.float32)).cuda()
     ea, eb = Engine(pa, max_batch=5), Engine(pb, max_batch=5)
