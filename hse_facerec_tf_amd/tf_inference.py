@@ -128,27 +128,98 @@ class TensorFlowInference:
         return self.engine.forward(x, (OUT_FEATURES,))["features"]
 
     def extract_files(self, paths: Sequence[str], batch: int = 256, crop_center: bool = False,
-                      device_preprocess: bool = True) -> np.ndarray:
+                      device_preprocess: bool = True, workers: Optional[int] = None, stats: Optional[dict] = None) -> np.ndarray:
         """The loop of facerec_test.py:394 with the per-image sess.run replaced by batched forwards.
-        With device_preprocess the host only decodes the files; runs of same-size images are resized
-        on the GPU (identical results: the resize is integer arithmetic)."""
+
+        device_preprocess (default): a PIPELINE -- `workers` host threads decode the files (PIL releases the GIL inside its
+        decoders; default: the cores this process may use, at most 32), decoded same-size images are packed into pinned
+        staging buffers, copied to the device on a copy stream (double-buffered) and resized + mean-subtracted + run through
+        the network on the compute stream while the next chunk decodes and uploads; features come back through pinned
+        memory.  The resize is integer arithmetic and a forward does not depend on how images are batched: results are
+        bit-identical to the serial per-image path (tests/test_pipeline_gpu.py).
+        crop_center or device_preprocess=False: the host does the reference's own preprocessing, image by image.
+        stats (optional dict) receives wall seconds of the run and the number of chunks."""
         batch = min(batch, self.engine.max_batch)
-        feats: List[np.ndarray] = []
-        for i in range(0, len(paths), batch):
-            chunk = paths[i:i + batch]
-            if device_preprocess and not crop_center:
-                imgs = [preprocess.imread_rgb(p) for p in chunk]
-                out = np.empty((len(imgs), self.feature_dim), np.float32)
+        if not (device_preprocess and not crop_center):
+            feats: List[np.ndarray] = []
+            for i in range(0, len(paths), batch):
+                xs = np.stack([self.preprocess_image(p, crop_center) for p in paths[i:i + batch]]).astype(np.float32)
+                feats.append(self.extract_batch(xs))
+            return np.concatenate(feats) if feats else np.zeros((0, self.feature_dim), np.float32)
+        return self._extract_files_pipelined(list(paths), batch, workers, stats)
+
+    def _extract_files_pipelined(self, paths: List[str], batch: int, workers: Optional[int], stats: Optional[dict]) -> np.ndarray:
+        import time
+        from concurrent.futures import ThreadPoolExecutor
+        from . import preprocess_device
+        torch = _lib.require_gpu()
+        n = len(paths)
+        out_host = torch.empty((n, self.feature_dim), dtype=torch.float32).pin_memory() if n else torch.empty((0, self.feature_dim))
+        if n == 0:
+            return out_host.numpy()
+        if workers is None:
+            try:
+                workers = len(os.sched_getaffinity(0))
+            except AttributeError:
+                workers = os.cpu_count() or 1
+            workers = max(1, min(workers, 32))
+        dev = self.engine.device
+        t0 = time.perf_counter()
+        chunks = [(i, min(i + batch, n)) for i in range(0, n, batch)]
+        with torch.cuda.device(dev), ThreadPoolExecutor(max_workers=workers) as pool:
+            compute = torch.cuda.current_stream(dev)
+            copy = torch.cuda.Stream(device=dev)
+            LOOK = 2                                          # chunks decoding ahead of the one on the GPU
+            futs = {}
+
+            def submit(ci):
+                if ci < len(chunks) and ci not in futs:
+                    lo, hi = chunks[ci]
+                    futs[ci] = [pool.submit(preprocess.imread_rgb, p) for p in paths[lo:hi]]
+            for ci in range(min(LOOK, len(chunks))):
+                submit(ci)
+            staging = {}                                      # (slot, H, W) -> pinned uint8 buffer [batch, H, W, 3]
+            slot_done = [None, None]                          # event: the GPU has consumed staging slot k
+            for ci, (lo, hi) in enumerate(chunks):
+                submit(ci + LOOK)
+                imgs = [f.result() for f in futs.pop(ci)]
+                slot = ci & 1
+                if slot_done[slot] is not None:
+                    slot_done[slot].synchronize()             # its uploads have been consumed: the pinned buffers are free
                 groups = {}
                 for j, im in enumerate(imgs):
                     groups.setdefault(im.shape[:2], []).append(j)
-                for _, idx in groups.items():
-                    out[idx] = self.extract_images(np.stack([imgs[j] for j in idx])).cpu().numpy()
-                feats.append(out)
-            else:
-                xs = np.stack([self.preprocess_image(p, crop_center) for p in chunk]).astype(np.float32)
-                feats.append(self.extract_batch(xs))
-        return np.concatenate(feats) if feats else np.zeros((0, self.feature_dim), np.float32)
+                for (H, W), idx in groups.items():
+                    key = (slot, H, W)
+                    buf = staging.get(key)
+                    if buf is None:
+                        buf = staging[key] = torch.empty((batch, H, W, 3), dtype=torch.uint8).pin_memory()
+                    hb = buf.numpy()
+                    for k, j in enumerate(idx):
+                        hb[k] = imgs[j]
+                    with torch.cuda.stream(copy):
+                        d_u8 = buf[:len(idx)].to(dev, non_blocking=True)
+                        up = torch.cuda.Event()
+                        up.record(copy)
+                    compute.wait_event(up)
+                    d_u8.record_stream(compute)
+                    x = preprocess_device.preprocess_pil(d_u8, (self.w, self.h), self.convert2BGR, self.imageNetUtilsMean)
+                    f = self.engine.forward(x, (OUT_FEATURES,))["features"]
+                    rows = torch.as_tensor(idx, dtype=torch.int64) + lo
+                    if len(idx) == hi - lo:                   # the usual case: one size per chunk -> one contiguous copy back
+                        out_host[lo:hi].copy_(f, non_blocking=True)
+                    else:
+                        tmp = f.cpu()
+                        out_host[rows] = tmp
+                ev = torch.cuda.Event()
+                ev.record(compute)
+                slot_done[slot] = ev
+            compute.synchronize()
+        if stats is not None:
+            stats["seconds"] = time.perf_counter() - t0
+            stats["chunks"] = len(chunks)
+            stats["workers"] = workers
+        return out_host.numpy().copy()
 
 
 def extract_dataset(tfInference, dataset_path: str, features_file: Optional[str] = None, batch: int = 256,

@@ -239,3 +239,28 @@ def test_batch_256_properties_at_full_size(torch_):
     ref = tfo.GraphOracle(MODEL_PB, np.float64).run(FETCH[0], {"input_1:0": x[rows].cpu().numpy()})
     assert rel(full[rows].cpu().numpy(), ref) < BAR
     tfi.close_session()
+
+
+def test_vgg2_mobilenet_shaped_graph_through_the_reference_registry(torch_, tmp_path):
+    """facerec_test.py:212 exactly: TensorFlowInference('models/vgg2_mobilenet.pb', input_tensor='input_1:0',
+    output_tensor='reshape_1/Reshape:0', learning_phase_tensor='conv1_bn/keras_learning_phase:0', convert2BGR=True,
+    imageNetUtilsMean=True) on a graph of that file's shape (tests/keras_mobilenet_graph.py: all 13 blocks, un-folded
+    BatchNormalization behind learning-phase Switch/Merge, Relu6, reshape_1) at 192x192 -- against the unfused oracle at the
+    1e-4 bar and against the shipped folded trunk."""
+    import keras_mobilenet_graph as kg
+    from hse_facerec_tf_amd import get_tf_face_recognizer, TensorFlowInference
+    data = kg.build(MODEL_PB, 192)
+    (tmp_path / "vgg2_mobilenet.pb").write_bytes(data)
+    tfi = get_tf_face_recognizer("vgg2_mobilenet", models_dir=str(tmp_path), max_batch=8)
+    assert (tfi.w, tfi.h) == (192, 192) and tfi.feature_dim == 1024 and tfi.tf_learning_phase == 'conv1_bn/keras_learning_phase:0'
+    x = np.random.RandomState(212).uniform(-128, 128, (3, 192, 192, 3)).astype(np.float32)
+    got = tfi.extract_batch(x)
+    want = tfo.GraphOracle(tfo.parse_graphdef(data), np.float64).run(
+        "reshape_1/Reshape:0", {"input_1:0": x[:2], "conv1_bn/keras_learning_phase:0": 0}).reshape(2, -1)
+    assert rel(got[:2], want) < 1e-4
+    folded = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(192, 192), max_batch=8)
+    assert rel(got, folded.extract_batch(x)) < 1e-5
+    # the file-path API of the reference on its demo image (preprocess_image + one run, facerec_test.py:114-122)
+    f1 = tfi.extract_features(TEST_IMAGE)
+    assert f1.shape == (1024,) and rel(f1, folded.extract_features(TEST_IMAGE)) < 1e-5
+    tfi.close_session(), folded.close_session()

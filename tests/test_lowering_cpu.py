@@ -296,3 +296,26 @@ def test_pointwise_math_selection_and_split_weight_image(graph):
     assert not img.any() and np.isfinite(descale).all()
     with pytest.raises(lowering.LoweringError):
         lowering.split_pointwise_weights(np.zeros((64, 48), np.float32))
+
+
+def test_full_keras_mobilenet_graph_of_the_missing_files_shape():
+    """The whole 13-block graph in the form of the reference's missing vgg2_mobilenet.pb (facerec_test.py:212): un-folded
+    BatchNormalization behind keras_learning_phase Switch/Merge after EVERY convolution, Relu6 ops, reshape_1/Reshape output.
+    It must lower to the very plan the shipped (folded, quantised) trunk lowers to, and compute the same function."""
+    import keras_mobilenet_graph as kg
+    from conftest import MODEL_PB
+    data = kg.build(MODEL_PB, 64)
+    g = graphdef.read_graph(data)
+    feeds = {"conv1_bn/keras_learning_phase:0": 0}
+    plan = lowering.lower_graph(g, "input_1:0", {OUT_FEATURES: "reshape_1/Reshape:0"}, None, feeds)
+    shipped = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0"}, (64, 64))
+    assert [L.kind for L in plan.layers] == [L.kind for L in shipped.layers]
+    assert [(L.a_log2, L.out_split, L.in_split) for L in plan.layers] == [(L.a_log2, L.out_split, L.in_split) for L in shipped.layers]
+    x = np.random.RandomState(0).uniform(-128, 128, (2, 64, 64, 3)).astype(np.float32)
+    got = plan_ref.run(plan.serialize(), x)["features"]
+    ref = tfo.GraphOracle(tfo.parse_graphdef(data)).run("reshape_1/Reshape:0", {"input_1:0": x, "conv1_bn/keras_learning_phase:0": 0})
+    assert ref.shape == (2, 1, 1, 1024)
+    assert rel(got, ref.reshape(2, -1)) < 1e-5
+    assert rel(got, plan_ref.run(shipped.serialize(), x)["features"]) < 1e-5          # == the shipped trunk's function
+    with pytest.raises(lowering.LoweringError):        # learning phase not fed
+        lowering.lower_graph(g, "input_1:0", {OUT_FEATURES: "reshape_1/Reshape:0"})
