@@ -19,6 +19,7 @@ rank 0 (contract in the task statement) with these extra objects:
                  S = ceil(N/P) per rank -> device preprocessing + extract -> ONE all-gather -> L2-normalise ->
                  stratified 50/50 split -> 1-NN (4582 x 4582 x 1024), wall time per phase
                  (facerec_test.py:377-432).
+  pipeline       (N = 1) the callers' view: H2D-inclusive and file-inclusive faces/s, never `value`.
   other_configs  (N = 1) the other BASELINE configs measured in the same process: ResNet-50 batch 128 bf16,
                  age/gender MobileNet-224 batch 512 with three outputs, MobileNet-192 with strict-fp32 pointwise
                  products.
@@ -54,6 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the H2D-inclusive / file-inclusive measurements")
+    ap.add_argument("--pipeline-files", type=int, default=2048)
     ap.add_argument("--config5-images", type=int, default=9164)
     ap.add_argument("--config5-classes", type=int, default=1680)
     ap.add_argument("--layers", action="store_true", help="also print per-layer times to stderr")
@@ -212,6 +215,78 @@ def run_config5(args, tfi, dev, world, rank, backend, dist):
         "nn_index_mismatches_vs_fp64": mismatch, "picks_not_nearest_within_1e-6": near_ties,
         "num_classes": res["num_classes"], "gathered_shard_equals_local": shard_ok,
     }
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the callers' view ("H2D-inclusive and file-inclusive numbers reported separately"), N = 1
+# ----------------------------------------------------------------------------------------------------------------
+def run_pipeline(args, tfi, dev):
+    """h2d_inclusive: decoded uint8 250x250 photos in pinned HOST memory -> copy stream -> device preprocessing + forward,
+    double-buffered.  file_inclusive: JPEG files on disk -> TensorFlowInference.extract_files (threaded decode + the same
+    pipeline): the loop of facerec_test.py:394 as a user would run it.  Neither is `value`."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from PIL import Image
+    from hse_facerec_tf_amd import preprocess, preprocess_device
+    B = args.batch
+    out = {}
+    rs = np.random.RandomState(123)
+    # ---- H2D-inclusive
+    host = [torch.from_numpy(rs.randint(0, 256, (B, 250, 250, 3), dtype=np.uint8)).pin_memory() for _ in range(2)]
+    copy = torch.cuda.Stream(device=dev)
+    compute = torch.cuda.current_stream(dev)
+    steps = max(10, min(args.steps, 50))
+
+    def one(i):
+        with torch.cuda.stream(copy):
+            d = host[i & 1].to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy)
+        compute.wait_event(ev)
+        d.record_stream(compute)
+        return tfi.extract_images(d)
+    for i in range(3):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        f = one(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out["h2d_inclusive"] = {"value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps,
+                            "what": "uint8 250x250x3 photos in pinned host memory (%.1f MB per batch) -> H2D on a copy stream, double-buffered, "
+                                    "-> PIL-bilinear resize + BGR + mean + MobileNet-192 on the compute stream" % (B * 250 * 250 * 3 / 1e6)}
+    # ---- file-inclusive
+    d = tempfile.mkdtemp(prefix="hsefr_bench_")
+    try:
+        distinct = 256
+        for i in range(distinct):
+            Image.fromarray(rs.randint(0, 256, (250, 250, 3), dtype=np.uint8)).save(os.path.join(d, "%04d.jpg" % i), quality=90)
+        paths = [os.path.join(d, "%04d.jpg" % (i % distinct)) for i in range(args.pipeline_files)]
+        try:
+            workers = max(1, min(len(os.sched_getaffinity(0)), 32))
+        except AttributeError:
+            workers = max(1, min(os.cpu_count() or 1, 32))
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            list(pool.map(preprocess.imread_rgb, paths[:2 * workers]))
+            t0 = time.perf_counter()
+            list(pool.map(preprocess.imread_rgb, paths))
+            t_dec = time.perf_counter() - t0
+        tfi.extract_files(paths[:B], batch=B)
+        st = {}
+        X = tfi.extract_files(paths, batch=B, stats=st)
+        assert X.shape == (len(paths), tfi.feature_dim) and bool(np.isfinite(X).all())
+        out["file_inclusive"] = {"value": round(len(paths) / st["seconds"], 1), "unit": "faces/s", "files": len(paths), "workers": st["workers"],
+                                 "host_decode_faces_per_s": round(len(paths) / t_dec, 1),
+                                 "what": "%d JPEG files (250x250, quality 90; %d distinct) -> TensorFlowInference.extract_files: %d decoder threads "
+                                         "(PIL), pinned staging, double-buffered upload, device preprocessing + forward; the decoders set the rate"
+                                         % (len(paths), distinct, st["workers"])}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    del preprocess_device
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -595,6 +670,12 @@ def main():
     other = None
     if world == 1 and not args.no_other_configs:
         other = run_other_configs(args, dev)
+    pipeline = None
+    if world == 1 and not args.no_pipeline:
+        try:
+            pipeline = run_pipeline(args, tfi, dev)
+        except Exception as e:          # a failing side measurement must not take the headline line down
+            pipeline = {"error": repr(e)}
 
     line = {
         "metric": "faces/sec embedding-extract (MobileNet-192, bs=256)",
@@ -622,6 +703,7 @@ def main():
         "allgather_ms": None if allgather_ms is None else round(allgather_ms, 4),
         "config5": config5,
         "other_configs": other,
+        "pipeline": pipeline,
         "device_bytes": eng.device_bytes,
         "csrc_hash": csrc_hash(),
     }

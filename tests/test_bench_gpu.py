@@ -37,8 +37,11 @@ def _check_config5(c5, n, world):
 
 
 def test_bench_line_contract_and_small_config5():
-    line = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
+    line = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--pipeline-files", "300",
                  "--config5-images", "700", "--config5-classes", "120"])
+    pl = line["pipeline"]
+    assert "error" not in pl and pl["h2d_inclusive"]["value"] > 0 and pl["file_inclusive"]["value"] > 0
+    assert pl["file_inclusive"]["value"] <= pl["h2d_inclusive"]["value"] * 1.05
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "config5"):
         assert k in line
