@@ -253,6 +253,37 @@ def test_batch_256_properties_at_full_size(torch_):
     tfi.close_session()
 
 
+def test_batch_512_properties_at_full_size(torch_):
+    """BASELINE config 4 at full size (age/gender multi-head MobileNet-224, batch 512, THREE outputs), where the oracle is
+    too slow: every image's features / age distribution / gender are independent of its batch position and neighbours
+    (bit-exact), the softmax rows sum to one, and a sample of rows matches the oracle at the 1e-4 bar."""
+    from hse_facerec_tf_amd import graphdef, lowering
+    from hse_facerec_tf_amd.engine import Engine
+    plan = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0", {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]})
+    assert plan.in_hwc == (224, 224, 3)
+    eng = Engine(plan, max_batch=512)
+    g = torch_.Generator(device="cuda").manual_seed(4)
+    x = (torch_.rand((512, 224, 224, 3), device="cuda", generator=g) * 256.0 - 128.0).contiguous()
+    full = {k: v.clone() for k, v in eng.forward(x, (0, 1, 2)).items()}
+    assert tuple(full["features"].shape) == (512, 1024) and tuple(full["age_probs"].shape) == (512, 100) and tuple(full["gender"].shape) == (512, 1)
+    assert all(bool(torch_.isfinite(v).all()) for v in full.values())
+    assert float((full["age_probs"].sum(dim=1) - 1).abs().max()) < 1e-5
+    assert 0.0 <= float(full["gender"].min()) and float(full["gender"].max()) <= 1.0
+    perm = torch_.randperm(512, device="cuda", generator=g)
+    again = eng.forward(x[perm].contiguous(), (0, 1, 2))
+    for k in full:
+        assert torch_.equal(again[k], full[k][perm]), k                                  # permutation equivariance
+    for lo, n in ((0, 1), (300, 5), (505, 7)):                                           # batch-size independence
+        part = eng.forward(x[lo:lo + n].contiguous(), (0, 1, 2))
+        for k in full:
+            assert torch_.equal(part[k], full[k][lo:lo + n]), (k, lo)
+    rows = [0, 257, 511]
+    ref = tfo.GraphOracle(MODEL_PB, np.float64).run(list(FETCH), {"input_1:0": x[rows].cpu().numpy()})
+    for k, r in zip(("features", "age_probs", "gender"), ref):
+        assert rel(full[k][rows].cpu().numpy(), r.reshape(3, -1)) < BAR, k
+    eng.close()
+
+
 def test_vgg2_mobilenet_shaped_graph_through_the_reference_registry(torch_, tmp_path):
     """facerec_test.py:212 exactly: TensorFlowInference('models/vgg2_mobilenet.pb', input_tensor='input_1:0',
     output_tensor='reshape_1/Reshape:0', learning_phase_tensor='conv1_bn/keras_learning_phase:0', convert2BGR=True,

@@ -103,6 +103,33 @@ def test_pca_variant_matches_sklearn_pipeline(torch_):
     assert abs(r["accuracy"] - float((want == y2[test]).mean())) < 0.02
 
 
+def test_config1_plumbing_100_lfw_sized_crops(torch_, tmp_path):
+    """BASELINE configs[0] (the reference's own plumbing case): 100 LFW-sized (250 x 250) JPEG crops of 20 subjects through the
+    file-path API -- dataset walk, labels, pipelined extract_files, npz cache, then the 1-NN protocol of facerec_test.py:401-432
+    -- each image's row equal, bit for bit, to the reference-shaped per-image call."""
+    from PIL import Image
+    from hse_facerec_tf_amd import TensorFlowInference, extract_dataset, identification
+    from conftest import MODEL_PB
+    rs = np.random.RandomState(123)                                        # the reference's own seed (facerec_test.py:22)
+    for s_ in range(20):
+        d = tmp_path / ("subject_%02d" % s_)
+        d.mkdir()
+        base = rs.randint(0, 256, (25, 25, 3)).astype(np.float32)
+        for i in range(5):
+            im = np.kron(base, np.ones((10, 10, 1), np.float32)) + rs.randn(250, 250, 3) * 20
+            Image.fromarray(np.clip(im, 0, 255).astype(np.uint8)).save(str(d / ("%d.jpg" % i)), quality=92)
+    tfi = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(192, 192), max_batch=32)
+    X, y = extract_dataset(tfi, str(tmp_path), str(tmp_path / "feats.npz"), batch=32)
+    assert X.shape == (100, 1024) and list(np.bincount(y)) == [5] * 20
+    for i in (0, 31, 32, 99):
+        d, f = divmod(i, 5)
+        assert np.array_equal(tfi.extract_features(str(tmp_path / ("subject_%02d" % d) / ("%d.jpg" % f))), X[i])
+    r = identification.one_nn_identification(X, y)
+    assert len(r["test"]) == 50 and r["num_classes"] == 20 and 0.0 <= r["accuracy"] <= 1.0
+    assert r["accuracy"] > 0.5                                             # blocky per-subject patterns are easy to tell apart
+    tfi.close_session()
+
+
 def test_extract_dataset_walk_cache_and_labels(torch_, tmp_path):
     """facerec_test.py:377-401 on a tiny synthetic 'LFW': directory walk, labels, batched extract, npz cache."""
     from PIL import Image
