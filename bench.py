@@ -521,7 +521,7 @@ def main():
     value = world * B * args.steps / elapsed
 
     classes = {
-        "stem_conv1_dw_pw_dw_fused": lambda L: L.kind == lowering.OP_STEM2_F16S,
+        "stem_conv1_dw_pw_dw_fused": lambda L: L.kind in (lowering.OP_STEM2_F16S, lowering.OP_STEM3_F16S),
         "stem_conv1_dw_pw_fused": lambda L: L.kind == lowering.OP_STEM_F16S,
         "conv1_3x3x3_s2": lambda L: L.kind == lowering.OP_CONV_C3,
         "depthwise3x3": lambda L: L.kind == lowering.OP_DWCONV3X3,
@@ -580,7 +580,7 @@ def main():
                 + sum(2 * 2 * 4 * int(np.prod(plan.layers[i].out_shape[:2])) * 32 for i in idx
                       if plan.layers[i].kind == lowering.OP_STEM_F16S) * B \
                 + sum(2 * 4 * ((plan.layers[i].in_shape[0] + 1) // 2) * ((plan.layers[i].in_shape[1] + 1) // 2) * (32 + 32 + 64) for i in idx
-                      if plan.layers[i].kind == lowering.OP_STEM2_F16S) * B
+                      if plan.layers[i].kind in (lowering.OP_STEM2_F16S, lowering.OP_STEM3_F16S)) * B
             launches = len(idx)
             note = None
             if name == "pointwise1x1_f32mfma":
@@ -632,7 +632,7 @@ def main():
                 Ls = [L for L in plan.layers if classes[k["kernel"]](L)]
                 dws = []
                 for L in Ls:
-                    if L.kind == lowering.OP_STEM2_F16S:
+                    if L.kind in (lowering.OP_STEM2_F16S, lowering.OP_STEM3_F16S):
                         h1 = (L.in_shape[0] + 1) // 2
                         dws += ["%dx%dx32/s1" % (h1, h1), "%dx%dx64/s2" % (h1, h1)]
                     elif L.kind == lowering.OP_STEM_F16S:
@@ -693,6 +693,7 @@ def main():
                    "backend": None if world == 1 else ("RCCL (torch 'nccl')" if args.backend == "nccl" else "gloo"),
                    # the knobs that change WHAT is benchmarked: effective values, env overrides included
                    "pw_math": "f16split" if any(L.a_log2 for L in plan.layers) else "f32",
+                   "input_bound": tfi.input_bound,
                    "plan_kinds": [int(L.kind) for L in plan.layers],
                    "env_overrides": {k: os.environ[k] for k in ("HSEFR_PW_MATH", "HSEFR_FUSE_STEM", "HSEFR_FUSE_BLOCKS") if k in os.environ},
                    "op_events": "second pass of the same %d steps, HIP events on the forward stream" % args.steps if use_events else None},

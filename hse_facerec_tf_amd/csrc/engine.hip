@@ -38,6 +38,7 @@ struct hsefr_engine {
     std::vector<hsefr_plan_op> ops;
     std::vector<void*> d_bufs;
     char* d_blob = nullptr;
+    int* d_overflow = nullptr;        // input-bound flag of STEM3 ops (hsefr_engine_input_overflow)
     size_t device_bytes = 0;
     int max_batch = 0;
     int device = 0;
@@ -142,6 +143,14 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                 HSEFR_REQUIRE(o.w_off != HSEFR_NO_OFFSET && o.scale_off != HSEFR_NO_OFFSET && o.shift_off != HSEFR_NO_OFFSET &&
                                   o.reserved > 0 && o.reserved <= 24,
                               HSEFR_ERR_INVALID, "plan op %u: split-f16 pointwise needs split rows, descale, shift and a_log2 in (0, 24]", i);
+                break;
+            case HSEFR_OP_STEM3_F16S:
+                HSEFR_REQUIRE(stem3_fused_supported(o.cin, 32, o.cout, o.stride, 1, 2, o.kh, o.kw & 15) && (o.reserved & 255) > 0 &&
+                                  (o.reserved & 255) <= 12 && (o.reserved >> 8) >= 64 - 8 && (o.reserved >> 8) <= 64 + 14 &&
+                                  o.w_off != HSEFR_NO_OFFSET && o.w2_off != HSEFR_NO_OFFSET && o.shift2_off != HSEFR_NO_OFFSET &&
+                                  o.w_off + 3008 * 4 <= h.blob_bytes && o.w2_off + 64 * 128 <= h.blob_bytes &&
+                                  o.shift2_off + 128 * 4 <= h.blob_bytes && o.in_buf == HSEFR_BUF_INPUT,
+                              HSEFR_ERR_UNSUPPORTED, "plan op %u: bounded fused stem cin=%d cout=%d stride=%d not covered", i, o.cin, o.cout, o.stride);
                 break;
             case HSEFR_OP_STEM2_F16S:
                 HSEFR_REQUIRE(stem2_fused_supported(o.cin, 32, o.cout, o.stride, 1, 2, o.kh, o.kw & 15) && o.reserved > 0 && o.reserved <= 12 &&
@@ -296,6 +305,10 @@ int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsef
         }
         e->device_bytes += h.blob_bytes;
     }
+    if (hipMalloc((void**)&e->d_overflow, 16) != hipSuccess || hipMemset(e->d_overflow, 0, 16) != hipSuccess) {
+        set_error("engine_create: hipMalloc for the overflow flag failed");
+        return fail(HSEFR_ERR_NOMEM);
+    }
     e->d_bufs.assign(h.n_buffers, nullptr);
     for (uint32_t i = 0; i < h.n_buffers; ++i) {
         const size_t bytes = (size_t)e->bufs[i].elems_per_image * e->bufs[i].elem_bytes * max_batch;
@@ -431,6 +444,16 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                        (const float*)blob_ptr(e, o.shift2_off), (float*)out, n, o.h, o.w, o.cin, o.stride,
                                        o.pad_t, o.pad_l, o.oh, o.ow, o.cout, HSEFR_ACT_RELU6, o.act, s);
                 break;
+            case HSEFR_OP_STEM3_F16S: {
+                const float* pk = (const float*)blob_ptr(e, o.w_off);
+                const float* ds2 = (const float*)blob_ptr(e, o.shift2_off);
+                const int h1 = (o.h + 1) / 2, w1 = (o.w + 1) / 2;
+                rc = launch_stem3_fused((const float*)in, pk + 1952, pk + 1952 + 1024, pk + 864, pk + 896, pk + 1184, pk + 1216,
+                                        blob_ptr(e, o.w2_off), ds2, ds2 + 64, pk + 1248, pk + 1824, pk + 1888, (float*)out, e->d_overflow, n,
+                                        o.h, o.w, o.pad_t, o.pad_l, h1, w1, (o.kw >> 4) & 1, (o.kw >> 5) & 1, o.oh, o.ow,
+                                        (o.reserved >> 8) - 64, o.reserved & 255, o.act, s);
+                break;
+            }
             case HSEFR_OP_STEM2_F16S: {
                 const float* pk = (const float*)blob_ptr(e, o.w_off);
                 const float* ds2 = (const float*)blob_ptr(e, o.shift2_off);
@@ -550,6 +573,14 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
     return HSEFR_OK;
 }
 
+int hsefr_engine_input_overflow(hsefr_engine* e, int* host_flag, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(e && host_flag, HSEFR_ERR_INVALID, "input_overflow: null argument");
+    HSEFR_HIP_CHECK(hipMemcpyAsync(host_flag, e->d_overflow, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HSEFR_HIP_CHECK(hipMemsetAsync(e->d_overflow, 0, sizeof(int), (hipStream_t)stream));
+    HSEFR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return HSEFR_OK;
+}
+
 int hsefr_engine_set_graph_batch(hsefr_engine* e, int max_n) {
     HSEFR_REQUIRE(e && max_n >= 0 && max_n <= e->max_batch, HSEFR_ERR_INVALID, "set_graph_batch: bad argument");
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
@@ -572,6 +603,7 @@ int hsefr_engine_destroy(hsefr_engine* e) {
     for (void* b : e->d_bufs)
         if (b) (void)hipFree(b);
     if (e->d_blob) (void)hipFree(e->d_blob);
+    if (e->d_overflow) (void)hipFree(e->d_overflow);
     for (auto ev : e->events) (void)hipEventDestroy(ev);
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
@@ -628,6 +660,17 @@ int hsefr_stem2_fused(const float* x, const float* conv_w, const float* conv_shi
                              d2scale && d2shift && y), HSEFR_ERR_INVALID, "stem2_fused: null pointer");
     return launch_stem2_fused(x, conv_w, conv_shift, wd1, d1scale, d1shift, w_split, descale, pshift, wd2, d2scale, d2shift, y, n,
                               h, w, cpad_t, cpad_l, h1, w1, pad_t2, pad_l2, oh2, ow2, a_log2, act, (hipStream_t)stream);
+}
+
+int hsefr_stem3_fused(const float* x, const void* cw_split, const float* cdescale, const float* conv_shift, const float* wd1,
+                      const float* d1scale, const float* d1shift, const void* w_split, const float* descale, const float* pshift,
+                      const float* wd2, const float* d2scale, const float* d2shift, float* y, int* d_overflow, int n, int h, int w,
+                      int cpad_t, int cpad_l, int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int in_log2, int a_log2,
+                      int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && cw_split && cdescale && conv_shift && wd1 && d1scale && d1shift && w_split && descale && pshift && wd2 &&
+                             d2scale && d2shift && y), HSEFR_ERR_INVALID, "stem3_fused: null pointer");
+    return launch_stem3_fused(x, cw_split, cdescale, conv_shift, wd1, d1scale, d1shift, w_split, descale, pshift, wd2, d2scale, d2shift, y,
+                              d_overflow, n, h, w, cpad_t, cpad_l, h1, w1, pad_t2, pad_l2, oh2, ow2, in_log2, a_log2, act, (hipStream_t)stream);
 }
 
 int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd, const float* dscale,

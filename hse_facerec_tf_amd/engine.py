@@ -101,6 +101,15 @@ class Engine:
             return ops.split_rows_decode(rows, L.out_split)
         return out
 
+    def input_overflow(self) -> bool:
+        """True if any forward since the last call fed a value outside the plan's declared input bound (lower_graph
+        input_bound; the results of such a forward are meaningless).  Synchronises the current stream and clears the flag."""
+        flag = ctypes.c_int(0)
+        with self._torch.cuda.device(self.device):
+            _lib.check(_lib.lib().hsefr_engine_input_overflow(self._h, ctypes.byref(flag), _lib.current_stream_ptr()),
+                       "hsefr_engine_input_overflow")
+        return bool(flag.value)
+
     # -- small batches as one hipGraph launch ---------------------------------------------------
     def set_graph_batch(self, max_n: int) -> None:
         """Forwards of at most max_n images replay a captured hipGraph (default 0 = off: no faster on the device)."""

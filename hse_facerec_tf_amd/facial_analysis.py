@@ -70,7 +70,8 @@ class FacialImageProcessing:
         in_node, _ = graph.get_tensor_by_name('input_1:0')
         _, w, h, _ = graph.placeholder_shape(in_node.name)
         self.w, self.h = int(w), int(h)
-        self.plan = lower_graph(graph, 'input_1:0', outs, (self.w, self.h))
+        # the preprocessing of facial_analysis.py:95-107 (uint8 pixels minus the ImageNet-Caffe BGR mean) bounds the input: |x| < 256
+        self.plan = lower_graph(graph, 'input_1:0', outs, (self.w, self.h), input_bound=256.0)
         self.sess = Engine(self.plan, max_batch=max_batch, device=device)
 
         def age_gender_fun(img):

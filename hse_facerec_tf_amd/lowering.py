@@ -33,6 +33,7 @@ OP_PWCONV_F16S = 12      # wire kind of a pointwise Layer whose a_log2 > 0 (the 
 OP_DWPW_F16S = 13        # fused block with split-f16 pointwise products for any channel count (csrc/dwpw_f16s.hip)
 OP_STEM_F16S = 14        # conv1 -> depthwise -> pointwise in one kernel (csrc/stem_fused.hip)
 OP_STEM2_F16S = 15       # ... -> pointwise -> the stride-2 depthwise of block 2 in one kernel (csrc/stem2_fused.hip)
+OP_STEM3_F16S = 17       # STEM2_F16S for an input with a declared bound: conv1 on the f16 MFMA too (csrc/stem3_fused.hip)
 OP_PWCONV_PS = 16        # wire kind of a split-f16 pointwise Layer whose input is stored PRE-SPLIT by its producer (csrc/pwconv_ps.hip)
 _BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
@@ -147,6 +148,7 @@ class Layer:
     scale3: Optional[np.ndarray] = None
     shift3: Optional[np.ndarray] = None
     pad3: Tuple[int, int] = (0, 0)
+    in_log2: int = 0                                   # STEM3_F16S: the input is pre-scaled by 2^in_log2 for its f16 split (|x| < 2^(15 - in_log2))
     out_split: int = 0                                 # DWCONV3X3: > 0 = output stored as split rows scaled by 2^out_split
     in_split: bool = False                             # PWCONV: the input buffer holds split rows (wire kind OP_PWCONV_PS)
     out_buf: int = BUF_NONE
@@ -195,14 +197,21 @@ class Plan:
             w2 = None if L.w2 is None else np.ascontiguousarray(L.w2.reshape(L.w2.shape[-2], L.w2.shape[-1]).T)
             shift2 = L.shift2
             kw_field = L.kw
-            if L.kind == OP_STEM2_F16S:
+            if L.kind in (OP_STEM2_F16S, OP_STEM3_F16S):
                 w = np.concatenate([L.w0.reshape(-1), L.shift0.reshape(-1), L.w.reshape(-1), L.scale.reshape(-1), L.shift.reshape(-1),
                                     L.w3.reshape(-1), L.scale3.reshape(-1), L.shift3.reshape(-1)]).astype(np.float32)
                 assert w.size == 1952
+                if L.kind == OP_STEM3_F16S:
+                    # conv1 as a [32 x 27 -> 32] contraction over k = dy*9 + dx*3 + ci, split like a pointwise kernel
+                    cw_t = np.zeros((32, 32), np.float32)
+                    cw_t[:, :27] = L.w0.reshape(27, 32).T
+                    cimg, cds = split_pointwise_weights(cw_t, L.in_log2)
+                    w = np.concatenate([w, np.ascontiguousarray(cimg).reshape(-1).view(np.float32), cds.astype(np.float32)])
+                    assert w.size == 3008
                 scale = None
                 w2, descale = split_pointwise_weights(w2, L.a_log2)
                 shift2 = np.concatenate([descale, L.shift2.astype(np.float32)])
-                aux = L.a_log2
+                aux = L.a_log2 if L.kind == OP_STEM2_F16S else (L.a_log2 | ((L.in_log2 + 64) << 8))
                 kw_field = 3 + 16 * L.pad3[0] + 32 * L.pad3[1]
             if L.kind == OP_DWPW_F16S:
                 w2, descale = split_pointwise_weights(w2, L.a_log2)
@@ -223,7 +232,7 @@ class Plan:
             oh, ow, cout = L.out_shape
             ops.append(_OP.pack(kind, L.act, in_buf, L.out_buf, res_buf, h, wd, cin, oh, ow, cout,
                                 L.kh, kw_field, L.stride, L.pad_t, L.pad_l, aux, put(w), put(scale),
-                                put(None if L.kind in (OP_STEM_F16S, OP_STEM2_F16S) else L.shift), put(w2), put(shift2)))
+                                put(None if L.kind in (OP_STEM_F16S, OP_STEM2_F16S, OP_STEM3_F16S) else L.shift), put(w2), put(shift2)))
         while len(blob) % 16:
             blob.append(0)
         out_buf = [BUF_NONE] * 3
@@ -265,7 +274,7 @@ class Plan:
             return 2 * oh * ow * L.in_shape[2] * 9 + 2 * oh * ow * cout * L.in_shape[2]
         if L.kind == OP_STEM_F16S:
             return 2 * oh * ow * 32 * 27 + 2 * oh * ow * 32 * 9 + 2 * oh * ow * cout * 32
-        if L.kind == OP_STEM2_F16S:
+        if L.kind in (OP_STEM2_F16S, OP_STEM3_F16S):
             h1, w1 = (L.in_shape[0] + 1) // 2, (L.in_shape[1] + 1) // 2
             return 2 * h1 * w1 * 32 * 27 + 2 * h1 * w1 * 32 * 9 + 2 * h1 * w1 * 64 * 32 + 2 * oh * ow * 64 * 9
         return 0
@@ -919,7 +928,7 @@ def presplit_activations(layers: List[Layer], keep: Sequence[int]) -> int:
 def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
                 feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32",
                 pw_math: Optional[str] = None, fuse_stem_block: Optional[bool] = None, stem_fusion: Optional[str] = None,
-                block_fusion: Optional[str] = None, presplit: Optional[str] = None) -> Plan:
+                block_fusion: Optional[str] = None, presplit: Optional[str] = None, input_bound: Optional[float] = None) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase.
     fuse: merge depthwise -> pointwise pairs into one kernel where a fused kernel covers the shape.  stem_fusion:
     'stem2' (default; env HSEFR_FUSE_STEM=0|1only|1 changes the default) = conv1 + block 1 + the depthwise of block 2 in one
@@ -929,6 +938,9 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
     'none'.
     pw_math: 'auto' (default; env HSEFR_PW_MATH overrides the default) = split-f16 products for every pointwise layer
     whose input the graph bounds (ReLU6), fp32 MFMA otherwise; 'f32' = fp32 MFMA everywhere.
+    input_bound: a bound the CALLER guarantees on |input| (the reference's preprocessing yields pixels minus a mean:
+    < 256; facerec_test.py:93-110).  With it the fused stem forms conv1's products on the f16 MFMA too (csrc/stem3_fused.hip)
+    and checks the bound on the device (Engine.input_overflow()); None = no assumption, exact-fp32 conv1.
     presplit: 'auto' (default; env HSEFR_PRESPLIT=auto|none) = depthwise layers feeding a split-f16 pointwise layer store
     their result pre-split and the GEMM stages both operands by LDS-DMA (presplit_activations); 'none' = fp32 tensors.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
@@ -991,6 +1003,15 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
         layers, remap = fuse_stem2(layers, [li for li, _ in out_layers.values()])
         out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
         tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
+        if input_bound is not None:
+            if not (input_bound > 0 and np.isfinite(input_bound)):
+                raise ValueError("input_bound must be a positive finite number, not %r" % (input_bound,))
+            in_log2 = int(np.floor(np.log2(32768.0 / float(input_bound))))          # largest scale with bound * 2^in_log2 <= 32768
+            in_log2 = max(-8, min(14, in_log2))
+            if float(input_bound) * 2.0 ** in_log2 <= 32768.0:
+                for L in layers:
+                    if L.kind == OP_STEM2_F16S:
+                        L.kind, L.in_log2 = OP_STEM3_F16S, in_log2
     if fuse:   # early MobileNet blocks: depthwise result stays on the CU (csrc/dwpw_fused.hip)
         layers, remap = fuse_dwpw(layers, [li for li, _ in out_layers.values()])
         out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}

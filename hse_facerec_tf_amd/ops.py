@@ -229,6 +229,37 @@ def stem2_fused(x, conv_w, conv_shift, w1_hwc, d1scale, d1shift, wp_t, pshift, w
 
 
 @_device_guarded
+def stem3_fused(x, conv_w, conv_shift, w1_hwc, d1scale, d1shift, wp_t, pshift, w2_hwc, d2scale, d2shift, act: int = ACT_RELU6,
+                a_log2: int = 12, in_log2: int = 7, prepared=None, overflow=None):
+    """stem2_fused for an input with the declared bound |x| < 2^(15 - in_log2) (csrc/stem3_fused.hip): conv1 on the f16 MFMA
+    from two-term splits.  overflow: optional int32 CUDA tensor [1] that is OR-ed with 1 when a value breaks the bound."""
+    torch = _lib.require_gpu()
+    from . import lowering
+    for t, nm in ((x, "x"), (conv_shift, "conv_shift"), (w1_hwc, "w1"), (d1scale, "d1scale"), (d1shift, "d1shift"),
+                  (pshift, "pshift"), (w2_hwc, "w2"), (d2scale, "d2scale"), (d2shift, "d2shift")):
+        _f32c(t, nm)
+    d_img, d_ds = prepared if prepared is not None else split_weights_device(wp_t, x.device, a_log2)
+    n, h, w, c = x.shape
+    cw = conv_w.detach().cpu().numpy() if hasattr(conv_w, "detach") else np.asarray(conv_w)
+    if c != 3 or tuple(cw.shape) != (3, 3, 3, 32) or tuple(w1_hwc.shape) != (3, 3, 32) or d_img.shape[0] != 64 or tuple(w2_hwc.shape) != (3, 3, 64):
+        raise NotImplementedError("stem3_fused covers 3 -> 32 -> 64 channels")
+    cw_t = np.zeros((32, 32), np.float32)
+    cw_t[:, :27] = cw.reshape(27, 32).T
+    cimg, cds = lowering.split_pointwise_weights(cw_t, in_log2)
+    d_cimg = torch.from_numpy(cimg.view(np.int16)).to(x.device)
+    d_cds = torch.from_numpy(cds).to(x.device)
+    h1, w1, pt, pl = _same(h, w, 3, 2)
+    oh2, ow2, pt2, pl2 = _same(h1, w1, 3, 2)
+    y = torch.empty((n, oh2, ow2, 64), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_stem3_fused(x.data_ptr(), d_cimg.data_ptr(), d_cds.data_ptr(), conv_shift.data_ptr(), w1_hwc.data_ptr(),
+                                            d1scale.data_ptr(), d1shift.data_ptr(), d_img.data_ptr(), d_ds.data_ptr(), pshift.data_ptr(),
+                                            w2_hwc.data_ptr(), d2scale.data_ptr(), d2shift.data_ptr(), y.data_ptr(),
+                                            None if overflow is None else overflow.data_ptr(), n, h, w, pt, pl, h1, w1, pt2, pl2,
+                                            oh2, ow2, in_log2, a_log2, act, _lib.current_stream_ptr()), "hsefr_stem3_fused")
+    return y
+
+
+@_device_guarded
 def dwpw_fused(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1):
     """One early MobileNet block in one kernel: depthwise 3x3 SAME + scale + shift + ReLU6 -> pointwise 1x1 + shift +
     ReLU6 (graph nodes #35-#49).  c in {32, 64}, cout in {64, 128}; wp_t is the pointwise kernel transposed [cout, c]."""

@@ -42,7 +42,7 @@ class TensorFlowInference:
     def __init__(self, frozen_graph_filename, input_tensor, output_tensor, learning_phase_tensor=None,
                  convert2BGR=True, imageNetUtilsMean=True, additional_input_value=0,
                  input_size: Optional[Tuple[int, int]] = None, max_batch: int = 256, device: Optional[int] = None,
-                 dtype: str = "auto"):
+                 dtype: str = "auto", input_bound: Optional[float] = 256.0):
         graph = load_graph(frozen_graph_filename, '')
         self.graph = graph
         # graph.get_tensor_by_name semantics: KeyError for unknown names (facerec_test.py:60-64)
@@ -71,16 +71,23 @@ class TensorFlowInference:
         # rows = self.w.  All models in scope are square.
         # dtype: 'f32' = exact fp32 kernels (MobileNet-style graphs), 'bf16' = bf16-MFMA kernels (ResNet-style graphs,
         # BASELINE config 3), 'auto' = fp32 when the graph is covered by the fp32 kernels, else bf16
+        # input_bound: what preprocess_image guarantees about the values this class feeds -- uint8 pixels minus a BGR mean lie
+        # in [-131.1, 151.1], the non-BGR branch in [-1, 1] (facerec_test.py:93-110): |x| < 256.  The fused stem uses it
+        # (csrc/stem3_fused.hip) and CHECKS it on the device; extract_batch with values outside it raises.  None = no
+        # assumption about extract_batch's input (exact-fp32 first convolution).
+        self.input_bound = input_bound
         from .lowering import LoweringError
         if dtype == "auto":
             try:
-                self.plan: Plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds)
+                self.plan: Plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds,
+                                              input_bound=input_bound)
                 dtype = "f32"
             except LoweringError:
                 self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype="bf16")
                 dtype = "bf16"
         else:
-            self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype=dtype)
+            self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype=dtype,
+                                    input_bound=input_bound if dtype == "f32" else None)
         self.dtype = dtype
         self.engine = Engine(self.plan, max_batch=max_batch, device=device)
         self.tf_sess = self.engine           # attribute name kept for callers that poke at it
@@ -103,15 +110,23 @@ class TensorFlowInference:
         preds = self.engine.forward(xd, (OUT_FEATURES,))["features"]
         return preds.cpu().numpy().reshape(-1)
 
+    def _check_bound(self, x_np) -> None:
+        if self.input_bound is not None and x_np.size and not float(np.abs(x_np).max()) < self.input_bound:
+            raise ValueError("input values reach %g: outside the bound %g this extractor was built for (preprocess_image's output "
+                             "is; pass input_bound=None or a larger bound for other data)" % (float(np.abs(x_np).max()), self.input_bound))
+
     def close_session(self):                 # facerec_test.py:124-125
         self.engine.close()
 
     # ---- batched entries (new) ------------------------------------------------------------------
     def extract_batch(self, x):
         """x: float32 [n, h, w, 3] NHWC, preprocessed as preprocess_image leaves it; a CUDA tensor
-        (returned: CUDA tensor [n, D], asynchronous) or a NumPy array (returned: NumPy array)."""
+        (returned: CUDA tensor [n, D], asynchronous) or a NumPy array (returned: NumPy array).  Values must respect
+        ``input_bound`` (NumPy input is checked here; for a CUDA tensor the device-side check is read with
+        ``self.engine.input_overflow()``)."""
         torch = _lib.require_gpu()
         if isinstance(x, np.ndarray):
+            self._check_bound(x)
             out = []
             for i in range(0, x.shape[0], self.engine.max_batch):
                 xd = torch.from_numpy(np.ascontiguousarray(x[i:i + self.engine.max_batch], dtype=np.float32))

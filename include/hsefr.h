@@ -98,6 +98,12 @@ typedef enum hsefr_op_kind {
                                   image, oh,ow,cout = the block output, pad_t/pad_l = the conv's; w_off = fp32 pack
                                   [conv HWIO 864 | conv shift 32 | dw 3x3x32 288 | dw scale 32 | dw shift 32];
                                   w2_off = split rows [64][64 f16]; shift2_off = [2][64] descale, shift; reserved = a_log2 */
+    HSEFR_OP_STEM3_F16S = 17,  /* STEM2_F16S for an input with a DECLARED BOUND |x| < 2^(15 - in_log2) (csrc/stem3_fused.hip): conv1's
+                                  products are formed on the f16 MFMA from two-term splits like the pointwise layers'.
+                                  w_off = the STEM2 fp32 pack (1952 floats) | conv1 split rows [32][64 f16] (1024 floats) |
+                                  conv1 descale [32]; `reserved` = a_log2 | (in_log2 + 64) << 8; the rest as STEM2_F16S.
+                                  An input value outside the bound raises the engine's overflow flag (see
+                                  hsefr_engine_input_overflow) -- the results of that forward are then meaningless.   */
     HSEFR_OP_PWCONV_PS = 16,   /* PWCONV_F16S whose INPUT buffer holds pre-split activations ("split rows", written by a
                                   DWCONV3X3 op with `reserved` = a_log2 > 0): both GEMM operands go to LDS by DMA
                                   (csrc/pwconv_ps.hip); operands as PWCONV_F16S; k % 32 == 0, cout % 128 == 0            */
@@ -195,6 +201,10 @@ int hsefr_engine_set_profiling(hsefr_engine* e, int depth);
 long long hsefr_engine_profiled_calls(const hsefr_engine* e);
 int hsefr_engine_op_times_ms(hsefr_engine* e, int slot, float* ms, int n_ops);
 
+/* Plans lowered with a declared input bound (HSEFR_OP_STEM3_F16S) check it on the device: *host_flag = 1 if any forward since
+ * the last call saw an input value outside the bound (its results are meaningless), else 0; the flag is then cleared.
+ * Synchronises `stream`.  Always 0 for plans without a bound. */
+int hsefr_engine_input_overflow(hsefr_engine* e, int* host_flag, hsefr_stream_t stream);
 int hsefr_engine_destroy(hsefr_engine* e); /* replaces tf_sess.close(), facerec_test.py:124-125 */
 
 /* ------------------------------------------------------------------------------------ */
@@ -266,6 +276,16 @@ int hsefr_stem2_fused(const float* x, const float* conv_w, const float* conv_shi
                       const float* d1shift, const void* w_split, const float* descale, const float* pshift, const float* wd2,
                       const float* d2scale, const float* d2shift, float* y, int n, int h, int w, int cpad_t, int cpad_l,
                       int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int a_log2, int act, hsefr_stream_t stream);
+
+/* hsefr_stem2_fused for an input with a declared bound |x| < 2^(15 - in_log2) (csrc/stem3_fused.hip): conv1 on the f16 MFMA
+ * from two-term splits.  cw_split / cdescale = the conv kernel [32][27 -> 32] (k = dy*9 + dx*3 + ci) prepared like a
+ * pointwise kernel with a_log2 := in_log2 (hse_facerec_tf_amd.lowering.split_pointwise_weights).  d_overflow (device int,
+ * may be NULL) is OR-ed with 1 when a value breaks the bound. */
+int hsefr_stem3_fused(const float* x, const void* cw_split, const float* cdescale, const float* conv_shift, const float* wd1,
+                      const float* d1scale, const float* d1shift, const void* w_split, const float* descale, const float* pshift,
+                      const float* wd2, const float* d2scale, const float* d2shift, float* y, int* d_overflow, int n, int h, int w,
+                      int cpad_t, int cpad_l, int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int in_log2, int a_log2,
+                      int act, hsefr_stream_t stream);
 
 /* One whole early MobileNet block (graph nodes #35-#49) fused: depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6
  * -> pointwise 1x1 + shift + ReLU6.  x [n,h,w,c], wd [3,3,c], wp_t [cout,c] (TF kernel transposed), y [n,oh,ow,cout];

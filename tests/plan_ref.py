@@ -103,18 +103,28 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             wt = unsplit_pointwise_weights(img, np.frombuffer(data, np.float32, cout, sc_off), _r).astype(dtype)
             assert 0 < _r <= 24 and float(np.abs(src).max()) * 2.0 ** _r < 32768, "split-f16 input bound violated"
             y = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
-        elif kind == 15:     # fused stem + the stride-2 depthwise of block 2
+        elif kind in (15, 17):     # fused stem + the stride-2 depthwise of block 2 (17: with a declared input bound)
             from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
             pk = arr(w_off, 1952)
+            k0 = pk[:864].reshape(3, 3, 3, 32)
+            a_log2 = _r & 255
+            if kind == 17:      # the conv kernel the device uses is the SPLIT image behind the fp32 pack: execute that one
+                in_log2 = (_r >> 8) - 64
+                cimg = np.frombuffer(data, np.uint16, 32 * 64, w_off + 1952 * 4).reshape(32, 1, 64)
+                cds = np.frombuffer(data, np.float32, 32, w_off + (1952 + 1024) * 4)
+                cw_t = unsplit_pointwise_weights(cimg, cds, in_log2)
+                assert np.abs(cw_t[:, 27:]).max() == 0 and np.abs(cw_t[:, :27].T.reshape(3, 3, 3, 32) - k0).max() <= 2.0 ** -21 * np.abs(k0).max()
+                k0 = cw_t[:, :27].T.reshape(3, 3, 3, 32).astype(dtype)
+                assert float(np.abs(src).max()) < 2.0 ** (15 - in_log2), "declared input bound violated"
             h1, w1 = (h + 1) // 2, (w + 1) // 2
             pb = max((h1 - 1) * 2 + 3 - h - pad_t, 0)
             pr = max((w1 - 1) * 2 + 3 - w - pad_l, 0)
-            c1 = _act(tfo.conv2d(src, pk[:864].reshape(3, 3, 3, 32), (2, 2), "", explicit_pads=(pad_t, pb, pad_l, pr)) + pk[864:896], 2)
+            c1 = _act(tfo.conv2d(src, k0, (2, 2), "", explicit_pads=(pad_t, pb, pad_l, pr)) + pk[864:896], 2)
             d1 = _act(tfo.depthwise_conv2d(np.pad(c1, ((0, 0), (1, 1), (1, 1), (0, 0))), pk[896:1184].reshape(3, 3, 32, 1), (1, 1), "VALID")
                       * pk[1184:1216] + pk[1216:1248], 2)
             img = np.frombuffer(data, np.uint16, 64 * 32 * 2, w2_off).reshape(64, 1, 64)
             ds = np.frombuffer(data, np.float32, 128, sh2_off)
-            wt = unsplit_pointwise_weights(img, ds[:64], _r).astype(dtype)
+            wt = unsplit_pointwise_weights(img, ds[:64], a_log2).astype(dtype)
             p1 = _act(PW(d1.reshape(-1, 32), wt) + ds[64:].astype(dtype), 2).reshape(n, h1, w1, 64)
             pt2, pl2 = (kw >> 4) & 1, (kw >> 5) & 1
             pb2 = max((oh - 1) * 2 + 3 - h1 - pt2, 0)

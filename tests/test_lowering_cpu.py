@@ -319,3 +319,27 @@ def test_full_keras_mobilenet_graph_of_the_missing_files_shape():
     assert rel(got, plan_ref.run(shipped.serialize(), x)["features"]) < 1e-5          # == the shipped trunk's function
     with pytest.raises(lowering.LoweringError):        # learning phase not fed
         lowering.lower_graph(g, "input_1:0", {OUT_FEATURES: "reshape_1/Reshape:0"})
+
+
+def test_declared_input_bound_selects_the_bounded_stem(graph):
+    """lower_graph(input_bound=...) turns the fused stem into wire kind 17 (conv1 on the f16 MFMA, csrc/stem3_fused.hip): the
+    conv kernel travels as split rows behind the fp32 pack, the scale exponent is the largest that keeps bound * 2^in_log2
+    within f16; the plan computes the same function; without a bound nothing changes."""
+    import plan_ref
+    plan = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), input_bound=256.0)
+    assert plan.layers[0].kind == lowering.OP_STEM3_F16S and plan.layers[0].in_log2 == 7
+    assert lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), input_bound=151.1).layers[0].in_log2 == 7
+    assert lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), input_bound=1.0).layers[0].in_log2 == 14
+    assert lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), input_bound=1000.0).layers[0].in_log2 == 5
+    assert lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96)).layers[0].kind == lowering.OP_STEM2_F16S
+    ops_ = plan_ref.parse(plan.serialize())["ops"]
+    assert ops_[0][0] == 17 and ops_[0][16] == (12 | ((7 + 64) << 8))
+    x = np.random.RandomState(3).randint(0, 256, (2, 96, 96, 3)).astype(np.float32) - np.array([103.939, 116.779, 123.68], np.float32)
+    got = plan_ref.run(plan.serialize(), x)
+    ref = plan_ref.run(lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96)).serialize(), x)
+    for k in ref:
+        assert rel(got[k], ref[k]) < 1e-5, k
+    with pytest.raises(AssertionError):                    # the CPU plan checker enforces the declared bound too
+        plan_ref.run(plan.serialize(), x * 3)
+    with pytest.raises(ValueError):
+        lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), input_bound=-1.0)
