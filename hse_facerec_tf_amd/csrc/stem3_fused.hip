@@ -33,7 +33,6 @@ namespace hsefr {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -57,6 +56,8 @@ struct Stem3Params {
     unsigned total;
     float a_scale, in_scale, in_bound;
     int reverse;
+    long long x_bytes, x_floats;   // size of the whole input tensor
+    unsigned long long* stamps;    // diagnostic builds (-DHSEFR_STEM_STAMPS) only
 };
 
 constexpr int PH = 4, PW = 8;                         // output patch (of the stride-2 depthwise)
@@ -158,15 +159,26 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
         ih0 = 2 * (y10 - 1) - p.cpad_t;
         iw0 = 2 * (x10 - 1) - p.cpad_l;
     };
+    // Pieces are aligned to 16 bytes of the INPUT TENSOR (one resource over the whole batch): a piece never straddles the
+    // tensor's first byte, and a window row lands in LDS shifted by s = (index of its first float) & 3 floats.
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes);
+    auto row_first_float = [&](const Cur& c, int row) {      // tensor index of the first float of window row `row` (may be < 0)
+        int ih0, iw0;
+        window_origin(c, ih0, iw0);
+        return ((c.n * p.H + ih0 + row) * p.W + iw0) * 3;
+    };
     auto load_window = [&](const Cur& c) {
         int ih0, iw0;
         window_origin(c, ih0, iw0);
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)c.n * p.H * p.W * 3, (long long)p.H * p.W * 12);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int ih = ih0 + ritem_row[k];
             const bool ok = ritem_row[k] < RAWH && ih >= 0 && ih < p.H;
-            const unsigned voff = ok ? (unsigned)((ih * p.W + iw0) * 12 + 16 * ritem_q[k]) : 0x80000000u;
+            const int f0 = ((c.n * p.H + ih) * p.W + iw0) * 3;
+            const int a = f0 & ~3;                                               // floor to a multiple of 4 (two's complement: also for f0 < 0)
+            const long long first = (long long)a + 4 * ritem_q[k];
+            const unsigned voff = ok ? (unsigned)(first * 4) : 0x80000000u;     // negative -> wraps beyond the resource -> zeros
+            // (a piece that straddles the END of the tensor is range-checked per dword: tools/buffer_oob_probe.hip)
             rawv[k] = bload16(rx, voff, 0);
         }
     };
@@ -183,11 +195,13 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
     park_window();
     __syncthreads();
 
+    STEM_STAMP_DECL;
     while (true) {
         const unsigned tn = t + gridDim.x;
         const bool more = tn < p.total;
         const Cur nxt = advance(cur);
         const int y10 = 2 * cur.th * PH - p.pad_t2, x10 = 2 * cur.tw * PW - p.pad_l2;
+        STEM_STAMP(0);
         // The thread index is made opaque once per patch: every stage's LDS addresses are then re-derived (a few VALU) instead
         // of being hoisted out of the loop as ~100 loop-invariant VGPRs -- which had the compiler spill to scratch.
         int tix = threadIdx.x;
@@ -204,15 +218,11 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
             bool bad = false;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-                const float* src = &Raw[(2 * ry + dy) * RAWP + 6 * rx];            // 9 floats, 8-byte aligned
+                const int sh = row_first_float(cur, 2 * ry + dy) & 3;               // the row's shift in LDS (0 for W % 4 == 0 and iw0 % 4 == 0)
+                const float* src = &Raw[(2 * ry + dy) * RAWP + sh + 6 * rx];        // 9 floats
                 float w9[9];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x2 d = *(const f32x2*)(src + 2 * i);
-                    w9[2 * i] = d[0];
-                    w9[2 * i + 1] = d[1];
-                }
-                w9[8] = src[8];
+                for (int i = 0; i < 9; ++i) w9[i] = src[i];
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int iw = iw0 + 2 * rx + dx;
@@ -248,8 +258,11 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
             const int y1 = y10 + q / R1W, x1 = x10 + q % R1W;
             Pv[tid] = (tid < R1PIX && y1 >= 0 && y1 < p.H1 && x1 >= 0 && x1 < p.W1) ? 1.f : 0.f;
         }
+        STEM_STAMP(1);
         __syncthreads();     // im2col rows complete; the window is dead
+        STEM_STAMP(2);
         if (more) load_window(nxt);      // next patch's window: in flight during stages B-E
+        STEM_STAMP(7);
 
         // ---- stage B: conv1, one 32-deep f16 MFMA step per product; 14 row blocks x 2 channel blocks = 28 pairs, 7 per wave ----
         // pair pr = 7 * wave + i covers row block pr >> 1, channel block pr & 1: the (row block, channel block) of slot i
@@ -289,7 +302,9 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
         };
         if (wave & 1) conv_stage(std::integral_constant<int, 1>());
         else conv_stage(std::integral_constant<int, 0>());
+        STEM_STAMP(3);
         __syncthreads();     // conv1 region complete; im2col rows dead
+        STEM_STAMP(2);
 
         // ---- stage C: depthwise 1.  Thread = (channel quad, run of <= 6 pixels of one region row): 3 x 8 taps read once ----
         {
@@ -332,7 +347,9 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
                 }
             }
         }
+        STEM_STAMP(4);
         __syncthreads();     // A tile complete (rows 153..159 hold stale bytes: their products are never stored); conv1 region dead
+        STEM_STAMP(2);
 
         // ---- stage D: pointwise on the f16 MFMA (K = 32 in one instruction); wave w = channels 16w..16w+15, all 10 row blocks
 #pragma unroll
@@ -364,7 +381,9 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
                 }
             }
         }
+        STEM_STAMP(5);
         __syncthreads();     // 96x96x64 patch complete; A tile dead
+        STEM_STAMP(2);
 
         // ---- stage E: depthwise 2 (stride 2) from LDS -> global; both output pixels of a thread in flight together ----
         {
@@ -393,6 +412,8 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
                 bstore16(v, ry, voff, 0);
             }
         }
+        STEM_STAMP(6);
+        STEM_STAMP_COUNT;
         if (!more) break;
         __syncthreads();     // the 96x96x64 patch is dead: U2 takes the next window
         park_window();
@@ -400,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
         t = tn;
         cur = nxt;
     }
+    STEM_STAMP_FLUSH(p.stamps, (int)(threadIdx.x & 63), wave);
 }
 
 }  // namespace
@@ -419,7 +441,8 @@ int launch_stem3_fused(const float* x, const void* cw_split, const float* cdesca
     HSEFR_REQUIRE(pad_t2 >= 0 && pad_t2 <= 1 && pad_l2 >= 0 && pad_l2 <= 1, HSEFR_ERR_INVALID, "stem3_fused: depthwise-2 padding %d,%d", pad_t2, pad_l2);
     HSEFR_REQUIRE(a_log2 > 0 && a_log2 <= 12, HSEFR_ERR_INVALID, "stem3_fused: a_log2=%d", a_log2);
     HSEFR_REQUIRE(in_log2 >= -8 && in_log2 <= 14, HSEFR_ERR_INVALID, "stem3_fused: in_log2=%d", in_log2);
-    HSEFR_REQUIRE((long long)h * w * 12 < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "stem3_fused: image too large");
+    HSEFR_REQUIRE((long long)n * h * w * 12 < (1ll << 32) - 64 && (long long)n * h * w * 3 < (1ll << 31) - 64, HSEFR_ERR_UNSUPPORTED,
+                  "stem3_fused: the input batch must stay below 4 GB (its offsets travel in 32 bits)");
     if (n == 0) return HSEFR_OK;
     Stem3Params p;
     p.x = x; p.cw_split = cw_split; p.cdescale = cdescale; p.cshift = cshift; p.wd1 = (const float4*)wd1; p.d1scale = (const float4*)d1scale;
@@ -435,6 +458,12 @@ int launch_stem3_fused(const float* x, const void* cw_split, const float* cdesca
     p.in_scale = ldexpf(1.f, in_log2);
     p.in_bound = ldexpf(1.f, 15 - in_log2);
     p.reverse = sweep_reverse();
+    p.x_floats = (long long)n * h * w * 3;
+    p.x_bytes = p.x_floats * 4;
+    p.stamps = nullptr;
+#ifdef HSEFR_STEM_STAMPS
+    p.stamps = stamp_buffer(s);
+#endif
     const unsigned g = p.total < 512u ? p.total : 512u;      // 512 % 8 == 0: the kernel's incremental patch cursor relies on it
 #define HSEFR_STEM3(A) hipLaunchKernelGGL((stem3_fused_kernel<A>), dim3(g), dim3(256), 0, s, p)
     if (act == HSEFR_ACT_RELU6) HSEFR_STEM3(HSEFR_ACT_RELU6);

@@ -60,15 +60,17 @@ def test_bounded_stem_vs_exact_stem_and_oracle(env, n, h, w):
     y3 = ops.stem3_fused(x, cw, csh, k1, sc1, sh1, None, psh, k2, sc2, sh2, prepared=prep, overflow=flag)
     y2 = ops.stem2_fused(x, cw, csh, k1, sc1, sh1, None, psh, k2, sc2, sh2, prepared=prep)
     assert tuple(y3.shape) == tuple(y2.shape) and int(flag.item()) == 0
-    # four fused layers of ReLU6-bounded values: the accumulated round-off bar of the existing fused-stem tests
-    assert float((y3 - y2).abs().max()) < 6 * 2 * TOL
+    # four fused layers of ReLU6-bounded values, conv1 channels with 40x weights in front: both kernels carry fp32-grade
+    # round-off relative to the sum of |terms| of conv1 (which is ~40 x the [0, 6] result there): 1e-5 of the value range
+    assert float((y3 - y2).abs().max()) < 6e-5
     if n * h * w <= 3 * 100 * 100:
         xn = x.cpu().numpy().astype(np.float64)
         c1 = act6(tfo.conv2d(xn, cw.cpu().numpy().astype(np.float64), (2, 2), "SAME") + csh.cpu().numpy())
         d1 = act6(tfo.depthwise_conv2d(c1, k1.cpu().numpy()[..., None].astype(np.float64), (1, 1), "SAME") * sc1.cpu().numpy() + sh1.cpu().numpy())
         p1 = act6(d1.reshape(-1, 32).dot(kp.T.astype(np.float64)) + psh.cpu().numpy()).reshape(d1.shape[:3] + (64,))
         want = act6(tfo.depthwise_conv2d(p1, k2.cpu().numpy()[..., None].astype(np.float64), (2, 2), "SAME") * sc2.cpu().numpy() + sh2.cpu().numpy())
-        assert float(np.abs(y3.cpu().numpy() - want).max()) < 6 * 2 * TOL
+        e3, e2 = float(np.abs(y3.cpu().numpy() - want).max()), float(np.abs(y2.cpu().numpy() - want).max())
+        assert e3 < 6e-5 and e3 < 2 * e2 + 1e-6, (e3, e2)          # as close to fp64 as the exact-fp32-conv1 kernel is
 
 
 def test_bounded_stem_full_size_every_element_and_run_to_run(env):
@@ -82,13 +84,13 @@ def test_bounded_stem_full_size_every_element_and_run_to_run(env):
     d2 = ops.dwconv3x3(ops.pwconv1x1_f16split(ops.dwconv3x3(ops.conv3x3_c3(x, cw, csh, 2), k1, sc1, sh1, 1), None, psh, prepared=prep), k2, sc2, sh2, 2)
     ys = [ops.stem3_fused(x, cw, csh, k1, sc1, sh1, None, psh, k2, sc2, sh2, prepared=prep) for _ in range(3)]
     assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
-    assert float((ys[0] - d2).abs().max()) < 6 * 2 * TOL
+    assert float((ys[0] - d2).abs().max()) < 6e-5
     # the synthetic workload of bench.py (U(-128, 128)) respects the bound too
     g = torch.Generator(device="cuda").manual_seed(5)
     xu = (torch.rand((64, 192, 192, 3), device="cuda", generator=g) * 256 - 128).contiguous()
     y3 = ops.stem3_fused(xu, cw, csh, k1, sc1, sh1, None, psh, k2, sc2, sh2, prepared=prep)
     y2 = ops.stem2_fused(xu, cw, csh, k1, sc1, sh1, None, psh, k2, sc2, sh2, prepared=prep)
-    assert float((y3 - y2).abs().max()) < 6 * 2 * TOL
+    assert float((y3 - y2).abs().max()) < 6e-5
 
 
 def test_the_declared_bound_is_checked_on_the_device(env):
@@ -110,7 +112,7 @@ def test_the_declared_bound_is_checked_on_the_device(env):
     x[1, 20, 31, 2] = 700.0
     y3 = ops.stem3_fused(x, cw, csh, k1, sc1, sh1, kp, psh, k2, sc2, sh2, in_log2=5, overflow=flag)
     assert int(flag.item()) == 0
-    assert float((y3 - ops.stem2_fused(x, cw, csh, k1, sc1, sh1, kp, psh, k2, sc2, sh2)).abs().max()) < 6 * 2 * TOL
+    assert float((y3 - ops.stem2_fused(x, cw, csh, k1, sc1, sh1, kp, psh, k2, sc2, sh2)).abs().max()) < 6e-5
 
 
 def test_engine_uses_the_bound_and_reports_violations(env):

@@ -315,6 +315,8 @@ def bench_stemstamps():
     for _ in range(4):
         if which == "1":
             ops.stem_fused(x, cw, csh, wd, dsc, dsh, w, sh)
+        elif which == "3":
+            ops.stem3_fused(x * 0.99, cw, csh, wd, dsc, dsh, w, sh, wd2, d2sc, d2sh)
         else:
             ops.stem2_fused(x, cw, csh, wd, dsc, dsh, w, sh, wd2, d2sc, d2sh)
     torch.cuda.synchronize()
@@ -323,6 +325,9 @@ def bench_stemstamps():
     b = buf[buf[:, 9] > 0].astype(np.float64)
     names = ["cursor + gather issue", "B conv1 mfma + region write", "barriers", "C depthwise 1 from LDS", "D pointwise mfma (+ patch write)",
              "E epilogue / depthwise 2 + stores", "scatter (wait gather)", "-"]
+    if which == "3":
+        names = ["cursor", "A' im2col from the window", "barriers (+ park next window)", "B conv1 mfma + region write", "C depthwise 1", "D pointwise mfma (+ patch write)",
+                 "E depthwise 2 + stores", "window loads issue"]
     print("%d waves, lifetime mean %.0f cycles, patches/wave %.1f -> %.0f cycles per patch" % (len(b), b[:, 8].mean(), b[:, 9].mean(), (b[:, 8] / b[:, 9]).mean()))
     for i, nm in enumerate(names):
         print("   %-26s %5.1f %%  %7.0f cycles per patch" % (nm, 100 * (b[:, i] / b[:, 8]).mean(), (b[:, i] / b[:, 9]).mean()))
