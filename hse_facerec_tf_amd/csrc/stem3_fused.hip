@@ -100,7 +100,12 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
     if (tid < 9 * 16) W2[tid] = p.wd2[tid];
     if (tid < 9 * 8) W1[tid] = p.wd1[tid];
     const int c4l = tid & 7;                         // depthwise-1 channel quad of this thread
-    const float4 d1sc = p.d1scale[c4l], d1sh = p.d1shift[c4l];
+    // depthwise 1 feeds the split: its scale / shift carry the 2^a_log2 pre-scale (a power of two commutes with every rounding
+    // here: relu6(s * sc + sh) * 2^a == clamp(s * (sc 2^a) + sh 2^a, 0, 6 * 2^a) bit for bit)
+    float4 d1sc = p.d1scale[c4l], d1sh = p.d1shift[c4l];
+    d1sc.x *= p.a_scale; d1sc.y *= p.a_scale; d1sc.z *= p.a_scale; d1sc.w *= p.a_scale;
+    d1sh.x *= p.a_scale; d1sh.y *= p.a_scale; d1sh.z *= p.a_scale; d1sh.w *= p.a_scale;
+    const float cap6 = 6.f * p.a_scale;
     const int c4o = tid & 15;                        // depthwise-2 channel quad of this thread
     const float4 d2sc = p.d2scale[c4o], d2sh = p.d2shift[c4o];
     // conv1: lane (n = 16 nb + l16, k-slice q4) holds the weight fragments of both channel blocks for good
@@ -201,6 +206,8 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
         const bool more = tn < p.total;
         const Cur nxt = advance(cur);
         const int y10 = 2 * cur.th * PH - p.pad_t2, x10 = 2 * cur.tw * PW - p.pad_l2;
+        // a patch whose conv1 region lies inside the 96x96 map has no pixel to zero: the validity factors are all 1 (uniform test)
+        const bool interior = y10 - 1 >= 0 && x10 - 1 >= 0 && y10 - 1 + R0H <= p.H1 && x10 - 1 + R0W <= p.W1;
         STEM_STAMP(0);
         // The thread index is made opaque once per patch: every stage's LDS addresses are then re-derived (a few VALU) instead
         // of being hoisted out of the loop as ~100 loop-invariant VGPRs -- which had the compiler spill to scratch.
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
             int ih0, iw0;
             window_origin(cur, ih0, iw0);
             float v[32];
-            bool bad = false;
+            float amax = 0.f;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int sh = row_first_float(cur, 2 * ry + dy) & 3;               // the row's shift in LDS (0 for W % 4 == 0 and iw0 % 4 == 0)
@@ -226,12 +233,14 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int iw = iw0 + 2 * rx + dx;
-                    const float m = (iw >= 0 && iw < p.W && tid < R0PIX) ? 1.f : 0.f;
+                    // column mask and the f16 pre-scale in ONE multiply (in_scale is a power of two: exact)
+                    const float m = (iw >= 0 && iw < p.W && tid < R0PIX) ? p.in_scale : 0.f;
 #pragma unroll
                     for (int ci = 0; ci < 3; ++ci) {
                         const float xv = w9[3 * dx + ci] * m;
-                        bad |= !(fabsf(xv) < p.in_bound);
-                        v[dy * 9 + dx * 3 + ci] = xv * p.in_scale;
+                        amax = fmaxf(amax, fabsf(xv));                       // (a NaN is caught below: fmaxf drops it, !(x < b) does not)
+                        amax = xv != xv ? __builtin_inff() : amax;
+                        v[dy * 9 + dx * 3 + ci] = xv;
                     }
                 }
             }
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
             }
             const int cy = y10 - 1 + ry, cx = x10 - 1 + rx;
             Cv[tid] = (tid < R0PIX && cy >= 0 && cy < p.H1 && cx >= 0 && cx < p.W1) ? 1.f : 0.f;
-            if (bad && p.overflow) atomicOr(p.overflow, 1);
+            if (!(amax < p.in_bound * p.in_scale) && p.overflow) atomicOr(p.overflow, 1);
         }
         if (tid < R1ROWS) {
             const int q = tid < R1PIX ? tid : 0;
@@ -293,10 +302,10 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
                 // lane: pixel m = 16 * rb + l16, channels nb*16 + 4*q4 + (0..3)   (operands swapped: weights first)
                 const int ri = (i + ODD) >> 1, nb = (i + ODD) & 1;
                 const int m = (rb0 + ri) * 16 + l16;
-                const float valid = Cv[m];
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = relu6(fmaf(acc[i][e], cds[nb][e], csh[nb][e])) * valid;
+                for (int e = 0; e < 4; ++e) o[e] = relu6(fmaf(acc[i][e], cds[nb][e], csh[nb][e]));
+                if (!interior) o = o * Cv[m];
                 *(f32x4*)(&Co[m * COP + 4 * (nb * 4 + q4)]) = o;
             }
         };
@@ -336,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
                     if (c0 + j < R1W) {
                         const f32x4 o = vfma(sum[j], as_v(d1sc), as_v(d1sh));
                         f32x4 v;
-                        v[0] = relu6(o[0]); v[1] = relu6(o[1]); v[2] = relu6(o[2]); v[3] = relu6(o[3]);
-                        v = v * p.a_scale;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(o[e], 0.f), cap6);
                         const f16x4 hi = __builtin_convertvector(v, f16x4);
                         const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
                         const int q = ry * R1W + c0 + j;
@@ -373,10 +382,10 @@ __global__ __launch_bounds__(256, 2) void stem3_fused_kernel(Stem3Params p) {
                 // lane: block-1 pixel m = 16*mb + l16, channels 16*wave + 4*q4 + (0..3)
                 const int m = (5 * half + i) * 16 + l16;
                 if (m < R1PIX) {
-                    const float valid = Pv[m];
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = relu6(fmaf(acc[i][e], pds[e], psh[e])) * valid;
+                    for (int e = 0; e < 4; ++e) o[e] = relu6(fmaf(acc[i][e], pds[e], psh[e]));
+                    if (!interior) o = o * Pv[m];
                     *(f32x4*)(&P1[m * P1P + wave * 16 + 4 * q4]) = o;
                 }
             }

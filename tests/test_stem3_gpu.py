@@ -70,7 +70,7 @@ def test_bounded_stem_vs_exact_stem_and_oracle(env, n, h, w):
         p1 = act6(d1.reshape(-1, 32).dot(kp.T.astype(np.float64)) + psh.cpu().numpy()).reshape(d1.shape[:3] + (64,))
         want = act6(tfo.depthwise_conv2d(p1, k2.cpu().numpy()[..., None].astype(np.float64), (2, 2), "SAME") * sc2.cpu().numpy() + sh2.cpu().numpy())
         e3, e2 = float(np.abs(y3.cpu().numpy() - want).max()), float(np.abs(y2.cpu().numpy() - want).max())
-        assert e3 < 6e-5 and e3 < 2 * e2 + 1e-6, (e3, e2)          # as close to fp64 as the exact-fp32-conv1 kernel is
+        assert e3 < 6e-5 and e3 < 4 * e2 + 2e-6, (e3, e2)          # within 4x of the exact-fp32-conv1 kernel's own distance to fp64 (the pointwise tests' rule)
 
 
 def test_bounded_stem_full_size_every_element_and_run_to_run(env):
