@@ -163,6 +163,8 @@ int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, i
 int launch_cv_resize(const unsigned char* in, float* out, int n, int H, int W, int oh, int ow, const int* x0, const int* x1,
                      const int* wx1, const int* y0, const int* y1, const int* wy1, int mode, const double* mean, hipStream_t s);
 
+int launch_area_level(const unsigned char* src, float* dst, int sh, int sw, int dh, int dw, hipStream_t s);
+int launch_area_crops(const unsigned char* src, const int* boxes, float* dst, int sh, int sw, int n, int size, hipStream_t s);
 int launch_pairwise_dist(const float* x, const float* y, int n, int m, int d, float* out, hipStream_t s);
 
 bool dwpw_fused_supported(int c, int cout, int stride, int act_dw, int act_pw);

@@ -783,6 +783,17 @@ int hsefr_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int 
     return launch_maxpool_f32(x, y, n, h, w, c, oh, ow, k, stride, pad_t, pad_l, (hipStream_t)stream);
 }
 
+int hsefr_mtcnn_pyramid_level(const unsigned char* d_frame, float* d_dst, int sh, int sw, int dh, int dw, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(d_frame && d_dst, HSEFR_ERR_INVALID, "mtcnn_pyramid_level: null pointer");
+    return launch_area_level(d_frame, d_dst, sh, sw, dh, dw, (hipStream_t)stream);
+}
+
+int hsefr_mtcnn_crops(const unsigned char* d_frame, const int* d_boxes, float* d_dst, int sh, int sw, int n, int size,
+                      hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (d_frame && d_boxes && d_dst), HSEFR_ERR_INVALID, "mtcnn_crops: null pointer");
+    return launch_area_crops(d_frame, d_boxes, d_dst, sh, sw, n, size, (hipStream_t)stream);
+}
+
 int hsefr_pairwise_dist(const float* x, const float* y, int n, int m, int d, float* out, hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || m == 0 || (x && y && out), HSEFR_ERR_INVALID, "pairwise_dist: null pointer");
     return launch_pairwise_dist(x, y, n, m, d, out, (hipStream_t)stream);

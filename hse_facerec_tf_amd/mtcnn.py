@@ -10,9 +10,12 @@ walker that fuses the patterns the file is made of:
     MaxPool                                                     -> hsefr_maxpool_f32
     RealDiv(Exp(x - Max(x)), Sum(Exp(..)))                      -> hsefr_softmax over the last axis
 
-The cascade logic (pyramid, box generation, NMS, regression, squaring, padded crops) is host NumPy, written to give
-the reference's numbers including its conventions: nets see transposed (W,H) images, boxes are 1-based inclusive,
-``np.fix`` truncation, INTER_AREA resizing (preprocess.resize_area).
+The image pyramid and the R-Net / O-Net crops (cv2.resize INTER_AREA, facial_analysis.py:507,546,575) are cut on the device
+from ONE upload of the frame (csrc/area_resize.hip: hsefr_mtcnn_pyramid_level / hsefr_mtcnn_crops, normalisation and the
+(W,H) transposition fused in); every P-Net level is launched before the first result is read back.  The box bookkeeping
+(threshold, NMS over a few hundred boxes, regression, squaring, window clipping) is host NumPy, written to give the
+reference's numbers including its conventions: boxes are 1-based inclusive, ``np.fix`` truncation.
+``device_resize=False`` keeps the round-1 path (host resizes through preprocess.resize_area).
 """
 from __future__ import annotations
 
@@ -229,10 +232,12 @@ class MTCNNDetector:
     THRESHOLDS = (0.6, 0.7, 0.9)       # facial_analysis.py:481
     FACTOR = 0.709                     # :483
 
-    def __init__(self, mtcnn_pb: Optional[str] = None, minsize: int = 32, device=None):
+    def __init__(self, mtcnn_pb: Optional[str] = None, minsize: int = 32, device=None, device_resize: bool = True):
         torch = _lib.require_gpu()
         self._torch = torch
         self.minsize = minsize
+        self.device_resize = device_resize
+        self._frame = None                 # the uint8 frame on the device (device_resize)
         self.device = _lib.cuda_device(device)
         self.net = _DeviceNet(read_graph(mtcnn_pb or MTCNN_PB), self.device)
 
@@ -259,13 +264,29 @@ class MTCNNDetector:
     def _to_device(self, a: np.ndarray):
         return self._torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
+    def _level_device(self, h: int, w: int, hs: int, ws: int):
+        """One pyramid level of the uploaded frame, normalised and transposed: CUDA float32 [1, ws, hs, 3]."""
+        torch = self._torch
+        out = torch.empty((1, ws, hs, 3), dtype=torch.float32, device=self.device)
+        with _lib.on_device(out):
+            _lib.check(_lib.lib().hsefr_mtcnn_pyramid_level(self._frame.data_ptr(), out.data_ptr(), h, w, hs, ws,
+                                                            _lib.current_stream_ptr()), "hsefr_mtcnn_pyramid_level")
+        return out
+
     def _stage1(self, img: np.ndarray) -> np.ndarray:
         h, w = img.shape[:2]
         found = [np.empty((0, 9))]
-        for scale in self.pyramid_scales(h, w):
+        scales = self.pyramid_scales(h, w)
+        maps = []
+        for scale in scales:                                         # launch every level first ...
             hs, ws = int(np.ceil(h * scale)), int(np.ceil(w * scale))
-            level = (preprocess.resize_area(img, ws, hs) - 127.5) * 0.0078125
-            reg_t, prob_t = self.pnet(self._to_device(np.transpose(level, (1, 0, 2))[None]))   # nets see (W, H)
+            if self.device_resize:
+                x = self._level_device(h, w, hs, ws)
+            else:
+                level = (preprocess.resize_area(img, ws, hs) - 127.5) * 0.0078125
+                x = self._to_device(np.transpose(level, (1, 0, 2))[None])           # nets see (W, H)
+            maps.append(self.pnet(x))
+        for scale, (reg_t, prob_t) in zip(scales, maps):             # ... then read the maps back
             prob = prob_t[0, :, :, 1].cpu().numpy()                  # [W', H']
             reg = reg_t[0].cpu().numpy()                             # [W', H', 4]
             xi, yi = np.nonzero(prob >= self.THRESHOLDS[0])
@@ -284,6 +305,16 @@ class MTCNNDetector:
     def _crops(self, img: np.ndarray, boxes: np.ndarray, size: int):
         h, w = img.shape[:2]
         bw, bh, x1, y1, x2, y2, tx1, ty1, tx2, ty2 = _crop_windows(boxes, w, h)
+        if self.device_resize:
+            torch = self._torch
+            n = boxes.shape[0]
+            tab = np.stack([x1, y1, x2, y2, tx1, ty1, bw, bh], axis=1).astype(np.int32)
+            d_tab = torch.from_numpy(np.ascontiguousarray(tab)).to(self.device)
+            out = torch.empty((n, size, size, 3), dtype=torch.float32, device=self.device)
+            with _lib.on_device(out):
+                _lib.check(_lib.lib().hsefr_mtcnn_crops(self._frame.data_ptr(), d_tab.data_ptr(), out.data_ptr(), h, w, n, size,
+                                                        _lib.current_stream_ptr()), "hsefr_mtcnn_crops")
+            return out
         out = np.zeros((boxes.shape[0], size, size, 3))
         for k in range(boxes.shape[0]):
             tile = np.zeros((int(bh[k]), int(bw[k]), 3))
@@ -294,6 +325,10 @@ class MTCNNDetector:
 
     def __call__(self, img: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         img = np.asarray(img)
+        if self.device_resize:
+            if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+                raise ValueError("the detector takes a uint8 RGB frame [H, W, 3]")
+            self._frame = self._torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
         points = np.array([])
         boxes = self._stage1(img)
         if boxes.shape[0]:

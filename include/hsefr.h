@@ -366,6 +366,18 @@ int hsefr_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_ind
 int hsefr_conv2d_direct(const float* x, const float* wgt, const float* bias, const float* alpha, float* y, int n, int h, int w, int c,
                         int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, hsefr_stream_t stream);
 
+/* cv2.resize(frame, (dw, dh), interpolation=cv2.INTER_AREA) of a uint8 RGB frame [sh,sw,3] for one level of the MTCNN image
+ * pyramid (facial_analysis.py:507), with the cascade's normalisation (v - 127.5) * 0.0078125 and its (W, H) transposition
+ * fused in: d_dst float32 [dw, dh, 3].  OpenCV's 8-bit semantics (float32 box accumulation, rounding to uint8). */
+int hsefr_mtcnn_pyramid_level(const unsigned char* d_frame, float* d_dst, int sh, int sw, int dh, int dw, hsefr_stream_t stream);
+
+/* The R-Net / O-Net inputs of the cascade (facial_analysis.py:546,575): for each of n boxes, the box-sized tile of the frame
+ * (zero outside it) resized to size x size with INTER_AREA in float64, normalised and transposed: d_dst float32
+ * [n, size, size, 3].  d_boxes int32 [n][8] = {x1, y1, x2, y2 (1-based inclusive window clipped to the frame), tx1, ty1
+ * (where the window lands in the tile), bw, bh (tile size)} as the reference's pad() computes them. */
+int hsefr_mtcnn_crops(const unsigned char* d_frame, const int* d_boxes, float* d_dst, int sh, int sw, int n, int size,
+                      hsefr_stream_t stream);
+
 /* MaxPool k x k / stride with windows clipped to the image (TF SAME/VALID: pass the TF pads), NHWC fp32. */
 int hsefr_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, int k, int stride, int pad_t, int pad_l,
                       hsefr_stream_t stream);

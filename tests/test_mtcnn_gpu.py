@@ -72,3 +72,56 @@ def test_process_image_full_dropin(z):
     assert rel(np.asarray(genders), z["genders"]) < 1e-4 and rel(np.asarray(feats), z["feats"]) < 1e-4
     assert [bool(FacialImageProcessing.is_male(g)[0]) for g in genders] == [bool(g >= 0.6) for g in z["genders"].ravel()]
     fip.close()
+
+
+def test_device_pyramid_levels_are_the_host_restatement_bit_for_bit(det):
+    """hsefr_mtcnn_pyramid_level against preprocess.resize_area (the INTER_AREA restatement the oracle uses) on every level of the
+    reference image's pyramid and on the special cases: exact 2x2 and 3x3 box factors, enlarging, identity."""
+    import torch
+    from hse_facerec_tf_amd import preprocess
+    img = opl.imread_rgb(TEST_IMAGE)
+    h, w = img.shape[:2]
+    det._frame = torch.from_numpy(np.ascontiguousarray(img)).to(det.device)
+    sizes = [(int(np.ceil(h * s)), int(np.ceil(w * s))) for s in det.pyramid_scales(h, w)]
+    sizes += [(h // 2, w // 2), (h // 3, w // 3 + (1 if w % 3 else 0)), (h, w), (h + 40, w + 25), (h // 2, w + 10)]
+    for hs, ws in sizes:
+        got = det._level_device(h, w, hs, ws)[0].cpu().numpy()
+        want = np.transpose((preprocess.resize_area(img, ws, hs) - 127.5) * 0.0078125, (1, 0, 2)).astype(np.float32)
+        assert got.shape == want.shape == (ws, hs, 3)
+        assert np.array_equal(got, want), (hs, ws, np.abs(got - want).max())
+
+
+def test_device_crops_match_the_host_restatement(det):
+    """hsefr_mtcnn_crops against the reference's pad() + cv2.resize(INTER_AREA) on boxes inside, across and outside the frame,
+    shrinking, enlarging and at size."""
+    import torch
+    img = opl.imread_rgb(TEST_IMAGE)
+    h, w = img.shape[:2]
+    rs = np.random.RandomState(3)
+    boxes = []
+    for _ in range(40):
+        side = int(rs.choice([10, 24, 25, 47, 48, 49, 96, 130, 300]))
+        x1 = int(rs.randint(-side // 2, w - side // 2))
+        y1 = int(rs.randint(-side // 2, h - side // 2))
+        boxes.append([x1, y1, x1 + side - 1, y1 + side - 1 + int(rs.randint(0, 2)), 0.9])
+    boxes = np.asarray(boxes, np.float64)
+    for size in (24, 48):
+        det.device_resize = True
+        det._frame = torch.from_numpy(np.ascontiguousarray(img)).to(det.device)
+        got = det._crops(img, boxes, size).cpu().numpy()
+        det.device_resize = False
+        want = det._crops(img, boxes, size).cpu().numpy()
+        det.device_resize = True
+        assert got.shape == want.shape == (40, size, size, 3)
+        assert np.abs(got - want).max() < 2e-6              # float64 box sums in another order: round-off of the final float32
+
+
+def test_device_and_host_resizing_find_the_same_faces(z):
+    from hse_facerec_tf_amd.mtcnn import MTCNNDetector
+    img = opl.imread_rgb(TEST_IMAGE)
+    a = MTCNNDetector(minsize=32, device_resize=True)(img)
+    b = MTCNNDetector(minsize=32, device_resize=False)(img)
+    assert a[0].shape == b[0].shape == (4, 5)
+    assert np.abs(a[0] - b[0]).max() < 1e-3 and np.abs(a[1] - b[1]).max() < 1e-3
+    with pytest.raises(ValueError):
+        MTCNNDetector(minsize=32)(img.astype(np.float32))
