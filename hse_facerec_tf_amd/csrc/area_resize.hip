@@ -21,7 +21,8 @@ struct AreaTap { int first, count; float w_first, w_mid, w_last; };      // taps
 // OpenCV's decimation cell of destination index d (preprocess.py _area_weights), ssize >= dsize
 __device__ __forceinline__ void area_cell(int d, int ssize, double scale, int& a, int& b, double& cell, bool& has_lo, double& w_lo, bool& has_hi,
                                           double& w_hi) {
-    const double lo = d * scale, hi = lo + scale;
+    // explicit mul / add: contracted into an fma, `hi` lands one ulp away and with it floor(hi) on integer boundaries
+    const double lo = __dmul_rn((double)d, scale), hi = __dadd_rn(lo, scale);
     cell = fmin(scale, (double)ssize - lo);
     a = (int)ceil(lo);
     b = (int)fmin(floor(hi), (double)(ssize - 1));
@@ -35,8 +36,8 @@ __device__ __forceinline__ void area_cell(int d, int ssize, double scale, int& a
 // INTER_AREA when enlarging: bilinear taps with the area-mode coordinate rule (preprocess.py _area_linear_taps)
 __device__ __forceinline__ void linear_tap(int d, int ssize, double scale, int& s0, int& s1, float& f) {
     const double inv = 1.0 / scale;
-    s0 = (int)floor(d * scale);
-    float ff = (float)((double)(d + 1) - (double)(s0 + 1) * inv);
+    s0 = (int)floor(__dmul_rn((double)d, scale));
+    float ff = (float)__dsub_rn((double)(d + 1), __dmul_rn((double)(s0 + 1), inv));
     ff = ff <= 0.f ? 0.f : ff - floorf(ff);
     if (s0 >= ssize - 1) { s0 = ssize - 1; ff = 0.f; }
     s1 = s0 + 1 < ssize ? s0 + 1 : ssize - 1;
