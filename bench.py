@@ -375,6 +375,48 @@ def run_other_configs(args, dev):
         eng.close()
     except Exception as e:
         out.append({"config": "BASELINE configs[1] pw_math=f32", "error": repr(e)})
+    # -- configs[2] in the fp32-grade mode (exact-fp32 general kernels; the 1e-4 mode of a ResNet): a correctness mode, timed for the record
+    try:
+        B = 32
+        plan = resnet50.build_plan(resnet50.synthetic_weights(123), (224, 224), "caffe", dtype="f32")
+        eng = Engine(plan, max_batch=B, device=dev.index)
+        dt = time_engine(eng, gen(B, 224), (0,), max(3, steps // 4), 1)
+        fl = resnet50.flops_per_image(plan)
+        out.append({"config": "BASELINE configs[2] in the fp32-grade mode: ResNet-50 batch %d, exact fp32 FMA convolutions (dtype='f32')" % B,
+                    "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": max(3, steps // 4), "dtype": "f32",
+                    "roofline": {"bound": "mfma", "achieved": round(fl * B / dt / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                 "frac": round(fl * B / dt / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                                 "note": "vector-FMA direct convolution; a parity mode (1e-4 bar), not a throughput mode"}})
+        eng.close()
+    except Exception as e:
+        out.append({"config": "BASELINE configs[2] fp32-grade mode", "error": repr(e)})
+    # -- the detector in front of the hot loop: FacialImageProcessing.process_image on the reference's own test photo
+    try:
+        from hse_facerec_tf_amd import FacialImageProcessing, preprocess
+        from hse_facerec_tf_amd.mtcnn import MTCNNDetector
+        photo = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "test_image.jpg")
+        bgr = np.ascontiguousarray(preprocess.imread_rgb(photo)[..., ::-1])
+        rec = {"config": "MTCNN detection + alignment of one %dx%d photo (FacialImageProcessing.process_image, minsize 32), per call"
+                         % (bgr.shape[1], bgr.shape[0]), "unit": "ms", "higher_is_better": False}
+        for name, dres in (("device_pyramid", True), ("host_pyramid", False)):
+            fp = FacialImageProcessing(mtcnn_detector=True, minsize=32, device=dev.index,
+                                       detector=MTCNNDetector(minsize=32, device=dev.index, device_resize=dres))
+            for _ in range(2):
+                r = fp.process_image(bgr)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                r = fp.process_image(bgr)
+            torch.cuda.synchronize(dev)
+            rec[name + "_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 2)
+            rec["faces"] = int(len(r[0]))
+            fp.close()
+        rec["value"] = rec["device_pyramid_ms"]
+        rec["note"] = ("device_pyramid: frame uploaded once as uint8, INTER_AREA pyramid levels and the 24x24/48x48 crops resampled on the "
+                       "GPU (csrc/area_resize.hip); host_pyramid: round 1's NumPy resampling; NMS and box regression on the host in both")
+        out.append(rec)
+    except Exception as e:
+        out.append({"config": "MTCNN process_image", "error": repr(e)})
     del rs
     return out
 

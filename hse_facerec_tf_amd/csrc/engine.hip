@@ -107,7 +107,13 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
         };
         const uint64_t co = o.cout, ci = o.cin, kk = (uint64_t)o.kh * o.kw;
         switch (o.kind) {
-            case HSEFR_OP_GAP: case HSEFR_OP_SOFTMAX: case HSEFR_OP_MAXPOOL_BF16: case HSEFR_OP_GAP_BF16:
+            case HSEFR_OP_GAP: case HSEFR_OP_SOFTMAX: case HSEFR_OP_MAXPOOL_BF16: case HSEFR_OP_GAP_BF16: case HSEFR_OP_MAXPOOL_F32:
+                break;
+            case HSEFR_OP_CONV_F32:
+                if (!need(o.w_off, kk * ci * co * 4, "kernel")) return HSEFR_ERR_INVALID;
+                if (o.scale_off != HSEFR_NO_OFFSET && !need(o.scale_off, co * 4, "scale")) return HSEFR_ERR_INVALID;
+                if (o.shift_off != HSEFR_NO_OFFSET && !need(o.shift_off, co * 4, "shift")) return HSEFR_ERR_INVALID;
+                HSEFR_REQUIRE(o.cout % 4 == 0, HSEFR_ERR_UNSUPPORTED, "plan op %u: fp32 convolution with cout=%d (must be a multiple of 4)", i, o.cout);
                 break;
             case HSEFR_OP_CONV_C3:
                 if (!need(o.w_off, kk * ci * co * 4, "kernel") || !need(o.shift_off, co * 4, "shift")) return HSEFR_ERR_INVALID;
@@ -427,6 +433,14 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                       (const float*)blob_ptr(e, o.shift_off),
                                       o.res_buf >= 0 ? tab[o.res_buf] : nullptr, out, n, o.h, o.w, o.cin, o.oh,
                                       o.ow, o.cout, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.act, s);
+                break;
+            case HSEFR_OP_CONV_F32:
+                rc = launch_conv2d_f32((const float*)in, (const float*)blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
+                                       (const float*)blob_ptr(e, o.shift_off), o.res_buf >= 0 ? (const float*)tab[o.res_buf] : nullptr,
+                                       (float*)out, n, o.h, o.w, o.cin, o.oh, o.ow, o.cout, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.act, s);
+                break;
+            case HSEFR_OP_MAXPOOL_F32:
+                rc = launch_maxpool_f32((const float*)in, (float*)out, n, o.h, o.w, o.cin, o.oh, o.ow, o.kh, o.stride, o.pad_t, o.pad_l, s);
                 break;
             case HSEFR_OP_STEM7X7_BF16:
                 rc = launch_stem7x7_bf16((const float*)in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
@@ -775,6 +789,13 @@ int hsefr_conv2d_direct(const float* x, const float* wgt, const float* bias, con
                         int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || (x && wgt && y), HSEFR_ERR_INVALID, "conv2d_direct: null pointer");
     return launch_conv2d_direct(x, wgt, bias, alpha, y, n, h, w, c, oh, ow, cout, kh, kw, stride, pad_t, pad_l, (hipStream_t)stream);
+}
+
+int hsefr_conv2d_f32(const float* x, const float* wgt, const float* scale, const float* shift, const float* res, float* y, int n, int h,
+                     int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act,
+                     hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wgt && y), HSEFR_ERR_INVALID, "conv2d_f32: null pointer");
+    return launch_conv2d_f32(x, wgt, scale, shift, res, y, n, h, w, c, oh, ow, cout, kh, kw, stride, pad_t, pad_l, act, (hipStream_t)stream);
 }
 
 int hsefr_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, int k, int stride, int pad_t, int pad_l,

@@ -64,7 +64,66 @@ __global__ __launch_bounds__(256) void maxpool_f32_kernel(const float* __restric
     y[i] = m;
 }
 
+// General NHWC fp32 convolution with the epilogue of the bf16 ResNet kernels (per-channel scale + shift, optional residual,
+// activation): the fp32-grade mode of ResNet-style graphs (facerec_test.py:213 at the 1e-4 bar; SURVEY 7 "hard parts").  A
+// thread owns four consecutive output channels of one pixel: the input value is a broadcast, the four weights one 16-byte
+// load.  Exact fp32 FMA chains -- a correctness mode, an order of magnitude slower than the bf16 MFMA path.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void conv2d_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ res, float* __restrict__ y,
+                                                         int H, int W, int C, int OH, int OW, int Cout, int KH, int KW, int stride, int pad_t,
+                                                         int pad_l, int act, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4n = Cout / 4;
+    const int co = (int)(i % c4n) * 4;
+    const long long p = i / c4n;
+    const int ow = (int)(p % OW);
+    const long long t = p / OW;
+    const int oh = (int)(t % OH);
+    const long long n = t / OH;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* xn = x + n * (long long)H * W * C;
+    for (int kh = 0; kh < KH; ++kh) {
+        const int ih = oh * stride - pad_t + kh;
+        if (ih < 0 || ih >= H) continue;
+        for (int kw = 0; kw < KW; ++kw) {
+            const int iw = ow * stride - pad_l + kw;
+            if (iw < 0 || iw >= W) continue;
+            const float* xp = xn + ((long long)ih * W + iw) * C;
+            const float* wp = w + (long long)((kh * KW + kw) * C) * Cout + co;
+            for (int c = 0; c < C; ++c) {
+                const f32x4 wv = *(const f32x4*)(wp + (long long)c * Cout);
+                const float xv = xp[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, wv[e], acc[e]);
+            }
+        }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = fmaf(acc[e], scale ? scale[co + e] : 1.f, shift ? shift[co + e] : 0.f);
+        if (res) v += res[p * Cout + co + e];
+        o[e] = apply_act_rt(v, act);
+    }
+    *(f32x4*)(y + p * Cout + co) = o;
+}
+
 }  // namespace
+
+int launch_conv2d_f32(const float* x, const float* w, const float* scale, const float* shift, const float* res, float* y, int n, int h,
+                      int wd, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act, hipStream_t s) {
+    HSEFR_REQUIRE(n >= 0 && h > 0 && wd > 0 && c > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && oh > 0 && ow > 0, HSEFR_ERR_INVALID,
+                  "conv2d_f32: bad shape");
+    HSEFR_REQUIRE(cout % 4 == 0, HSEFR_ERR_UNSUPPORTED, "conv2d_f32: cout=%d must be a multiple of 4", cout);
+    if (n == 0) return HSEFR_OK;
+    const long long total = (long long)n * oh * ow * (cout / 4);
+    HSEFR_REQUIRE((total + 255) / 256 < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv2d_f32: grid too large");
+    hipLaunchKernelGGL(conv2d_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scale, shift, res, y, h, wd, c, oh, ow,
+                       cout, kh, kw, stride, pad_t, pad_l, act, total);
+    return launch_status("conv2d_f32");
+}
 
 int launch_conv2d_direct(const float* x, const float* w, const float* bias, const float* alpha, float* y, int n, int h, int wd, int c,
                          int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, hipStream_t s) {

@@ -34,6 +34,7 @@ OP_DWPW_F16S = 13        # fused block with split-f16 pointwise products for any
 OP_STEM_F16S = 14        # conv1 -> depthwise -> pointwise in one kernel (csrc/stem_fused.hip)
 OP_STEM2_F16S = 15       # ... -> pointwise -> the stride-2 depthwise of block 2 in one kernel (csrc/stem2_fused.hip)
 OP_STEM3_F16S = 17       # STEM2_F16S for an input with a declared bound: conv1 on the f16 MFMA too (csrc/stem3_fused.hip)
+OP_CONV_F32, OP_MAXPOOL_F32 = 18, 19   # general KxK fp32 convolution / clipped max-pool: the fp32-grade mode of ResNet-style graphs
 OP_PWCONV_PS = 16        # wire kind of a split-f16 pointwise Layer whose input is stored PRE-SPLIT by its producer (csrc/pwconv_ps.hip)
 _BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
@@ -266,7 +267,7 @@ class Plan:
     def layer_flops(L: "Layer") -> int:
         """Algorithmic multiply-add flops of ONE layer per image (fused layers: the sum of what they replace)."""
         oh, ow, cout = L.out_shape
-        if L.kind in (OP_CONV_C3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16):
+        if L.kind in (OP_CONV_C3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32):
             return 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
         if L.kind == OP_DWCONV3X3:
             return 2 * oh * ow * cout * 9
@@ -290,6 +291,7 @@ class _Lowerer:
     def __init__(self, g: Graph, input_name: str, in_hw: Tuple[int, int], feeds: Dict[str, object], dtype: str = "f32"):
         self.g = g
         self.bf16 = dtype == "bf16"
+        self.general = dtype in ("bf16", "f32g")      # general conv / pool / residual graphs (ResNet-style)
         self.input_name = input_name
         self.in_hw = in_hw
         self.feeds = feeds
@@ -473,7 +475,7 @@ class _Lowerer:
             self.pending_pad = getattr(self, "pending_pad", {})
             self.pending_pad[node.name] = (int(pads[1][0]), int(pads[1][1]), int(pads[2][0]), int(pads[2][1]))
             return r
-        if op in ("MaxPool", "AvgPool") and self.bf16:
+        if op in ("MaxPool", "AvgPool") and self.general:
             src_node = acts[0][0]
             src = self.finished(self.lower_node(src_node))
             h, wd, c = self.shape_of(src)
@@ -482,8 +484,8 @@ class _Lowerer:
             if op == "AvgPool":
                 if (k[1], k[2]) != (h, wd) or node.attr_s("padding") != "VALID" or epad:
                     raise LoweringError("%s: only a global VALID AvgPool is supported" % node.name)
-                return self.new_layer(Layer(OP_GAP_BF16, node.name, src, (h, wd, c), (1, 1, c), sealed=True), node)
-            if (k[1], k[2]) != (3, 3) or (st[1], st[2]) != (2, 2) or c % 8:
+                return self.new_layer(Layer(OP_GAP_BF16 if self.bf16 else OP_GAP, node.name, src, (h, wd, c), (1, 1, c), sealed=True), node)
+            if (k[1], k[2]) != (3, 3) or (st[1], st[2]) != (2, 2) or (self.bf16 and c % 8):
                 raise LoweringError("%s: only 3x3/2 max-pooling is supported" % node.name)
             if epad:
                 if node.attr_s("padding") != "VALID" or (src >= 0 and self.layers[src].act not in (ACT_RELU, ACT_RELU6)):
@@ -495,9 +497,9 @@ class _Lowerer:
                 ow, pl = tf_same_padding(wd, 3, 2)
             else:
                 oh, ow, pt, pl = (h - 3) // 2 + 1, (wd - 3) // 2 + 1, 0, 0
-            return self.new_layer(Layer(OP_MAXPOOL_BF16, node.name, src, (h, wd, c), (oh, ow, c), kh=3, kw=3, stride=2, pad_t=pt,
+            return self.new_layer(Layer(OP_MAXPOOL_BF16 if self.bf16 else OP_MAXPOOL_F32, node.name, src, (h, wd, c), (oh, ow, c), kh=3, kw=3, stride=2, pad_t=pt,
                                         pad_l=pl, sealed=True), node)
-        if op == "Conv2D" and self.bf16:
+        if op == "Conv2D" and self.general:
             if node.attr_s("data_format", "NHWC") != "NHWC":
                 raise LoweringError("%s: only NHWC graphs are supported" % node.name)
             src_node = acts[0][0]
@@ -519,7 +521,11 @@ class _Lowerer:
                 ow, pl = tf_same_padding(wd, kw, s[1])
             else:
                 oh, ow, pt, pl = (h - kh) // s[1] + 1, (wd - kw) // s[1] + 1, 0, 0
-            if c == 3 and (kh, kw) == (7, 7) and s[1] == 2 and (pt, pl) == (3, 3) and cout == 64 and src < 0:
+            if not self.bf16:
+                if cout % 4:
+                    raise LoweringError("%s: fp32 Conv2D with %d output channels (must be a multiple of 4)" % (node.name, cout))
+                kind = OP_CONV_F32
+            elif c == 3 and (kh, kw) == (7, 7) and s[1] == 2 and (pt, pl) == (3, 3) and cout == 64 and src < 0:
                 kind = OP_STEM7X7_BF16
             elif c % 64 == 0 and cout % 64 == 0 and kh <= 7 and kw <= 7:
                 kind = OP_CONV_BF16
@@ -527,12 +533,12 @@ class _Lowerer:
                 raise LoweringError("%s: no bf16 kernel for Conv2D k=%r stride %d pads (%d,%d)" % (node.name, w.shape, s[1], pt, pl))
             return self.new_layer(Layer(kind, node.name, src, (h, wd, c), (oh, ow, cout), w=w, kh=kh, kw=kw, stride=s[1],
                                         pad_t=pt, pad_l=pl), node)
-        if op in ("Add", "AddV2") and self.bf16 and len(acts) == 2:
+        if op in ("Add", "AddV2") and self.general and len(acts) == 2:
             # residual sum: folded into the epilogue of whichever branch ends in an open conv layer
             ia, ib = self.lower_node(acts[0][0]), self.lower_node(acts[1][0])
             for (i_main, n_main, i_res) in ((ia, acts[0][0], ib), (ib, acts[1][0], ia)):
                 L = self.layers[i_main] if i_main >= 0 else None
-                if (L is not None and L.kind == OP_CONV_BF16 and not L.sealed and L.act == ACT_NONE and L.res < 0 and
+                if (L is not None and L.kind in (OP_CONV_BF16, OP_CONV_F32) and not L.sealed and L.act == ACT_NONE and L.res < 0 and
                         self.live_consumers(n_main.name) == 1 and i_res >= 0 and i_res != i_main):
                     self.finished(i_res)
                     if i_res > i_main:      # the shortcut branch was lowered after this conv: run the conv last
@@ -632,12 +638,12 @@ class _Lowerer:
 
         if L.res >= 0 and op not in ("Relu", "Relu6", "Minimum", "Maximum"):
             raise LoweringError("%s: affine op after a fused residual sum" % node.name)
-        if op in ("Mul",) and not L.sealed and L.act == ACT_NONE and L.kind in (OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16):
+        if op in ("Mul",) and not L.sealed and L.act == ACT_NONE and L.kind in (OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32):
             v = vec(consts[0])
             L.scale = v if L.scale is None else L.scale * v
             if L.shift is not None:
                 L.shift = L.shift * v
-        elif op in ("Add", "AddV2", "BiasAdd") and not L.sealed and L.act == ACT_NONE and L.kind in (OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16):
+        elif op in ("Add", "AddV2", "BiasAdd") and not L.sealed and L.act == ACT_NONE and L.kind in (OP_CONV_C3, OP_DWCONV3X3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32):
             v = vec(consts[0])
             L.shift = v if L.shift is None else L.shift + v
         elif op == "Sub" and not L.sealed and L.act == ACT_NONE and ins[0][0] is acts[0][0]:
@@ -944,7 +950,11 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
     presplit: 'auto' (default; env HSEFR_PRESPLIT=auto|none) = depthwise layers feeding a split-f16 pointwise layer store
     their result pre-split and the GEMM stages both operands by LDS-DMA (presplit_activations); 'none' = fp32 tensors.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
-    (general KxK Conv2D, Pad, FusedBatchNorm / Mul+Add, residual Add, MaxPool 3x3/2, global AvgPool / Mean)."""
+    (general KxK Conv2D, Pad, FusedBatchNorm / Mul+Add, residual Add, MaxPool 3x3/2, global AvgPool / Mean); 'f32g': the
+    same ResNet-style graph patterns on exact-fp32 kernels (OP_CONV_F32 / OP_MAXPOOL_F32 / OP_GAP) -- the fp32-grade mode
+    that meets the 1e-4 bar on a ResNet, an order of magnitude slower than 'bf16'."""
+    if dtype not in ("f32", "bf16", "f32g"):
+        raise ValueError("dtype must be 'f32', 'bf16' or 'f32g', not %r" % (dtype,))
     in_node, _ = g.get_tensor_by_name(input_tensor)
     shape = g.placeholder_shape(in_node.name)
     if input_hw is None:
@@ -976,6 +986,8 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
             L.shift = np.zeros(L.out_shape[2], np.float32)
         if L.kind == OP_DWCONV3X3 and L.scale is None:
             L.scale = np.ones(L.out_shape[2], np.float32)
+        if L.kind == OP_CONV_F32 and L.act not in (ACT_NONE, ACT_RELU, ACT_RELU6):
+            raise LoweringError("%s: activation %d on a general convolution" % (L.name, L.act))
         if L.kind in (OP_CONV_BF16, OP_STEM7X7_BF16):
             cout = L.out_shape[2]
             L.scale = np.ones(cout, np.float32) if L.scale is None else L.scale.astype(np.float32)

@@ -359,6 +359,32 @@ def conv2d_direct(x, w_hwio, bias=None, alpha=None, stride: int = 1, padding: st
 
 
 @_device_guarded
+def conv2d_f32(x, w_hwio, scale=None, shift=None, stride: int = 1, pad: int = 0, res=None, act: int = ACT_NONE):
+    """General Conv2D in exact fp32 + per-channel scale / shift + optional residual + activation (the fp32-grade mode of the
+    ResNet-style graphs).  x [n,h,w,c], w_hwio [kh,kw,c,cout] with cout % 4 == 0, symmetric zero padding `pad`."""
+    torch = _lib.require_gpu()
+    _f32c(x, "x"), _f32c(w_hwio, "w")
+    n, h, w, c = x.shape
+    kh, kw, wc, cout = w_hwio.shape
+    if wc != c:
+        raise ValueError("kernel expects %d input channels, tensor has %d" % (wc, c))
+    oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    if oh <= 0 or ow <= 0:
+        raise ValueError("kernel %dx%d does not fit a %dx%d tensor padded by %d" % (kh, kw, h, w, pad))
+    y = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    if res is not None and tuple(_f32c(res, "res").shape) != tuple(y.shape):
+        raise ValueError("residual shape %r, output shape %r" % (tuple(res.shape), tuple(y.shape)))
+    for v, name in ((scale, "scale"), (shift, "shift")):
+        if v is not None and _f32c(v, name).numel() != cout:
+            raise ValueError("%s has %d elements for %d output channels" % (name, v.numel(), cout))
+    _lib.check(_lib.lib().hsefr_conv2d_f32(x.data_ptr(), w_hwio.data_ptr(), None if scale is None else scale.data_ptr(),
+                                           None if shift is None else shift.data_ptr(), None if res is None else res.data_ptr(),
+                                           y.data_ptr(), n, h, w, c, oh, ow, cout, kh, kw, stride, pad, pad, act,
+                                           _lib.current_stream_ptr()), "hsefr_conv2d_f32")
+    return y
+
+
+@_device_guarded
 def maxpool(x, k: int, stride: int, padding: str = "SAME"):
     torch = _lib.require_gpu()
     _f32c(x, "x")

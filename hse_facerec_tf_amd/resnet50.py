@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from . import lowering
-from .lowering import (ACT_NONE, ACT_RELU, OP_CONV_BF16, OP_GAP_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16, OUT_FEATURES,
+from .lowering import (ACT_NONE, ACT_RELU, OP_CONV_BF16, OP_CONV_F32, OP_GAP, OP_GAP_BF16, OP_MAXPOOL_F32, OP_MAXPOOL_BF16, OP_STEM7X7_BF16, OUT_FEATURES,
                        Layer, Plan, assign_buffers)
 
 STAGES = [("conv2", 3, 64, 256, 1), ("conv3", 4, 128, 512, 2), ("conv4", 6, 256, 1024, 2), ("conv5", 3, 512, 2048, 2)]
@@ -83,8 +83,13 @@ def pack_stem_weight(kernel_hwio: np.ndarray) -> np.ndarray:
     return to_bf16_bits(img.reshape(64, 256))
 
 
-def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224, 224), pool: str = "caffe") -> Plan:
-    """pool='caffe': pad-0 ceil-mode max-pool (112 -> 56); pool='valid': keras_vggface's valid pool (112 -> 55)."""
+def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224, 224), pool: str = "caffe", dtype: str = "bf16") -> Plan:
+    """pool='caffe': pad-0 ceil-mode max-pool (112 -> 56); pool='valid': keras_vggface's valid pool (112 -> 55).
+    dtype='bf16': the bf16-MFMA kernels (BASELINE config 3's throughput mode); dtype='f32': the same layers on the exact-fp32
+    general kernels (OP_CONV_F32 / OP_MAXPOOL_F32 / OP_GAP) -- the fp32-grade mode, 1e-4 against the fp64 oracle."""
+    if dtype not in ("bf16", "f32"):
+        raise ValueError("dtype must be 'bf16' or 'f32', not %r" % (dtype,))
+    f32 = dtype == "f32"
     H, W = input_hw
     layers: List[Layer] = []
 
@@ -96,7 +101,8 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
         return (h + 2 * pad - k) // s + 1
 
     oh, ow = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
-    cur = add(Layer(OP_STEM7X7_BF16, "conv1_7x7_s2", -1, (H, W, 3), (oh, ow, 64), w=pack_stem_weight(weights["conv1_7x7_s2/kernel"]),
+    cur = add(Layer(OP_CONV_F32 if f32 else OP_STEM7X7_BF16, "conv1_7x7_s2", -1, (H, W, 3), (oh, ow, 64),
+                    w=weights["conv1_7x7_s2/kernel"].astype(np.float32) if f32 else pack_stem_weight(weights["conv1_7x7_s2/kernel"]),
                     scale=weights["conv1_7x7_s2/scale"], shift=weights["conv1_7x7_s2/shift"], act=ACT_RELU, kh=7, kw=7,
                     stride=2, pad_t=3, pad_l=3))
     if pool == "caffe":
@@ -105,14 +111,15 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
         ph, pw = (oh - 3) // 2 + 1, (ow - 3) // 2 + 1
     else:
         raise ValueError(pool)
-    cur = add(Layer(OP_MAXPOOL_BF16, "pool1_3x3_s2", cur, (oh, ow, 64), (ph, pw, 64), kh=3, kw=3, stride=2))
+    cur = add(Layer(OP_MAXPOOL_F32 if f32 else OP_MAXPOOL_BF16, "pool1_3x3_s2", cur, (oh, ow, 64), (ph, pw, 64), kh=3, kw=3, stride=2))
     h, w_, cin = ph, pw, 64
 
     def conv(name, src, hwc, k, cout, stride, act, res=-1):
         hh, ww, cc = hwc
         pad = (k - 1) // 2
         o = (conv_out(hh, k, stride, pad), conv_out(ww, k, stride, pad), cout)
-        return add(Layer(OP_CONV_BF16, name, src, hwc, o, w=pack_conv_weight(weights[name + "/kernel"]),
+        return add(Layer(OP_CONV_F32 if f32 else OP_CONV_BF16, name, src, hwc, o,
+                         w=weights[name + "/kernel"].astype(np.float32) if f32 else pack_conv_weight(weights[name + "/kernel"]),
                          scale=weights[name + "/scale"], shift=weights[name + "/shift"], act=act, kh=k, kw=k,
                          stride=stride, pad_t=pad, pad_l=pad, res=res))
 
@@ -126,7 +133,7 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
             sc = conv(pre + "_1x1_proj", x_in, x_shape, 1, cout, s, ACT_NONE) if b == 1 else x_in
             cur = conv(pre + "_1x1_increase", t, layers[t].out_shape, 1, cout, 1, ACT_RELU, res=sc)
             h, w_, cin = layers[cur].out_shape
-    gap = add(Layer(OP_GAP_BF16, "pool5_7x7_s1", cur, (h, w_, cin), (1, 1, cin)))
+    gap = add(Layer(OP_GAP if f32 else OP_GAP_BF16, "pool5_7x7_s1", cur, (h, w_, cin), (1, 1, cin)))
     for L in layers:
         L.sealed = True
     buffers = assign_buffers(layers, {gap})
@@ -137,7 +144,7 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
 def flops_per_image(plan: Plan) -> int:
     tot = 0
     for L in plan.layers:
-        if L.kind in (OP_CONV_BF16, OP_STEM7X7_BF16):
+        if L.kind in (OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32):
             oh, ow, cout = L.out_shape
             tot += 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
     return tot
@@ -158,11 +165,12 @@ class ResNet50Extractor:
     close_session); preprocessing flags are those of facerec_test.py:213 (BGR, VGGFace2 mean)."""
 
     def __init__(self, weights: Optional[Dict[str, np.ndarray]] = None, input_size: Tuple[int, int] = (224, 224),
-                 max_batch: int = 128, device: Optional[int] = None, pool: str = "caffe", seed: int = 123):
+                 max_batch: int = 128, device: Optional[int] = None, pool: str = "caffe", seed: int = 123, dtype: str = "bf16"):
         from .engine import Engine
         self.w, self.h = input_size
         self.convert2BGR, self.imageNetUtilsMean = True, False
-        self.plan = build_plan(weights if weights is not None else synthetic_weights(seed), (self.h, self.w), pool)
+        self.plan = build_plan(weights if weights is not None else synthetic_weights(seed), (self.h, self.w), pool, dtype)
+        self.dtype = dtype
         self.engine = Engine(self.plan, max_batch=max_batch, device=device)
         self.feature_dim = 2048
 

@@ -69,8 +69,10 @@ class TensorFlowInference:
         self.tf_learning_phase = learning_phase_tensor
         # NB the reference unpacks the NHWC placeholder shape as (_, w, h, _) and feeds [h?, w?]:
         # rows = self.w.  All models in scope are square.
-        # dtype: 'f32' = exact fp32 kernels (MobileNet-style graphs), 'bf16' = bf16-MFMA kernels (ResNet-style graphs,
-        # BASELINE config 3), 'auto' = fp32 when the graph is covered by the fp32 kernels, else bf16
+        # dtype: 'f32' = fp32-grade results: the MobileNet kernels when the graph is MobileNet-shaped, else the general
+        # exact-fp32 kernels (ResNet-style graphs at the 1e-4 bar, an order of magnitude slower than bf16);
+        # 'bf16' = bf16-MFMA kernels (ResNet-style graphs, BASELINE config 3), 'auto' = the MobileNet fp32 kernels when
+        # they cover the graph, else bf16.  self.dtype names what was chosen ('f32', 'f32g' = general fp32, 'bf16').
         # input_bound: what preprocess_image guarantees about the values this class feeds -- uint8 pixels minus a BGR mean lie
         # in [-131.1, 151.1], the non-BGR branch in [-1, 1] (facerec_test.py:93-110): |x| < 256.  The fused stem uses it
         # (csrc/stem3_fused.hip) and CHECKS it on the device; extract_batch with values outside it raises.  None = no
@@ -85,9 +87,15 @@ class TensorFlowInference:
             except LoweringError:
                 self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype="bf16")
                 dtype = "bf16"
+        elif dtype == "f32":
+            try:
+                self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds,
+                                        input_bound=input_bound)
+            except LoweringError:
+                self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype="f32g")
+                dtype = "f32g"
         else:
-            self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype=dtype,
-                                    input_bound=input_bound if dtype == "f32" else None)
+            self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype=dtype)
         self.dtype = dtype
         self.engine = Engine(self.plan, max_batch=max_batch, device=device)
         self.tf_sess = self.engine           # attribute name kept for callers that poke at it

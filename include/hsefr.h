@@ -98,6 +98,10 @@ typedef enum hsefr_op_kind {
                                   image, oh,ow,cout = the block output, pad_t/pad_l = the conv's; w_off = fp32 pack
                                   [conv HWIO 864 | conv shift 32 | dw 3x3x32 288 | dw scale 32 | dw shift 32];
                                   w2_off = split rows [64][64 f16]; shift2_off = [2][64] descale, shift; reserved = a_log2 */
+    HSEFR_OP_CONV_F32 = 18,    /* general KxK conv, stride, zero padding, fp32 NHWC in/out, exact fp32 FMA; epilogue as CONV_BF16
+                                  (per-channel scale + shift, optional residual buffer, act): the fp32-grade mode of
+                                  ResNet-style graphs (csrc/smallnet.hip).  w_off = TF HWIO kernel fp32, cout % 4 == 0  */
+    HSEFR_OP_MAXPOOL_F32 = 19, /* k x k / stride max-pool with windows clipped to the image, fp32 (kh = kw = k)          */
     HSEFR_OP_STEM3_F16S = 17,  /* STEM2_F16S for an input with a DECLARED BOUND |x| < 2^(15 - in_log2) (csrc/stem3_fused.hip): conv1's
                                   products are formed on the f16 MFMA from two-term splits like the pointwise layers'.
                                   w_off = the STEM2 fp32 pack (1952 floats) | conv1 split rows [32][64 f16] (1024 floats) |
@@ -377,6 +381,13 @@ int hsefr_mtcnn_pyramid_level(const unsigned char* d_frame, float* d_dst, int sh
  * (where the window lands in the tile), bw, bh (tile size)} as the reference's pad() computes them. */
 int hsefr_mtcnn_crops(const unsigned char* d_frame, const int* d_boxes, float* d_dst, int sh, int sw, int n, int size,
                       hsefr_stream_t stream);
+
+/* General Conv2D in exact fp32 (FMA chains) + per-channel scale (NULL = 1) + shift (NULL = 0) + optional residual + act:
+ * x [n,h,w,c], wgt [kh,kw,c,cout] (TF HWIO), res / y [n,oh,ow,cout], cout multiple of 4.  The fp32-grade mode of the
+ * ResNet-style graphs; an order of magnitude slower than hsefr_conv_bf16. */
+int hsefr_conv2d_f32(const float* x, const float* wgt, const float* scale, const float* shift, const float* res, float* y, int n, int h,
+                     int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act,
+                     hsefr_stream_t stream);
 
 /* MaxPool k x k / stride with windows clipped to the image (TF SAME/VALID: pass the TF pads), NHWC fp32. */
 int hsefr_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, int k, int stride, int pad_t, int pad_l,

@@ -29,8 +29,8 @@ def bf16_round(a: np.ndarray) -> np.ndarray:
     return u.astype(np.uint32).view(np.float32).astype(np.float64)
 
 
-def _conv_bn(x, w, name, stride, pad):
-    k = bf16_round(w[name + "/kernel"])
+def _conv_bn(x, w, name, stride, pad, rnd=bf16_round):
+    k = rnd(w[name + "/kernel"])
     y = tfo.conv2d(x, k, (stride, stride), "", explicit_pads=(pad, pad, pad, pad))
     return y * w[name + "/scale"].astype(np.float64) + w[name + "/shift"].astype(np.float64)
 
@@ -50,11 +50,21 @@ def _maxpool_3x3_s2(x, mode):
     return out
 
 
-def forward(weights: Dict[str, np.ndarray], x_nhwc: np.ndarray, pool: str = "caffe", return_all: bool = False):
-    """x: [n,h,w,3] float (BGR, VGGFace2-mean-subtracted as facerec_test.py:103-106 leaves it) -> [n,2048]."""
+def forward(weights: Dict[str, np.ndarray], x_nhwc: np.ndarray, pool: str = "caffe", return_all: bool = False,
+            storage: str = "bf16"):
+    """x: [n,h,w,3] float (BGR, VGGFace2-mean-subtracted as facerec_test.py:103-106 leaves it) -> [n,2048].
+    storage='bf16': the bf16 pipeline's contract (above); storage='exact': no rounding anywhere -- the fp64 network the
+    reference's fp32 TensorFlow run approximates, the checker of the product's fp32-grade mode (1e-4 bar)."""
     acts = {}
+    if storage == "exact":
+        bf16_round = lambda a: np.asarray(a, np.float64)        # noqa: E731
+    else:
+        assert storage == "bf16"
+        bf16_round = globals()["bf16_round"]
+    _cb = _conv_bn
+    _conv_bn_l = lambda x, w, name, stride, pad: _cb(x, w, name, stride, pad, bf16_round)   # noqa: E731
     x = bf16_round(x_nhwc)                                    # the stem kernel converts the image to bf16
-    x = bf16_round(np.maximum(_conv_bn(x, weights, "conv1_7x7_s2", 2, 3), 0))
+    x = bf16_round(np.maximum(_conv_bn_l(x, weights, "conv1_7x7_s2", 2, 3), 0))
     acts["conv1_7x7_s2"] = x
     x = _maxpool_3x3_s2(x, pool)
     acts["pool1_3x3_s2"] = x
@@ -63,10 +73,10 @@ def forward(weights: Dict[str, np.ndarray], x_nhwc: np.ndarray, pool: str = "caf
         for b in range(1, blocks + 1):
             pre = "%s_%d" % (stage, b)
             s = stride if b == 1 else 1
-            r = bf16_round(np.maximum(_conv_bn(x, weights, pre + "_1x1_reduce", s, 0), 0))
-            t = bf16_round(np.maximum(_conv_bn(r, weights, pre + "_3x3", 1, 1), 0))
-            shortcut = bf16_round(_conv_bn(x, weights, pre + "_1x1_proj", s, 0)) if b == 1 else x
-            inc = bf16_round(_conv_bn(t, weights, pre + "_1x1_increase", 1, 0))
+            r = bf16_round(np.maximum(_conv_bn_l(x, weights, pre + "_1x1_reduce", s, 0), 0))
+            t = bf16_round(np.maximum(_conv_bn_l(r, weights, pre + "_3x3", 1, 1), 0))
+            shortcut = bf16_round(_conv_bn_l(x, weights, pre + "_1x1_proj", s, 0)) if b == 1 else x
+            inc = bf16_round(_conv_bn_l(t, weights, pre + "_1x1_increase", 1, 0))
             x = bf16_round(np.maximum(inc + shortcut, 0))
             acts[pre + "_1x1_reduce"], acts[pre + "_3x3"], acts[pre + "_1x1_increase"] = r, t, x
             if b == 1:

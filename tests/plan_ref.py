@@ -197,6 +197,27 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
                     y = np.maximum(y, xp[:, dy:dy + 2 * (oh - 1) + 1:2, dx:dx + 2 * (ow - 1) + 1:2, :])
         elif kind == 9:
             y = src.mean(axis=(1, 2)).reshape(n, 1, 1, cin)
+        elif kind == 18:     # general fp32 conv: HWIO kernel, optional per-channel scale / shift, optional residual, act
+            k = arr(w_off, kh * kw * cin * cout).reshape(kh, kw, cin, cout)
+            pb = max((oh - 1) * stride + kh - h - pad_t, 0)
+            pr = max((ow - 1) * stride + kw - w - pad_l, 0)
+            y = tfo.conv2d(src, k, (stride, stride), "", explicit_pads=(pad_t, pb, pad_l, pr))
+            if sc_off != NO_OFFSET:
+                y = y * arr(sc_off, cout)
+            if sh_off != NO_OFFSET:
+                y = y + arr(sh_off, cout)
+            if res is not None:
+                y = y + res.reshape(y.shape)
+            y = _act(y, act)
+        elif kind == 19:     # k x k / stride max-pool with clipped windows, fp32
+            assert kh == kw
+            pb = max((oh - 1) * stride + kh - h - pad_t, 0)
+            pr = max((ow - 1) * stride + kh - w - pad_l, 0)
+            xp = np.pad(src, ((0, 0), (pad_t, pb), (pad_l, pr), (0, 0)), constant_values=-np.inf)
+            y = np.full((n, oh, ow, cin), -np.inf)
+            for dy in range(kh):
+                for dx in range(kh):
+                    y = np.maximum(y, xp[:, dy:dy + stride * (oh - 1) + 1:stride, dx:dx + stride * (ow - 1) + 1:stride, :])
         else:
             raise AssertionError("unknown op kind %d" % kind)
         assert y.shape[1:] == (oh, ow, cout), (i, y.shape, (oh, ow, cout))

@@ -80,3 +80,45 @@ def test_generic_lowering_of_a_resnet_style_graph(pool, bn, head, hw):
     assert rel(got, want) < 2e-2                                     # bf16 storage (plan) vs exact fp64 graph (oracle)
     with pytest.raises(lowering.LoweringError):                      # the fp32 MobileNet kernels do not cover this graph
         lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"})
+
+
+@pytest.mark.parametrize("size,pool", [(64, "caffe"), (70, "valid")])
+def test_fp32_grade_plan_equals_exact_oracle(size, pool):
+    """the fp32-grade mode of the ResNet builder -- same topology on the exact-fp32 general kernels,
+    checked against the oracle WITHOUT bf16 storage emulation."""
+    from hse_facerec_tf_amd import lowering
+    w = resnet50.synthetic_weights(7)
+    x = np.random.RandomState(3).uniform(-120, 130, (1, size, size, 3)).astype(np.float32)
+    plan = resnet50.build_plan(w, (size, size), pool, dtype="f32")
+    kinds = [L.kind for L in plan.layers]
+    assert kinds[0] == lowering.OP_CONV_F32 and kinds[1] == lowering.OP_MAXPOOL_F32 and kinds[-1] == lowering.OP_GAP
+    assert kinds.count(lowering.OP_CONV_F32) == 53 and all(L.out_bytes == 4 * int(np.prod(L.out_shape)) for L in plan.layers)
+    assert resnet50.flops_per_image(plan) == resnet50.flops_per_image(resnet50.build_plan(w, (size, size), pool))
+    got = plan_ref.run(plan.serialize(), x)["features"]
+    want = ores.forward(w, x, pool, storage="exact")
+    assert rel(got, want) < 1e-12
+    assert 1e-4 < rel(ores.forward(w, x, pool), want) < 2e-2      # what the bf16 pipeline gives up, for scale
+    with pytest.raises(ValueError):
+        resnet50.build_plan(w, (size, size), pool, dtype="f16")
+
+
+@pytest.mark.parametrize("pool,bn,head,hw", [("SAME", "fused", "avgpool", 40), ("PADVALID", "muladd", "mean", 38)])
+def test_generic_lowering_of_a_resnet_style_graph_to_the_fp32_grade_plan(pool, bn, head, hw):
+    import mini_resnet_graph
+    from hse_facerec_tf_amd import graphdef, lowering
+    from oracle import tf_graph as tfo
+    data, dim = mini_resnet_graph.build(3, hw, pool, bn, 64, head)
+    g = graphdef.read_graph(data)
+    plan = lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"}, dtype="f32g")
+    kinds = [L.kind for L in plan.layers]
+    assert kinds[0] == lowering.OP_CONV_F32 and kinds[1] == lowering.OP_MAXPOOL_F32 and kinds[-1] == lowering.OP_GAP
+    assert kinds.count(lowering.OP_CONV_F32) == 1 + 3 * 3 + 2
+    by = {L.name: L for L in plan.layers}
+    assert by["conv2_1_1x1_increase"].res == [i for i, L in enumerate(plan.layers) if L.name == "conv2_1_1x1_proj"][0]
+    x = np.random.RandomState(1).uniform(-100, 120, (2, hw, hw, 3)).astype(np.float32)
+    got = plan_ref.run(plan.serialize(), x)["features"]
+    want = tfo.GraphOracle(tfo.parse_graphdef(data), np.float64).run("pool5_7x7_s1:0", {"input:0": x}).reshape(2, -1)
+    assert got.shape == want.shape == (2, dim)
+    assert rel(got, want) < 1e-6          # fp32 constants of the folded BatchNorm vs the fp64 graph
+    with pytest.raises(ValueError):
+        lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"}, dtype="fp32")

@@ -184,3 +184,69 @@ def test_resnet_style_frozen_graph_through_the_dropin_class(env, tmp_path, pool,
     assert got.shape == want.shape
     assert np.abs(got - want).max() / np.abs(want).max() < 2e-2
     tfi.close_session()
+
+
+@pytest.mark.parametrize("n,hw,c,cout,k,stride,pad,res,act", [(2, 9, 8, 12, 3, 1, 1, True, 1), (1, 23, 3, 64, 7, 2, 3, False, 1),
+                                                                (3, 7, 64, 256, 1, 1, 0, True, 0), (2, 14, 20, 8, 1, 2, 0, False, 2)])
+def test_conv2d_f32_vs_oracle(env, n, hw, c, cout, k, stride, pad, res, act):
+    """The general exact-fp32 convolution (OP_CONV_F32) against the fp64 oracle: 1e-6 (fp32 accumulation of k*k*c terms)."""
+    torch, ops, resnet50 = env
+    rs = np.random.RandomState(hw * 7 + c)
+    x = rs.uniform(-3, 3, (n, hw, hw, c)).astype(np.float32)
+    kern = (rs.randn(k, k, c, cout) / np.sqrt(k * k * c)).astype(np.float32)
+    sc, sh = rs.uniform(0.5, 1.5, cout).astype(np.float32), rs.randn(cout).astype(np.float32)
+    want = tfo.conv2d(x.astype(np.float64), kern.astype(np.float64), (stride, stride), "", explicit_pads=(pad, pad, pad, pad)) * sc + sh
+    r = rs.randn(*want.shape).astype(np.float32) if res else None
+    if res:
+        want = want + r
+    want = np.maximum(want, 0) if act else want
+    want = np.minimum(want, 6) if act == 2 else want
+    got = ops.conv2d_f32(torch.from_numpy(x).cuda(), torch.from_numpy(kern).cuda(), torch.from_numpy(sc).cuda(), torch.from_numpy(sh).cuda(),
+                         stride=stride, pad=pad, res=None if r is None else torch.from_numpy(r).cuda(), act=act).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-6 * max(np.abs(want).max(), 1.0)
+    with pytest.raises(Exception):
+        ops.conv2d_f32(torch.from_numpy(x).cuda(), torch.from_numpy(kern[..., :cout - 1].copy()).cuda())      # cout % 4 != 0
+
+
+@pytest.mark.parametrize("size,pool,n", [(64, "caffe", 2), (224, "caffe", 1)])
+def test_resnet50_fp32_grade_mode_meets_the_1e4_bar(env, size, pool, n):
+    """ResNet-50 in the fp32-grade mode against the exact (unrounded) oracle at the bar BASELINE states
+    for features (max abs err <= 1e-4 relative to the feature scale); the bf16 mode on the same input for scale."""
+    torch, ops, resnet50 = env
+    w = resnet50.synthetic_weights(123)
+    x = np.random.RandomState(size).uniform(-120, 130, (n, size, size, 3)).astype(np.float32)
+    want = ores.forward(w, x, pool, storage="exact")
+    ext = resnet50.ResNet50Extractor(w, (size, size), max_batch=4, pool=pool, dtype="f32")
+    got = ext.extract_batch(torch.from_numpy(x).cuda()).cpu().numpy()
+    ext.close_session()
+    assert got.shape == want.shape == (n, 2048)
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err < 1e-5, err
+    assert np.abs(got - want).max() < 1e-4
+    ext16 = resnet50.ResNet50Extractor(w, (size, size), max_batch=4, pool=pool)
+    e16 = np.abs(ext16.extract_batch(torch.from_numpy(x).cuda()).cpu().numpy() - want).max() / np.abs(want).max()
+    ext16.close_session()
+    assert err < e16 / 50
+
+
+@pytest.mark.parametrize("pool,bn,head,hw", [("SAME", "fused", "avgpool", 40), ("PADVALID", "muladd", "mean", 38)])
+def test_resnet_style_frozen_graph_in_the_fp32_grade_mode(env, tmp_path, pool, bn, head, hw):
+    """TensorFlowInference(dtype='f32') on a ResNet-style .pb: the MobileNet kernels do not cover it, so the general
+    exact-fp32 lowering runs (tfi.dtype == 'f32g'); 1e-5 against the fp64 graph."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import mini_resnet_graph
+    from hse_facerec_tf_amd import TensorFlowInference
+    torch, ops, resnet50 = env
+    data, dim = mini_resnet_graph.build(3, hw, pool, bn, 64, head)
+    pb = tmp_path / "mini_resnet.pb"
+    pb.write_bytes(data)
+    tfi = TensorFlowInference(str(pb), input_tensor='input:0', output_tensor='pool5_7x7_s1:0', convert2BGR=True,
+                              imageNetUtilsMean=False, max_batch=4, dtype="f32")
+    assert tfi.dtype == "f32g" and tfi.feature_dim == dim
+    x = np.random.RandomState(1).uniform(-100, 120, (3, hw, hw, 3)).astype(np.float32)
+    got = tfi.extract_batch(x)
+    want = tfo.GraphOracle(tfo.parse_graphdef(data), np.float64).run("pool5_7x7_s1:0", {"input:0": x}).reshape(3, -1)
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-5
+    tfi.close_session()
