@@ -51,7 +51,9 @@ for k, v in traffic.items():
     if v.get("SQ_LDS_IDX_ACTIVE"):
         v["lds_conflict_share"] = round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"], 4)
 traffic = {k: v for k, v in traffic.items() if "hbm_bytes_per_launch" in v and not k.startswith("void at::") and not k.startswith("__amd")}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); "
+sys.path.insert(0, root)
+import bench  # noqa: E402  (csrc_hash: bench.py marks the traffic figures stale when the kernels changed since this profile)
+json.dump({"csrc_hash": bench.csrc_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); "
                      "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
            "kernels": traffic}, open(os.path.join(out, "%s_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
