@@ -153,6 +153,8 @@ int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const
 bool conv1x1_bf16_enabled(bool has_res, int k, int cout);
 int launch_stem7x7_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h,
                         int w, int oh, int ow, int act, hipStream_t s);
+int launch_stem7x7_pool_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h, int w,
+                             int ph, int pw, int pool_pad_t, int pool_pad_l, hipStream_t s);
 int launch_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int pad_t, int pad_l,
                              hipStream_t s);
 int launch_gap_bf16(const void* x, float* y, int n, int hw, int c, hipStream_t s);

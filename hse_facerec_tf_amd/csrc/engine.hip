@@ -85,7 +85,8 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
         for (uint64_t off : {o.w_off, o.scale_off, o.shift_off, o.w2_off, o.shift2_off})
             HSEFR_REQUIRE(off == HSEFR_NO_OFFSET || (off < h.blob_bytes && off % 16 == 0), HSEFR_ERR_INVALID,
                           "plan op %u: blob offset %llu out of range / unaligned", i, (unsigned long long)off);
-        const bool out_bf16 = o.kind == HSEFR_OP_CONV_BF16 || o.kind == HSEFR_OP_MAXPOOL_BF16 || o.kind == HSEFR_OP_STEM7X7_BF16;
+        const bool out_bf16 = o.kind == HSEFR_OP_CONV_BF16 || o.kind == HSEFR_OP_MAXPOOL_BF16 || o.kind == HSEFR_OP_STEM7X7_BF16 ||
+                              o.kind == HSEFR_OP_STEM7X7_POOL_BF16;
         const bool in_bf16 = o.kind == HSEFR_OP_CONV_BF16 || o.kind == HSEFR_OP_MAXPOOL_BF16 || o.kind == HSEFR_OP_GAP_BF16;
         const uint64_t out_bytes = (uint64_t)o.oh * o.ow * o.cout * (out_bf16 ? 2 : 4);
         const uint64_t out_cap = bufs[o.out_buf].elems_per_image * bufs[o.out_buf].elem_bytes;
@@ -135,6 +136,10 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                 if (!need(o.w_off, kk * ci * co * 2, "kernel") || !need(o.scale_off, co * 4, "scale") || !need(o.shift_off, co * 4, "shift"))
                     return HSEFR_ERR_INVALID;
                 break;
+            case HSEFR_OP_STEM7X7_POOL_BF16:
+                HSEFR_REQUIRE(o.act == HSEFR_ACT_RELU && (o.reserved & ~0x11) == 0 && o.cin == 3 && o.cout == 64, HSEFR_ERR_INVALID,
+                              "plan op %u: fused stem + pool needs ReLU, 3 -> 64 channels and pool pads in {0, 1}", i);
+                [[fallthrough]];
             case HSEFR_OP_STEM7X7_BF16:
                 if (!need(o.w_off, 64 * 256 * 2, "kernel") || !need(o.scale_off, co * 4, "scale") || !need(o.shift_off, co * 4, "shift"))
                     return HSEFR_ERR_INVALID;
@@ -446,6 +451,11 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                 rc = launch_stem7x7_bf16((const float*)in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
                                          (const float*)blob_ptr(e, o.shift_off), out, n, o.h, o.w, o.oh, o.ow, o.act, s);
                 break;
+            case HSEFR_OP_STEM7X7_POOL_BF16:
+                rc = launch_stem7x7_pool_bf16((const float*)in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
+                                              (const float*)blob_ptr(e, o.shift_off), out, n, o.h, o.w, o.oh, o.ow, o.reserved & 15,
+                                              (o.reserved >> 4) & 15, s);
+                break;
             case HSEFR_OP_MAXPOOL_BF16:
                 rc = launch_maxpool3x3s2_bf16(in, out, n, o.h, o.w, o.cin, o.oh, o.ow, o.pad_t, o.pad_l, s);
                 break;
@@ -741,6 +751,12 @@ int hsefr_stem7x7_bf16(const float* x, const void* wgt_t, const float* scale, co
                        int w, int oh, int ow, int act, hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || (x && wgt_t && scale && shift && y), HSEFR_ERR_INVALID, "stem7x7: null pointer");
     return launch_stem7x7_bf16(x, wgt_t, scale, shift, y, n, h, w, oh, ow, act, (hipStream_t)stream);
+}
+
+int hsefr_stem7x7_pool_bf16(const float* x, const void* wgt_t, const float* scale, const float* shift, void* y, int n, int h, int w,
+                            int ph, int pw, int pool_pad_t, int pool_pad_l, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wgt_t && scale && shift && y), HSEFR_ERR_INVALID, "stem7x7_pool: null pointer");
+    return launch_stem7x7_pool_bf16(x, wgt_t, scale, shift, y, n, h, w, ph, pw, pool_pad_t, pool_pad_l, (hipStream_t)stream);
 }
 
 int hsefr_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int pad_t, int pad_l,

@@ -35,8 +35,9 @@ OP_STEM_F16S = 14        # conv1 -> depthwise -> pointwise in one kernel (csrc/s
 OP_STEM2_F16S = 15       # ... -> pointwise -> the stride-2 depthwise of block 2 in one kernel (csrc/stem2_fused.hip)
 OP_STEM3_F16S = 17       # STEM2_F16S for an input with a declared bound: conv1 on the f16 MFMA too (csrc/stem3_fused.hip)
 OP_CONV_F32, OP_MAXPOOL_F32 = 18, 19   # general KxK fp32 convolution / clipped max-pool: the fp32-grade mode of ResNet-style graphs
+OP_STEM7X7_POOL_BF16 = 20   # STEM7X7_BF16 (ReLU) + the 3x3/2 max-pool behind it in one kernel (csrc/stem7x7_pool.hip)
 OP_PWCONV_PS = 16        # wire kind of a split-f16 pointwise Layer whose input is stored PRE-SPLIT by its producer (csrc/pwconv_ps.hip)
-_BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16)
+_BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16, OP_STEM7X7_POOL_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
 BUF_INPUT, BUF_NONE = -1, -2
 PLAN_MAGIC = 0x314C505246455348
@@ -214,6 +215,8 @@ class Plan:
                 shift2 = np.concatenate([descale, L.shift2.astype(np.float32)])
                 aux = L.a_log2 if L.kind == OP_STEM2_F16S else (L.a_log2 | ((L.in_log2 + 64) << 8))
                 kw_field = 3 + 16 * L.pad3[0] + 32 * L.pad3[1]
+            if L.kind == OP_STEM7X7_POOL_BF16:
+                aux = L.pad3[0] | (L.pad3[1] << 4)
             if L.kind == OP_DWPW_F16S:
                 w2, descale = split_pointwise_weights(w2, L.a_log2)
                 shift2 = np.concatenate([descale, L.shift2.astype(np.float32)])
@@ -275,6 +278,8 @@ class Plan:
             return 2 * oh * ow * L.in_shape[2] * 9 + 2 * oh * ow * cout * L.in_shape[2]
         if L.kind == OP_STEM_F16S:
             return 2 * oh * ow * 32 * 27 + 2 * oh * ow * 32 * 9 + 2 * oh * ow * cout * 32
+        if L.kind == OP_STEM7X7_POOL_BF16:
+            return 2 * ((L.in_shape[0] - 1) // 2 + 1) * ((L.in_shape[1] - 1) // 2 + 1) * 64 * 147
         if L.kind in (OP_STEM2_F16S, OP_STEM3_F16S):
             h1, w1 = (L.in_shape[0] + 1) // 2, (L.in_shape[1] + 1) // 2
             return 2 * h1 * w1 * 32 * 27 + 2 * h1 * w1 * 32 * 9 + 2 * h1 * w1 * 64 * 32 + 2 * oh * ow * 64 * 9
@@ -749,6 +754,39 @@ def fuse_dwpw(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Di
     return new_layers, remap
 
 
+def fuse_stem_pool(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
+    """ResNet stem: conv 7x7/2 (3 -> 64, ReLU) whose ONLY consumer is a 3x3/2 max-pool with top/left padding 0 or 1 becomes one
+    layer (csrc/stem7x7_pool.hip): the 112x112x64 map never reaches HBM.  Call AFTER the bf16 post-conditions (packed weight
+    image, scale and shift present).  Returns (layers, old -> new index; the conv maps to -1)."""
+    consumers: Dict[int, List[int]] = {}
+    for i, L in enumerate(layers):
+        for s in (L.src, L.res):
+            if s >= 0:
+                consumers.setdefault(s, []).append(i)
+    remap = {i: i for i in range(len(layers))}
+    for i, L in enumerate(layers):
+        cons = consumers.get(i, [])
+        if not (L.kind == OP_STEM7X7_BF16 and L.act == ACT_RELU and i not in keep and len(cons) == 1):
+            continue
+        P = layers[cons[0]]
+        oh, ow = L.out_shape[0], L.out_shape[1]
+        if not (P.kind == OP_MAXPOOL_BF16 and P.src == i and P.pad_t in (0, 1) and P.pad_l in (0, 1) and
+                2 * (P.out_shape[0] - 1) - P.pad_t < oh and 2 * (P.out_shape[1] - 1) - P.pad_l < ow):
+            continue
+        S = Layer(OP_STEM7X7_POOL_BF16, P.name, -1, L.in_shape, P.out_shape, w=L.w, scale=L.scale, shift=L.shift, act=ACT_RELU,
+                  kh=7, kw=7, stride=2, pad_t=3, pad_l=3, sealed=True, pad3=(P.pad_t, P.pad_l), tensors=list(P.tensors))
+        new_layers = [x for j, x in enumerate(layers) if j != i]
+        new_layers[cons[0] - 1] = S
+        remap = {j: (-1 if j == i else (j if j < i else j - 1)) for j in range(len(layers))}
+        for x in new_layers:
+            if x.src >= 0:
+                x.src = remap[x.src]
+            if x.res >= 0:
+                x.res = remap[x.res]
+        return new_layers, remap
+    return layers, remap
+
+
 def fuse_stem(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
     """conv 3x3/2 (3 -> 32, ReLU6) whose only consumer is a fused depthwise(stride 1) -> pointwise(32 -> 64) block becomes
     ONE layer (csrc/stem_fused.hip): the 96x96x32 map in between never reaches HBM.  Returns (layers, old -> new index)."""
@@ -1024,6 +1062,10 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
                 for L in layers:
                     if L.kind == OP_STEM2_F16S:
                         L.kind, L.in_log2 = OP_STEM3_F16S, in_log2
+    if fuse and dtype == "bf16":      # ResNet stem: conv1 + pool1 in one kernel
+        layers, remap = fuse_stem_pool(layers, [li for li, _ in out_layers.values()])
+        out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
+        tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
     if fuse:   # early MobileNet blocks: depthwise result stays on the CU (csrc/dwpw_fused.hip)
         layers, remap = fuse_dwpw(layers, [li for li, _ in out_layers.values()])
         out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}

@@ -460,6 +460,26 @@ def stem7x7_bf16(x, w_packed, scale, shift, act: int = ACT_RELU):
 
 
 @_device_guarded
+def stem7x7_pool_bf16(x, w_packed, scale, shift, ceil_mode: bool = True, pool_pad: int = 0):
+    """conv1 7x7/2 pad 3 (3 -> 64) + scale + shift + ReLU + max-pool 3x3/2 in one kernel: x [n,h,w,3] fp32 -> [n,ph,pw,64] bf16.
+    ceil_mode / pool_pad as in maxpool3x3s2_bf16 (Caffe ceil mode pads 0; pool_pad 1 = an explicit Pad(1) + VALID pool)."""
+    torch = _lib.require_gpu()
+    _f32c(x, "x"), _bf16c(w_packed, "w"), _f32c(scale, "scale"), _f32c(shift, "shift")
+    n, h, w, c = x.shape
+    if c != 3 or tuple(w_packed.shape) != (64, 256):
+        raise ValueError("stem7x7_pool: x must be [n,h,w,3] and the weight image [64,256]")
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if ceil_mode:
+        ph, pw = -(-(oh + 2 * pool_pad - 3) // 2) + 1, -(-(ow + 2 * pool_pad - 3) // 2) + 1
+    else:
+        ph, pw = (oh + 2 * pool_pad - 3) // 2 + 1, (ow + 2 * pool_pad - 3) // 2 + 1
+    y = torch.empty((n, ph, pw, 64), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().hsefr_stem7x7_pool_bf16(x.data_ptr(), w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                                  n, h, w, ph, pw, pool_pad, pool_pad, _lib.current_stream_ptr()), "hsefr_stem7x7_pool_bf16")
+    return y
+
+
+@_device_guarded
 def maxpool3x3s2_bf16(x, ceil_mode: bool = True):
     torch = _lib.require_gpu()
     _bf16c(x, "x")

@@ -83,10 +83,12 @@ def pack_stem_weight(kernel_hwio: np.ndarray) -> np.ndarray:
     return to_bf16_bits(img.reshape(64, 256))
 
 
-def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224, 224), pool: str = "caffe", dtype: str = "bf16") -> Plan:
+def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224, 224), pool: str = "caffe", dtype: str = "bf16",
+               fuse: bool = True) -> Plan:
     """pool='caffe': pad-0 ceil-mode max-pool (112 -> 56); pool='valid': keras_vggface's valid pool (112 -> 55).
     dtype='bf16': the bf16-MFMA kernels (BASELINE config 3's throughput mode); dtype='f32': the same layers on the exact-fp32
-    general kernels (OP_CONV_F32 / OP_MAXPOOL_F32 / OP_GAP) -- the fp32-grade mode, 1e-4 against the fp64 oracle."""
+    general kernels (OP_CONV_F32 / OP_MAXPOOL_F32 / OP_GAP) -- the fp32-grade mode, 1e-4 against the fp64 oracle.
+    fuse (bf16 only): conv1 + pool1 run as one kernel (lowering.fuse_stem_pool); False keeps every layer's tensor."""
     if dtype not in ("bf16", "f32"):
         raise ValueError("dtype must be 'bf16' or 'f32', not %r" % (dtype,))
     f32 = dtype == "f32"
@@ -136,6 +138,9 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
     gap = add(Layer(OP_GAP if f32 else OP_GAP_BF16, "pool5_7x7_s1", cur, (h, w_, cin), (1, 1, cin)))
     for L in layers:
         L.sealed = True
+    if fuse and not f32:
+        layers, remap = lowering.fuse_stem_pool(layers, [gap])
+        gap = remap[gap]
     buffers = assign_buffers(layers, {gap})
     names = {L.name: i for i, L in enumerate(layers)}
     return Plan(layers, (H, W, 3), buffers, {OUT_FEATURES: (gap, cin)}, names)
@@ -144,6 +149,8 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
 def flops_per_image(plan: Plan) -> int:
     tot = 0
     for L in plan.layers:
+        if L.kind == lowering.OP_STEM7X7_POOL_BF16:
+            tot += Plan.layer_flops(L)
         if L.kind in (OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32):
             oh, ow, cout = L.out_shape
             tot += 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
@@ -153,7 +160,7 @@ def flops_per_image(plan: Plan) -> int:
 def activation_bytes_per_image(plan: Plan) -> int:
     tot = 0
     for L in plan.layers:
-        in_b = 4 if L.kind == OP_STEM7X7_BF16 else 2
+        in_b = 4 if L.kind in (OP_STEM7X7_BF16, lowering.OP_STEM7X7_POOL_BF16) else 2
         tot += int(np.prod(L.in_shape)) * in_b + L.out_bytes
         if L.res >= 0:
             tot += plan.layers[L.res].out_bytes
@@ -165,11 +172,12 @@ class ResNet50Extractor:
     close_session); preprocessing flags are those of facerec_test.py:213 (BGR, VGGFace2 mean)."""
 
     def __init__(self, weights: Optional[Dict[str, np.ndarray]] = None, input_size: Tuple[int, int] = (224, 224),
-                 max_batch: int = 128, device: Optional[int] = None, pool: str = "caffe", seed: int = 123, dtype: str = "bf16"):
+                 max_batch: int = 128, device: Optional[int] = None, pool: str = "caffe", seed: int = 123, dtype: str = "bf16",
+                 fuse: bool = True):
         from .engine import Engine
         self.w, self.h = input_size
         self.convert2BGR, self.imageNetUtilsMean = True, False
-        self.plan = build_plan(weights if weights is not None else synthetic_weights(seed), (self.h, self.w), pool, dtype)
+        self.plan = build_plan(weights if weights is not None else synthetic_weights(seed), (self.h, self.w), pool, dtype, fuse)
         self.dtype = dtype
         self.engine = Engine(self.plan, max_batch=max_batch, device=device)
         self.feature_dim = 2048

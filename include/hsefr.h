@@ -102,6 +102,9 @@ typedef enum hsefr_op_kind {
                                   (per-channel scale + shift, optional residual buffer, act): the fp32-grade mode of
                                   ResNet-style graphs (csrc/smallnet.hip).  w_off = TF HWIO kernel fp32, cout % 4 == 0  */
     HSEFR_OP_MAXPOOL_F32 = 19, /* k x k / stride max-pool with windows clipped to the image, fp32 (kh = kw = k)          */
+    HSEFR_OP_STEM7X7_POOL_BF16 = 20, /* STEM7X7_BF16 (act must be ReLU) + the 3x3 / 2 max-pool behind it in one kernel
+                                  (csrc/stem7x7_pool.hip): fp32 image in, POOLED bf16 map out (oh, ow = pooled size);
+                                  reserved = pool_pad_t | pool_pad_l << 4, each 0 or 1; blob operands as STEM7X7_BF16    */
     HSEFR_OP_STEM3_F16S = 17,  /* STEM2_F16S for an input with a DECLARED BOUND |x| < 2^(15 - in_log2) (csrc/stem3_fused.hip): conv1's
                                   products are formed on the f16 MFMA from two-term splits like the pointwise layers'.
                                   w_off = the STEM2 fp32 pack (1952 floats) | conv1 split rows [32][64 f16] (1024 floats) |
@@ -388,6 +391,12 @@ int hsefr_mtcnn_crops(const unsigned char* d_frame, const int* d_boxes, float* d
 int hsefr_conv2d_f32(const float* x, const float* wgt, const float* scale, const float* shift, const float* res, float* y, int n, int h,
                      int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act,
                      hsefr_stream_t stream);
+
+/* conv1 7x7/2 pad 3 (3 -> 64) + scale + shift + ReLU + max-pool 3x3/2 in one kernel: x fp32 [n,h,w,3], wgt_t as
+ * hsefr_stem7x7_bf16, y bf16 [n,ph,pw,64].  Pool windows start at 2 * p - pool_pad and are clipped to the conv map
+ * (pool_pad 0 with ph = ceil((oh - 3) / 2) + 1 is Caffe's ceil mode; TF SAME / an explicit Pad pass 0 or 1). */
+int hsefr_stem7x7_pool_bf16(const float* x, const void* wgt_t, const float* scale, const float* shift, void* y, int n, int h, int w,
+                            int ph, int pw, int pool_pad_t, int pool_pad_l, hsefr_stream_t stream);
 
 /* MaxPool k x k / stride with windows clipped to the image (TF SAME/VALID: pass the TF pads), NHWC fp32. */
 int hsefr_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, int k, int stride, int pad_t, int pad_l,

@@ -76,7 +76,7 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
         assert in_buf != out_buf, "op %d writes the buffer it reads" % i
         assert res_buf != out_buf
         if check_buffers:
-            assert p["bufs"][out_buf][0] * p["bufs"][out_buf][1] >= oh * ow * cout * (2 if kind in (7, 8, 10) else 4)
+            assert p["bufs"][out_buf][0] * p["bufs"][out_buf][1] >= oh * ow * cout * (2 if kind in (7, 8, 10, 20) else 4)
         if kind == 1:
             k = arr(w_off, kh * kw * cin * cout).reshape(kh, kw, cin, cout)
             pb = (oh - 1) * stride + kh - h - pad_t
@@ -187,6 +187,23 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             pr = max((ow - 1) * 2 + 7 - w - 3, 0)
             y = tfo.conv2d(bf16_round(src), k, (2, 2), "", explicit_pads=(3, pb, 3, pr))
             y = bf16_round(_act(y * arr(sc_off, 64) + arr(sh_off, 64), act))
+        elif kind == 20:     # kind 10 (ReLU) + kind 8 in one op: oh, ow are the POOLED size, _r = pool_pad_t | pool_pad_l << 4
+            assert act == 1 and cin == 3 and cout == 64 and (_r & ~0x11) == 0
+            wimg = arr_bf16(w_off, 64 * 256).reshape(64, 8, 32)
+            k = wimg[:, :7, :21].reshape(64, 7, 7, 3).transpose(1, 2, 3, 0)
+            ch, cw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            pb = max((ch - 1) * 2 + 7 - h - 3, 0)
+            pr = max((cw - 1) * 2 + 7 - w - 3, 0)
+            c1 = tfo.conv2d(bf16_round(src), k, (2, 2), "", explicit_pads=(3, pb, 3, pr))
+            c1 = bf16_round(_act(c1 * arr(sc_off, 64) + arr(sh_off, 64), act))
+            ppt, ppl = _r & 15, _r >> 4
+            pb = max((oh - 1) * 2 + 3 - ch - ppt, 0)
+            pr = max((ow - 1) * 2 + 3 - cw - ppl, 0)
+            xp = np.pad(c1, ((0, 0), (ppt, pb), (ppl, pr), (0, 0)), constant_values=-np.inf)
+            y = np.full((n, oh, ow, 64), -np.inf)
+            for dy in range(3):
+                for dx in range(3):
+                    y = np.maximum(y, xp[:, dy:dy + 2 * (oh - 1) + 1:2, dx:dx + 2 * (ow - 1) + 1:2, :])
         elif kind == 8:      # 3x3/2 max-pool with clipped windows
             pb = max((oh - 1) * 2 + 3 - h - pad_t, 0)
             pr = max((ow - 1) * 2 + 3 - w - pad_l, 0)

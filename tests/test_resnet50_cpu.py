@@ -18,13 +18,19 @@ def test_topology_counts_and_sizes():
     assert len(convs) == 1 + 3 * 16 + 4                      # stem + 16 bottlenecks x 3 + 4 projections = 53 convs
     params = sum(k * k * ci * co for _, k, ci, co, _ in convs)
     assert abs(params / 1e6 - 23.45) < 0.1                   # 23.45 M parameters (95 MB fp32 file)
-    plan = resnet50.build_plan(resnet50.synthetic_weights(1), (224, 224), "caffe")
+    from hse_facerec_tf_amd import lowering
+    fused = resnet50.build_plan(resnet50.synthetic_weights(1), (224, 224), "caffe")
+    assert fused.layers[0].kind == lowering.OP_STEM7X7_POOL_BF16 and fused.layers[0].out_shape == (56, 56, 64) and fused.layers[0].pad3 == (0, 0)
+    assert len(fused.layers) == 54 and fused.layers[1].src == 0
+    plan = resnet50.build_plan(resnet50.synthetic_weights(1), (224, 224), "caffe", fuse=False)
+    assert resnet50.flops_per_image(fused) == resnet50.flops_per_image(plan)
+    assert resnet50.activation_bytes_per_image(plan) - resnet50.activation_bytes_per_image(fused) == 2 * 112 * 112 * 64 * 2   # conv1's map: one write, one read
     assert plan.layers[1].out_shape == (56, 56, 64)           # Caffe ceil-mode pool: 112 -> 56
     assert plan.layers[-2].out_shape == (7, 7, 2048) and plan.layers[-1].out_shape == (1, 1, 2048)
     assert abs(resnet50.flops_per_image(plan) / 1e9 - 7.71) < 0.05     # 7.71 GFLOP / image
     assert abs(resnet50.activation_bytes_per_image(plan) / 1e6 - 54.7) < 8   # ~54.7 MB / image in bf16
     valid = resnet50.build_plan(resnet50.synthetic_weights(1), (224, 224), "valid")
-    assert valid.layers[1].out_shape == (55, 55, 64)          # keras_vggface valid pool: 112 -> 55
+    assert valid.layers[0].out_shape == (55, 55, 64)          # keras_vggface valid pool: 112 -> 55
     # stride placement: on the first 1x1 (reduce) and on the projection of stages 3-5
     by = {L.name: L for L in plan.layers}
     assert by["conv3_1_1x1_reduce"].stride == 2 and by["conv3_1_1x1_proj"].stride == 2 and by["conv3_1_3x3"].stride == 1
@@ -44,11 +50,12 @@ def test_bf16_bit_conversion_matches_oracle_rounding():
     assert back[-3] == np.float32(1.0) and back[-2] == np.float32(1.015625)     # ties to even
 
 
-@pytest.mark.parametrize("size,pool", [(64, "caffe"), (70, "valid")])
-def test_plan_equals_oracle(size, pool):
+@pytest.mark.parametrize("size,pool,fuse", [(64, "caffe", True), (70, "valid", True), (64, "caffe", False), (70, "valid", False)])
+def test_plan_equals_oracle(size, pool, fuse):
     w = resnet50.synthetic_weights(7)
     x = np.random.RandomState(3).uniform(-120, 130, (1, size, size, 3)).astype(np.float32)
-    plan = resnet50.build_plan(w, (size, size), pool)
+    plan = resnet50.build_plan(w, (size, size), pool, fuse=fuse)
+    assert len(plan.layers) == (54 if fuse else 55)
     got = plan_ref.run(plan.serialize(), x)["features"]
     want = ores.forward(w, x, pool)
     assert got.shape == want.shape == (1, 2048)
@@ -56,7 +63,7 @@ def test_plan_equals_oracle(size, pool):
     assert rel(got, want) < 1e-6
 
 
-@pytest.mark.parametrize("pool,bn,head,hw", [("SAME", "fused", "avgpool", 40), ("PADVALID", "muladd", "mean", 38)])
+@pytest.mark.parametrize("pool,bn,head,hw", [("SAME", "fused", "avgpool", 40), ("PADVALID", "muladd", "mean", 38), ("SAME", "fused", "avgpool", 38)])
 def test_generic_lowering_of_a_resnet_style_graph(pool, bn, head, hw):
     """a Caffe-converted ResNet-style frozen graph lowers to the bf16 plan generically (Pad+VALID
     stem, FusedBatchNorm or Mul/Add, residual Add fused into the conv epilogue, max-pool, global pool)."""
@@ -65,7 +72,15 @@ def test_generic_lowering_of_a_resnet_style_graph(pool, bn, head, hw):
     from oracle import tf_graph as tfo
     data, dim = mini_resnet_graph.build(3, hw, pool, bn, 64, head)
     g = graphdef.read_graph(data)
-    plan = lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"}, dtype="bf16")
+    fused = lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"}, dtype="bf16")
+    x = np.random.RandomState(1).uniform(-100, 120, (2, hw, hw, 3)).astype(np.float32)
+    plan = lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"}, dtype="bf16", fuse=False)
+    assert fused.layers[0].kind == lowering.OP_STEM7X7_POOL_BF16 and len(fused.layers) == len(plan.layers) - 1
+    assert fused.layers[0].pad3 == (plan.layers[1].pad_t, plan.layers[1].pad_l) == ((1, 1) if (pool, hw) == ("SAME", 38) else (0, 0))
+    assert np.array_equal(plan_ref.run(fused.serialize(), x)["features"], plan_ref.run(plan.serialize(), x)["features"])
+    # conv1's tensor requested as an output keeps the stem unfused
+    both = lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0", 1: "conv1/relu:0"}, dtype="bf16")
+    assert both.layers[0].kind == lowering.OP_STEM7X7_BF16
     kinds = [L.kind for L in plan.layers]
     assert kinds[0] == lowering.OP_STEM7X7_BF16 and kinds[1] == lowering.OP_MAXPOOL_BF16 and kinds[-1] == lowering.OP_GAP_BF16
     assert kinds.count(lowering.OP_CONV_BF16) == 3 * 3 + 2          # 3 bottlenecks x 3 convs + 2 projections

@@ -249,3 +249,51 @@ def test_resnet_style_frozen_graph_in_the_fp32_grade_mode(env, tmp_path, pool, b
     want = tfo.GraphOracle(tfo.parse_graphdef(data), np.float64).run("pool5_7x7_s1:0", {"input:0": x}).reshape(3, -1)
     assert np.abs(got - want).max() / np.abs(want).max() < 1e-5
     tfi.close_session()
+
+
+@pytest.mark.parametrize("n,h,w,ceil,ppad", [(2, 64, 64, True, 0), (1, 224, 224, True, 0), (1, 224, 224, False, 0), (3, 37, 51, True, 0),
+                                              (2, 38, 38, False, 1), (1, 70, 45, False, 0), (2, 30, 29, True, 1)])
+def test_fused_stem_pool_vs_oracle(env, n, h, w, ceil, ppad):
+    """conv1 + ReLU + pool1 in one kernel (csrc/stem7x7_pool.hip) against the oracle's conv -> bf16 -> clipped max-pool, and
+    against the two-kernel path (same rounding points; fp32 accumulation order differs: rare one-ulp bf16 differences)."""
+    torch, ops, resnet50 = env
+    rs = np.random.RandomState(h * 3 + w)
+    x = rs.uniform(-130, 150, (n, h, w, 3)).astype(np.float32)
+    kern = (rs.randn(7, 7, 3, 64) * 0.02).astype(np.float32)
+    sc = rs.uniform(0.5, 1.5, 64).astype(np.float32)
+    sh = rs.randn(64).astype(np.float32)
+    c1 = ores.bf16_round(np.maximum(tfo.conv2d(ores.bf16_round(x), ores.bf16_round(kern), (2, 2), "", explicit_pads=(3, 3, 3, 3)) * sc + sh, 0))
+    oh, ow = c1.shape[1:3]
+    ph = (-(-(oh + 2 * ppad - 3) // 2) if ceil else (oh + 2 * ppad - 3) // 2) + 1
+    pw = (-(-(ow + 2 * ppad - 3) // 2) if ceil else (ow + 2 * ppad - 3) // 2) + 1
+    pb, pr = max((ph - 1) * 2 + 3 - oh - ppad, 0), max((pw - 1) * 2 + 3 - ow - ppad, 0)
+    xp = np.pad(c1, ((0, 0), (ppad, pb), (ppad, pr), (0, 0)), constant_values=-np.inf)
+    want = np.full((n, ph, pw, 64), -np.inf)
+    for dy in range(3):
+        for dx in range(3):
+            want = np.maximum(want, xp[:, dy:dy + 2 * (ph - 1) + 1:2, dx:dx + 2 * (pw - 1) + 1:2, :])
+    xd, wd = torch.from_numpy(x).cuda(), ops.bf16_from_bits(resnet50.pack_stem_weight(kern))
+    scd, shd = torch.from_numpy(sc).cuda(), torch.from_numpy(sh).cuda()
+    got = ops.stem7x7_pool_bf16(xd, wd, scd, shd, ceil_mode=ceil, pool_pad=ppad)
+    assert tuple(got.shape) == want.shape
+    ok, err = close_bf16(got.float().cpu().numpy(), want)
+    assert ok, "max rel err %.3e" % err
+    if ppad == 0:
+        two = ops.maxpool3x3s2_bf16(ops.stem7x7_bf16(xd, wd, scd, shd), ceil)
+        d = (got.float() - two.float()).abs()
+        assert float((d > 0).float().mean()) < 2e-3 and bool((d <= 0.0079 * two.float().abs() + 1e-6).all())      # <= one bf16 ulp, rarely
+
+
+def test_resnet50_fused_stem_equals_unfused_network(env):
+    """The whole network with and without the fused stem: same features to bf16-pipeline accuracy (the only difference is the
+    accumulation order inside conv1), and the fused plan is what ResNet50Extractor runs by default."""
+    torch, ops, resnet50 = env
+    from hse_facerec_tf_amd import lowering
+    w = resnet50.synthetic_weights(123)
+    x = torch.from_numpy(np.random.RandomState(9).uniform(-120, 130, (3, 224, 224, 3)).astype(np.float32)).cuda()
+    a = resnet50.ResNet50Extractor(w, (224, 224), max_batch=4)
+    b = resnet50.ResNet50Extractor(w, (224, 224), max_batch=4, fuse=False)
+    assert a.plan.layers[0].kind == lowering.OP_STEM7X7_POOL_BF16 and b.plan.layers[0].kind == lowering.OP_STEM7X7_BF16
+    fa, fb = a.extract_batch(x), b.extract_batch(x)
+    assert float((fa - fb).abs().max() / fb.abs().max()) < 5e-3
+    a.close_session(), b.close_session()
