@@ -153,6 +153,10 @@ int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const
 bool conv1x1_bf16_enabled(bool has_res, int k, int cout);
 int launch_stem7x7_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h,
                         int w, int oh, int ow, int act, hipStream_t s);
+bool conv_dma_forced();
+bool conv_dma_bf16_supported(long long n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw);
+int launch_conv_dma_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
+                         int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act, hipStream_t s);
 int launch_stem7x7_pool_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h, int w,
                              int ph, int pw, int pool_pad_t, int pool_pad_l, hipStream_t s);
 int launch_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int pad_t, int pad_l,
@@ -225,6 +229,8 @@ void set_pw_tile(int v);
 void set_pws_tile(int v);
 void set_ps_mb(int v);
 void set_ps_grid(int v);
+void set_cd_rb(int v);
+void set_cd_off(int v);
 int read_ps_stamps(void* host_out, size_t bytes);
 void set_pw_ablate(int v);
 void set_pw_dma(int v);

@@ -243,6 +243,8 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "pws_tile")) { set_pws_tile(value); return HSEFR_OK; }
     if (!strcmp(key, "ps_mb")) { set_ps_mb(value); return HSEFR_OK; }
     if (!strcmp(key, "ps_grid")) { set_ps_grid(value); return HSEFR_OK; }
+    if (!strcmp(key, "cd_rb")) { set_cd_rb(value); return HSEFR_OK; }
+    if (!strcmp(key, "cd_off")) { set_cd_off(value); return HSEFR_OK; }
     if (!strcmp(key, "c11")) { set_c11(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_look")) { set_dw_look(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_look2")) { set_dw_look2(value); return HSEFR_OK; }

@@ -35,7 +35,11 @@ def close_bf16(got, want):
     (2, 14, 14, 64, 64, 1, 1, False, 1), (2, 14, 14, 64, 256, 1, 1, True, 1), (1, 28, 28, 256, 128, 1, 2, False, 1),
     (2, 13, 11, 128, 128, 3, 1, False, 1), (1, 56, 56, 64, 64, 3, 1, False, 1), (3, 7, 7, 512, 512, 3, 1, False, 1),
     (2, 7, 7, 512, 2048, 1, 1, True, 1), (1, 15, 15, 256, 512, 1, 2, False, 0), (1, 9, 9, 1024, 256, 1, 1, False, 1),
-    (5, 5, 5, 64, 192, 3, 1, True, 0)])
+    (5, 5, 5, 64, 192, 3, 1, True, 0),
+    # the LDS-DMA implicit GEMM (csrc/conv_dma_bf16.hip): stride-2 projection from 512 channels, many tiles per workgroup with a
+    # ragged last tile, residual + ReLU on a 3x3, a 5x5 kernel, stride 2 with padding
+    (2, 9, 9, 512, 128, 1, 2, False, 0), (37, 14, 14, 64, 256, 3, 1, True, 1), (3, 11, 13, 128, 64, 5, 1, False, 1),
+    (2, 12, 12, 64, 128, 3, 2, False, 1)])
 def test_conv_bf16_vs_oracle(env, n, h, w, c, cout, k, s, res, act):
     torch, ops, resnet50 = env
     rs = np.random.RandomState(h * 7 + c + cout + k)
