@@ -230,6 +230,7 @@ void set_pws_tile(int v);
 void set_ps_mb(int v);
 void set_ps_grid(int v);
 void set_cd_rb(int v);
+int read_cd_stamps(void* host_out, size_t bytes);
 void set_cd_off(int v);
 int read_ps_stamps(void* host_out, size_t bytes);
 void set_pw_ablate(int v);

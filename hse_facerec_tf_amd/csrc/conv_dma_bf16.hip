@@ -36,6 +36,19 @@ typedef unsigned short u16;
 
 constexpr int ROWB = 128;       // bytes per LDS row: 64 bf16 = one K-step
 
+#ifdef HSEFR_CD_STAMPS
+// Diagnostic build only (HSEFR_DEV=1 HSEFR_EXTRA_FLAGS=-DHSEFR_CD_STAMPS build.sh): per-wave s_memtime sums of the step phases.
+__device__ unsigned long long g_cd_stamps[256 * 12 * 8];
+#define CD_STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); st[i] += _t - tprev; tprev = _t; } while (0)
+#define CD_STAMP_DECL unsigned long long st[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tprev = __builtin_amdgcn_s_memtime(); const unsigned long long tstart = tprev
+#define CD_STAMP_FLUSH do { if (lane == 0 && blockIdx.x < 256) { unsigned long long* o = g_cd_stamps + (blockIdx.x * 12 + wave) * 8; \
+    for (int i_ = 0; i_ < 6; ++i_) o[i_] = st[i_]; o[6] = __builtin_amdgcn_s_memtime() - tstart; o[7] = nsteps; } } while (0)
+#else
+#define CD_STAMP(i) do { } while (0)
+#define CD_STAMP_DECL do { } while (0)
+#define CD_STAMP_FLUSH do { } while (0)
+#endif
+
 __device__ __forceinline__ int swz_key(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 __device__ __forceinline__ unsigned f2bf_bits(float f) {  // round-to-nearest-even (inputs are finite)
     unsigned u = __float_as_uint(f);
@@ -75,8 +88,9 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
     constexpr int BM = WAVES_M * 16 * RB, BN = WAVES_N * 32;
     constexpr int STAGE = (BM + BN) * ROWB;
     constexpr int NPIECE = (BM + BN) / 8;
-    constexpr int PPW = NPIECE / 4;
-    static_assert(NPIECE % 4 == 0, "pieces divide over the four loader waves");
+    constexpr int APW = BM / 32, BPW = BN / 32;     // pieces per loader wave and K-step: activation (gathered) | weight
+    constexpr int PPW = APW + BPW;
+    static_assert(NPIECE == 4 * PPW, "pieces divide over the four loader waves");
     constexpr int E_OFF = 3 * STAGE;               // epilogue constants by tile parity: [scale piece 1 KiB | shift piece 1 KiB] x 2
     static_assert(E_OFF + 4096 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[E_OFF + 4096];
@@ -104,8 +118,14 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
         const int lw = wave - 8;
         const char* w_ptr = nullptr;      // weight rows of the prefetch cursor's tile
         long long w_bytes = 0;
-        // per piece: byte offset of the lane's 16 B for tap (0, 0), slab 0 (A) or K-step 0 (B); tap validity bits (B: all ones)
-        unsigned pbase[PPW], pmask[PPW];
+        // Every loader wave carries APW gathered activation pieces and BPW weight pieces per step (compile-time roles: the issue
+        // loop is branch-free).  Per activation piece: byte offset of the lane's 16 B for tap (0, 0), slab 0, and the tap validity bits.
+        unsigned pbase[APW], pmask[APW], pvb[BPW];
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int r = (lw * BPW + j) * 8 + (lane >> 3);
+            pvb[j] = (unsigned)r * wrowbytes + 16u * (unsigned)((lane & 7) ^ swz_key(r));
+        }
         auto piece = [&](const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
                          "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff))
@@ -120,29 +140,22 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
             w_ptr = (const char*)p.wt + (long long)pf_n0 * wrowbytes;
             w_bytes = (long long)(p.Cout - pf_n0) * wrowbytes;
 #pragma unroll
-            for (int j = 0; j < PPW; ++j) {
-                const int pc = lw * PPW + j;                       // wave-uniform
-                if (pc < BM / 8) {
-                    const int r = pc * 8 + (lane >> 3);
-                    const unsigned chunk = (unsigned)((lane & 7) ^ swz_key(r));
-                    const unsigned m = mm0 + (unsigned)r;
-                    const unsigned mc = m < p.M ? m : p.M - 1u;
-                    const unsigned n = mc / ohow, rem = mc - n * ohow;
-                    const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;
-                    const int ih0 = (int)oh * p.stride - p.pad_t, iw0 = (int)ow * p.stride - p.pad_l;
-                    pbase[j] = (unsigned)(((int)(n * (unsigned)p.H) + ih0) * p.W + iw0) * (unsigned)(p.C * 2) + 16u * chunk;
-                    unsigned mk = 0;
-                    for (int kh = 0, t = 0; kh < p.KH; ++kh)
-                        for (int kw = 0; kw < p.KW; ++kw, ++t) {
-                            const bool ok = (unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W;
-                            mk |= (ok ? 1u : 0u) << t;
-                        }
-                    pmask[j] = m < p.M ? mk : 0u;
-                } else {
-                    const int r = (pc - BM / 8) * 8 + (lane >> 3);
-                    pbase[j] = (unsigned)r * wrowbytes + 16u * (unsigned)((lane & 7) ^ swz_key(r));
-                    pmask[j] = 0xFFFFFFFFu;
-                }
+            for (int j = 0; j < APW; ++j) {
+                const int r = (lw * APW + j) * 8 + (lane >> 3);
+                const unsigned chunk = (unsigned)((lane & 7) ^ swz_key(r));
+                const unsigned m = mm0 + (unsigned)r;
+                const unsigned mc = m < p.M ? m : p.M - 1u;
+                const unsigned n = mc / ohow, rem = mc - n * ohow;
+                const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;
+                const int ih0 = (int)oh * p.stride - p.pad_t, iw0 = (int)ow * p.stride - p.pad_l;
+                pbase[j] = (unsigned)(((int)(n * (unsigned)p.H) + ih0) * p.W + iw0) * (unsigned)(p.C * 2) + 16u * chunk;
+                unsigned mk = 0;
+                for (int kh = 0, t = 0; kh < p.KH; ++kh)
+                    for (int kw = 0; kw < p.KW; ++kw, ++t) {
+                        const bool ok = (unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W;
+                        mk |= (ok ? 1u : 0u) << t;
+                    }
+                pmask[j] = m < p.M ? mk : 0u;
             }
         };
         auto issue_step = [&]() __attribute__((always_inline)) {
@@ -153,16 +166,19 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
             const unsigned a_adv = (unsigned)((pf_kh * p.W + pf_kw) * p.C * 2 + pf_cs * 128);
             const unsigned b_adv = (unsigned)(pf_tap * CS + pf_cs) * 128u;
             const __amdgpu_buffer_rsrc_t rx = make_rsrc_sgpr(p.x, p.x_bytes), rw = make_rsrc_sgpr(w_ptr, w_bytes);
+            // (offsets in registers of their own, all computed before the first piece goes out; pieces spread over 8 L2 channels
+            // instead of 8 neighbouring pixels were tried: no effect on the issue rate)
+            unsigned voff[PPW];
 #pragma unroll
-            for (int j = 0; j < PPW; ++j) {
-                const int pc = lw * PPW + j;
-                const bool isa = pc < BM / 8;
-                // the step's advance is added on the VALU: a border pixel's tap-(0,0) offset is "negative" (wrapped) and only the
-                // SUM is a valid offset -- the bounds check must see the sum in the VGPR, not a wrapped VGPR plus an SGPR
-                const unsigned voff = ((pmask[j] >> pf_tap) & 1u) ? pbase[j] + (isa ? a_adv : b_adv) : 0x80000000u;
-                if (isa) piece(rx, base + pc * 1024, voff, 0u);
-                else piece(rw, base + pc * 1024, voff, 0u);
-            }
+            for (int j = 0; j < APW; ++j) voff[j] = ((pmask[j] >> pf_tap) & 1u) ? pbase[j] + a_adv : 0x80000000u;
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) voff[APW + j] = pvb[j] + b_adv;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) asm volatile("" : "+v"(voff[j]));
+#pragma unroll
+            for (int j = 0; j < APW; ++j) piece(rx, base + (lw * APW + j) * 1024, voff[j], 0u);
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) piece(rw, base + BM * ROWB + (lw * BPW + j) * 1024, voff[APW + j], 0u);
             ++pf_step;
             ++pf_kt;
             ++pf_tap;
@@ -181,6 +197,7 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
         int ckt = 0;
         // k counts ISSUED steps: step k goes out, then (k >= 1) step k - 1 is waited for and handed over at the barrier; the MFMA
         // waves work on step k - 2.  One call site of issue_step: the per-tile address decode is inlined once.
+        CD_STAMP_DECL;
         for (unsigned k = 0; k < nsteps + 2; ++k) {
             if (k >= 2 && ckt == 0 && lw == 3) {
                 // the tile's epilogue constants by LDS-DMA: scale[n0 .. n0 + 127] as lanes 0-31 of one piece, shift[..] as lanes
@@ -192,17 +209,22 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
                 piece(rs, eb + 1024, lane >= 32 ? 16u * (unsigned)(lane - 32) : 0x80000000u, 0u);
             }
             issue_step();
+            CD_STAMP(0);
             if (k == 0) continue;
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // step k - 1 (and the constants) have landed: vmcnt retires in order
+            CD_STAMP(1);
             __syncthreads();
+            CD_STAMP(2);
             if (k >= 2 && ++ckt == KT) {
                 ckt = 0;
                 unsigned mm0;
                 tile_origin(++ci, mm0, e_n0);
                 __syncthreads();                            // pause while the MFMA waves store the tile
+                CD_STAMP(3);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CD_STAMP_FLUSH;
         return;
     }
 
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
             for (int nb = 0; nb < 2; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-    // epilogue geometry: pixel row l16 of each 16-row block, channels wn * 32 + 8 lq .. + 7: 16 bytes
+    // epilogue geometry: one pixel per lane and 16-row block, channels wn * 32 + 8 lq .. + 7: 16 bytes
     const unsigned yvoff = ((unsigned)(wm * 16 * RB + l16) * (unsigned)p.Cout + (unsigned)(wn * 32 + 8 * lq)) * 2u;
 
     unsigned m0;
@@ -236,6 +258,7 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
     int ckt = 0;
     tile_origin(0, m0, n0);
     __syncthreads();                                        // (the loaders' prologue barrier: step 0 has landed)
+    CD_STAMP_DECL;
 
     constexpr int HB = RB >= 4 ? 2 : 1;                     // row blocks whose MFMAs are held back behind the step barrier
     const bf16x8 fzero = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -273,7 +296,9 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
 #pragma unroll
         for (int i = 0; i < HB; ++i) { h_a0[i] = a0[RB - HB + i]; h_a1[i] = a1[RB - HB + i]; }
         h_b00 = b00; h_b01 = b01; h_b10 = b10; h_b11 = b11;
+        CD_STAMP(0);
         __syncthreads();                                // step g + 1 has landed; slot g % 3 is released
+        CD_STAMP(1);
         if (++ckt == KT) {
 #pragma unroll
             for (int i = 0; i < HB; ++i) mfma_block(RB - HB + i, h_a0[i], h_a1[i], h_b00, h_b01, h_b10, h_b11);
@@ -321,10 +346,13 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
             zero_acc();
             ckt = 0;
             tile_origin(++ci, m0, n0);
+            CD_STAMP(2);
             __syncthreads();                            // lets the loaders go on
+            CD_STAMP(3);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stores issued from asm: drained before the wave ends
+    CD_STAMP_FLUSH;
 }
 
 struct DmaCfg { int waves_m, rb; };
@@ -365,6 +393,17 @@ int launch_cfg(ConvDmaParams& p, hipStream_t s) {
 }  // namespace
 
 #ifdef HSEFR_DEV
+int read_cd_stamps(void* host_out, size_t bytes) {
+#ifdef HSEFR_CD_STAMPS
+    HSEFR_REQUIRE(bytes <= sizeof(unsigned long long) * 256 * 12 * 8, HSEFR_ERR_INVALID, "read_cd_stamps: too many bytes");
+    HSEFR_HIP_CHECK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_cd_stamps), bytes));
+    return HSEFR_OK;
+#else
+    (void)host_out; (void)bytes;
+    set_error("read_cd_stamps: library built without -DHSEFR_CD_STAMPS");
+    return HSEFR_ERR_UNSUPPORTED;
+#endif
+}
 void set_cd_rb(int v) { g_cd_rb = v; }
 void set_cd_off(int v) { g_cd_off = v; }
 #endif

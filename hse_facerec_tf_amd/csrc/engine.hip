@@ -270,6 +270,7 @@ int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_
 int hsefr_debug_read_stamps(void* host_out, size_t bytes) {
     // the split-f16 GEMM's stamps, (bytes == 512*4*10*8) the fused stem's, or (bytes == 256*12*8*8) the pre-split GEMM's
     if (bytes == 256 * 12 * 8 * 8) return read_ps_stamps(host_out, bytes);
+    if (bytes == 256 * 12 * 8 * 8 - 8) return read_cd_stamps(host_out, bytes);      // (one word short: the bf16 DMA convolution's)
     return bytes == 512 * 4 * 10 * 8 ? read_stem_stamps(host_out, bytes) : read_pws_stamps(host_out, bytes);
 }
 

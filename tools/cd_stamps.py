@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Where the waves of the bf16 LDS-DMA convolution (csrc/conv_dma_bf16.hip) spend their cycles.  Needs the stamped development build:
+    HSEFR_DEV=1 HSEFR_EXTRA_FLAGS=-DHSEFR_CD_STAMPS bash hse_facerec_tf_amd/csrc/build.sh      (rm -rf csrc/build_dev first)
+    python tools/cd_stamps.py [layer ...]      (layer names of tools/kbench_conv.py)
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+os.environ.setdefault("HSEFR_LIB", "libhsefr_dev.so")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from hse_facerec_tf_amd import _lib, ops
+from kbench_conv import LAYERS, B
+
+g = torch.Generator(device="cuda").manual_seed(0)
+_lib.check(_lib.lib().hsefr_debug_set(b"cd_off", 2))
+RB = int(os.environ.get("CD_RB", "0"))
+_lib.check(_lib.lib().hsefr_debug_set(b"cd_rb", RB))
+for name in sys.argv[1:] or ["c4_3x3", "c4_red", "c4_inc"]:
+    hw, c, cout, k, s, res = LAYERS[name]
+    x = (torch.rand((B, hw, hw, c), device="cuda", generator=g) * 2).to(torch.bfloat16)
+    w = (torch.randn((cout, k * k * c), device="cuda", generator=g) / (k * k * c) ** 0.5).to(torch.bfloat16)
+    sc, sh = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
+    oh = (hw + 2 * (k // 2) - k) // s + 1
+    r = (torch.rand((B, oh, oh, cout), device="cuda", generator=g)).to(torch.bfloat16) if res else None
+    for _ in range(5):
+        ops.conv_bf16(x, w, sc, sh, k, k, stride=s, pad=k // 2, res=r)
+    torch.cuda.synchronize()
+    buf = np.zeros(256 * 12 * 8 - 1, np.uint64)
+    _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+    b = np.concatenate([buf, [0]]).astype(np.float64).reshape(256, 12, 8)
+    for role, sl, names in (("MFMA waves", slice(0, 8), ["ds_read + mfma issue", "step barrier", "epilogue", "tile barrier"]),
+                            ("loader waves", slice(8, 12), ["DMA issue", "vmcnt wait", "step barrier", "tile barrier"])):
+        rr = b[:, sl, :].reshape(-1, 8)
+        rr = rr[rr[:, 7] > 0]
+        print("%s %s: %d waves, lifetime %.0f cycles (min %.0f max %.0f), %.1f steps -> %.0f cycles per step" %
+              (name, role, len(rr), rr[:, 6].mean(), rr[:, 6].min(), rr[:, 6].max(), rr[:, 7].mean(), (rr[:, 6] / rr[:, 7]).mean()))
+        for i, nm in enumerate(names):
+            print("   %-22s %5.1f %%  %7.0f cycles per step" % (nm, 100 * (rr[:, i] / rr[:, 6]).mean(), (rr[:, i] / rr[:, 7]).mean()))
