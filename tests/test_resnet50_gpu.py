@@ -39,7 +39,10 @@ def close_bf16(got, want):
     # the LDS-DMA implicit GEMM (csrc/conv_dma_bf16.hip): stride-2 projection from 512 channels, many tiles per workgroup with a
     # ragged last tile, residual + ReLU on a 3x3, a 5x5 kernel, stride 2 with padding
     (2, 9, 9, 512, 128, 1, 2, False, 0), (37, 14, 14, 64, 256, 3, 1, True, 1), (3, 11, 13, 128, 64, 5, 1, False, 1),
-    (2, 12, 12, 64, 128, 3, 2, False, 1)])
+    (2, 12, 12, 64, 128, 3, 2, False, 1),
+    # the window 3x3 kernel (csrc/conv3x3_win_bf16.hip; maps at least 40 wide): its four tile shapes, ragged image groups, residual
+    (2, 6, 40, 64, 128, 3, 1, True, 1), (1, 4, 48, 128, 256, 3, 1, False, 1), (3, 2, 44, 64, 64, 3, 1, False, 0),
+    (1, 28, 56, 64, 64, 3, 1, True, 1), (2, 5, 41, 192, 192, 3, 1, False, 1)])
 def test_conv_bf16_vs_oracle(env, n, h, w, c, cout, k, s, res, act):
     torch, ops, resnet50 = env
     rs = np.random.RandomState(h * 7 + c + cout + k)

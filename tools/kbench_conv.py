@@ -55,6 +55,7 @@ def main():
         fn = lambda: ops.conv_bf16(x, w, sc, sh, k, k, stride=s, pad=k // 2, res=r)
         flops = 2.0 * B * oh * oh * cout * k * k * c
         knob("cd_off", 1)
+        knob("w3_off", 1)
         t_old = timeit(fn)
         knob("cd_off", 2)
         out = "%-8s old %6.1f us (%4.0f TF) | dma" % (name, t_old, flops / t_old / 1e6)
@@ -65,7 +66,11 @@ def main():
             out += "  RB%d %6.1f" % (rb, t)
         knob("cd_rb", 0)
         t = timeit(fn)
+        if k == 3 and s == 1:
+            knob("w3_off", 2)
+            out += "  | window %6.1f" % timeit(fn)
         knob("cd_off", 0)
+        knob("w3_off", 0)
         t_prod = timeit(fn)
         out += "  | auto %6.1f us (%4.0f TF) | product dispatch %6.1f us" % (t, flops / t / 1e6, t_prod)
         print(out, flush=True)
