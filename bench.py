@@ -398,9 +398,9 @@ def run_other_configs(args, dev):
         bgr = np.ascontiguousarray(preprocess.imread_rgb(photo)[..., ::-1])
         rec = {"config": "MTCNN detection + alignment of one %dx%d photo (FacialImageProcessing.process_image, minsize 32), per call"
                          % (bgr.shape[1], bgr.shape[0]), "unit": "ms", "higher_is_better": False}
-        for name, dres in (("device_pyramid", True), ("host_pyramid", False)):
+        for name, dres, dbox in (("device_cascade", True, True), ("device_pyramid_host_boxes", True, False), ("host_pyramid", False, False)):
             fp = FacialImageProcessing(mtcnn_detector=True, minsize=32, device=dev.index,
-                                       detector=MTCNNDetector(minsize=32, device=dev.index, device_resize=dres))
+                                       detector=MTCNNDetector(minsize=32, device=dev.index, device_resize=dres, device_boxes=dbox))
             for _ in range(2):
                 r = fp.process_image(bgr)
             torch.cuda.synchronize(dev)
@@ -411,9 +411,11 @@ def run_other_configs(args, dev):
             rec[name + "_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 2)
             rec["faces"] = int(len(r[0]))
             fp.close()
-        rec["value"] = rec["device_pyramid_ms"]
-        rec["note"] = ("device_pyramid: frame uploaded once as uint8, INTER_AREA pyramid levels and the 24x24/48x48 crops resampled on the "
-                       "GPU (csrc/area_resize.hip); host_pyramid: round 1's NumPy resampling; NMS and box regression on the host in both")
+        rec["value"] = rec["device_cascade_ms"]
+        rec["note"] = ("device_cascade (default): frame uploaded once as uint8; INTER_AREA pyramid levels and 24x24 / 48x48 crops "
+                       "(csrc/area_resize.hip), candidate generation, NMS, box regression, squaring, crop windows and landmarks "
+                       "(csrc/mtcnn_post.hip) all on the GPU, three box-count read-backs per frame; device_pyramid_host_boxes: the box "
+                       "logic in NumPy (identical results); host_pyramid: round 1's NumPy resampling as well")
         out.append(rec)
     except Exception as e:
         out.append({"config": "MTCNN process_image", "error": repr(e)})

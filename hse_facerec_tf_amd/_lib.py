@@ -61,6 +61,11 @@ SIGNATURES = {
     "hsefr_conv2d_f32": (c_int, [_fp] * 6 + [c_int] * 13 + [c_void_p]),
     "hsefr_maxpool_f32": (c_int, [_fp, _fp] + [c_int] * 10 + [c_void_p]),
     "hsefr_mtcnn_pyramid_level": (c_int, [_fp, _fp, c_int, c_int, c_int, c_int, c_void_p]),
+    "hsefr_mtcnn_post_capacity": (c_int, []),
+    "hsefr_mtcnn_stage1_level": (c_int, [_fp, _fp, c_int, c_int, ctypes.c_double, ctypes.c_float, _fp, _fp, c_void_p]),
+    "hsefr_mtcnn_stage1_finish": (c_int, [_fp, _fp, _fp, _fp, c_int, c_int, c_void_p]),
+    "hsefr_mtcnn_stage_finish": (c_int, [c_int, _fp, c_int, _fp, _fp, _fp, ctypes.c_float, _fp, _fp, _fp, _fp, c_int, c_int, c_void_p]),
+    "hsefr_mtcnn_nms": (c_int, [_fp, c_int, ctypes.c_double, c_int, _fp, _fp, c_void_p]),
     "hsefr_mtcnn_crops": (c_int, [_fp, _fp, _fp, c_int, c_int, c_int, c_int, c_void_p]),
     "hsefr_pairwise_dist": (c_int, [_fp, _fp, c_int, c_int, c_int, _fp, c_void_p]),
     "hsefr_nn1": (c_int, [_fp, _fp, c_int, c_int, c_int, _fp, _fp, c_void_p]),

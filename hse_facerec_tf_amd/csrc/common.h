@@ -153,6 +153,13 @@ int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const
 bool conv1x1_bf16_enabled(bool has_res, int k, int cout);
 int launch_stem7x7_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h,
                         int w, int oh, int ow, int act, hipStream_t s);
+int mtcnn_post_capacity();
+int launch_mtcnn_stage1_level(const float* prob, const float* reg, int w, int h, double scale, float thr, double* found, int* counters,
+                              hipStream_t s);
+int launch_mtcnn_stage1_finish(const double* found, int* counters, double* boxes, int* tab, int img_w, int img_h, hipStream_t s);
+int launch_mtcnn_stage23_finish(int stage, const double* boxes_in, int n, const float* prob, const float* reg, const float* pts, float thr,
+                                double* boxes_out, int* tab_out, float* points_out, int* counters, int img_w, int img_h, hipStream_t s);
+int launch_mtcnn_nms(const double* boxes, int n, double thr, int use_min, int* keep, int* n_keep, hipStream_t s);
 bool conv3x3_win_forced();
 bool conv3x3_win_bf16_supported(long long n, int h, int w, int c, int cout);
 int launch_conv3x3_win_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,

@@ -830,6 +830,35 @@ int hsefr_mtcnn_pyramid_level(const unsigned char* d_frame, float* d_dst, int sh
     return launch_area_level(d_frame, d_dst, sh, sw, dh, dw, (hipStream_t)stream);
 }
 
+int hsefr_mtcnn_post_capacity(void) { return mtcnn_post_capacity(); }
+
+int hsefr_mtcnn_stage1_level(const float* prob, const float* reg, int w, int h, double scale, float thr, double* found, int* counters,
+                             hsefr_stream_t stream) {
+    HSEFR_REQUIRE(prob && reg && found && counters, HSEFR_ERR_INVALID, "mtcnn_stage1_level: null pointer");
+    return launch_mtcnn_stage1_level(prob, reg, w, h, scale, thr, found, counters, (hipStream_t)stream);
+}
+
+int hsefr_mtcnn_stage1_finish(const double* found, int* counters, double* boxes, int* crop_table, int img_w, int img_h,
+                              hsefr_stream_t stream) {
+    HSEFR_REQUIRE(found && counters && boxes && crop_table && img_w > 0 && img_h > 0, HSEFR_ERR_INVALID, "mtcnn_stage1_finish: bad argument");
+    return launch_mtcnn_stage1_finish(found, counters, boxes, crop_table, img_w, img_h, (hipStream_t)stream);
+}
+
+int hsefr_mtcnn_stage_finish(int stage, const double* boxes_in, int n, const float* prob, const float* reg, const float* pts, float thr,
+                             double* boxes_out, int* crop_table, float* points_out, int* counters, int img_w, int img_h,
+                             hsefr_stream_t stream) {
+    HSEFR_REQUIRE(counters && boxes_out && (n == 0 || (boxes_in && prob && reg)), HSEFR_ERR_INVALID, "mtcnn_stage_finish: null pointer");
+    HSEFR_REQUIRE(stage == 2 ? crop_table != nullptr : (stage == 3 && (n == 0 || pts) && points_out), HSEFR_ERR_INVALID,
+                  "mtcnn_stage_finish: stage %d needs %s", stage, stage == 2 ? "a crop table" : "landmarks in and out");
+    return launch_mtcnn_stage23_finish(stage, boxes_in, n, prob, reg, pts, thr, boxes_out, crop_table, points_out, counters, img_w, img_h,
+                                       (hipStream_t)stream);
+}
+
+int hsefr_mtcnn_nms(const double* boxes, int n, double thr, int use_min, int* keep, int* n_keep, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n_keep && (n == 0 || (boxes && keep)), HSEFR_ERR_INVALID, "mtcnn_nms: null pointer");
+    return launch_mtcnn_nms(boxes, n, thr, use_min, keep, n_keep, (hipStream_t)stream);
+}
+
 int hsefr_mtcnn_crops(const unsigned char* d_frame, const int* d_boxes, float* d_dst, int sh, int sw, int n, int size,
                       hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || (d_frame && d_boxes && d_dst), HSEFR_ERR_INVALID, "mtcnn_crops: null pointer");

@@ -167,7 +167,9 @@ def _iou_suppress(boxes: np.ndarray, threshold: float, use_min: bool) -> np.ndar
         return np.empty((0,), np.int64)
     x1, y1, x2, y2, score = (boxes[:, i] for i in range(5))
     area = (x2 - x1 + 1) * (y2 - y1 + 1)
-    order = np.argsort(score)
+    # descending score, ties by ascending index (np.argsort's default order among ties is unspecified; the device kernel
+    # csrc/mtcnn_post.hip uses the same explicit rule)
+    order = np.argsort(-score.astype(np.float32), kind="stable")[::-1]
     keep = []
     while order.size:
         top, rest = order[-1], order[:-1]
@@ -232,11 +234,19 @@ class MTCNNDetector:
     THRESHOLDS = (0.6, 0.7, 0.9)       # facial_analysis.py:481
     FACTOR = 0.709                     # :483
 
-    def __init__(self, mtcnn_pb: Optional[str] = None, minsize: int = 32, device=None, device_resize: bool = True):
+    def __init__(self, mtcnn_pb: Optional[str] = None, minsize: int = 32, device=None, device_resize: bool = True,
+                 device_boxes: Optional[bool] = None):
+        """device_resize: pyramid levels and crops resampled on the GPU (csrc/area_resize.hip); device_boxes (default: as
+        device_resize): candidate generation, NMS, box regression, squaring, crop windows and landmarks on the GPU too
+        (csrc/mtcnn_post.hip) -- the host then only reads three box counts per frame."""
         torch = _lib.require_gpu()
         self._torch = torch
         self.minsize = minsize
         self.device_resize = device_resize
+        self.device_boxes = device_resize if device_boxes is None else bool(device_boxes)
+        if self.device_boxes and not device_resize:
+            raise ValueError("device_boxes needs device_resize (the crops are cut from the frame on the device)")
+        self.host_fallbacks = 0            # frames redone on the host because a candidate list overflowed
         self._frame = None                 # the uint8 frame on the device (device_resize)
         self.device = _lib.cuda_device(device)
         self.net = _DeviceNet(read_graph(mtcnn_pb or MTCNN_PB), self.device)
@@ -323,12 +333,68 @@ class MTCNNDetector:
         out = (out - 127.5) * 0.0078125
         return self._to_device(np.transpose(out, (0, 2, 1, 3)))      # [n, W, H, 3]
 
+    # ---- the cascade with its box logic on the device (csrc/mtcnn_post.hip) ------------------------------------------------
+    def _detect_device(self, img: np.ndarray):
+        """Returns (boxes, points), or None when a candidate list overflowed the device capacity (caller falls back)."""
+        torch, L = self._torch, _lib.lib()
+        h, w = img.shape[:2]
+        cap = int(L.hsefr_mtcnn_post_capacity())
+        dev = self.device
+        with _lib.on_device(self._frame):
+            st = _lib.current_stream_ptr()
+            counters = torch.zeros(8, dtype=torch.int32, device=dev)
+            found = torch.empty((cap, 9), dtype=torch.float64, device=dev)
+            boxes1 = torch.empty((cap, 5), dtype=torch.float64, device=dev)
+            tab = torch.empty((cap, 8), dtype=torch.int32, device=dev)
+            thr = [float(np.float32(t)) for t in self.THRESHOLDS]
+            for scale in self.pyramid_scales(h, w):
+                hs, ws = int(np.ceil(h * scale)), int(np.ceil(w * scale))
+                reg_t, prob_t = self.pnet(self._level_device(h, w, hs, ws))
+                reg_t, prob_t = reg_t.contiguous(), prob_t.contiguous()
+                _lib.check(L.hsefr_mtcnn_stage1_level(prob_t.data_ptr(), reg_t.data_ptr(), int(prob_t.shape[1]), int(prob_t.shape[2]),
+                                                      float(scale), thr[0], found.data_ptr(), counters.data_ptr(), st), "hsefr_mtcnn_stage1_level")
+            _lib.check(L.hsefr_mtcnn_stage1_finish(found.data_ptr(), counters.data_ptr(), boxes1.data_ptr(), tab.data_ptr(), w, h, st),
+                       "hsefr_mtcnn_stage1_finish")
+            c = counters.cpu().numpy()
+            if c[4]:
+                return None
+            n1 = int(c[1])
+            if n1 == 0:
+                return np.empty((0, 9)), np.array([])
+            crops = torch.empty((n1, 24, 24, 3), dtype=torch.float32, device=dev)
+            _lib.check(L.hsefr_mtcnn_crops(self._frame.data_ptr(), tab.data_ptr(), crops.data_ptr(), h, w, n1, 24, st), "hsefr_mtcnn_crops")
+            reg_t, prob_t = self.rnet(crops)
+            reg_t, prob_t = reg_t.contiguous(), prob_t.contiguous()
+            boxes2 = torch.empty((cap, 5), dtype=torch.float64, device=dev)
+            _lib.check(L.hsefr_mtcnn_stage_finish(2, boxes1.data_ptr(), n1, prob_t.data_ptr(), reg_t.data_ptr(), None, thr[1], boxes2.data_ptr(),
+                                                  tab.data_ptr(), None, counters.data_ptr(), w, h, st), "hsefr_mtcnn_stage_finish")
+            n2 = int(counters.cpu().numpy()[2])
+            if n2 == 0:
+                return np.empty((0, 5)), np.array([])
+            crops = torch.empty((n2, 48, 48, 3), dtype=torch.float32, device=dev)
+            _lib.check(L.hsefr_mtcnn_crops(self._frame.data_ptr(), tab.data_ptr(), crops.data_ptr(), h, w, n2, 48, st), "hsefr_mtcnn_crops")
+            reg_t, pts_t, prob_t = self.onet(crops)
+            reg_t, pts_t, prob_t = reg_t.contiguous(), pts_t.contiguous(), prob_t.contiguous()
+            boxes3 = torch.empty((cap, 5), dtype=torch.float64, device=dev)
+            points3 = torch.empty((cap, 10), dtype=torch.float32, device=dev)
+            _lib.check(L.hsefr_mtcnn_stage_finish(3, boxes2.data_ptr(), n2, prob_t.data_ptr(), reg_t.data_ptr(), pts_t.data_ptr(), thr[2],
+                                                  boxes3.data_ptr(), None, points3.data_ptr(), counters.data_ptr(), w, h, st), "hsefr_mtcnn_stage_finish")
+            n3 = int(counters.cpu().numpy()[3])
+            if n3 == 0:
+                return np.empty((0, 5)), np.empty((10, 0), np.float32)
+            return boxes3[:n3].cpu().numpy(), np.ascontiguousarray(points3[:n3].cpu().numpy().T)
+
     def __call__(self, img: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         img = np.asarray(img)
         if self.device_resize:
             if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
                 raise ValueError("the detector takes a uint8 RGB frame [H, W, 3]")
             self._frame = self._torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
+        if self.device_boxes:
+            res = self._detect_device(img)
+            if res is not None:
+                return res
+            self.host_fallbacks += 1
         points = np.array([])
         boxes = self._stage1(img)
         if boxes.shape[0]:

@@ -378,6 +378,29 @@ int hsefr_conv2d_direct(const float* x, const float* wgt, const float* bias, con
  * fused in: d_dst float32 [dw, dh, 3].  OpenCV's 8-bit semantics (float32 box accumulation, rounding to uint8). */
 int hsefr_mtcnn_pyramid_level(const unsigned char* d_frame, float* d_dst, int sh, int sw, int dh, int dw, hsefr_stream_t stream);
 
+/* MTCNN's box logic on the device (generateBoundingBox / nms / bbreg / rerec / pad, facial_analysis.py:354-476, as driven by
+ * mtcnn_detect_faces :478-604): float64 boxes, float32 scores / regressions / landmarks, NumPy's rounding points; greedy NMS by
+ * descending score, ties by ascending index.  `counters` = int32[8] on the device, zeroed by the caller per frame:
+ * [0] survivors of the pyramid levels so far, [1] / [2] / [3] boxes after stage 1 / 2 / 3, [4] overflow (a list exceeded
+ * hsefr_mtcnn_post_capacity() boxes: the frame must be redone on the host).  All lists hold hsefr_mtcnn_post_capacity() rows.
+ *   stage1_level : P-Net maps of one level, prob [w,h,2] and reg [w,h,4] (the nets see the transposed frame), cells with
+ *                  prob >= thr -> boxes at 1/scale -> NMS 0.5 -> appended to found [cap,9] = x1,y1,x2,y2,score,reg0..3
+ *   stage1_finish: NMS 0.7 over found -> regression -> square -> truncate -> boxes [cap,5] and the crop table [cap,8] of
+ *                  hsefr_mtcnn_crops
+ *   stage_finish : stage 2 (R-Net: prob [n,2], reg [n,4]; score > thr -> NMS 0.7 -> regression -> square -> truncate -> boxes + crop
+ *                  table) or stage 3 (O-Net: + pts [n,10]; score > thr -> landmarks -> regression -> NMS 0.7 'Min' -> boxes [cap,5]
+ *                  and points [cap,10] float32)
+ *   nms          : plain NMS of boxes [n,5] (n <= capacity): keep[] = kept indices in pick order                                  */
+int hsefr_mtcnn_post_capacity(void);
+int hsefr_mtcnn_stage1_level(const float* prob, const float* reg, int w, int h, double scale, float thr, double* found, int* counters,
+                             hsefr_stream_t stream);
+int hsefr_mtcnn_stage1_finish(const double* found, int* counters, double* boxes, int* crop_table, int img_w, int img_h,
+                              hsefr_stream_t stream);
+int hsefr_mtcnn_stage_finish(int stage, const double* boxes_in, int n, const float* prob, const float* reg, const float* pts, float thr,
+                             double* boxes_out, int* crop_table, float* points_out, int* counters, int img_w, int img_h,
+                             hsefr_stream_t stream);
+int hsefr_mtcnn_nms(const double* boxes, int n, double thr, int use_min, int* keep, int* n_keep, hsefr_stream_t stream);
+
 /* The R-Net / O-Net inputs of the cascade (facial_analysis.py:546,575): for each of n boxes, the box-sized tile of the frame
  * (zero outside it) resized to size x size with INTER_AREA in float64, normalised and transposed: d_dst float32
  * [n, size, size, 3].  d_boxes int32 [n][8] = {x1, y1, x2, y2 (1-based inclusive window clipped to the frame), tx1, ty1

@@ -128,3 +128,63 @@ def test_device_and_host_resizing_find_the_same_faces(z):
     assert np.abs(a[0] - b[0]).max() < 1e-3 and np.abs(a[1] - b[1]).max() < 1e-3
     with pytest.raises(ValueError):
         MTCNNDetector(minsize=32)(img.astype(np.float32))
+
+
+@pytest.mark.parametrize("n,thr,use_min,seed", [(1, 0.5, False, 0), (37, 0.5, False, 1), (400, 0.7, False, 2), (2048, 0.7, True, 3), (300, 0.3, True, 4)])
+def test_device_nms_is_the_host_nms(n, thr, use_min, seed):
+    """csrc/mtcnn_post.hip's greedy NMS against mtcnn._iou_suppress: same kept indices in the same order, including score TIES
+    (descending score, ascending index) and heavily overlapping clusters."""
+    import torch
+    from hse_facerec_tf_amd import _lib, mtcnn
+    rs = np.random.RandomState(seed)
+    cx, cy = rs.uniform(0, 300, n), rs.uniform(0, 300, n)
+    if n > 30:            # clusters of near-duplicates
+        cx[n // 2:] = cx[:n - n // 2] + rs.uniform(-3, 3, n - n // 2)
+        cy[n // 2:] = cy[:n - n // 2] + rs.uniform(-3, 3, n - n // 2)
+    s = rs.uniform(8, 60, n)
+    score = rs.uniform(0.6, 1.0, n).astype(np.float32)
+    if n > 10:
+        score[::7] = score[3]                                  # exact ties
+    boxes = np.stack([np.fix(cx - s), np.fix(cy - s), np.fix(cx + s), np.fix(cy + s), score.astype(np.float64)], axis=1)
+    want = mtcnn._iou_suppress(boxes, thr, use_min)
+    d = torch.from_numpy(boxes).cuda()
+    keep = torch.empty(n, dtype=torch.int32, device="cuda")
+    nk = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().hsefr_mtcnn_nms(d.data_ptr(), n, float(thr), int(use_min), keep.data_ptr(), nk.data_ptr(), _lib.current_stream_ptr()))
+    got = keep[:int(nk.item())].cpu().numpy()
+    assert np.array_equal(got, want)
+    assert 0 < len(got) <= n
+
+
+def _variants(img):
+    yield "original", img
+    yield "flipped", np.ascontiguousarray(img[:, ::-1])
+    yield "cropped", np.ascontiguousarray(img[40:520, 100:700])
+    yield "half", np.ascontiguousarray(img[::2, ::2])
+    yield "dark", (img.astype(np.float32) * 0.6).astype(np.uint8)
+    yield "no face", np.ascontiguousarray(img[:90, :200])
+
+
+def test_device_box_logic_is_the_host_box_logic():
+    """The whole cascade with candidate generation / NMS / regression / squaring / crop windows / landmarks on the GPU against the
+    same cascade with that logic in NumPy (same nets, same device pyramid and crops): identical boxes and landmarks, frame by
+    frame, on the reference's photo and five variants of it (one without any face)."""
+    from hse_facerec_tf_amd import preprocess
+    from hse_facerec_tf_amd.mtcnn import MTCNNDetector
+    img = preprocess.imread_rgb(TEST_IMAGE)
+    dev = MTCNNDetector(minsize=32)                     # default: device_resize and device_boxes
+    host = MTCNNDetector(minsize=32, device_boxes=False)
+    assert dev.device_boxes and not host.device_boxes
+    total = 0
+    for name, frame in _variants(img):
+        bd, pd = dev(frame)
+        bh, ph = host(frame)
+        assert bd.shape[0] == bh.shape[0], name
+        total += bd.shape[0]
+        if bd.shape[0]:
+            assert bd.shape == bh.shape and pd.shape == ph.shape == (10, bd.shape[0]), name
+            assert np.array_equal(bd, bh), (name, np.abs(bd - bh).max())
+            assert np.array_equal(pd, ph), (name, np.abs(pd - ph).max())
+    assert total >= 8 and dev.host_fallbacks == 0
+    with pytest.raises(ValueError):
+        MTCNNDetector(minsize=32, device_resize=False, device_boxes=True)
