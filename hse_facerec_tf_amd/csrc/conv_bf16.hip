@@ -461,10 +461,10 @@ int launch_conv_bf16(const void* x, const void* wt, const float* scale, const fl
         return launch_conv3x3_win_bf16(x, wt, scale, shift, res, y, n, h, w, c, cout, act, s);
     // the LDS-DMA implicit GEMM (conv_dma_bf16.hip) where it measured faster at ResNet-50's shapes (tools/kbench_conv.py, batch 128):
     // the K-deep layers -- 3x3 convolutions up to ~150k output pixels (45 vs 63 us on the 14x14x256 layers), the stride-2
-    // projections from 512+ channels, the 1x1 reductions from 1024+ channels.  The other 1x1 layers and the 64-channel stage stay
+    // 1x1 layers from 256+ channels (a strided gather costs the DMA nothing: 57 vs 84 us on 56x56x256 -> 28x28x512), the 1x1 reductions from 1024+ channels.  The other 1x1 layers and the 64-channel stage stay
     // on the register-staged kernels (few K-steps per tile: the DMA pipeline's per-tile costs are not amortised, and the
     // residual is prefetched there).
-    const bool deep = (kh * kw > 1 && P <= 150000) || (kh * kw == 1 && stride == 2 && c >= 512) || (kh * kw == 1 && c >= 1024 && !res);
+    const bool deep = (kh * kw > 1 && P <= 150000) || (kh * kw == 1 && stride == 2 && c >= 256) || (kh * kw == 1 && c >= 1024 && !res);
     if ((deep || conv_dma_forced()) && conv_dma_bf16_supported(n, h, w, c, oh, ow, cout, kh, kw))
         return launch_conv_dma_bf16(x, wt, scale, shift, res, y, n, h, w, c, oh, ow, cout, kh, kw, stride, pad_t, pad_l, act, s);
     ConvParams p;

@@ -19,7 +19,9 @@ LAYERS = {
     "c3_3x3": (28, 128, 128, 3, 1, False), "c3_red": (28, 512, 128, 1, 1, False), "c3_inc": (28, 128, 512, 1, 1, True),
     "c4_3x3": (14, 256, 256, 3, 1, False), "c4_red": (14, 1024, 256, 1, 1, False), "c4_inc": (14, 256, 1024, 1, 1, True),
     "c5_3x3": (7, 512, 512, 3, 1, False), "c5_red": (7, 2048, 512, 1, 1, False), "c5_inc": (7, 512, 2048, 1, 1, True),
-    "c4_proj": (28, 512, 1024, 1, 2, False),
+    "c4_proj": (28, 512, 1024, 1, 2, False), "c3_proj": (56, 256, 512, 1, 2, False), "c5_proj": (14, 1024, 2048, 1, 2, False),
+    "c3_red2": (56, 256, 128, 1, 2, False), "c4_red2": (28, 512, 256, 1, 2, False), "c5_red2": (14, 1024, 512, 1, 2, False),
+    "c2_proj": (56, 64, 256, 1, 1, False),
 }
 
 
