@@ -580,6 +580,7 @@ def main():
         "fused_dw3x3_pw1x1_f16split": lambda L: L.kind == lowering.OP_DWPW_F16S,
         "pointwise1x1_f32mfma": lambda L: L.kind == lowering.OP_PWCONV_F32 and L.a_log2 == 0,
         "pointwise1x1_f16split": lambda L: L.kind == lowering.OP_PWCONV_F32 and L.a_log2 > 0,
+        "fused_pw1x1_dw3x3_f16split": lambda L: L.kind == lowering.OP_PWDW_PS,
         "gap": lambda L: L.kind == lowering.OP_GAP,
     }
     # HBM traffic per launch measured with rocprofv3 PMC counters (separate --pmc FETCH_SIZE / WRITE_SIZE
@@ -597,10 +598,12 @@ def main():
             traffic_stale = pj.get("csrc_hash") != csrc_hash()
             prefixes = {"stem_conv1_dw_pw_dw_fused": ("stem2_fused_kernel", "stem3_"), "stem_conv1_dw_pw_fused": "stem_fused_kernel", "conv1_3x3x3_s2": "conv3x3_c3",
                         "depthwise3x3": "dwconv3x3_kernel",
-                        "pointwise1x1_f32mfma": "pwconv_f32_", "pointwise1x1_f16split": ("pwconv_f16s_kernel", "pwconv_ps_"), "gap": "hsefr::gap_kernel",
+                        "pointwise1x1_f32mfma": "pwconv_f32_",
+                        "pointwise1x1_f16split": lambda k: k.startswith("pwconv_f16s_kernel") or (k.startswith("pwconv_ps_") and "true>" not in k),
+                        "fused_pw1x1_dw3x3_f16split": lambda k: k.startswith("pwconv_ps_") and "true>" in k, "gap": "hsefr::gap_kernel",
                         "fused_dw3x3_pw1x1": "dwpw_fused_kernel", "fused_dw3x3_pw1x1_f16split": ("dwpw3_f16s_kernel", "dwpw2_f16s_kernel", "dwpw_f16s_kernel")}
             for cls, pre in prefixes.items():
-                rows = [v for k, v in prof.items() if k.startswith(pre)]      # str.startswith takes a tuple of prefixes too
+                rows = [v for k, v in prof.items() if (pre(k) if callable(pre) else k.startswith(pre))]      # (startswith takes a tuple too)
                 n = sum(r["launches"] for r in rows)
                 if n:
                     traffic_by_class[cls] = sum(r["launches"] * r["hbm_bytes_per_launch"] for r in rows) / n
@@ -627,7 +630,7 @@ def main():
             flops = sum(plan.layer_flops(plan.layers[i]) for i in idx) * B          # the class's OWN layers
             # a fused block also saves writing + re-reading the depthwise result: report both byte counts
             unfused_extra = sum(2 * 4 * int(np.prod(plan.layers[i].out_shape[:2])) * plan.layers[i].in_shape[2] for i in idx
-                                if plan.layers[i].kind in (lowering.OP_DWPW_F32, lowering.OP_DWPW_F16S)) * B \
+                                if plan.layers[i].kind in (lowering.OP_DWPW_F32, lowering.OP_DWPW_F16S, lowering.OP_PWDW_PS)) * B \
                 + sum(2 * 2 * 4 * int(np.prod(plan.layers[i].out_shape[:2])) * 32 for i in idx
                       if plan.layers[i].kind == lowering.OP_STEM_F16S) * B \
                 + sum(2 * 4 * ((plan.layers[i].in_shape[0] + 1) // 2) * ((plan.layers[i].in_shape[1] + 1) // 2) * (32 + 32 + 64) for i in idx
@@ -636,7 +639,7 @@ def main():
             note = None
             if name == "pointwise1x1_f32mfma":
                 bound, achieved, peak, unit = "mfma", flops / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
-            elif name == "pointwise1x1_f16split":
+            elif name in ("pointwise1x1_f16split", "fused_pw1x1_dw3x3_f16split"):
                 # every fp32 product costs 3 f16 MFMA products, so the matrix roofline for ALGORITHMIC flops is the dense
                 # f16 peak / 3; the class is priced against whichever of the two rooflines is the higher floor
                 t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F16_PEAK_TF / 3 * 1e12)

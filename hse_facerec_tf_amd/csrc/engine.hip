@@ -144,6 +144,15 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                 if (!need(o.w_off, 64 * 256 * 2, "kernel") || !need(o.scale_off, co * 4, "scale") || !need(o.shift_off, co * 4, "shift"))
                     return HSEFR_ERR_INVALID;
                 break;
+            case HSEFR_OP_PWCONV_PS_DW:
+                HSEFR_REQUIRE(pwconv_ps_dw_supported(0, o.cin, o.cout, o.w, o.h * o.w) && o.oh == o.h && o.ow == o.w, HSEFR_ERR_UNSUPPORTED,
+                              "plan op %u: fused pointwise + depthwise on a %dx%d map (288 %% (h * w) must be 0)", i, o.h, o.w);
+                if (!need(o.w_off, ci * co * 4, "split rows") || !need(o.scale_off, co * 4, "descale") || !need(o.shift_off, co * 4, "shift") ||
+                    !need(o.w2_off, 11 * co * 4, "depthwise constants"))
+                    return HSEFR_ERR_INVALID;
+                HSEFR_REQUIRE((o.reserved & 255) > 0 && (o.reserved & 255) <= 24 && (o.reserved >> 8) >= 1 && (o.reserved >> 8) <= 12,
+                              HSEFR_ERR_INVALID, "plan op %u: a_log2 / out_log2 out of range (reserved %d)", i, o.reserved);
+                break;
             case HSEFR_OP_PWCONV_PS:
                 HSEFR_REQUIRE(pwconv_ps_supported(0, o.cin, o.cout), HSEFR_ERR_UNSUPPORTED,
                               "plan op %u: pre-split pointwise cin=%d cout=%d not covered", i, o.cin, o.cout);
@@ -413,6 +422,11 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                           (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
                                           (float*)out, n, o.h, o.w, o.cin, o.stride, o.pad_t, o.pad_l, o.oh, o.ow, o.act, s);
                 break;
+            case HSEFR_OP_PWCONV_PS_DW:
+                rc = launch_pwconv_ps_dw(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
+                                         (const float*)blob_ptr(e, o.w2_off), out, (long long)n * o.h * o.w, o.cin, o.cout, o.act, o.w,
+                                         o.h * o.w, o.reserved >> 8, s);
+                break;
             case HSEFR_OP_PWCONV_PS:
                 rc = launch_pwconv_ps(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
                                       (const float*)blob_ptr(e, o.shift_off), (float*)out, (long long)n * o.h * o.w, o.cin, o.cout,
@@ -661,6 +675,13 @@ int hsefr_dwconv3x3_bn_relu6_split(const float* x, const float* wgt, const float
                                    int a_log2, hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || (x && wgt && scale && shift && y_split), HSEFR_ERR_INVALID, "dwconv3x3_split: null pointer");
     return launch_dwconv3x3_split(x, wgt, scale, shift, y_split, n, h, w, c, stride, pad_t, pad_l, oh, ow, act, a_log2, (hipStream_t)stream);
+}
+
+int hsefr_pwconv1x1_presplit_dw(const void* x_split, const void* w_split, const float* descale, const float* shift, const float* dw_consts,
+                                void* y_split, long long m, int k, int cout, int act, int map_w, int map_hw, int out_log2,
+                                hsefr_stream_t stream) {
+    HSEFR_REQUIRE(m == 0 || (x_split && w_split && descale && shift && dw_consts && y_split), HSEFR_ERR_INVALID, "pwconv1x1_presplit_dw: null pointer");
+    return launch_pwconv_ps_dw(x_split, w_split, descale, shift, dw_consts, y_split, m, k, cout, act, map_w, map_hw, out_log2, (hipStream_t)stream);
 }
 
 int hsefr_pwconv1x1_presplit(const void* x_split, const void* w_split, const float* descale, const float* shift, float* y,

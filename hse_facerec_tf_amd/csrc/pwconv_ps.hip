@@ -32,6 +32,14 @@
 //   * epilogue straight from the accumulators: a lane's 4 consecutive channels are one 16-byte store, an instruction covers
 //     16 rows x 64 B and the neighbouring channel block completes the lines (no LDS round trip, no barrier between tiles).
 //
+// DW = true: the NEXT block's depthwise 3x3 (stride 1, SAME) + scale + shift + ReLU6 runs in this kernel's epilogue and the tile
+// leaves as that layer's SPLIT ROWS -- the pointwise result never exists in HBM and the depthwise kernel disappears (MobileNet's
+// 12x12x512 and 6x6x1024 blocks: a 288-row tile is 2 or 8 WHOLE images, so the 3x3 neighbourhoods never leave the tile).  The
+// epilogue walks the tile's four 32-channel chunks: the two MFMA waves that own chunk c park their activated results in the LDS
+// stage the last K-step just released (288 rows x 128 B), then ALL TWELVE waves -- the loaders are idle here anyway -- compute the
+// depthwise from LDS, lane = (pixel, channel quad), borders through a zero row, constants fetched once per tile by LDS-DMA into
+// the same stage, and store 16-byte halves of split rows (the DPP pairing of dwconv.hip).  Two barriers per chunk.
+//
 // Every output element is accumulated over K in ONE fixed order by ONE wave: results are bit-identical run to run and
 // independent of the grid.  (They are NOT bit-identical to pwconv_f16s.hip: a 16x16x32 MFMA sums its 32 products in a
 // different internal order than two 32x32x16 steps -- same error bound, same 2e-6 test bar.)
@@ -63,11 +71,24 @@ constexpr int BN = 128;
 // swizzle key of a tile row: the 16-B chunk c of row r lives at chunk position c ^ key(r) (pwconv_f16s.hip's swizzle)
 __device__ __forceinline__ int swz_key(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
 
-template <int MB, int ACT>
+// the depthwise layer fused behind the GEMM (DW kernels): dwc = [11][Cout] floats (taps 0..8 row-major, then scale and shift, the
+// latter two already multiplied by out_scale), W = H = map edge, ys = its split-row output
+struct PsDwParams {
+    const float* dwc;
+    void* ys;
+    int W, HW;
+    float clamp_hi;       // 6 * out_scale
+};
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MB, int ACT, bool DW>
 __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restrict__ xs, const void* __restrict__ wsplit,
                                                            const float* __restrict__ descale, const float* __restrict__ shift,
                                                            float* __restrict__ y, long long M, int K, int Cout, unsigned tiles_n,
-                                                           unsigned total_tiles, int reverse) {
+                                                           unsigned total_tiles, int reverse, PsDwParams dw) {
     constexpr int BM = 32 * MB;
     constexpr int STAGE = (BM + BN) * ROWB;
     constexpr int NPIECE = (BM + BN) / 8;          // 1-KiB DMA pieces per K-step (8 rows each): 52 | 48
@@ -95,6 +116,70 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
         nn0 = (lt - tm * tiles_n) * BN;
     };
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // ---- DW epilogue, shared by both roles: the depthwise of one 32-channel chunk of the tile from the chunk buffer cb ----
+    // cb layout: rows 0 .. BM-1 = the chunk's activated pointwise results [pixel][32 ch] fp32, two zero rows (taps outside the
+    // map read them), then the tile's depthwise constants [12][128 ch] floats (taps 0..8, scale, shift, unused).
+    constexpr int CB_ZROW = BM;
+    constexpr int CB_CONST = (BM + 2) * ROWB;
+    static_assert(!DW || CB_CONST + 12 * 512 <= STAGE, "the chunk buffer fits one stage");
+    // per item of this lane: bit t = tap t lies inside the map.  Recomputed at every tile's epilogue from an OPAQUE copy of the lane
+    // id: as loop invariants these three registers (and what hipcc hoisted with them) lived through the K loop and spilled there.
+    unsigned nb_mask[3] = {0, 0, 0};
+    auto dw_masks = [&]() __attribute__((always_inline)) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int H = dw.HW / dw.W;
+#pragma unroll
+        for (int k3 = 0; k3 < 3; ++k3) {
+            const int P = (ln >> 3) + 8 * wave + 96 * k3;
+            const int pl = P % dw.HW, yy = pl / dw.W, xx = pl - yy * dw.W;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ny = yy + t / 3 - 1, nx = xx + t % 3 - 1;
+                mk |= ((unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)dw.W ? 1u : 0u) << t;
+            }
+            nb_mask[k3] = mk;
+        }
+    };
+    auto dw_chunk = [&](int c, const unsigned char* cb, long long tm0, int tn0) __attribute__((always_inline)) {
+        const int q = lane & 7;
+        const unsigned char* cp = cb + CB_CONST + (32 * c + 4 * q) * 4;
+        f32x4 tap[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) tap[t] = *(const f32x4*)(cp + t * 512);
+        const f32x4 sc = *(const f32x4*)(cp + 9 * 512), sh = *(const f32x4*)(cp + 10 * 512);
+        // split rows of the output: pixel m, 32-channel group -> 128 B; this lane stores the 16-byte unit q/2 of the hi half
+        // (even quad) or of the lo half (odd quad) after swapping one 8-byte half with its neighbour lane (dwconv.hip)
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc((char*)dw.ys + (tm0 * Cout + tn0) * 4ll, ((M - tm0) * Cout - tn0) * 4ll);
+        const bool odd = q & 1;
+        const unsigned unit = odd ? 4u + (unsigned)(q >> 1) : (unsigned)(q >> 1);
+#pragma unroll
+        for (int k3 = 0; k3 < 3; ++k3) {
+            const int P = (lane >> 3) + 8 * wave + 96 * k3;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int row = ((nb_mask[k3] >> t) & 1u) ? P + (t / 3 - 1) * dw.W + (t % 3 - 1) : CB_ZROW;
+                const f32x4 v = *(const f32x4*)(cb + row * ROWB + 16 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = fmaf(v[e], tap[t][e], a[e]);
+            }
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(fmaf(a[e], sc[e], sh[e]), 0.f), dw.clamp_hi);
+            const f16x4 hi = __builtin_convertvector(o, f16x4);
+            const f16x4 lo = __builtin_convertvector(o - __builtin_convertvector(hi, f32x4), f16x4);
+            const u32x2 hb = __builtin_bit_cast(u32x2, hi), lb = __builtin_bit_cast(u32x2, lo);
+            const u32x2 send = odd ? hb : lb;
+            u32x2 recv;
+            recv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);
+            recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
+            const u32x4 out = odd ? u32x4{recv.x, recv.y, lb.x, lb.y} : u32x4{hb.x, hb.y, recv.x, recv.y};
+            bstore16_welded(__builtin_bit_cast(f32x4, out), ro, (unsigned)P * (unsigned)Cout * 4u + (unsigned)c * 128u + 16u * unit, 0u);
+        }
+    };
 
     if (wave >= 8) {
         // =================================== loader waves 8..11: all the vector-memory reads ===================================
@@ -166,8 +251,32 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             if (++ckt == KT) {
                 ckt = 0;
                 long long mm0;
-                tile_origin(++ci, mm0, e_n0);
-                __syncthreads();                            // pause while the MFMA waves store the tile (shared path to L2)
+                if constexpr (DW) {
+                    // the tile's depthwise runs on all twelve waves out of the stage the last step released
+                    int tn0;
+                    tile_origin(ci, mm0, tn0);
+                    unsigned char* cb = smem + (unsigned)(((ci + 1u) * (unsigned)KT - 1u) % 3u) * STAGE;
+                    if (lw == 3) {
+                        const __amdgpu_buffer_rsrc_t rc = make_rsrc(dw.dwc, 11ll * Cout * 4);
+                        const unsigned cbl = lds0 + (unsigned)(cb - smem) + CB_CONST;
+#pragma unroll
+                        for (int j = 0; j < 6; ++j)      // piece j = constant rows 2 j (lanes 0-31) and 2 j + 1 (lanes 32-63; row 11: out of range)
+                            piece(rc, cbl + j * 1024, (unsigned)(2 * j + (lane >> 5)) * (unsigned)Cout * 4u + (unsigned)tn0 * 4u + 16u * (unsigned)(lane & 31), 0u);
+                    }
+                    if (lw == 2 && lane < 16) *(f32x4*)(cb + CB_ZROW * ROWB + 16 * lane) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    dw_masks();
+#pragma unroll 1
+                    for (int c = 0; c < 4; ++c) {
+                        __syncthreads();
+                        dw_chunk(c, cb, mm0, tn0);
+                        __syncthreads();
+                    }
+                    tile_origin(++ci, mm0, e_n0);
+                } else {
+                    tile_origin(++ci, mm0, e_n0);
+                    __syncthreads();                            // pause while the MFMA waves store the tile (shared path to L2)
+                }
                 PS_STAMP(3);
             }
         }
@@ -265,29 +374,57 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             // completes the 128-byte lines right behind it (L2 merges the halves).  The store path of a CU (64 B/clk to L2)
             // is shared with the loaders' DMA: they pause at the barrier below until the tile is out (stamps: 2300 cycles
             // of stores alone became 6500-7200 when both ran together, all of it MFMA-wave stall).
-            const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + m0 * Cout + n0, ((M - m0) * Cout - n0) * 4ll);
             f32x4 e_ds[2], e_sh[2];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 e_ds[nb] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * 2048 + (wn * 32 + 16 * nb + 4 * lq) * 4);
                 e_sh[nb] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * 2048 + 1024 + 512 + (wn * 32 + 16 * nb + 4 * lq) * 4);
             }
+            if constexpr (DW) {
+                // activated results in place, then chunk by chunk through LDS into the depthwise (all twelve waves)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+                for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    f32x4 o;
+                    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(fmaf(acc[mb][nb][e], e_ds[nb][e], e_sh[nb][e]));
-                    // rows beyond M fall outside the resource and are dropped by the hardware
-                    // (asm store with its wait state welded on: every vector-memory wait in this kernel is explicit)
-                    bstore16_welded(o, ry, yvoff + 64u * nb, __builtin_amdgcn_readfirstlane((unsigned)(16 * mb) * (unsigned)Cout * 4u));
+                        for (int e = 0; e < 4; ++e) acc[mb][nb][e] = apply_act<ACT>(fmaf(acc[mb][nb][e], e_ds[nb][e], e_sh[nb][e]));
+                unsigned char* cb = smem + (g % 3u) * STAGE;
+                dw_masks();
+#pragma unroll 1
+                for (int c = 0; c < 4; ++c) {
+                    if (wn == c) {
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                            for (int nb = 0; nb < 2; ++nb)
+                                *(f32x4*)(cb + (wm * 16 * MB + 16 * mb + l16) * ROWB + (16 * nb + 4 * lq) * 4) = acc[mb][nb];
+                    }
+                    __syncthreads();
+                    dw_chunk(c, cb, m0, n0);
+                    __syncthreads();                    // (the last one lets the loaders go on)
                 }
+                PS_STAMP(2);
+            } else {
+                const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + m0 * Cout + n0, ((M - m0) * Cout - n0) * 4ll);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(fmaf(acc[mb][nb][e], e_ds[nb][e], e_sh[nb][e]));
+                        // rows beyond M fall outside the resource and are dropped by the hardware
+                        // (asm store with its wait state welded on: every vector-memory wait in this kernel is explicit)
+                        bstore16_welded(o, ry, yvoff + 64u * nb, __builtin_amdgcn_readfirstlane((unsigned)(16 * mb) * (unsigned)Cout * 4u));
+                    }
+            }
             zero_acc();
             ckt = 0;
             tile_origin(++ci, m0, n0);
-            PS_STAMP(2);
-            __syncthreads();                            // lets the loaders go on
+            if constexpr (!DW) {
+                PS_STAMP(2);
+                __syncthreads();                            // lets the loaders go on
+            }
             PS_STAMP(3);
         }
     }
@@ -320,9 +457,10 @@ int launch_mb(const void* xs, const void* wsplit, const float* descale, const fl
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit: too many tiles");
     unsigned g = (unsigned)(total < 256 ? total : 256);
     if (g_ps_grid > 0 && (unsigned)g_ps_grid < g) g = (unsigned)g_ps_grid;
+    const PsDwParams nodw{nullptr, nullptr, 0, 0, 0.f};
 #define HSEFR_PS_LAUNCH(A)                                                                                                 \
-    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, y, m, k, cout, tiles_n, \
-                       (unsigned)total, sweep_reverse())
+    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, false>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, y, m, k, cout, tiles_n, \
+                       (unsigned)total, sweep_reverse(), nodw)
     if (act == HSEFR_ACT_RELU6) HSEFR_PS_LAUNCH(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_PS_LAUNCH(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_PS_LAUNCH(HSEFR_ACT_NONE);
@@ -348,6 +486,35 @@ int read_ps_stamps(void* host_out, size_t bytes) {
 #endif
 }
 #endif
+
+bool pwconv_ps_dw_supported(long long m, int k, int cout, int map_w, int map_hw) {
+    // a 288-row tile must hold whole maps; 3 x 3 / stride 1 / SAME; square or not, any edge >= 1
+    return pwconv_ps_supported(m, k, cout) && map_w > 0 && map_hw > 0 && map_hw % map_w == 0 && 288 % map_hw == 0 && m % map_hw == 0;
+}
+
+int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale, const float* shift, const float* dwc, void* ys, long long m,
+                        int k, int cout, int act, int map_w, int map_hw, int out_log2, hipStream_t s) {
+    HSEFR_REQUIRE(pwconv_ps_dw_supported(m, k, cout, map_w, map_hw), HSEFR_ERR_UNSUPPORTED,
+                  "pwconv_presplit_dw: m=%lld k=%d cout=%d map %d (w %d) not covered (288 %% map == 0)", m, k, cout, map_hw, map_w);
+    HSEFR_REQUIRE(out_log2 >= 1 && out_log2 <= 12, HSEFR_ERR_INVALID, "pwconv_presplit_dw: out_log2=%d", out_log2);
+    if (m == 0) return HSEFR_OK;
+    constexpr int MB = 9;
+    const long long tiles_m = (m + 32 * MB - 1) / (32 * MB);
+    const unsigned tiles_n = cout / BN;
+    const long long total = tiles_m * tiles_n;
+    HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_dw: too many tiles");
+    const unsigned g = (unsigned)(total < 256 ? total : 256);
+    const PsDwParams dw{dwc, ys, map_w, map_hw, 6.f * (float)(1 << out_log2)};
+#define HSEFR_PSDW_LAUNCH(A)                                                                                                     \
+    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, true>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
+                       tiles_n, (unsigned)total, sweep_reverse(), dw)
+    if (act == HSEFR_ACT_RELU6) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6);
+    else if (act == HSEFR_ACT_RELU) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU);
+    else if (act == HSEFR_ACT_NONE) HSEFR_PSDW_LAUNCH(HSEFR_ACT_NONE);
+    else { set_error("pwconv_presplit_dw: act %d", act); return HSEFR_ERR_UNSUPPORTED; }
+#undef HSEFR_PSDW_LAUNCH
+    return launch_status("pwconv_presplit_dw");
+}
 
 bool pwconv_ps_supported(long long m, int k, int cout) {
     // byte offsets inside a tile and inside the output travel in 32 bits

@@ -36,6 +36,7 @@ OP_STEM2_F16S = 15       # ... -> pointwise -> the stride-2 depthwise of block 2
 OP_STEM3_F16S = 17       # STEM2_F16S for an input with a declared bound: conv1 on the f16 MFMA too (csrc/stem3_fused.hip)
 OP_CONV_F32, OP_MAXPOOL_F32 = 18, 19   # general KxK fp32 convolution / clipped max-pool: the fp32-grade mode of ResNet-style graphs
 OP_STEM7X7_POOL_BF16 = 20   # STEM7X7_BF16 (ReLU) + the 3x3/2 max-pool behind it in one kernel (csrc/stem7x7_pool.hip)
+OP_PWDW_PS = 21          # pre-split pointwise + the NEXT block's depthwise in the GEMM's epilogue (csrc/pwconv_ps.hip, DW = true)
 OP_PWCONV_PS = 16        # wire kind of a split-f16 pointwise Layer whose input is stored PRE-SPLIT by its producer (csrc/pwconv_ps.hip)
 _BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16, OP_STEM7X7_POOL_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
@@ -217,6 +218,14 @@ class Plan:
                 kw_field = 3 + 16 * L.pad3[0] + 32 * L.pad3[1]
             if L.kind == OP_STEM7X7_POOL_BF16:
                 aux = L.pad3[0] | (L.pad3[1] << 4)
+            if L.kind == OP_PWDW_PS:
+                w = np.ascontiguousarray(w.reshape(w.shape[-2], w.shape[-1]).T)      # [1,1,K,Cout] -> [Cout,K]
+                w, scale = split_pointwise_weights(w, L.a_log2)
+                c = L.out_shape[2]
+                amp = np.float32(2.0 ** L.out_split)
+                w2 = np.concatenate([L.w3.reshape(9, c), (L.scale3 * amp).reshape(1, c), (L.shift3 * amp).reshape(1, c)]).astype(np.float32)
+                aux = L.a_log2 | (L.out_split << 8)
+                kw_field = 3
             if L.kind == OP_DWPW_F16S:
                 w2, descale = split_pointwise_weights(w2, L.a_log2)
                 shift2 = np.concatenate([descale, L.shift2.astype(np.float32)])
@@ -278,6 +287,8 @@ class Plan:
             return 2 * oh * ow * L.in_shape[2] * 9 + 2 * oh * ow * cout * L.in_shape[2]
         if L.kind == OP_STEM_F16S:
             return 2 * oh * ow * 32 * 27 + 2 * oh * ow * 32 * 9 + 2 * oh * ow * cout * 32
+        if L.kind == OP_PWDW_PS:
+            return 2 * oh * ow * cout * L.in_shape[2] + 2 * oh * ow * cout * 9
         if L.kind == OP_STEM7X7_POOL_BF16:
             return 2 * ((L.in_shape[0] - 1) // 2 + 1) * ((L.in_shape[1] - 1) // 2 + 1) * 64 * 147
         if L.kind in (OP_STEM2_F16S, OP_STEM3_F16S):
@@ -969,10 +980,55 @@ def presplit_activations(layers: List[Layer], keep: Sequence[int]) -> int:
     return n
 
 
+def pwdw_fusable(pw: Layer, dw: Layer) -> bool:
+    """A pre-split pointwise layer followed ONLY by a stride-1 depthwise layer that itself stores split rows, on maps a 288-row GEMM
+    tile holds whole (12x12, 6x6, ...): csrc/pwconv_ps.hip runs the depthwise in the GEMM's epilogue."""
+    h, w, _ = dw.in_shape
+    return (pw.kind == OP_PWCONV_F32 and pw.a_log2 > 0 and pw.in_split and pw.out_shape[2] % 128 == 0 and
+            dw.kind == OP_DWCONV3X3 and dw.stride == 1 and dw.act == ACT_RELU6 and 0 < dw.out_split <= 12 and
+            dw.pad_t == 1 and dw.pad_l == 1 and dw.out_shape == dw.in_shape and 288 % (h * w) == 0)
+
+
+def fuse_pwdw(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
+    """Merge pointwise -> depthwise pairs (pwdw_fusable) into one PWDW_PS layer: the pointwise result never reaches HBM and the
+    depthwise kernel disappears.  Returns (layers, old index -> new index; a merged pointwise maps to -1)."""
+    consumers: Dict[int, List[int]] = {}
+    for i, L in enumerate(layers):
+        for s in (L.src, L.res):
+            if s >= 0:
+                consumers.setdefault(s, []).append(i)
+    merged: Dict[int, int] = {}        # depthwise index -> pointwise index
+    for i, L in enumerate(layers):
+        cons = consumers.get(i, [])
+        if i not in keep and len(cons) == 1 and layers[cons[0]].src == i and pwdw_fusable(L, layers[cons[0]]):
+            merged[cons[0]] = i
+    gone = set(merged.values())
+    new_layers: List[Layer] = []
+    remap: Dict[int, int] = {}
+    for i, L in enumerate(layers):
+        if i in gone:
+            remap[i] = -1
+            continue
+        if i in merged:
+            pw = layers[merged[i]]
+            L = Layer(OP_PWDW_PS, L.name, pw.src, pw.in_shape, L.out_shape, w=pw.w, shift=pw.shift, act=pw.act, sealed=True,
+                      a_log2=pw.a_log2, in_split=True, w3=L.w, scale3=L.scale, shift3=L.shift, out_split=L.out_split, kh=3, kw=3,
+                      stride=1, pad_t=1, pad_l=1, tensors=list(L.tensors))
+        new_layers.append(L)
+        remap[i] = len(new_layers) - 1
+    for L in new_layers:
+        if L.src >= 0:
+            L.src = remap[L.src]
+        if L.res >= 0:
+            L.res = remap[L.res]
+    return new_layers, remap
+
+
 def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: Optional[Tuple[int, int]] = None,
                 feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32",
                 pw_math: Optional[str] = None, fuse_stem_block: Optional[bool] = None, stem_fusion: Optional[str] = None,
-                block_fusion: Optional[str] = None, presplit: Optional[str] = None, input_bound: Optional[float] = None) -> Plan:
+                block_fusion: Optional[str] = None, presplit: Optional[str] = None, input_bound: Optional[float] = None,
+                pwdw_fusion: Optional[str] = None) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase.
     fuse: merge depthwise -> pointwise pairs into one kernel where a fused kernel covers the shape.  stem_fusion:
     'stem2' (default; env HSEFR_FUSE_STEM=0|1only|1 changes the default) = conv1 + block 1 + the depthwise of block 2 in one
@@ -987,6 +1043,9 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
     and checks the bound on the device (Engine.input_overflow()); None = no assumption, exact-fp32 conv1.
     presplit: 'auto' (default; env HSEFR_PRESPLIT=auto|none) = depthwise layers feeding a split-f16 pointwise layer store
     their result pre-split and the GEMM stages both operands by LDS-DMA (presplit_activations); 'none' = fp32 tensors.
+    pwdw_fusion: 'auto' (default; env HSEFR_FUSE_PWDW=auto|none) = a pre-split pointwise layer followed only by a stride-1
+    depthwise layer on a map that a 288-row GEMM tile holds whole (12x12, 6x6) runs that depthwise in its epilogue (fuse_pwdw):
+    the pointwise tensor never reaches HBM and the depthwise launch disappears; 'none'.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
     (general KxK Conv2D, Pad, FusedBatchNorm / Mul+Add, residual Add, MaxPool 3x3/2, global AvgPool / Mean); 'f32g': the
     same ResNet-style graph patterns on exact-fp32 kernels (OP_CONV_F32 / OP_MAXPOOL_F32 / OP_GAP) -- the fp32-grade mode
@@ -1089,5 +1148,12 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
             raise ValueError("presplit must be 'auto' or 'none', not %r" % (presplit,))
         if presplit == "auto":
             presplit_activations(layers, [li for li, _ in out_layers.values()])
+            pwdw_fusion = pwdw_fusion or os.environ.get("HSEFR_FUSE_PWDW", "auto")
+            if pwdw_fusion not in ("auto", "none"):
+                raise ValueError("pwdw_fusion must be 'auto' or 'none', not %r" % (pwdw_fusion,))
+            if fuse and pwdw_fusion == "auto":
+                layers, remap = fuse_pwdw(layers, [li for li, _ in out_layers.values()])
+                out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
+                tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
     buffers = assign_buffers(layers, {li for li, _ in out_layers.values()})
     return Plan(layers, (input_hw[0], input_hw[1], low.in_c), buffers, out_layers, tensor_layer)

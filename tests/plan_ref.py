@@ -103,6 +103,20 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             wt = unsplit_pointwise_weights(img, np.frombuffer(data, np.float32, cout, sc_off), _r).astype(dtype)
             assert 0 < _r <= 24 and float(np.abs(src).max()) * 2.0 ** _r < 32768, "split-f16 input bound violated"
             y = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
+        elif kind == 21:     # pre-split pointwise + the next block's depthwise 3x3 / 1 / SAME (+ scale + shift + ReLU6), output as split rows
+            a_log2, out_log2 = _r & 255, _r >> 8
+            assert split_fmt.get(in_buf, 0) == a_log2, "op %d reads buffer %d in the wrong storage format" % (i, in_buf)
+            assert cin % 32 == 0 and cout % 128 == 0 and 288 % (h * w) == 0 and (oh, ow) == (h, w) and 0 < out_log2 <= 12
+            from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
+            img = np.frombuffer(data, np.uint16, cout * cin * 2, w_off).reshape(cout, cin // 32, 64)
+            wt = unsplit_pointwise_weights(img, np.frombuffer(data, np.float32, cout, sc_off), a_log2).astype(dtype)
+            assert float(np.abs(src).max()) * 2.0 ** a_log2 < 32768, "split-f16 input bound violated"
+            mid = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, h, w, cout)
+            dwc = arr(w2_off, 11 * cout).reshape(11, cout)
+            amp = 2.0 ** out_log2
+            xp = np.pad(mid, ((0, 0), (1, 1), (1, 1), (0, 0)))
+            y = tfo.depthwise_conv2d(xp, dwc[:9].reshape(3, 3, cout, 1), (1, 1), "VALID")
+            y = np.minimum(np.maximum(y * (dwc[9] / amp) + dwc[10] / amp, 0), 6)
         elif kind in (15, 17):     # fused stem + the stride-2 depthwise of block 2 (17: with a declared input bound)
             from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
             pk = arr(w_off, 1952)
@@ -238,10 +252,10 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
         else:
             raise AssertionError("unknown op kind %d" % kind)
         assert y.shape[1:] == (oh, ow, cout), (i, y.shape, (oh, ow, cout))
-        if kind not in (12, 16):
+        if kind not in (12, 16, 21):
             assert split_fmt.get(in_buf, 0) == 0 or in_buf == -1, "op %d (kind %d) reads split rows it cannot decode" % (i, kind)
         mem[out_buf] = y
-        split_fmt[out_buf] = _r if kind == 2 else 0
+        split_fmt[out_buf] = _r if kind == 2 else (_r >> 8 if kind == 21 else 0)
     outs = {}
     for slot, name in enumerate(("features", "age_probs", "gender")):
         if p["out_buf"][slot] >= 0:

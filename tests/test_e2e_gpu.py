@@ -173,6 +173,11 @@ def test_every_layer_matches_the_oracle(torch_):
         elif L.kind == lowering.OP_DWPW_F16S:
             y = ops.dwpw_f16split(src, d(L.w.reshape(3, 3, -1)), d(L.scale), d(L.shift), L.w2.reshape(L.w2.shape[2], L.w2.shape[3]).T,
                                   d(L.shift2), L.stride, L.act, L.a_log2)
+        elif L.kind == lowering.OP_PWDW_PS:
+            assert float(src.max()) <= 6.0 and float(src.min()) >= 0.0
+            ys = ops.pwconv1x1_presplit_dw(ops.split_rows_encode(src, L.a_log2), L.w.reshape(L.w.shape[2], L.w.shape[3]).T, d(L.shift),
+                                           d(L.w3.reshape(3, 3, -1)), d(L.scale3), d(L.shift3), L.act, L.a_log2, L.out_split)
+            y = ops.split_rows_decode(ys, L.out_split)
         elif L.kind == lowering.OP_GAP:
             y = ops.gap(src)
         elif L.kind == lowering.OP_DENSE:

@@ -25,6 +25,13 @@ def graph():
     return graphdef.read_graph(MODEL_PB)
 
 
+@pytest.fixture(autouse=True)
+def _structure_tests_without_pwdw(monkeypatch):
+    """The layer-table tests below count depthwise / pointwise layers of the passes they are about; the pointwise -> depthwise
+    epilogue fusion (fuse_pwdw, on by default) has its own test, which asks for it explicitly."""
+    monkeypatch.setenv("HSEFR_FUSE_PWDW", "none")
+
+
 def test_product_reader_agrees_with_oracle_reader(graph):
     nodes = tfo.load_graphdef(MODEL_PB)
     assert [n.name for n in nodes] == [n.name for n in graph.nodes]
@@ -343,3 +350,39 @@ def test_declared_input_bound_selects_the_bounded_stem(graph):
         plan_ref.run(plan.serialize(), x * 3)
     with pytest.raises(ValueError):
         lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), input_bound=-1.0)
+
+
+def test_pointwise_depthwise_epilogue_fusion(graph):
+    """fuse_pwdw: on the 12x12 and 6x6 maps (whole images inside a 288-row GEMM tile) the depthwise layer behind a pre-split
+    pointwise layer runs in that GEMM's epilogue: six depthwise launches and six fp32 tensors less at 192x192, same graph."""
+    import plan_ref
+    base = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), input_bound=256.0, pwdw_fusion="none")
+    fused = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), input_bound=256.0, pwdw_fusion="auto")
+    kb, kf = [L.kind for L in base.layers], [L.kind for L in fused.layers]
+    assert kf.count(lowering.OP_PWDW_PS) == 6 and len(kf) == len(kb) - 6
+    assert kb.count(lowering.OP_DWCONV3X3) - kf.count(lowering.OP_DWCONV3X3) == 6
+    for L in fused.layers:
+        if L.kind == lowering.OP_PWDW_PS:
+            assert L.in_split and L.out_split == 12 and L.a_log2 == 12 and 288 % (L.out_shape[0] * L.out_shape[1]) == 0
+            assert L.in_shape[:2] == L.out_shape[:2] and L.out_shape[2] % 128 == 0 and L.w3.shape[:2] == (3, 3)
+            nxt = [M for M in fused.layers if M.src >= 0 and fused.layers[M.src] is L]
+            assert len(nxt) == 1 and nxt[0].in_split            # its split rows feed the next pre-split GEMM
+    # the fused layer stands for the DEPTHWISE tensor; the pointwise tensor in between no longer exists
+    assert "conv_dw_8_relu/clip_by_value" in fused.tensor_layer and "conv_pw_7_relu/clip_by_value" not in fused.tensor_layer
+    assert fused.flops_per_image() == base.flops_per_image()
+    assert base.bytes_per_image() - fused.bytes_per_image() == 2 * 4 * (5 * 12 * 12 * 512 + 6 * 6 * 1024)
+    # a requested pointwise tensor keeps its pair unfused; 224-pixel input (14x14 and 7x7 maps: 288 % 196 != 0, 288 % 49 != 0) fuses nothing
+    keep = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0", OUT_AGE: "conv_pw_8_relu/clip_by_value:0"}, (192, 192),
+                                input_bound=256.0, pwdw_fusion="auto")
+    assert [L.kind for L in keep.layers].count(lowering.OP_PWDW_PS) == 5
+    assert lowering.OP_PWDW_PS not in [L.kind for L in lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (224, 224), pwdw_fusion="auto").layers]
+    with pytest.raises(ValueError):
+        lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), pwdw_fusion="all")
+    # the serialised plan evaluates to the same graph (fp64 executor of the wire format)
+    x = np.random.RandomState(5).uniform(-120, 130, (1, 96, 96, 3)).astype(np.float32)
+    p96 = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), input_bound=256.0, pwdw_fusion="auto")
+    assert [L.kind for L in p96.layers].count(lowering.OP_PWDW_PS) == 6          # 6x6 maps (five 512-channel blocks) and the 3x3 map (288 % 9 == 0)
+    got = plan_ref.run(p96.serialize(), x)
+    want = plan_ref.run(lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), fuse=False).serialize(), x)
+    for k in want:
+        assert rel(got[k], want[k]) < 1e-5
