@@ -243,6 +243,7 @@ void set_pw_tile(int v);
 void set_pws_tile(int v);
 void set_ps_mb(int v);
 void set_ps_grid(int v);
+void set_psdw_mode(int v);
 void set_cd_rb(int v);
 void set_w3_off(int v);
 int read_w3_stamps(void* host_out, size_t bytes);

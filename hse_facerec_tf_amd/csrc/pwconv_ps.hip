@@ -32,7 +32,7 @@
 //   * epilogue straight from the accumulators: a lane's 4 consecutive channels are one 16-byte store, an instruction covers
 //     16 rows x 64 B and the neighbouring channel block completes the lines (no LDS round trip, no barrier between tiles).
 //
-// DW = true: the NEXT block's depthwise 3x3 (stride 1, SAME) + scale + shift + ReLU6 runs in this kernel's epilogue and the tile
+// DWM != 0: the NEXT block's depthwise 3x3 (stride 1, SAME) + scale + shift + ReLU6 runs in this kernel's epilogue and the tile
 // leaves as that layer's SPLIT ROWS -- the pointwise result never exists in HBM and the depthwise kernel disappears (MobileNet's
 // 12x12x512 and 6x6x1024 blocks: a 288-row tile is 2 or 8 WHOLE images, so the 3x3 neighbourhoods never leave the tile).  The
 // epilogue walks the tile's four 32-channel chunks: the two MFMA waves that own chunk c park their activated results in the LDS
@@ -84,7 +84,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MB, int ACT, bool DW>
+template <int MB, int ACT, int DWM>
 __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restrict__ xs, const void* __restrict__ wsplit,
                                                            const float* __restrict__ descale, const float* __restrict__ shift,
                                                            float* __restrict__ y, long long M, int K, int Cout, unsigned tiles_n,
@@ -116,19 +116,34 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
         nn0 = (lt - tm * tiles_n) * BN;
     };
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+    constexpr bool DW = DWM != 0;       // 1: any map that divides the tile (borders by validity masks); 2: 12 x 12 maps, zero-bordered chunk buffer
 
     // ---- DW epilogue, shared by both roles: the depthwise of one 32-channel chunk of the tile from the chunk buffer cb ----
     // cb layout: rows 0 .. BM-1 = the chunk's activated pointwise results [pixel][32 ch] fp32, two zero rows (taps outside the
     // map read them), then the tile's depthwise constants [12][128 ch] floats (taps 0..8, scale, shift, unused).
+    // DWM == 2 (12 x 12 maps, two per tile): the maps sit in the buffer with ZERO cells around them at a pitch of 13 rows per
+    // image row -- one zero cell serves as the right neighbour of x = 11 and as the left neighbour of the next row's x = 0 --
+    // and 13 zero rows above, between and below the two maps: pixel (i, y, x) is row 14 + 169 i + 13 y + x, a tap (dy, dx) is
+    // that row + 13 (dy - 1) + (dx - 1), always a valid row: no masks, and the nine offsets are instruction immediates.
+    constexpr int PITCH = 13, IMGROWS = 13 * PITCH;                  // 12 image rows + 1 border row of 13 cells
+    constexpr int CB_ROWS = DWM == 2 ? 1 + PITCH + 2 * IMGROWS : BM + 2;
     constexpr int CB_ZROW = BM;
-    constexpr int CB_CONST = (BM + 2) * ROWB;
-    static_assert(!DW || CB_CONST + 12 * 512 <= STAGE, "the chunk buffer fits one stage");
+    constexpr int CB_CONST = CB_ROWS * ROWB;
     // per item of this lane: bit t = tap t lies inside the map.  Recomputed at every tile's epilogue from an OPAQUE copy of the lane
     // id: as loop invariants these three registers (and what hipcc hoisted with them) lived through the K loop and spilled there.
-    unsigned nb_mask[3] = {0, 0, 0};
+    unsigned nb_mask[3] = {0, 0, 0};   // (DWM == 2: the byte offset of the item's tap (-1, -1) in the chunk buffer instead)
     auto dw_masks = [&]() __attribute__((always_inline)) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        if constexpr (DWM == 2) {
+#pragma unroll
+            for (int k3 = 0; k3 < 3; ++k3) {
+                const int P = (ln >> 3) + 8 * wave + 96 * k3;
+                const int img = P >= 144 ? 1 : 0, pl = P - 144 * img, yy = pl / 12, xx = pl - 12 * yy;
+                nb_mask[k3] = (unsigned)((169 * img + PITCH * yy + xx) * ROWB + 16 * (ln & 7));
+            }
+            return;
+        }
         const int H = dw.HW / dw.W;
 #pragma unroll
         for (int k3 = 0; k3 < 3; ++k3) {
@@ -161,8 +176,13 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int row = ((nb_mask[k3] >> t) & 1u) ? P + (t / 3 - 1) * dw.W + (t % 3 - 1) : CB_ZROW;
-                const f32x4 v = *(const f32x4*)(cb + row * ROWB + 16 * q);
+                f32x4 v;
+                if constexpr (DWM == 2) {
+                    v = *(const f32x4*)(cb + nb_mask[k3] + ((t / 3) * PITCH + t % 3) * ROWB);
+                } else {
+                    const int row = ((nb_mask[k3] >> t) & 1u) ? P + (t / 3 - 1) * dw.W + (t % 3 - 1) : CB_ZROW;
+                    v = *(const f32x4*)(cb + row * ROWB + 16 * q);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[e] = fmaf(v[e], tap[t][e], a[e]);
             }
@@ -263,7 +283,17 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                         for (int j = 0; j < 6; ++j)      // piece j = constant rows 2 j (lanes 0-31) and 2 j + 1 (lanes 32-63; row 11: out of range)
                             piece(rc, cbl + j * 1024, (unsigned)(2 * j + (lane >> 5)) * (unsigned)Cout * 4u + (unsigned)tn0 * 4u + 16u * (unsigned)(lane & 31), 0u);
                     }
-                    if (lw == 2 && lane < 16) *(f32x4*)(cb + CB_ZROW * ROWB + 16 * lane) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (DWM == 2) {
+                        // the zero cells of the bordered layout (the stage still holds the last step's operands): every row that is
+                        // not a pixel -- row 0, the border rows, cell 12 of every image row
+                        for (int r = (wave - 8) * 8 + (lane >> 3); r < CB_ROWS; r += 32) {
+                            const int rr = r - 1 - PITCH, i2 = rr >= 169 ? 1 : 0, r2 = rr - 169 * i2;
+                            const bool pixel = rr >= 0 && r2 < 12 * PITCH && r2 % PITCH != 12;
+                            if (!pixel) *(f32x4*)(cb + r * ROWB + 16 * (lane & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    } else {
+                        if (lw == 2 && lane < 16) *(f32x4*)(cb + CB_ZROW * ROWB + 16 * lane) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     dw_masks();
 #pragma unroll 1
@@ -397,7 +427,14 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                             for (int nb = 0; nb < 2; ++nb)
-                                *(f32x4*)(cb + (wm * 16 * MB + 16 * mb + l16) * ROWB + (16 * nb + 4 * lq) * 4) = acc[mb][nb];
+                            {
+                                int row = wm * 16 * MB + 16 * mb + l16;
+                                if constexpr (DWM == 2) {        // (MB == 9: wave row wm is image wm of the tile)
+                                    const int pl = 16 * mb + l16, yy = pl / 12;
+                                    row = 1 + PITCH + 169 * wm + PITCH * yy + (pl - 12 * yy);
+                                }
+                                *(f32x4*)(cb + row * ROWB + (16 * nb + 4 * lq) * 4) = acc[mb][nb];
+                            }
                     }
                     __syncthreads();
                     dw_chunk(c, cb, m0, n0);
@@ -447,6 +484,7 @@ int choose_mb(long long m, int cout, int forced) {
 
 HSEFR_KNOB(g_ps_mb, 0);   // dev builds: 8 | 9 = forced tile height / 32
 HSEFR_KNOB(g_ps_grid, 0); // dev builds: > 0 = forced number of persistent workgroups (contention experiments)
+HSEFR_KNOB(g_psdw_mode, 0); // dev builds: 1 = the masked depthwise epilogue on 12 x 12 maps too (A/B against the bordered one)
 
 template <int MB>
 int launch_mb(const void* xs, const void* wsplit, const float* descale, const float* shift, float* y, long long m, int k, int cout,
@@ -459,7 +497,7 @@ int launch_mb(const void* xs, const void* wsplit, const float* descale, const fl
     if (g_ps_grid > 0 && (unsigned)g_ps_grid < g) g = (unsigned)g_ps_grid;
     const PsDwParams nodw{nullptr, nullptr, 0, 0, 0.f};
 #define HSEFR_PS_LAUNCH(A)                                                                                                 \
-    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, false>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, y, m, k, cout, tiles_n, \
+    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, 0>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, y, m, k, cout, tiles_n, \
                        (unsigned)total, sweep_reverse(), nodw)
     if (act == HSEFR_ACT_RELU6) HSEFR_PS_LAUNCH(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_PS_LAUNCH(HSEFR_ACT_RELU);
@@ -474,6 +512,7 @@ int launch_mb(const void* xs, const void* wsplit, const float* descale, const fl
 #ifdef HSEFR_DEV
 void set_ps_mb(int v) { g_ps_mb = v; }
 void set_ps_grid(int v) { g_ps_grid = v; }
+void set_psdw_mode(int v) { g_psdw_mode = v; }
 int read_ps_stamps(void* host_out, size_t bytes) {
 #ifdef HSEFR_PS_STAMPS
     HSEFR_REQUIRE(bytes <= sizeof(unsigned long long) * 256 * 12 * 8, HSEFR_ERR_INVALID, "read_ps_stamps: too many bytes");
@@ -505,12 +544,14 @@ int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_dw: too many tiles");
     const unsigned g = (unsigned)(total < 256 ? total : 256);
     const PsDwParams dw{dwc, ys, map_w, map_hw, 6.f * (float)(1 << out_log2)};
-#define HSEFR_PSDW_LAUNCH(A)                                                                                                     \
-    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, true>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
+#define HSEFR_PSDW_LAUNCH(A, MODE)                                                                                               \
+    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, MODE>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
                        tiles_n, (unsigned)total, sweep_reverse(), dw)
-    if (act == HSEFR_ACT_RELU6) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6);
-    else if (act == HSEFR_ACT_RELU) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU);
-    else if (act == HSEFR_ACT_NONE) HSEFR_PSDW_LAUNCH(HSEFR_ACT_NONE);
+    const bool bordered = map_w == 12 && map_hw == 144 && g_psdw_mode != 1;      // the zero-bordered chunk buffer (12 x 12 maps)
+    if (act == HSEFR_ACT_RELU6 && bordered) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6, 2);
+    else if (act == HSEFR_ACT_RELU6) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6, 1);
+    else if (act == HSEFR_ACT_RELU) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU, 1);
+    else if (act == HSEFR_ACT_NONE) HSEFR_PSDW_LAUNCH(HSEFR_ACT_NONE, 1);
     else { set_error("pwconv_presplit_dw: act %d", act); return HSEFR_ERR_UNSUPPORTED; }
 #undef HSEFR_PSDW_LAUNCH
     return launch_status("pwconv_presplit_dw");
