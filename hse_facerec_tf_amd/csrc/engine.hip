@@ -145,8 +145,9 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                     return HSEFR_ERR_INVALID;
                 break;
             case HSEFR_OP_PWCONV_PS_DW:
-                HSEFR_REQUIRE(pwconv_ps_dw_supported(0, o.cin, o.cout, o.w, o.h * o.w) && o.oh == o.h && o.ow == o.w, HSEFR_ERR_UNSUPPORTED,
-                              "plan op %u: fused pointwise + depthwise on a %dx%d map (288 %% (h * w) must be 0)", i, o.h, o.w);
+                HSEFR_REQUIRE(pwconv_ps_dw_supported(0, o.cin, o.cout, o.w, o.h * o.w, o.stride) && o.oh * o.stride == o.h && o.ow * o.stride == o.w &&
+                                  (o.stride == 1 ? (o.pad_t == 1 && o.pad_l == 1) : (o.pad_t == 0 && o.pad_l == 0)),
+                              HSEFR_ERR_UNSUPPORTED, "plan op %u: fused pointwise + depthwise (stride %d) on a %dx%d map not covered", i, o.stride, o.h, o.w);
                 if (!need(o.w_off, ci * co * 4, "split rows") || !need(o.scale_off, co * 4, "descale") || !need(o.shift_off, co * 4, "shift") ||
                     !need(o.w2_off, 11 * co * 4, "depthwise constants"))
                     return HSEFR_ERR_INVALID;
@@ -426,7 +427,7 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
             case HSEFR_OP_PWCONV_PS_DW:
                 rc = launch_pwconv_ps_dw(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
                                          (const float*)blob_ptr(e, o.w2_off), out, (long long)n * o.h * o.w, o.cin, o.cout, o.act, o.w,
-                                         o.h * o.w, o.reserved >> 8, s);
+                                         o.h * o.w, o.stride, o.reserved >> 8, s);
                 break;
             case HSEFR_OP_PWCONV_PS:
                 rc = launch_pwconv_ps(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
@@ -679,10 +680,11 @@ int hsefr_dwconv3x3_bn_relu6_split(const float* x, const float* wgt, const float
 }
 
 int hsefr_pwconv1x1_presplit_dw(const void* x_split, const void* w_split, const float* descale, const float* shift, const float* dw_consts,
-                                void* y_split, long long m, int k, int cout, int act, int map_w, int map_hw, int out_log2,
+                                void* y_split, long long m, int k, int cout, int act, int map_w, int map_hw, int dw_stride, int out_log2,
                                 hsefr_stream_t stream) {
     HSEFR_REQUIRE(m == 0 || (x_split && w_split && descale && shift && dw_consts && y_split), HSEFR_ERR_INVALID, "pwconv1x1_presplit_dw: null pointer");
-    return launch_pwconv_ps_dw(x_split, w_split, descale, shift, dw_consts, y_split, m, k, cout, act, map_w, map_hw, out_log2, (hipStream_t)stream);
+    return launch_pwconv_ps_dw(x_split, w_split, descale, shift, dw_consts, y_split, m, k, cout, act, map_w, map_hw, dw_stride, out_log2,
+                               (hipStream_t)stream);
 }
 
 int hsefr_pwconv1x1_presplit(const void* x_split, const void* w_split, const float* descale, const float* shift, float* y,

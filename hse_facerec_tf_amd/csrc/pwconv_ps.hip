@@ -116,7 +116,10 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
         nn0 = (lt - tm * tiles_n) * BN;
     };
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-    constexpr bool DW = DWM != 0;       // 1: any map that divides the tile (borders by validity masks); 2: 12 x 12 maps, zero-bordered chunk buffer
+    // 1: any map that divides the tile, stride 1 (borders by validity masks); 2: 12 x 12 maps, stride 1, zero-bordered chunk buffer;
+    // 3: 12 x 12 maps, depthwise stride 2 (TF SAME on an even map: no top / left padding) -> 6 x 6, same buffer
+    constexpr bool DW = DWM != 0;
+    constexpr bool BORDERED = DWM >= 2;
 
     // ---- DW epilogue, shared by both roles: the depthwise of one 32-channel chunk of the tile from the chunk buffer cb ----
     // cb layout: rows 0 .. BM-1 = the chunk's activated pointwise results [pixel][32 ch] fp32, two zero rows (taps outside the
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     // and 13 zero rows above, between and below the two maps: pixel (i, y, x) is row 14 + 169 i + 13 y + x, a tap (dy, dx) is
     // that row + 13 (dy - 1) + (dx - 1), always a valid row: no masks, and the nine offsets are instruction immediates.
     constexpr int PITCH = 13, IMGROWS = 13 * PITCH;                  // 12 image rows + 1 border row of 13 cells
-    constexpr int CB_ROWS = DWM == 2 ? 1 + PITCH + 2 * IMGROWS : BM + 2;
+    constexpr int CB_ROWS = BORDERED ? 1 + PITCH + 2 * IMGROWS : BM + 2;
     constexpr int CB_ZROW = BM;
     constexpr int CB_CONST = CB_ROWS * ROWB;
     // per item of this lane: bit t = tap t lies inside the map.  Recomputed at every tile's epilogue from an OPAQUE copy of the lane
@@ -142,6 +145,12 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                 const int img = P >= 144 ? 1 : 0, pl = P - 144 * img, yy = pl / 12, xx = pl - 12 * yy;
                 nb_mask[k3] = (unsigned)((169 * img + PITCH * yy + xx) * ROWB + 16 * (ln & 7));
             }
+            return;
+        }
+        if constexpr (DWM == 3) {      // one item: output pixel P of the tile's 2 x 36; its window starts at input (2 oy, 2 ox)
+            const int P = min((ln >> 3) + 8 * wave, 71);
+            const int img = P >= 36 ? 1 : 0, pl = P - 36 * img, oy = pl / 6, ox = pl - 6 * oy;
+            nb_mask[0] = (unsigned)((1 + PITCH + 169 * img + PITCH * 2 * oy + 2 * ox) * ROWB + 16 * (ln & 7));
             return;
         }
         const int H = dw.HW / dw.W;
@@ -167,17 +176,19 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
         const f32x4 sc = *(const f32x4*)(cp + 9 * 512), sh = *(const f32x4*)(cp + 10 * 512);
         // split rows of the output: pixel m, 32-channel group -> 128 B; this lane stores the 16-byte unit q/2 of the hi half
         // (even quad) or of the lo half (odd quad) after swapping one 8-byte half with its neighbour lane (dwconv.hip)
-        const __amdgpu_buffer_rsrc_t ro = make_rsrc((char*)dw.ys + (tm0 * Cout + tn0) * 4ll, ((M - tm0) * Cout - tn0) * 4ll);
+        // (stride 2: a quarter of the pixels -- the tile's 288 input pixels are output pixels tm0 / 4 .. + 71)
+        constexpr int OSH = DWM == 3 ? 2 : 0;
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc((char*)dw.ys + ((tm0 >> OSH) * Cout + tn0) * 4ll, (((M - tm0) >> OSH) * Cout - tn0) * 4ll);
         const bool odd = q & 1;
         const unsigned unit = odd ? 4u + (unsigned)(q >> 1) : (unsigned)(q >> 1);
 #pragma unroll
-        for (int k3 = 0; k3 < 3; ++k3) {
+        for (int k3 = 0; k3 < (DWM == 3 ? 1 : 3); ++k3) {
             const int P = (lane >> 3) + 8 * wave + 96 * k3;
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 f32x4 v;
-                if constexpr (DWM == 2) {
+                if constexpr (BORDERED) {
                     v = *(const f32x4*)(cb + nb_mask[k3] + ((t / 3) * PITCH + t % 3) * ROWB);
                 } else {
                     const int row = ((nb_mask[k3] >> t) & 1u) ? P + (t / 3 - 1) * dw.W + (t % 3 - 1) : CB_ZROW;
@@ -197,7 +208,9 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             recv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);
             recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
             const u32x4 out = odd ? u32x4{recv.x, recv.y, lb.x, lb.y} : u32x4{hb.x, hb.y, recv.x, recv.y};
-            bstore16_welded(__builtin_bit_cast(f32x4, out), ro, (unsigned)P * (unsigned)Cout * 4u + (unsigned)c * 128u + 16u * unit, 0u);
+            // (stride 2: lanes past the tile's 72 output pixels computed a duplicate of pixel 71; an out-of-range offset drops their store)
+            const unsigned ovoff = (DWM == 3 && P >= 72) ? 0x80000000u : (unsigned)P * (unsigned)Cout * 4u + (unsigned)c * 128u + 16u * unit;
+            bstore16_welded(__builtin_bit_cast(f32x4, out), ro, ovoff, 0u);
         }
     };
 
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                         for (int j = 0; j < 6; ++j)      // piece j = constant rows 2 j (lanes 0-31) and 2 j + 1 (lanes 32-63; row 11: out of range)
                             piece(rc, cbl + j * 1024, (unsigned)(2 * j + (lane >> 5)) * (unsigned)Cout * 4u + (unsigned)tn0 * 4u + 16u * (unsigned)(lane & 31), 0u);
                     }
-                    if constexpr (DWM == 2) {
+                    if constexpr (BORDERED) {
                         // the zero cells of the bordered layout (the stage still holds the last step's operands): every row that is
                         // not a pixel -- row 0, the border rows, cell 12 of every image row
                         for (int r = (wave - 8) * 8 + (lane >> 3); r < CB_ROWS; r += 32) {
@@ -429,7 +442,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                             for (int nb = 0; nb < 2; ++nb)
                             {
                                 int row = wm * 16 * MB + 16 * mb + l16;
-                                if constexpr (DWM == 2) {        // (MB == 9: wave row wm is image wm of the tile)
+                                if constexpr (BORDERED) {        // (MB == 9: wave row wm is image wm of the tile)
                                     const int pl = 16 * mb + l16, yy = pl / 12;
                                     row = 1 + PITCH + 169 * wm + PITCH * yy + (pl - 12 * yy);
                                 }
@@ -526,15 +539,18 @@ int read_ps_stamps(void* host_out, size_t bytes) {
 }
 #endif
 
-bool pwconv_ps_dw_supported(long long m, int k, int cout, int map_w, int map_hw) {
-    // a 288-row tile must hold whole maps; 3 x 3 / stride 1 / SAME; square or not, any edge >= 1
-    return pwconv_ps_supported(m, k, cout) && map_w > 0 && map_hw > 0 && map_hw % map_w == 0 && 288 % map_hw == 0 && m % map_hw == 0;
+bool pwconv_ps_dw_supported(long long m, int k, int cout, int map_w, int map_hw, int dw_stride) {
+    // a 288-row tile must hold whole maps; 3 x 3 / SAME; stride 1 on any such map (square or not), stride 2 on 12 x 12 maps
+    return pwconv_ps_supported(m, k, cout) && map_w > 0 && map_hw > 0 && map_hw % map_w == 0 && 288 % map_hw == 0 && m % map_hw == 0 &&
+           (dw_stride == 1 || (dw_stride == 2 && map_w == 12 && map_hw == 144));
 }
 
 int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale, const float* shift, const float* dwc, void* ys, long long m,
-                        int k, int cout, int act, int map_w, int map_hw, int out_log2, hipStream_t s) {
-    HSEFR_REQUIRE(pwconv_ps_dw_supported(m, k, cout, map_w, map_hw), HSEFR_ERR_UNSUPPORTED,
-                  "pwconv_presplit_dw: m=%lld k=%d cout=%d map %d (w %d) not covered (288 %% map == 0)", m, k, cout, map_hw, map_w);
+                        int k, int cout, int act, int map_w, int map_hw, int dw_stride, int out_log2, hipStream_t s) {
+    HSEFR_REQUIRE(pwconv_ps_dw_supported(m, k, cout, map_w, map_hw, dw_stride), HSEFR_ERR_UNSUPPORTED,
+                  "pwconv_presplit_dw: m=%lld k=%d cout=%d map %d (w %d) stride %d not covered (288 %% map == 0; stride 2: 12x12)", m, k, cout,
+                  map_hw, map_w, dw_stride);
+    HSEFR_REQUIRE(dw_stride == 1 || act == HSEFR_ACT_RELU6, HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_dw: the stride-2 epilogue is built for ReLU6");
     HSEFR_REQUIRE(out_log2 >= 1 && out_log2 <= 12, HSEFR_ERR_INVALID, "pwconv_presplit_dw: out_log2=%d", out_log2);
     if (m == 0) return HSEFR_OK;
     constexpr int MB = 9;
@@ -548,7 +564,8 @@ int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale
     hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, MODE>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
                        tiles_n, (unsigned)total, sweep_reverse(), dw)
     const bool bordered = map_w == 12 && map_hw == 144 && g_psdw_mode != 1;      // the zero-bordered chunk buffer (12 x 12 maps)
-    if (act == HSEFR_ACT_RELU6 && bordered) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6, 2);
+    if (dw_stride == 2) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6, 3);
+    else if (act == HSEFR_ACT_RELU6 && bordered) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6, 2);
     else if (act == HSEFR_ACT_RELU6) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6, 1);
     else if (act == HSEFR_ACT_RELU) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU, 1);
     else if (act == HSEFR_ACT_NONE) HSEFR_PSDW_LAUNCH(HSEFR_ACT_NONE, 1);

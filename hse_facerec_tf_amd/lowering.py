@@ -288,7 +288,7 @@ class Plan:
         if L.kind == OP_STEM_F16S:
             return 2 * oh * ow * 32 * 27 + 2 * oh * ow * 32 * 9 + 2 * oh * ow * cout * 32
         if L.kind == OP_PWDW_PS:
-            return 2 * oh * ow * cout * L.in_shape[2] + 2 * oh * ow * cout * 9
+            return 2 * L.in_shape[0] * L.in_shape[1] * cout * L.in_shape[2] + 2 * oh * ow * cout * 9
         if L.kind == OP_STEM7X7_POOL_BF16:
             return 2 * ((L.in_shape[0] - 1) // 2 + 1) * ((L.in_shape[1] - 1) // 2 + 1) * 64 * 147
         if L.kind in (OP_STEM2_F16S, OP_STEM3_F16S):
@@ -984,9 +984,13 @@ def pwdw_fusable(pw: Layer, dw: Layer) -> bool:
     """A pre-split pointwise layer followed ONLY by a stride-1 depthwise layer that itself stores split rows, on maps a 288-row GEMM
     tile holds whole (12x12, 6x6, ...): csrc/pwconv_ps.hip runs the depthwise in the GEMM's epilogue."""
     h, w, _ = dw.in_shape
-    return (pw.kind == OP_PWCONV_F32 and pw.a_log2 > 0 and pw.in_split and pw.out_shape[2] % 128 == 0 and
-            dw.kind == OP_DWCONV3X3 and dw.stride == 1 and dw.act == ACT_RELU6 and 0 < dw.out_split <= 12 and
-            dw.pad_t == 1 and dw.pad_l == 1 and dw.out_shape == dw.in_shape and 288 % (h * w) == 0)
+    if not (pw.kind == OP_PWCONV_F32 and pw.a_log2 > 0 and pw.in_split and pw.out_shape[2] % 128 == 0 and
+            dw.kind == OP_DWCONV3X3 and dw.act == ACT_RELU6 and 0 < dw.out_split <= 12 and 288 % (h * w) == 0):
+        return False
+    if dw.stride == 1:
+        return dw.pad_t == 1 and dw.pad_l == 1 and dw.out_shape == dw.in_shape
+    # stride 2: the 12x12 -> 6x6 layer (TF SAME on an even map pads bottom / right only); the GEMM's own activation must be ReLU6
+    return dw.stride == 2 and (h, w) == (12, 12) and (dw.pad_t, dw.pad_l) == (0, 0) and dw.out_shape[:2] == (6, 6) and pw.act == ACT_RELU6
 
 
 def fuse_pwdw(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
@@ -1013,7 +1017,7 @@ def fuse_pwdw(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Di
             pw = layers[merged[i]]
             L = Layer(OP_PWDW_PS, L.name, pw.src, pw.in_shape, L.out_shape, w=pw.w, shift=pw.shift, act=pw.act, sealed=True,
                       a_log2=pw.a_log2, in_split=True, w3=L.w, scale3=L.scale, shift3=L.shift, out_split=L.out_split, kh=3, kw=3,
-                      stride=1, pad_t=1, pad_l=1, tensors=list(L.tensors))
+                      stride=L.stride, pad_t=L.pad_t, pad_l=L.pad_l, tensors=list(L.tensors))
         new_layers.append(L)
         remap[i] = len(new_layers) - 1
     for L in new_layers:

@@ -125,10 +125,12 @@ def pwconv1x1_presplit(xs, w_t, shift, act: int = ACT_RELU6, a_log2: int = 12, p
 
 
 @_device_guarded
-def pwconv1x1_presplit_dw(xs, w_t, shift, dw_w_hwc, dw_scale, dw_shift, act: int = ACT_RELU6, a_log2: int = 12, out_log2: int = 12, prepared=None):
+def pwconv1x1_presplit_dw(xs, w_t, shift, dw_w_hwc, dw_scale, dw_shift, act: int = ACT_RELU6, a_log2: int = 12, out_log2: int = 12, prepared=None,
+                          dw_stride: int = 1):
     """pwconv1x1_presplit with the NEXT block's depthwise 3x3 / stride 1 / SAME + scale + shift + ReLU6 in its epilogue
     (csrc/pwconv_ps.hip, DW = true).  xs = split rows [n, h, w, k/32, 2, 32] with 288 % (h * w) == 0; dw_w_hwc [3, 3, cout].
-    Returns the depthwise result as split rows [n, h, w, cout/32, 2, 32] scaled by 2^out_log2 (split_rows_decode)."""
+    Returns the depthwise result as split rows [n, h/s, w/s, cout/32, 2, 32] scaled by 2^out_log2 (split_rows_decode); dw_stride 2
+    (12x12 maps only) is TF SAME on an even map: no top / left padding."""
     torch = _lib.require_gpu()
     _f32c(shift, "shift"), _f32c(dw_w_hwc, "dw_w"), _f32c(dw_scale, "dw_scale"), _f32c(dw_shift, "dw_shift")
     if not (xs.is_cuda and xs.dtype == torch.float16 and xs.is_contiguous() and xs.dim() == 6 and tuple(xs.shape[-2:]) == (2, 32)):
@@ -140,9 +142,10 @@ def pwconv1x1_presplit_dw(xs, w_t, shift, dw_w_hwc, dw_scale, dw_shift, act: int
         raise ValueError("depthwise operands must be [3,3,%d], [%d], [%d]" % (cout, cout, cout))
     amp = float(2 ** out_log2)
     consts = torch.cat([dw_w_hwc.reshape(9, cout), (dw_scale * amp).reshape(1, cout), (dw_shift * amp).reshape(1, cout)]).contiguous()
-    ys = torch.empty((n, h, w, cout // 32, 2, 32), dtype=torch.float16, device=xs.device)
+    ys = torch.empty((n, h // dw_stride, w // dw_stride, cout // 32, 2, 32), dtype=torch.float16, device=xs.device)
     _lib.check(_lib.lib().hsefr_pwconv1x1_presplit_dw(xs.data_ptr(), d_img.data_ptr(), d_ds.data_ptr(), shift.data_ptr(), consts.data_ptr(),
-                                                      ys.data_ptr(), n * h * w, k, cout, act, w, h * w, out_log2, _lib.current_stream_ptr()),
+                                                      ys.data_ptr(), n * h * w, k, cout, act, w, h * w, dw_stride, out_log2,
+                                                      _lib.current_stream_ptr()),
                "hsefr_pwconv1x1_presplit_dw")
     return ys
 

@@ -359,22 +359,24 @@ def test_pointwise_depthwise_epilogue_fusion(graph):
     base = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), input_bound=256.0, pwdw_fusion="none")
     fused = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), input_bound=256.0, pwdw_fusion="auto")
     kb, kf = [L.kind for L in base.layers], [L.kind for L in fused.layers]
-    assert kf.count(lowering.OP_PWDW_PS) == 6 and len(kf) == len(kb) - 6
-    assert kb.count(lowering.OP_DWCONV3X3) - kf.count(lowering.OP_DWCONV3X3) == 6
+    assert kf.count(lowering.OP_PWDW_PS) == 7 and len(kf) == len(kb) - 7       # dw_7 .. dw_11, dw_12 (stride 2), dw_13
+    assert kb.count(lowering.OP_DWCONV3X3) - kf.count(lowering.OP_DWCONV3X3) == 7
     for L in fused.layers:
         if L.kind == lowering.OP_PWDW_PS:
-            assert L.in_split and L.out_split == 12 and L.a_log2 == 12 and 288 % (L.out_shape[0] * L.out_shape[1]) == 0
-            assert L.in_shape[:2] == L.out_shape[:2] and L.out_shape[2] % 128 == 0 and L.w3.shape[:2] == (3, 3)
+            assert L.in_split and L.out_split == 12 and L.a_log2 == 12 and 288 % (L.in_shape[0] * L.in_shape[1]) == 0
+            assert (L.in_shape[0], L.in_shape[1]) == (L.out_shape[0] * L.stride, L.out_shape[1] * L.stride)
+            assert L.out_shape[2] % 128 == 0 and L.w3.shape[:2] == (3, 3)
+            assert L.stride == 1 or (L.in_shape[:2] == (12, 12) and (L.pad_t, L.pad_l) == (0, 0))
             nxt = [M for M in fused.layers if M.src >= 0 and fused.layers[M.src] is L]
             assert len(nxt) == 1 and nxt[0].in_split            # its split rows feed the next pre-split GEMM
     # the fused layer stands for the DEPTHWISE tensor; the pointwise tensor in between no longer exists
     assert "conv_dw_8_relu/clip_by_value" in fused.tensor_layer and "conv_pw_7_relu/clip_by_value" not in fused.tensor_layer
     assert fused.flops_per_image() == base.flops_per_image()
-    assert base.bytes_per_image() - fused.bytes_per_image() == 2 * 4 * (5 * 12 * 12 * 512 + 6 * 6 * 1024)
+    assert base.bytes_per_image() - fused.bytes_per_image() == 2 * 4 * (6 * 12 * 12 * 512 + 6 * 6 * 1024)
     # a requested pointwise tensor keeps its pair unfused; 224-pixel input (14x14 and 7x7 maps: 288 % 196 != 0, 288 % 49 != 0) fuses nothing
     keep = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0", OUT_AGE: "conv_pw_8_relu/clip_by_value:0"}, (192, 192),
                                 input_bound=256.0, pwdw_fusion="auto")
-    assert [L.kind for L in keep.layers].count(lowering.OP_PWDW_PS) == 5
+    assert [L.kind for L in keep.layers].count(lowering.OP_PWDW_PS) == 6
     assert lowering.OP_PWDW_PS not in [L.kind for L in lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (224, 224), pwdw_fusion="auto").layers]
     with pytest.raises(ValueError):
         lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), pwdw_fusion="all")

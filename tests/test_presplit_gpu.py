@@ -162,13 +162,15 @@ def test_whole_network_presplit_vs_fp32_tensors(env):
     ea.close(), eb.close()
 
 
-@pytest.mark.parametrize("n,h,w,k,cout,act", [(2, 12, 12, 512, 512, 2), (5, 12, 12, 256, 512, 2), (8, 6, 6, 512, 1024, 2), (19, 6, 6, 1024, 1024, 2),
-                                              (3, 3, 3, 256, 128, 2), (4, 4, 3, 256, 256, 1), (1, 12, 12, 288, 384, 0)])
-def test_pointwise_with_depthwise_epilogue_vs_oracle(n, h, w, k, cout, act):
+@pytest.mark.parametrize("n,h,w,k,cout,act,s", [(2, 12, 12, 512, 512, 2, 1), (5, 12, 12, 256, 512, 2, 1), (8, 6, 6, 512, 1024, 2, 1), (19, 6, 6, 1024, 1024, 2, 1),
+                                                (3, 3, 3, 256, 128, 2, 1), (4, 4, 3, 256, 256, 1, 1), (1, 12, 12, 288, 384, 0, 1),
+                                                (2, 12, 12, 512, 512, 2, 2), (7, 12, 12, 256, 384, 2, 2)])
+def test_pointwise_with_depthwise_epilogue_vs_oracle(n, h, w, k, cout, act, s):
     """csrc/pwconv_ps.hip with DW = true: pointwise on split rows + the next block's depthwise 3x3 / 1 / SAME + scale + shift + ReLU6
     in the epilogue, output as split rows -- against the fp64 oracle of the two layers, at the pre-split GEMM's 2e-6 bar
     (relative to the output scale).  Shapes: MobileNet's 12x12x512 and 6x6x1024 blocks, odd image counts (tiles with fewer
-    maps than they hold: rows beyond M), a 3x3 map, a non-square map, K and Cout that are not powers of two."""
+    maps than they hold: rows beyond M), a 3x3 map, a non-square map, K and Cout that are not powers of two, and the stride-2
+    depthwise of the 12x12 -> 6x6 block."""
     import torch
     from hse_facerec_tf_amd import ops
     from oracle import tf_graph as tfo
@@ -183,18 +185,19 @@ def test_pointwise_with_depthwise_epilogue_vs_oracle(n, h, w, k, cout, act):
     mid = x.reshape(-1, k).astype(np.float64).dot(wt.T.astype(np.float64)) + sh
     mid = np.minimum(np.maximum(mid, 0), 6) if act == 2 else (np.maximum(mid, 0) if act == 1 else mid)
     mid = mid.reshape(n, h, w, cout)
-    want = tfo.depthwise_conv2d(np.pad(mid, ((0, 0), (1, 1), (1, 1), (0, 0))), dww.reshape(3, 3, cout, 1).astype(np.float64), (1, 1), "VALID")
+    pad0 = 1 if s == 1 else 0          # TF SAME: stride 2 on an even map pads bottom / right only
+    want = tfo.depthwise_conv2d(np.pad(mid, ((0, 0), (pad0, 1), (pad0, 1), (0, 0))), dww.reshape(3, 3, cout, 1).astype(np.float64), (s, s), "VALID")
     want = np.minimum(np.maximum(want * dsc + dsh, 0), 6)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    ys = ops.pwconv1x1_presplit_dw(ops.split_rows_encode(d(x), 12), wt, d(sh), d(dww), d(dsc), d(dsh), act, 12, 12)
-    assert tuple(ys.shape) == (n, h, w, cout // 32, 2, 32)
+    ys = ops.pwconv1x1_presplit_dw(ops.split_rows_encode(d(x), 12), wt, d(sh), d(dww), d(dsc), d(dsh), act, 12, 12, dw_stride=s)
+    assert tuple(ys.shape) == (n, h // s, w // s, cout // 32, 2, 32)
     got = ops.split_rows_decode(ys, 12).cpu().numpy()
     # error scale: the depthwise sums up to 9 pointwise results of magnitude |mid| (<= 6 with ReLU6) times |tap| * scale
     scale = np.abs(dww).sum(axis=(0, 1)) * dsc * max(np.abs(mid).max(), 1.0) + np.abs(dsh) + 1.0
     assert (np.abs(got - want) / scale).max() < 2e-6
     # the same numbers as the unfused pair on the device (pre-split GEMM, then the split-row depthwise kernel), up to the depthwise's summation order
     mid_d = ops.pwconv1x1_presplit(ops.split_rows_encode(d(x), 12), wt, d(sh), act, 12)
-    two = ops.split_rows_decode(ops.dwconv3x3_split(mid_d, d(dww), d(dsc), d(dsh), 1, 2, 12), 12).cpu().numpy()
+    two = ops.split_rows_decode(ops.dwconv3x3_split(mid_d, d(dww), d(dsc), d(dsh), s, 2, 12), 12).cpu().numpy()
     assert (np.abs(got - two) / scale).max() < 1e-6
     with pytest.raises(Exception):            # a 5x5 map: a 288-row tile does not hold whole maps
         ops.pwconv1x1_presplit_dw(ops.split_rows_encode(d(rs.uniform(0, 6, (1, 5, 5, k)).astype(np.float32)), 12), wt, d(sh), d(dww), d(dsc), d(dsh),
