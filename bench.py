@@ -580,7 +580,7 @@ def main():
         "fused_dw3x3_pw1x1_f16split": lambda L: L.kind == lowering.OP_DWPW_F16S,
         "pointwise1x1_f32mfma": lambda L: L.kind == lowering.OP_PWCONV_F32 and L.a_log2 == 0,
         "pointwise1x1_f16split": lambda L: L.kind == lowering.OP_PWCONV_F32 and L.a_log2 > 0,
-        "fused_pw1x1_dw3x3_f16split": lambda L: L.kind == lowering.OP_PWDW_PS,
+        "fused_pw1x1_dw3x3_f16split": lambda L: L.kind in (lowering.OP_PWDW_PS, lowering.OP_PWGAP_PS),
         "gap": lambda L: L.kind == lowering.OP_GAP,
     }
     # HBM traffic per launch measured with rocprofv3 PMC counters (separate --pmc FETCH_SIZE / WRITE_SIZE

@@ -36,6 +36,7 @@ SIGNATURES = {
     "hsefr_conv_c3_bias_act": (c_int, [_fp, _fp, _fp, _fp] + [c_int] * 12 + [c_void_p]),
     "hsefr_dwconv3x3_bn_relu6": (c_int, [_fp, _fp, _fp, _fp, _fp] + [c_int] * 10 + [c_void_p]),
     "hsefr_dwconv3x3_bn_relu6_split": (c_int, [_fp, _fp, _fp, _fp, _fp] + [c_int] * 11 + [c_void_p]),
+    "hsefr_pwconv1x1_presplit_gap": (c_int, [_fp, c_void_p, _fp, _fp, _fp, c_longlong, c_int, c_int, c_int, c_int, c_void_p]),
     "hsefr_pwconv1x1_presplit_dw": (c_int, [_fp, c_void_p, _fp, _fp, _fp, _fp, c_longlong] + [c_int] * 7 + [c_void_p]),
     "hsefr_pwconv1x1_presplit": (c_int, [_fp, c_void_p, _fp, _fp, _fp, c_longlong, c_int, c_int, c_int, c_void_p]),
     "hsefr_pwconv1x1_bias_relu6": (c_int, [_fp, _fp, _fp, _fp, c_longlong, c_int, c_int, c_int, c_void_p]),

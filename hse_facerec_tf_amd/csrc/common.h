@@ -135,6 +135,9 @@ int launch_pwconv_f16s(const float* x, const void* wsplit, const float* descale,
                        long long m, int k, int cout, int a_log2, int act, hipStream_t s);
 // pre-split activations (csrc/pwconv_ps.hip): xs = split rows [m][k/32][hi 32 x f16 | lo 32 x f16], scaled by 2^a_log2 (folded in descale)
 bool pwconv_ps_supported(long long m, int k, int cout);
+bool pwconv_ps_gap_supported(long long m, int k, int cout, int map_hw);
+int launch_pwconv_ps_gap(const void* xs, const void* wsplit, const float* descale, const float* shift, float* y, long long m, int k, int cout,
+                         int act, int map_hw, hipStream_t s);
 bool pwconv_ps_dw_supported(long long m, int k, int cout, int map_w, int map_hw, int dw_stride);
 int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale, const float* shift, const float* dwc, void* ys, long long m,
                         int k, int cout, int act, int map_w, int map_hw, int dw_stride, int out_log2, hipStream_t s);

@@ -144,6 +144,13 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                 if (!need(o.w_off, 64 * 256 * 2, "kernel") || !need(o.scale_off, co * 4, "scale") || !need(o.shift_off, co * 4, "shift"))
                     return HSEFR_ERR_INVALID;
                 break;
+            case HSEFR_OP_PWCONV_PS_GAP:
+                HSEFR_REQUIRE(pwconv_ps_gap_supported(0, o.cin, o.cout, o.h * o.w) && o.oh == 1 && o.ow == 1, HSEFR_ERR_UNSUPPORTED,
+                              "plan op %u: fused pointwise + global pool on a %dx%d map not covered", i, o.h, o.w);
+                if (!need(o.w_off, ci * co * 4, "split rows") || !need(o.scale_off, co * 4, "descale") || !need(o.shift_off, co * 4, "shift"))
+                    return HSEFR_ERR_INVALID;
+                HSEFR_REQUIRE(o.reserved > 0 && o.reserved <= 24, HSEFR_ERR_INVALID, "plan op %u: a_log2 out of range (reserved %d)", i, o.reserved);
+                break;
             case HSEFR_OP_PWCONV_PS_DW:
                 HSEFR_REQUIRE(pwconv_ps_dw_supported(0, o.cin, o.cout, o.w, o.h * o.w, o.stride) && o.oh * o.stride == o.h && o.ow * o.stride == o.w &&
                                   (o.stride == 1 ? (o.pad_t == 1 && o.pad_l == 1) : (o.pad_t == 0 && o.pad_l == 0)),
@@ -424,6 +431,10 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                           (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
                                           (float*)out, n, o.h, o.w, o.cin, o.stride, o.pad_t, o.pad_l, o.oh, o.ow, o.act, s);
                 break;
+            case HSEFR_OP_PWCONV_PS_GAP:
+                rc = launch_pwconv_ps_gap(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
+                                          (float*)out, (long long)n * o.h * o.w, o.cin, o.cout, o.act, o.h * o.w, s);
+                break;
             case HSEFR_OP_PWCONV_PS_DW:
                 rc = launch_pwconv_ps_dw(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
                                          (const float*)blob_ptr(e, o.w2_off), out, (long long)n * o.h * o.w, o.cin, o.cout, o.act, o.w,
@@ -677,6 +688,12 @@ int hsefr_dwconv3x3_bn_relu6_split(const float* x, const float* wgt, const float
                                    int a_log2, hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || (x && wgt && scale && shift && y_split), HSEFR_ERR_INVALID, "dwconv3x3_split: null pointer");
     return launch_dwconv3x3_split(x, wgt, scale, shift, y_split, n, h, w, c, stride, pad_t, pad_l, oh, ow, act, a_log2, (hipStream_t)stream);
+}
+
+int hsefr_pwconv1x1_presplit_gap(const void* x_split, const void* w_split, const float* descale, const float* shift, float* y,
+                                 long long m, int k, int cout, int act, int map_hw, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(m == 0 || (x_split && w_split && descale && shift && y), HSEFR_ERR_INVALID, "pwconv1x1_presplit_gap: null pointer");
+    return launch_pwconv_ps_gap(x_split, w_split, descale, shift, y, m, k, cout, act, map_hw, (hipStream_t)stream);
 }
 
 int hsefr_pwconv1x1_presplit_dw(const void* x_split, const void* w_split, const float* descale, const float* shift, const float* dw_consts,

@@ -118,8 +118,10 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
     // 1: any map that divides the tile, stride 1 (borders by validity masks); 2: 12 x 12 maps, stride 1, zero-bordered chunk buffer;
     // 3: 12 x 12 maps, depthwise stride 2 (TF SAME on an even map: no top / left padding) -> 6 x 6, same buffer
+    // 4: no depthwise -- the global average pool behind the GEMM (the network's last pointwise layer): the tile's maps are summed
+    //    from the chunk buffer and only [maps][128 channels] means leave the kernel
     constexpr bool DW = DWM != 0;
-    constexpr bool BORDERED = DWM >= 2;
+    constexpr bool BORDERED = DWM == 2 || DWM == 3;
 
     // ---- DW epilogue, shared by both roles: the depthwise of one 32-channel chunk of the tile from the chunk buffer cb ----
     // cb layout: rows 0 .. BM-1 = the chunk's activated pointwise results [pixel][32 ch] fp32, two zero rows (taps outside the
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     auto dw_masks = [&]() __attribute__((always_inline)) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        if constexpr (DWM == 4) return;
         if constexpr (DWM == 2) {
 #pragma unroll
             for (int k3 = 0; k3 < 3; ++k3) {
@@ -168,6 +171,31 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
         }
     };
     auto dw_chunk = [&](int c, const unsigned char* cb, long long tm0, int tn0) __attribute__((always_inline)) {
+        if constexpr (DWM == 4) {
+            // global average pool of the chunk: wave i < BM / HW sums map i; lane = (channel quad, one of 8 row groups), the groups
+            // are folded with three xor-shuffles, group 0 stores the four means
+            const int maps = BM / dw.HW;
+            if (wave < maps) {
+                const int q = lane & 7, part = lane >> 3;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                for (int r = part; r < dw.HW; r += 8) {
+                    const f32x4 v = *(const f32x4*)(cb + (wave * dw.HW + r) * ROWB + 16 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sum[e] += v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sum[e] += __shfl_xor(sum[e], 8);
+                    sum[e] += __shfl_xor(sum[e], 16);
+                    sum[e] += __shfl_xor(sum[e], 32);
+                    sum[e] *= dw.clamp_hi;                  // (this mode: 1 / HW)
+                }
+                const long long map0 = tm0 / dw.HW, nmaps = M / dw.HW;
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc((char*)dw.ys + (map0 * Cout + tn0) * 4ll, ((nmaps - map0) * Cout - tn0) * 4ll);
+                bstore16_welded(sum, ro, part == 0 ? (unsigned)wave * (unsigned)Cout * 4u + (unsigned)(32 * c + 4 * q) * 4u : 0x80000000u, 0u);
+            }
+            return;
+        }
         const int q = lane & 7;
         const unsigned char* cp = cb + CB_CONST + (32 * c + 4 * q) * 4;
         f32x4 tap[9];
@@ -289,7 +317,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                     int tn0;
                     tile_origin(ci, mm0, tn0);
                     unsigned char* cb = smem + (unsigned)(((ci + 1u) * (unsigned)KT - 1u) % 3u) * STAGE;
-                    if (lw == 3) {
+                    if (DWM != 4 && lw == 3) {
                         const __amdgpu_buffer_rsrc_t rc = make_rsrc(dw.dwc, 11ll * Cout * 4);
                         const unsigned cbl = lds0 + (unsigned)(cb - smem) + CB_CONST;
 #pragma unroll
@@ -304,7 +332,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                             const bool pixel = rr >= 0 && r2 < 12 * PITCH && r2 % PITCH != 12;
                             if (!pixel) *(f32x4*)(cb + r * ROWB + 16 * (lane & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
-                    } else {
+                    } else if constexpr (DWM == 1) {
                         if (lw == 2 && lane < 16) *(f32x4*)(cb + CB_ZROW * ROWB + 16 * lane) = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -572,6 +600,34 @@ int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale
     else { set_error("pwconv_presplit_dw: act %d", act); return HSEFR_ERR_UNSUPPORTED; }
 #undef HSEFR_PSDW_LAUNCH
     return launch_status("pwconv_presplit_dw");
+}
+
+bool pwconv_ps_gap_supported(long long m, int k, int cout, int map_hw) {
+    // a 288-row tile holds whole maps, at most eight of them (one wave sums one map)
+    return pwconv_ps_supported(m, k, cout) && map_hw >= 36 && 288 % map_hw == 0 && m % map_hw == 0;
+}
+
+int launch_pwconv_ps_gap(const void* xs, const void* wsplit, const float* descale, const float* shift, float* y, long long m, int k, int cout,
+                         int act, int map_hw, hipStream_t s) {
+    HSEFR_REQUIRE(pwconv_ps_gap_supported(m, k, cout, map_hw), HSEFR_ERR_UNSUPPORTED,
+                  "pwconv_presplit_gap: m=%lld k=%d cout=%d map %d not covered (288 %% map == 0, map >= 36)", m, k, cout, map_hw);
+    if (m == 0) return HSEFR_OK;
+    constexpr int MB = 9;
+    const long long tiles_m = (m + 32 * MB - 1) / (32 * MB);
+    const unsigned tiles_n = cout / BN;
+    const long long total = tiles_m * tiles_n;
+    HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_gap: too many tiles");
+    const unsigned g = (unsigned)(total < 256 ? total : 256);
+    const PsDwParams dw{nullptr, y, 0, map_hw, 1.0f / (float)map_hw};
+#define HSEFR_PSGAP_LAUNCH(A)                                                                                                    \
+    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, 4>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
+                       tiles_n, (unsigned)total, sweep_reverse(), dw)
+    if (act == HSEFR_ACT_RELU6) HSEFR_PSGAP_LAUNCH(HSEFR_ACT_RELU6);
+    else if (act == HSEFR_ACT_RELU) HSEFR_PSGAP_LAUNCH(HSEFR_ACT_RELU);
+    else if (act == HSEFR_ACT_NONE) HSEFR_PSGAP_LAUNCH(HSEFR_ACT_NONE);
+    else { set_error("pwconv_presplit_gap: act %d", act); return HSEFR_ERR_UNSUPPORTED; }
+#undef HSEFR_PSGAP_LAUNCH
+    return launch_status("pwconv_presplit_gap");
 }
 
 bool pwconv_ps_supported(long long m, int k, int cout) {

@@ -37,6 +37,7 @@ OP_STEM3_F16S = 17       # STEM2_F16S for an input with a declared bound: conv1 
 OP_CONV_F32, OP_MAXPOOL_F32 = 18, 19   # general KxK fp32 convolution / clipped max-pool: the fp32-grade mode of ResNet-style graphs
 OP_STEM7X7_POOL_BF16 = 20   # STEM7X7_BF16 (ReLU) + the 3x3/2 max-pool behind it in one kernel (csrc/stem7x7_pool.hip)
 OP_PWDW_PS = 21          # pre-split pointwise + the NEXT block's depthwise in the GEMM's epilogue (csrc/pwconv_ps.hip, DW = true)
+OP_PWGAP_PS = 22         # pre-split pointwise + the global average pool behind it in the GEMM's epilogue
 OP_PWCONV_PS = 16        # wire kind of a split-f16 pointwise Layer whose input is stored PRE-SPLIT by its producer (csrc/pwconv_ps.hip)
 _BF16_OUT = (OP_CONV_BF16, OP_MAXPOOL_BF16, OP_STEM7X7_BF16, OP_STEM7X7_POOL_BF16)
 OUT_FEATURES, OUT_AGE, OUT_GENDER = 0, 1, 2
@@ -218,6 +219,10 @@ class Plan:
                 kw_field = 3 + 16 * L.pad3[0] + 32 * L.pad3[1]
             if L.kind == OP_STEM7X7_POOL_BF16:
                 aux = L.pad3[0] | (L.pad3[1] << 4)
+            if L.kind == OP_PWGAP_PS:
+                w = np.ascontiguousarray(w.reshape(w.shape[-2], w.shape[-1]).T)
+                w, scale = split_pointwise_weights(w, L.a_log2)
+                aux = L.a_log2
             if L.kind == OP_PWDW_PS:
                 w = np.ascontiguousarray(w.reshape(w.shape[-2], w.shape[-1]).T)      # [1,1,K,Cout] -> [Cout,K]
                 w, scale = split_pointwise_weights(w, L.a_log2)
@@ -287,6 +292,8 @@ class Plan:
             return 2 * oh * ow * L.in_shape[2] * 9 + 2 * oh * ow * cout * L.in_shape[2]
         if L.kind == OP_STEM_F16S:
             return 2 * oh * ow * 32 * 27 + 2 * oh * ow * 32 * 9 + 2 * oh * ow * cout * 32
+        if L.kind == OP_PWGAP_PS:
+            return 2 * L.in_shape[0] * L.in_shape[1] * cout * L.in_shape[2]
         if L.kind == OP_PWDW_PS:
             return 2 * L.in_shape[0] * L.in_shape[1] * cout * L.in_shape[2] + 2 * oh * ow * cout * 9
         if L.kind == OP_STEM7X7_POOL_BF16:
@@ -993,6 +1000,36 @@ def pwdw_fusable(pw: Layer, dw: Layer) -> bool:
     return dw.stride == 2 and (h, w) == (12, 12) and (dw.pad_t, dw.pad_l) == (0, 0) and dw.out_shape[:2] == (6, 6) and pw.act == ACT_RELU6
 
 
+def fuse_pwgap(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
+    """A pre-split pointwise layer followed ONLY by the global average pool, on maps a 288-row GEMM tile holds whole (at most eight):
+    the pool runs in the GEMM's epilogue (csrc/pwconv_ps.hip) and the pointwise tensor is never written."""
+    consumers: Dict[int, List[int]] = {}
+    for i, L in enumerate(layers):
+        for s in (L.src, L.res):
+            if s >= 0:
+                consumers.setdefault(s, []).append(i)
+    remap = {i: i for i in range(len(layers))}
+    for i, L in enumerate(layers):
+        cons = consumers.get(i, [])
+        h, w, c = L.out_shape
+        if not (L.kind == OP_PWCONV_F32 and L.a_log2 > 0 and L.in_split and c % 128 == 0 and i not in keep and len(cons) == 1 and
+                layers[cons[0]].kind == OP_GAP and layers[cons[0]].src == i and 288 % (h * w) == 0 and h * w >= 36):
+            continue
+        G = layers[cons[0]]
+        F = Layer(OP_PWGAP_PS, G.name, L.src, L.in_shape, G.out_shape, w=L.w, shift=L.shift, act=L.act, sealed=True, a_log2=L.a_log2,
+                  in_split=True, tensors=list(G.tensors))
+        new_layers = [x for j, x in enumerate(layers) if j != i]
+        new_layers[cons[0] - 1] = F
+        remap = {j: (-1 if j == i else (j if j < i else j - 1)) for j in range(len(layers))}
+        for x in new_layers:
+            if x.src >= 0:
+                x.src = remap[x.src]
+            if x.res >= 0:
+                x.res = remap[x.res]
+        return new_layers, remap
+    return layers, remap
+
+
 def fuse_pwdw(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
     """Merge pointwise -> depthwise pairs (pwdw_fusable) into one PWDW_PS layer: the pointwise result never reaches HBM and the
     depthwise kernel disappears.  Returns (layers, old index -> new index; a merged pointwise maps to -1)."""
@@ -1049,7 +1086,8 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
     their result pre-split and the GEMM stages both operands by LDS-DMA (presplit_activations); 'none' = fp32 tensors.
     pwdw_fusion: 'auto' (default; env HSEFR_FUSE_PWDW=auto|none) = a pre-split pointwise layer followed only by a stride-1
     depthwise layer on a map that a 288-row GEMM tile holds whole (12x12, 6x6) runs that depthwise in its epilogue (fuse_pwdw):
-    the pointwise tensor never reaches HBM and the depthwise launch disappears; 'none'.
+    the pointwise tensor never reaches HBM and the depthwise launch disappears (the last pointwise layer takes the global
+    average pool the same way: fuse_pwgap); 'none'.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
     (general KxK Conv2D, Pad, FusedBatchNorm / Mul+Add, residual Add, MaxPool 3x3/2, global AvgPool / Mean); 'f32g': the
     same ResNet-style graph patterns on exact-fp32 kernels (OP_CONV_F32 / OP_MAXPOOL_F32 / OP_GAP) -- the fp32-grade mode
@@ -1157,6 +1195,9 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
                 raise ValueError("pwdw_fusion must be 'auto' or 'none', not %r" % (pwdw_fusion,))
             if fuse and pwdw_fusion == "auto":
                 layers, remap = fuse_pwdw(layers, [li for li, _ in out_layers.values()])
+                out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
+                tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
+                layers, remap = fuse_pwgap(layers, [li for li, _ in out_layers.values()])
                 out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
                 tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
     buffers = assign_buffers(layers, {li for li, _ in out_layers.values()})

@@ -125,6 +125,23 @@ def pwconv1x1_presplit(xs, w_t, shift, act: int = ACT_RELU6, a_log2: int = 12, p
 
 
 @_device_guarded
+def pwconv1x1_presplit_gap(xs, w_t, shift, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
+    """pwconv1x1_presplit with the global average pool in its epilogue (csrc/pwconv_ps.hip): xs = split rows [n, h, w, k/32, 2, 32]
+    with 288 % (h * w) == 0 and h * w >= 36 -> fp32 [n, cout] means; the pointwise tensor is never written."""
+    torch = _lib.require_gpu()
+    _f32c(shift, "shift")
+    if not (xs.is_cuda and xs.dtype == torch.float16 and xs.is_contiguous() and xs.dim() == 6 and tuple(xs.shape[-2:]) == (2, 32)):
+        raise ValueError("xs must be a contiguous float16 CUDA tensor [n, h, w, k/32, 2, 32]")
+    d_img, d_ds = prepared if prepared is not None else split_weights_device(w_t, xs.device, a_log2)
+    n, h, w = int(xs.shape[0]), int(xs.shape[1]), int(xs.shape[2])
+    k, cout = xs.shape[3] * 32, d_img.shape[0]
+    y = torch.empty((n, cout), dtype=torch.float32, device=xs.device)
+    _lib.check(_lib.lib().hsefr_pwconv1x1_presplit_gap(xs.data_ptr(), d_img.data_ptr(), d_ds.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                                       n * h * w, k, cout, act, h * w, _lib.current_stream_ptr()), "hsefr_pwconv1x1_presplit_gap")
+    return y
+
+
+@_device_guarded
 def pwconv1x1_presplit_dw(xs, w_t, shift, dw_w_hwc, dw_scale, dw_shift, act: int = ACT_RELU6, a_log2: int = 12, out_log2: int = 12, prepared=None,
                           dw_stride: int = 1):
     """pwconv1x1_presplit with the NEXT block's depthwise 3x3 / stride 1 / SAME + scale + shift + ReLU6 in its epilogue

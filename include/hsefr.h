@@ -110,6 +110,8 @@ typedef enum hsefr_op_kind {
                                   (1, or 2 on 12 x 12 maps with pad 0), oh / ow = its output size.
                                   w2_off = [11][cout] fp32: taps 0..8, scale * 2^out_log2, shift * 2^out_log2;
                                   reserved = a_log2 | out_log2 << 8                                                         */
+    HSEFR_OP_PWCONV_PS_GAP = 22, /* PWCONV_PS + the global average pool behind it in the GEMM's epilogue: output [1,1,cout] fp32 per image
+                                  (h * w must divide 288 and be >= 36); blob operands as PWCONV_PS, reserved = a_log2            */
     HSEFR_OP_STEM3_F16S = 17,  /* STEM2_F16S for an input with a DECLARED BOUND |x| < 2^(15 - in_log2) (csrc/stem3_fused.hip): conv1's
                                   products are formed on the f16 MFMA from two-term splits like the pointwise layers'.
                                   w_off = the STEM2 fp32 pack (1952 floats) | conv1 split rows [32][64 f16] (1024 floats) |
@@ -264,6 +266,11 @@ int hsefr_pwconv1x1_f16split(const float* x, const void* w_split, const float* d
  * as hsefr_pwconv1x1_f16split (not bit-identical to it: a different MFMA shape sums the products in another order). */
 int hsefr_pwconv1x1_presplit(const void* x_split, const void* w_split, const float* descale, const float* shift, float* y,
                              long long m, int k, int cout, int act, hsefr_stream_t stream);
+
+/* hsefr_pwconv1x1_presplit with the global average pool fused into its epilogue: y = [m / map_hw][cout] fp32 means over each map's
+ * map_hw pixels (288 % map_hw == 0, map_hw >= 36); the pointwise tensor itself is not written. */
+int hsefr_pwconv1x1_presplit_gap(const void* x_split, const void* w_split, const float* descale, const float* shift, float* y,
+                                 long long m, int k, int cout, int act, int map_hw, hsefr_stream_t stream);
 
 /* hsefr_pwconv1x1_presplit with the next block's depthwise 3x3 / SAME + scale + shift + ReLU6 fused into its epilogue: the result
  * leaves as that depthwise layer's split rows y_split (scaled by 2^out_log2; m / dw_stride^2 pixels).  The m rows are maps of

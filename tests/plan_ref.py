@@ -103,6 +103,13 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             wt = unsplit_pointwise_weights(img, np.frombuffer(data, np.float32, cout, sc_off), _r).astype(dtype)
             assert 0 < _r <= 24 and float(np.abs(src).max()) * 2.0 ** _r < 32768, "split-f16 input bound violated"
             y = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
+        elif kind == 22:     # pre-split pointwise + global average pool
+            assert split_fmt.get(in_buf, 0) == _r and cin % 32 == 0 and cout % 128 == 0 and 288 % (h * w) == 0 and h * w >= 36 and (oh, ow) == (1, 1)
+            from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
+            img = np.frombuffer(data, np.uint16, cout * cin * 2, w_off).reshape(cout, cin // 32, 64)
+            wt = unsplit_pointwise_weights(img, np.frombuffer(data, np.float32, cout, sc_off), _r).astype(dtype)
+            assert float(np.abs(src).max()) * 2.0 ** _r < 32768, "split-f16 input bound violated"
+            y = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, h * w, cout).mean(axis=1).reshape(n, 1, 1, cout)
         elif kind == 21:     # pre-split pointwise + the next block's depthwise 3x3 / 1 / SAME (+ scale + shift + ReLU6), output as split rows
             a_log2, out_log2 = _r & 255, _r >> 8
             assert split_fmt.get(in_buf, 0) == a_log2, "op %d reads buffer %d in the wrong storage format" % (i, in_buf)
@@ -253,7 +260,7 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
         else:
             raise AssertionError("unknown op kind %d" % kind)
         assert y.shape[1:] == (oh, ow, cout), (i, y.shape, (oh, ow, cout))
-        if kind not in (12, 16, 21):
+        if kind not in (12, 16, 21, 22):
             assert split_fmt.get(in_buf, 0) == 0 or in_buf == -1, "op %d (kind %d) reads split rows it cannot decode" % (i, kind)
         mem[out_buf] = y
         split_fmt[out_buf] = _r if kind == 2 else (_r >> 8 if kind == 21 else 0)

@@ -178,6 +178,9 @@ def test_every_layer_matches_the_oracle(torch_):
             ys = ops.pwconv1x1_presplit_dw(ops.split_rows_encode(src, L.a_log2), L.w.reshape(L.w.shape[2], L.w.shape[3]).T, d(L.shift),
                                            d(L.w3.reshape(3, 3, -1)), d(L.scale3), d(L.shift3), L.act, L.a_log2, L.out_split)
             y = ops.split_rows_decode(ys, L.out_split)
+        elif L.kind == lowering.OP_PWGAP_PS:
+            y = ops.pwconv1x1_presplit_gap(ops.split_rows_encode(src, L.a_log2), L.w.reshape(L.w.shape[2], L.w.shape[3]).T, d(L.shift), L.act,
+                                           L.a_log2).reshape(src.shape[0], 1, 1, -1)
         elif L.kind == lowering.OP_GAP:
             y = ops.gap(src)
         elif L.kind == lowering.OP_DENSE:

@@ -359,7 +359,7 @@ def test_pointwise_depthwise_epilogue_fusion(graph):
     base = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), input_bound=256.0, pwdw_fusion="none")
     fused = lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (192, 192), input_bound=256.0, pwdw_fusion="auto")
     kb, kf = [L.kind for L in base.layers], [L.kind for L in fused.layers]
-    assert kf.count(lowering.OP_PWDW_PS) == 7 and len(kf) == len(kb) - 7       # dw_7 .. dw_11, dw_12 (stride 2), dw_13
+    assert kf.count(lowering.OP_PWDW_PS) == 7 and kf.count(lowering.OP_PWGAP_PS) == 1 and len(kf) == len(kb) - 8       # dw_7 .. dw_11, dw_12 (stride 2), dw_13; the pool
     assert kb.count(lowering.OP_DWCONV3X3) - kf.count(lowering.OP_DWCONV3X3) == 7
     for L in fused.layers:
         if L.kind == lowering.OP_PWDW_PS:
@@ -372,7 +372,8 @@ def test_pointwise_depthwise_epilogue_fusion(graph):
     # the fused layer stands for the DEPTHWISE tensor; the pointwise tensor in between no longer exists
     assert "conv_dw_8_relu/clip_by_value" in fused.tensor_layer and "conv_pw_7_relu/clip_by_value" not in fused.tensor_layer
     assert fused.flops_per_image() == base.flops_per_image()
-    assert base.bytes_per_image() - fused.bytes_per_image() == 2 * 4 * (6 * 12 * 12 * 512 + 6 * 6 * 1024)
+    assert base.bytes_per_image() - fused.bytes_per_image() == 2 * 4 * (6 * 12 * 12 * 512 + 2 * 6 * 6 * 1024)
+    assert fused.layers[fused.tensor_layer["global_pooling/Mean"]].kind == lowering.OP_PWGAP_PS and "conv_pw_13_relu/clip_by_value" not in fused.tensor_layer
     # a requested pointwise tensor keeps its pair unfused; 224-pixel input (14x14 and 7x7 maps: 288 % 196 != 0, 288 % 49 != 0) fuses nothing
     keep = lowering.lower_graph(graph, "input_1:0", {OUT_FEATURES: "global_pooling/Mean:0", OUT_AGE: "conv_pw_8_relu/clip_by_value:0"}, (192, 192),
                                 input_bound=256.0, pwdw_fusion="auto")

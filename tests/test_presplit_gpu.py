@@ -202,3 +202,27 @@ def test_pointwise_with_depthwise_epilogue_vs_oracle(n, h, w, k, cout, act, s):
     with pytest.raises(Exception):            # a 5x5 map: a 288-row tile does not hold whole maps
         ops.pwconv1x1_presplit_dw(ops.split_rows_encode(d(rs.uniform(0, 6, (1, 5, 5, k)).astype(np.float32)), 12), wt, d(sh), d(dww), d(dsc), d(dsh),
                                   act, 12, 12)
+
+
+@pytest.mark.parametrize("n,h,w,k,cout,act", [(8, 6, 6, 1024, 1024, 2), (19, 6, 6, 512, 384, 2), (3, 12, 12, 256, 128, 1), (5, 6, 12, 288, 256, 0)])
+def test_pointwise_with_global_pool_epilogue_vs_oracle(n, h, w, k, cout, act):
+    """csrc/pwconv_ps.hip, epilogue mode 4: pointwise on split rows + the global average pool, against the fp64 oracle and against
+    the unfused pair on the device (maps of 36, 72 and 144 pixels; image counts that leave the last tile partly empty)."""
+    import torch
+    from hse_facerec_tf_amd import ops
+    rs = np.random.RandomState(n + h * 7 + k)
+    x = rs.uniform(0, 6, (n, h, w, k)).astype(np.float32)
+    wt = (rs.randn(cout, k) / np.sqrt(k)).astype(np.float32)
+    sh = rs.randn(cout).astype(np.float32)
+    mid = x.reshape(-1, k).astype(np.float64).dot(wt.T.astype(np.float64)) + sh
+    mid = np.minimum(np.maximum(mid, 0), 6) if act == 2 else (np.maximum(mid, 0) if act == 1 else mid)
+    want = mid.reshape(n, h * w, cout).mean(axis=1)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    xs = ops.split_rows_encode(d(x), 12)
+    got = ops.pwconv1x1_presplit_gap(xs, wt, d(sh), act, 12)
+    assert tuple(got.shape) == (n, cout)
+    assert np.abs(got.cpu().numpy() - want).max() < 2e-6 * max(np.abs(mid).max(), 1.0)
+    two = ops.gap(ops.pwconv1x1_presplit(xs, wt, d(sh), act, 12)).reshape(n, cout)
+    assert float((got - two).abs().max()) < 1e-6 * max(np.abs(mid).max(), 1.0)
+    with pytest.raises(Exception):            # 3x3 maps: more than eight per tile
+        ops.pwconv1x1_presplit_gap(ops.split_rows_encode(d(x[:, :3, :3].copy()), 12), wt, d(sh), act, 12)
