@@ -599,8 +599,8 @@ def main():
             prefixes = {"stem_conv1_dw_pw_dw_fused": ("stem2_fused_kernel", "stem3_"), "stem_conv1_dw_pw_fused": "stem_fused_kernel", "conv1_3x3x3_s2": "conv3x3_c3",
                         "depthwise3x3": "dwconv3x3_kernel",
                         "pointwise1x1_f32mfma": "pwconv_f32_",
-                        "pointwise1x1_f16split": lambda k: k.startswith("pwconv_f16s_kernel") or (k.startswith("pwconv_ps_") and "true>" not in k),
-                        "fused_pw1x1_dw3x3_f16split": lambda k: k.startswith("pwconv_ps_") and "true>" in k, "gap": "hsefr::gap_kernel",
+                        "pointwise1x1_f16split": lambda k: k.startswith("pwconv_f16s_kernel") or (k.startswith("pwconv_ps_") and k.rstrip().endswith(", 0>")),
+                        "fused_pw1x1_dw3x3_f16split": lambda k: k.startswith("pwconv_ps_") and not k.rstrip().endswith(", 0>"), "gap": "hsefr::gap_kernel",
                         "fused_dw3x3_pw1x1": "dwpw_fused_kernel", "fused_dw3x3_pw1x1_f16split": ("dwpw3_f16s_kernel", "dwpw2_f16s_kernel", "dwpw_f16s_kernel")}
             for cls, pre in prefixes.items():
                 rows = [v for k, v in prof.items() if (pre(k) if callable(pre) else k.startswith(pre))]      # (startswith takes a tuple too)
