@@ -315,3 +315,26 @@ def test_vgg2_mobilenet_shaped_graph_through_the_reference_registry(torch_, tmp_
     f1 = tfi.extract_features(TEST_IMAGE)
     assert f1.shape == (1024,) and rel(f1, folded.extract_features(TEST_IMAGE)) < 1e-5
     tfi.close_session(), folded.close_session()
+
+
+def test_epilogue_fused_plan_is_deterministic_and_equals_the_unfused_plan(torch_):
+    """The depthwise / pool epilogues of the pre-split GEMMs (lowering.fuse_pwdw / fuse_pwgap, on by default): 40 forwards of one
+    batch are bit-identical (the epilogue hands tiles between waves through LDS: a missing barrier would show up as run-to-run
+    noise), every batch size gives the rows of the full batch, and the features equal the unfused plan's to rounding."""
+    from hse_facerec_tf_amd import graphdef, lowering
+    from hse_facerec_tf_amd.engine import Engine
+    g = graphdef.read_graph(MODEL_PB)
+    fused = lowering.lower_graph(g, "input_1:0", {0: FETCH[0]}, (192, 192), input_bound=256.0)
+    plain = lowering.lower_graph(g, "input_1:0", {0: FETCH[0]}, (192, 192), input_bound=256.0, pwdw_fusion="none")
+    kinds = [L.kind for L in fused.layers]
+    assert kinds.count(lowering.OP_PWDW_PS) == 7 and kinds.count(lowering.OP_PWGAP_PS) == 1 and lowering.OP_PWDW_PS not in [L.kind for L in plain.layers]
+    x = torch_.from_numpy(np.random.RandomState(21).uniform(-128, 128, (37, 192, 192, 3)).astype(np.float32)).cuda()
+    ef, ep = Engine(fused, max_batch=37), Engine(plain, max_batch=37)
+    ref = ef.forward(x)["features"].clone()
+    for _ in range(40):
+        assert torch_.equal(ef.forward(x)["features"], ref)
+    for n in (1, 2, 3, 8, 36):
+        assert torch_.equal(ef.forward(x[:n].contiguous())["features"], ref[:n])
+    want = ep.forward(x)["features"]
+    assert float((ref - want).abs().max() / want.abs().max()) < 2e-6
+    ef.close(), ep.close()
