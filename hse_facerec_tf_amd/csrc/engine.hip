@@ -146,7 +146,7 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                 break;
             case HSEFR_OP_PWCONV_PS_GAP:
                 HSEFR_REQUIRE(pwconv_ps_gap_supported(0, o.cin, o.cout, o.h * o.w) && o.oh == 1 && o.ow == 1, HSEFR_ERR_UNSUPPORTED,
-                              "plan op %u: fused pointwise + global pool on a %dx%d map not covered", i, o.h, o.w);
+                              "plan op %u: fused pointwise + global pool on a %dx%d map not covered (33 .. 288 pixels)", i, o.h, o.w);
                 if (!need(o.w_off, ci * co * 4, "split rows") || !need(o.scale_off, co * 4, "descale") || !need(o.shift_off, co * 4, "shift"))
                     return HSEFR_ERR_INVALID;
                 HSEFR_REQUIRE(o.reserved > 0 && o.reserved <= 24, HSEFR_ERR_INVALID, "plan op %u: a_log2 out of range (reserved %d)", i, o.reserved);

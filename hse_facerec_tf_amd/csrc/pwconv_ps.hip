@@ -77,7 +77,9 @@ struct PsDwParams {
     const float* dwc;
     void* ys;
     int W, HW;
-    float clamp_hi;       // 6 * out_scale
+    float clamp_hi;       // 6 * out_scale (pool mode: 1 / HW)
+    int tile_rows;        // rows of the matrix a tile ADVANCES by = whole maps per tile x HW (<= 32 MB; the tile's remaining rows are
+                          // computed but belong to the next tile: 14 x 14 maps ride in 224-row tiles, five 7 x 7 maps in 256-row ones)
 };
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     auto tile_origin = [&](unsigned i, long long& mm0, int& nn0) {
         const unsigned lt = xcd_remap_dir(blockIdx.x + (i < ntile ? i : ntile - 1) * gridDim.x, total_tiles, reverse);
         const unsigned tm = tn_pow2 ? lt >> tn_shift : lt / tiles_n;
-        mm0 = (long long)tm * BM;
+        mm0 = (long long)tm * (DWM != 0 ? dw.tile_rows : BM);
         nn0 = (lt - tm * tiles_n) * BN;
     };
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -161,20 +163,20 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
         for (int k3 = 0; k3 < 3; ++k3) {
             const int P = (ln >> 3) + 8 * wave + 96 * k3;
             const int pl = P % dw.HW, yy = pl / dw.W, xx = pl - yy * dw.W;
-            unsigned mk = 0;
+            unsigned mk = P < dw.tile_rows ? 1u << 16 : 0u;      // bit 16: the pixel belongs to this tile (else: computed on zeros, not stored)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int ny = yy + t / 3 - 1, nx = xx + t % 3 - 1;
-                mk |= ((unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)dw.W ? 1u : 0u) << t;
+                mk |= (P < dw.tile_rows && (unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)dw.W ? 1u : 0u) << t;
             }
             nb_mask[k3] = mk;
         }
     };
     auto dw_chunk = [&](int c, const unsigned char* cb, long long tm0, int tn0) __attribute__((always_inline)) {
         if constexpr (DWM == 4) {
-            // global average pool of the chunk: wave i < BM / HW sums map i; lane = (channel quad, one of 8 row groups), the groups
+            // global average pool of the chunk: wave i < (maps per tile) sums map i; lane = (channel quad, one of 8 row groups), the groups
             // are folded with three xor-shuffles, group 0 stores the four means
-            const int maps = BM / dw.HW;
+            const int maps = dw.tile_rows / dw.HW;
             if (wave < maps) {
                 const int q = lane & 7, part = lane >> 3;
                 f32x4 sum = {0.f, 0.f, 0.f, 0.f};
@@ -237,7 +239,8 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
             const u32x4 out = odd ? u32x4{recv.x, recv.y, lb.x, lb.y} : u32x4{hb.x, hb.y, recv.x, recv.y};
             // (stride 2: lanes past the tile's 72 output pixels computed a duplicate of pixel 71; an out-of-range offset drops their store)
-            const unsigned ovoff = (DWM == 3 && P >= 72) ? 0x80000000u : (unsigned)P * (unsigned)Cout * 4u + (unsigned)c * 128u + 16u * unit;
+            const bool drop = (DWM == 3 && P >= 72) || (DWM == 1 && !(nb_mask[k3] >> 16));
+            const unsigned ovoff = drop ? 0x80000000u : (unsigned)P * (unsigned)Cout * 4u + (unsigned)c * 128u + 16u * unit;
             bstore16_welded(__builtin_bit_cast(f32x4, out), ro, ovoff, 0u);
         }
     };
@@ -536,7 +539,7 @@ int launch_mb(const void* xs, const void* wsplit, const float* descale, const fl
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit: too many tiles");
     unsigned g = (unsigned)(total < 256 ? total : 256);
     if (g_ps_grid > 0 && (unsigned)g_ps_grid < g) g = (unsigned)g_ps_grid;
-    const PsDwParams nodw{nullptr, nullptr, 0, 0, 0.f};
+    const PsDwParams nodw{nullptr, nullptr, 0, 0, 0.f, 32 * MB};
 #define HSEFR_PS_LAUNCH(A)                                                                                                 \
     hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, 0>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, y, m, k, cout, tiles_n, \
                        (unsigned)total, sweep_reverse(), nodw)
@@ -567,35 +570,66 @@ int read_ps_stamps(void* host_out, size_t bytes) {
 }
 #endif
 
+// Tile height for maps of map_hw pixels: 32 MB rows hold floor(32 MB / map_hw) whole maps; the best filled of MB = 9, 8, 7
+static int dw_tile_mb(int map_hw) {
+    int best = 0;
+    double eff = 0;
+    for (int mb = 9; mb >= 7; --mb) {
+        const int maps = 32 * mb / map_hw;
+        const double e = (double)(maps * map_hw) / (32 * mb);
+        if (maps >= 1 && e > eff + 1e-9) { eff = e; best = mb; }
+    }
+    return best;
+}
+
 bool pwconv_ps_dw_supported(long long m, int k, int cout, int map_w, int map_hw, int dw_stride) {
-    // a 288-row tile must hold whole maps; 3 x 3 / SAME; stride 1 on any such map (square or not), stride 2 on 12 x 12 maps
-    return pwconv_ps_supported(m, k, cout) && map_w > 0 && map_hw > 0 && map_hw % map_w == 0 && 288 % map_hw == 0 && m % map_hw == 0 &&
+    // 3 x 3 / SAME; stride 1 on any map of at most 288 pixels (square or not), stride 2 on 12 x 12 maps
+    return pwconv_ps_supported(m, k, cout) && map_w > 0 && map_hw > 0 && map_hw % map_w == 0 && map_hw <= 288 && m % map_hw == 0 &&
            (dw_stride == 1 || (dw_stride == 2 && map_w == 12 && map_hw == 144));
+}
+
+template <int MB, int MODE>
+static int launch_psdw_relu6(const void* xs, const void* wsplit, const float* descale, const float* shift, long long m, int k, int cout,
+                             PsDwParams dw, hipStream_t s) {
+    const long long tiles_m = (m + dw.tile_rows - 1) / dw.tile_rows;
+    const unsigned tiles_n = cout / BN;
+    const long long total = tiles_m * tiles_n;
+    HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_dw: too many tiles");
+    const unsigned g = (unsigned)(total < 256 ? total : 256);
+    hipLaunchKernelGGL((pwconv_ps_kernel<MB, HSEFR_ACT_RELU6, MODE>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k,
+                       cout, tiles_n, (unsigned)total, sweep_reverse(), dw);
+    return launch_status("pwconv_presplit_dw");
 }
 
 int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale, const float* shift, const float* dwc, void* ys, long long m,
                         int k, int cout, int act, int map_w, int map_hw, int dw_stride, int out_log2, hipStream_t s) {
     HSEFR_REQUIRE(pwconv_ps_dw_supported(m, k, cout, map_w, map_hw, dw_stride), HSEFR_ERR_UNSUPPORTED,
-                  "pwconv_presplit_dw: m=%lld k=%d cout=%d map %d (w %d) stride %d not covered (288 %% map == 0; stride 2: 12x12)", m, k, cout,
+                  "pwconv_presplit_dw: m=%lld k=%d cout=%d map %d (w %d) stride %d not covered (map <= 288 pixels; stride 2: 12x12)", m, k, cout,
                   map_hw, map_w, dw_stride);
     HSEFR_REQUIRE(dw_stride == 1 || act == HSEFR_ACT_RELU6, HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_dw: the stride-2 epilogue is built for ReLU6");
     HSEFR_REQUIRE(out_log2 >= 1 && out_log2 <= 12, HSEFR_ERR_INVALID, "pwconv_presplit_dw: out_log2=%d", out_log2);
     if (m == 0) return HSEFR_OK;
+    const int mb = (map_w == 12 && map_hw == 144) || act != HSEFR_ACT_RELU6 ? 9 : dw_tile_mb(map_hw);
+    PsDwParams dw{dwc, ys, map_w, map_hw, 6.f * (float)(1 << out_log2), (32 * mb / map_hw) * map_hw};
+    if (act == HSEFR_ACT_RELU6) {
+        const bool bordered = map_w == 12 && map_hw == 144 && g_psdw_mode != 1;      // the zero-bordered chunk buffer (12 x 12 maps)
+        if (dw_stride == 2) return launch_psdw_relu6<9, 3>(xs, wsplit, descale, shift, m, k, cout, dw, s);
+        if (bordered) return launch_psdw_relu6<9, 2>(xs, wsplit, descale, shift, m, k, cout, dw, s);
+        if (mb == 7) return launch_psdw_relu6<7, 1>(xs, wsplit, descale, shift, m, k, cout, dw, s);
+        if (mb == 8) return launch_psdw_relu6<8, 1>(xs, wsplit, descale, shift, m, k, cout, dw, s);
+        return launch_psdw_relu6<9, 1>(xs, wsplit, descale, shift, m, k, cout, dw, s);
+    }
+    // other activations of the GEMM (none / ReLU): the masked epilogue at MB = 9
     constexpr int MB = 9;
-    const long long tiles_m = (m + 32 * MB - 1) / (32 * MB);
+    const long long tiles_m = (m + dw.tile_rows - 1) / dw.tile_rows;
     const unsigned tiles_n = cout / BN;
     const long long total = tiles_m * tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_dw: too many tiles");
     const unsigned g = (unsigned)(total < 256 ? total : 256);
-    const PsDwParams dw{dwc, ys, map_w, map_hw, 6.f * (float)(1 << out_log2)};
 #define HSEFR_PSDW_LAUNCH(A, MODE)                                                                                               \
     hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, MODE>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
                        tiles_n, (unsigned)total, sweep_reverse(), dw)
-    const bool bordered = map_w == 12 && map_hw == 144 && g_psdw_mode != 1;      // the zero-bordered chunk buffer (12 x 12 maps)
-    if (dw_stride == 2) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6, 3);
-    else if (act == HSEFR_ACT_RELU6 && bordered) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6, 2);
-    else if (act == HSEFR_ACT_RELU6) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU6, 1);
-    else if (act == HSEFR_ACT_RELU) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU, 1);
+    if (act == HSEFR_ACT_RELU) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU, 1);
     else if (act == HSEFR_ACT_NONE) HSEFR_PSDW_LAUNCH(HSEFR_ACT_NONE, 1);
     else { set_error("pwconv_presplit_dw: act %d", act); return HSEFR_ERR_UNSUPPORTED; }
 #undef HSEFR_PSDW_LAUNCH
@@ -603,22 +637,18 @@ int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale
 }
 
 bool pwconv_ps_gap_supported(long long m, int k, int cout, int map_hw) {
-    // a 288-row tile holds whole maps, at most eight of them (one wave sums one map)
-    return pwconv_ps_supported(m, k, cout) && map_hw >= 36 && 288 % map_hw == 0 && m % map_hw == 0;
+    // whole maps in a tile, at most eight of them (one wave sums one map)
+    return pwconv_ps_supported(m, k, cout) && map_hw >= 33 && map_hw <= 288 && m % map_hw == 0;
 }
 
-int launch_pwconv_ps_gap(const void* xs, const void* wsplit, const float* descale, const float* shift, float* y, long long m, int k, int cout,
-                         int act, int map_hw, hipStream_t s) {
-    HSEFR_REQUIRE(pwconv_ps_gap_supported(m, k, cout, map_hw), HSEFR_ERR_UNSUPPORTED,
-                  "pwconv_presplit_gap: m=%lld k=%d cout=%d map %d not covered (288 %% map == 0, map >= 36)", m, k, cout, map_hw);
-    if (m == 0) return HSEFR_OK;
-    constexpr int MB = 9;
-    const long long tiles_m = (m + 32 * MB - 1) / (32 * MB);
+template <int MB>
+static int launch_psgap(const void* xs, const void* wsplit, const float* descale, const float* shift, long long m, int k, int cout, int act,
+                        PsDwParams dw, hipStream_t s) {
+    const long long tiles_m = (m + dw.tile_rows - 1) / dw.tile_rows;
     const unsigned tiles_n = cout / BN;
     const long long total = tiles_m * tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_gap: too many tiles");
     const unsigned g = (unsigned)(total < 256 ? total : 256);
-    const PsDwParams dw{nullptr, y, 0, map_hw, 1.0f / (float)map_hw};
 #define HSEFR_PSGAP_LAUNCH(A)                                                                                                    \
     hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, 4>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
                        tiles_n, (unsigned)total, sweep_reverse(), dw)
@@ -628,6 +658,18 @@ int launch_pwconv_ps_gap(const void* xs, const void* wsplit, const float* descal
     else { set_error("pwconv_presplit_gap: act %d", act); return HSEFR_ERR_UNSUPPORTED; }
 #undef HSEFR_PSGAP_LAUNCH
     return launch_status("pwconv_presplit_gap");
+}
+
+int launch_pwconv_ps_gap(const void* xs, const void* wsplit, const float* descale, const float* shift, float* y, long long m, int k, int cout,
+                         int act, int map_hw, hipStream_t s) {
+    HSEFR_REQUIRE(pwconv_ps_gap_supported(m, k, cout, map_hw), HSEFR_ERR_UNSUPPORTED,
+                  "pwconv_presplit_gap: m=%lld k=%d cout=%d map %d not covered (33 <= map <= 288 pixels)", m, k, cout, map_hw);
+    if (m == 0) return HSEFR_OK;
+    const int mb = act == HSEFR_ACT_RELU6 ? dw_tile_mb(map_hw) : 9;
+    const PsDwParams dw{nullptr, y, 0, map_hw, 1.0f / (float)map_hw, (32 * mb / map_hw) * map_hw};
+    if (act == HSEFR_ACT_RELU6 && mb == 7) return launch_psgap<7>(xs, wsplit, descale, shift, m, k, cout, act, dw, s);
+    if (act == HSEFR_ACT_RELU6 && mb == 8) return launch_psgap<8>(xs, wsplit, descale, shift, m, k, cout, act, dw, s);
+    return launch_psgap<9>(xs, wsplit, descale, shift, m, k, cout, act, dw, s);
 }
 
 bool pwconv_ps_supported(long long m, int k, int cout) {

@@ -988,11 +988,12 @@ def presplit_activations(layers: List[Layer], keep: Sequence[int]) -> int:
 
 
 def pwdw_fusable(pw: Layer, dw: Layer) -> bool:
-    """A pre-split pointwise layer followed ONLY by a stride-1 depthwise layer that itself stores split rows, on maps a 288-row GEMM
-    tile holds whole (12x12, 6x6, ...): csrc/pwconv_ps.hip runs the depthwise in the GEMM's epilogue."""
+    """A pre-split pointwise layer followed ONLY by a depthwise layer that itself stores split rows, on maps of at most 288 pixels
+    (whole maps ride in one GEMM tile: 12x12 and 6x6 fill it, 14x14 takes a 224-row tile, five 7x7 maps a 256-row one):
+    csrc/pwconv_ps.hip runs the depthwise in the GEMM's epilogue."""
     h, w, _ = dw.in_shape
     if not (pw.kind == OP_PWCONV_F32 and pw.a_log2 > 0 and pw.in_split and pw.out_shape[2] % 128 == 0 and
-            dw.kind == OP_DWCONV3X3 and dw.act == ACT_RELU6 and 0 < dw.out_split <= 12 and 288 % (h * w) == 0):
+            dw.kind == OP_DWCONV3X3 and dw.act == ACT_RELU6 and 0 < dw.out_split <= 12 and h * w <= 288):
         return False
     if dw.stride == 1:
         return dw.pad_t == 1 and dw.pad_l == 1 and dw.out_shape == dw.in_shape
@@ -1001,7 +1002,7 @@ def pwdw_fusable(pw: Layer, dw: Layer) -> bool:
 
 
 def fuse_pwgap(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
-    """A pre-split pointwise layer followed ONLY by the global average pool, on maps a 288-row GEMM tile holds whole (at most eight):
+    """A pre-split pointwise layer followed ONLY by the global average pool, on maps of 33 .. 288 pixels (at most eight per GEMM tile):
     the pool runs in the GEMM's epilogue (csrc/pwconv_ps.hip) and the pointwise tensor is never written."""
     consumers: Dict[int, List[int]] = {}
     for i, L in enumerate(layers):
@@ -1013,7 +1014,7 @@ def fuse_pwgap(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], D
         cons = consumers.get(i, [])
         h, w, c = L.out_shape
         if not (L.kind == OP_PWCONV_F32 and L.a_log2 > 0 and L.in_split and c % 128 == 0 and i not in keep and len(cons) == 1 and
-                layers[cons[0]].kind == OP_GAP and layers[cons[0]].src == i and 288 % (h * w) == 0 and h * w >= 36):
+                layers[cons[0]].kind == OP_GAP and layers[cons[0]].src == i and 33 <= h * w <= 288):
             continue
         G = layers[cons[0]]
         F = Layer(OP_PWGAP_PS, G.name, L.src, L.in_shape, G.out_shape, w=L.w, shift=L.shift, act=L.act, sealed=True, a_log2=L.a_log2,
@@ -1085,7 +1086,7 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
     presplit: 'auto' (default; env HSEFR_PRESPLIT=auto|none) = depthwise layers feeding a split-f16 pointwise layer store
     their result pre-split and the GEMM stages both operands by LDS-DMA (presplit_activations); 'none' = fp32 tensors.
     pwdw_fusion: 'auto' (default; env HSEFR_FUSE_PWDW=auto|none) = a pre-split pointwise layer followed only by a stride-1
-    depthwise layer on a map that a 288-row GEMM tile holds whole (12x12, 6x6) runs that depthwise in its epilogue (fuse_pwdw):
+    depthwise layer on a map of at most 288 pixels (whole maps per GEMM tile) runs that depthwise in its epilogue (fuse_pwdw):
     the pointwise tensor never reaches HBM and the depthwise launch disappears (the last pointwise layer takes the global
     average pool the same way: fuse_pwgap); 'none'.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels

@@ -127,7 +127,7 @@ def pwconv1x1_presplit(xs, w_t, shift, act: int = ACT_RELU6, a_log2: int = 12, p
 @_device_guarded
 def pwconv1x1_presplit_gap(xs, w_t, shift, act: int = ACT_RELU6, a_log2: int = 12, prepared=None):
     """pwconv1x1_presplit with the global average pool in its epilogue (csrc/pwconv_ps.hip): xs = split rows [n, h, w, k/32, 2, 32]
-    with 288 % (h * w) == 0 and h * w >= 36 -> fp32 [n, cout] means; the pointwise tensor is never written."""
+    with 33 <= h * w <= 288 -> fp32 [n, cout] means; the pointwise tensor is never written."""
     torch = _lib.require_gpu()
     _f32c(shift, "shift")
     if not (xs.is_cuda and xs.dtype == torch.float16 and xs.is_contiguous() and xs.dim() == 6 and tuple(xs.shape[-2:]) == (2, 32)):
@@ -145,7 +145,7 @@ def pwconv1x1_presplit_gap(xs, w_t, shift, act: int = ACT_RELU6, a_log2: int = 1
 def pwconv1x1_presplit_dw(xs, w_t, shift, dw_w_hwc, dw_scale, dw_shift, act: int = ACT_RELU6, a_log2: int = 12, out_log2: int = 12, prepared=None,
                           dw_stride: int = 1):
     """pwconv1x1_presplit with the NEXT block's depthwise 3x3 / stride 1 / SAME + scale + shift + ReLU6 in its epilogue
-    (csrc/pwconv_ps.hip, DW = true).  xs = split rows [n, h, w, k/32, 2, 32] with 288 % (h * w) == 0; dw_w_hwc [3, 3, cout].
+    (csrc/pwconv_ps.hip, DW = true).  xs = split rows [n, h, w, k/32, 2, 32] with h * w <= 288; dw_w_hwc [3, 3, cout].
     Returns the depthwise result as split rows [n, h/s, w/s, cout/32, 2, 32] scaled by 2^out_log2 (split_rows_decode); dw_stride 2
     (12x12 maps only) is TF SAME on an even map: no top / left padding."""
     torch = _lib.require_gpu()

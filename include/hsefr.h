@@ -106,12 +106,12 @@ typedef enum hsefr_op_kind {
                                   (csrc/stem7x7_pool.hip): fp32 image in, POOLED bf16 map out (oh, ow = pooled size);
                                   reserved = pool_pad_t | pool_pad_l << 4, each 0 or 1; blob operands as STEM7X7_BF16    */
     HSEFR_OP_PWCONV_PS_DW = 21, /* PWCONV_PS + the NEXT block's depthwise 3x3 (stride 1, SAME) + scale + shift + ReLU6 in the GEMM's epilogue,
-                                  output = that depthwise layer's split rows (csrc/pwconv_ps.hip): h * w must divide 288; stride = the depthwise's
+                                  output = that depthwise layer's split rows (csrc/pwconv_ps.hip): h * w <= 288; stride = the depthwise's
                                   (1, or 2 on 12 x 12 maps with pad 0), oh / ow = its output size.
                                   w2_off = [11][cout] fp32: taps 0..8, scale * 2^out_log2, shift * 2^out_log2;
                                   reserved = a_log2 | out_log2 << 8                                                         */
     HSEFR_OP_PWCONV_PS_GAP = 22, /* PWCONV_PS + the global average pool behind it in the GEMM's epilogue: output [1,1,cout] fp32 per image
-                                  (h * w must divide 288 and be >= 36); blob operands as PWCONV_PS, reserved = a_log2            */
+                                  (33 <= h * w <= 288); blob operands as PWCONV_PS, reserved = a_log2            */
     HSEFR_OP_STEM3_F16S = 17,  /* STEM2_F16S for an input with a DECLARED BOUND |x| < 2^(15 - in_log2) (csrc/stem3_fused.hip): conv1's
                                   products are formed on the f16 MFMA from two-term splits like the pointwise layers'.
                                   w_off = the STEM2 fp32 pack (1952 floats) | conv1 split rows [32][64 f16] (1024 floats) |
@@ -268,13 +268,13 @@ int hsefr_pwconv1x1_presplit(const void* x_split, const void* w_split, const flo
                              long long m, int k, int cout, int act, hsefr_stream_t stream);
 
 /* hsefr_pwconv1x1_presplit with the global average pool fused into its epilogue: y = [m / map_hw][cout] fp32 means over each map's
- * map_hw pixels (288 % map_hw == 0, map_hw >= 36); the pointwise tensor itself is not written. */
+ * map_hw pixels (33 <= map_hw <= 288); the pointwise tensor itself is not written. */
 int hsefr_pwconv1x1_presplit_gap(const void* x_split, const void* w_split, const float* descale, const float* shift, float* y,
                                  long long m, int k, int cout, int act, int map_hw, hsefr_stream_t stream);
 
 /* hsefr_pwconv1x1_presplit with the next block's depthwise 3x3 / SAME + scale + shift + ReLU6 fused into its epilogue: the result
  * leaves as that depthwise layer's split rows y_split (scaled by 2^out_log2; m / dw_stride^2 pixels).  The m rows are maps of
- * map_hw = map_h * map_w pixels, 288 % map_hw == 0; dw_stride 1, or 2 on 12 x 12 maps (TF SAME on an even map: no top / left
+ * map_hw = map_h * map_w <= 288 pixels (whole maps per GEMM tile); dw_stride 1, or 2 on 12 x 12 maps (TF SAME on an even map: no top / left
  * padding).  dw_consts = [11][cout] floats: the depthwise taps (row-major 3x3), then its scale and shift, the last two already
  * multiplied by 2^out_log2. */
 int hsefr_pwconv1x1_presplit_dw(const void* x_split, const void* w_split, const float* descale, const float* shift, const float* dw_consts,

@@ -104,7 +104,7 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             assert 0 < _r <= 24 and float(np.abs(src).max()) * 2.0 ** _r < 32768, "split-f16 input bound violated"
             y = _act(PW(src.reshape(-1, cin), wt) + arr(sh_off, cout), act).reshape(n, oh, ow, cout)
         elif kind == 22:     # pre-split pointwise + global average pool
-            assert split_fmt.get(in_buf, 0) == _r and cin % 32 == 0 and cout % 128 == 0 and 288 % (h * w) == 0 and h * w >= 36 and (oh, ow) == (1, 1)
+            assert split_fmt.get(in_buf, 0) == _r and cin % 32 == 0 and cout % 128 == 0 and 33 <= h * w <= 288 and (oh, ow) == (1, 1)
             from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
             img = np.frombuffer(data, np.uint16, cout * cin * 2, w_off).reshape(cout, cin // 32, 64)
             wt = unsplit_pointwise_weights(img, np.frombuffer(data, np.float32, cout, sc_off), _r).astype(dtype)
@@ -113,7 +113,7 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
         elif kind == 21:     # pre-split pointwise + the next block's depthwise 3x3 / 1 / SAME (+ scale + shift + ReLU6), output as split rows
             a_log2, out_log2 = _r & 255, _r >> 8
             assert split_fmt.get(in_buf, 0) == a_log2, "op %d reads buffer %d in the wrong storage format" % (i, in_buf)
-            assert cin % 32 == 0 and cout % 128 == 0 and 288 % (h * w) == 0 and (oh * stride, ow * stride) == (h, w) and 0 < out_log2 <= 12
+            assert cin % 32 == 0 and cout % 128 == 0 and h * w <= 288 and (oh * stride, ow * stride) == (h, w) and 0 < out_log2 <= 12
             assert (stride, pad_t, pad_l) == (1, 1, 1) or ((stride, pad_t, pad_l) == (2, 0, 0) and (h, w) == (12, 12) and act == 2)
             from hse_facerec_tf_amd.lowering import unsplit_pointwise_weights
             img = np.frombuffer(data, np.uint16, cout * cin * 2, w_off).reshape(cout, cin // 32, 64)

@@ -164,7 +164,8 @@ def test_whole_network_presplit_vs_fp32_tensors(env):
 
 @pytest.mark.parametrize("n,h,w,k,cout,act,s", [(2, 12, 12, 512, 512, 2, 1), (5, 12, 12, 256, 512, 2, 1), (8, 6, 6, 512, 1024, 2, 1), (19, 6, 6, 1024, 1024, 2, 1),
                                                 (3, 3, 3, 256, 128, 2, 1), (4, 4, 3, 256, 256, 1, 1), (1, 12, 12, 288, 384, 0, 1),
-                                                (2, 12, 12, 512, 512, 2, 2), (7, 12, 12, 256, 384, 2, 2)])
+                                                (2, 12, 12, 512, 512, 2, 2), (7, 12, 12, 256, 384, 2, 2),
+                                                (3, 14, 14, 512, 512, 2, 1), (11, 7, 7, 1024, 1024, 2, 1), (4, 10, 10, 256, 256, 2, 1), (2, 16, 18, 256, 128, 2, 1)])
 def test_pointwise_with_depthwise_epilogue_vs_oracle(n, h, w, k, cout, act, s):
     """csrc/pwconv_ps.hip with DW = true: pointwise on split rows + the next block's depthwise 3x3 / 1 / SAME + scale + shift + ReLU6
     in the epilogue, output as split rows -- against the fp64 oracle of the two layers, at the pre-split GEMM's 2e-6 bar
@@ -199,12 +200,13 @@ def test_pointwise_with_depthwise_epilogue_vs_oracle(n, h, w, k, cout, act, s):
     mid_d = ops.pwconv1x1_presplit(ops.split_rows_encode(d(x), 12), wt, d(sh), act, 12)
     two = ops.split_rows_decode(ops.dwconv3x3_split(mid_d, d(dww), d(dsc), d(dsh), s, 2, 12), 12).cpu().numpy()
     assert (np.abs(got - two) / scale).max() < 1e-6
-    with pytest.raises(Exception):            # a 5x5 map: a 288-row tile does not hold whole maps
-        ops.pwconv1x1_presplit_dw(ops.split_rows_encode(d(rs.uniform(0, 6, (1, 5, 5, k)).astype(np.float32)), 12), wt, d(sh), d(dww), d(dsc), d(dsh),
+    with pytest.raises(Exception):            # a 17x17 map does not fit a 288-row tile
+        ops.pwconv1x1_presplit_dw(ops.split_rows_encode(d(rs.uniform(0, 6, (1, 17, 17, k)).astype(np.float32)), 12), wt, d(sh), d(dww), d(dsc), d(dsh),
                                   act, 12, 12)
 
 
-@pytest.mark.parametrize("n,h,w,k,cout,act", [(8, 6, 6, 1024, 1024, 2), (19, 6, 6, 512, 384, 2), (3, 12, 12, 256, 128, 1), (5, 6, 12, 288, 256, 0)])
+@pytest.mark.parametrize("n,h,w,k,cout,act", [(8, 6, 6, 1024, 1024, 2), (19, 6, 6, 512, 384, 2), (3, 12, 12, 256, 128, 1), (5, 6, 12, 288, 256, 0),
+                                              (12, 7, 7, 1024, 1024, 2), (2, 14, 14, 256, 128, 2)])
 def test_pointwise_with_global_pool_epilogue_vs_oracle(n, h, w, k, cout, act):
     """csrc/pwconv_ps.hip, epilogue mode 4: pointwise on split rows + the global average pool, against the fp64 oracle and against
     the unfused pair on the device (maps of 36, 72 and 144 pixels; image counts that leave the last tile partly empty)."""
@@ -225,4 +227,4 @@ def test_pointwise_with_global_pool_epilogue_vs_oracle(n, h, w, k, cout, act):
     two = ops.gap(ops.pwconv1x1_presplit(xs, wt, d(sh), act, 12)).reshape(n, cout)
     assert float((got - two).abs().max()) < 1e-6 * max(np.abs(mid).max(), 1.0)
     with pytest.raises(Exception):            # 3x3 maps: more than eight per tile
-        ops.pwconv1x1_presplit_gap(ops.split_rows_encode(d(x[:, :3, :3].copy()), 12), wt, d(sh), act, 12)
+        ops.pwconv1x1_presplit_gap(ops.split_rows_encode(d(np.ascontiguousarray(x[:, :3, :3])), 12), wt, d(sh), act, 12)
