@@ -86,7 +86,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MB, int ACT, int DWM>
+template <int MB, int ACT, int DWM, int MW = 12>
 __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restrict__ xs, const void* __restrict__ wsplit,
                                                            const float* __restrict__ descale, const float* __restrict__ shift,
                                                            float* __restrict__ y, long long M, int K, int Cout, unsigned tiles_n,
@@ -128,12 +128,14 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     // ---- DW epilogue, shared by both roles: the depthwise of one 32-channel chunk of the tile from the chunk buffer cb ----
     // cb layout: rows 0 .. BM-1 = the chunk's activated pointwise results [pixel][32 ch] fp32, two zero rows (taps outside the
     // map read them), then the tile's depthwise constants [12][128 ch] floats (taps 0..8, scale, shift, unused).
-    // DWM == 2 (12 x 12 maps, two per tile): the maps sit in the buffer with ZERO cells around them at a pitch of 13 rows per
-    // image row -- one zero cell serves as the right neighbour of x = 11 and as the left neighbour of the next row's x = 0 --
-    // and 13 zero rows above, between and below the two maps: pixel (i, y, x) is row 14 + 169 i + 13 y + x, a tap (dy, dx) is
-    // that row + 13 (dy - 1) + (dx - 1), always a valid row: no masks, and the nine offsets are instruction immediates.
-    constexpr int PITCH = 13, IMGROWS = 13 * PITCH;                  // 12 image rows + 1 border row of 13 cells
-    constexpr int CB_ROWS = BORDERED ? 1 + PITCH + 2 * IMGROWS : BM + 2;
+    // DWM == 2 / 3 (square MW x MW maps, MAPS = 32 MB / MW^2 whole ones per tile: 12 x 12 -> 2 in 288 rows, 14 x 14 -> 1 in 224,
+    // 7 x 7 -> 5 in 256): the maps sit in the buffer with ZERO cells around them at a pitch of MW + 1 rows per image row -- one
+    // zero cell serves as the right neighbour of x = MW - 1 and as the left neighbour of the next row's x = 0 -- and MW + 1 zero
+    // rows above, between and below the maps: pixel (i, y, x) is row 1 + PITCH + IMG i + PITCH y + x, a tap (dy, dx) is that
+    // row + PITCH (dy - 1) + (dx - 1), always a valid row: no masks, and the nine offsets are instruction immediates.
+    constexpr int PITCH = MW + 1, IMG = (MW + 1) * PITCH;               // MW image rows + 1 border row
+    constexpr int MAPS = BM / (MW * MW), MHW = MW * MW;
+    constexpr int CB_ROWS = BORDERED ? 1 + PITCH + MAPS * IMG : BM + 2;
     constexpr int CB_ZROW = BM;
     constexpr int CB_CONST = CB_ROWS * ROWB;
     // per item of this lane: bit t = tap t lies inside the map.  Recomputed at every tile's epilogue from an OPAQUE copy of the lane
@@ -147,15 +149,16 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
 #pragma unroll
             for (int k3 = 0; k3 < 3; ++k3) {
                 const int P = (ln >> 3) + 8 * wave + 96 * k3;
-                const int img = P >= 144 ? 1 : 0, pl = P - 144 * img, yy = pl / 12, xx = pl - 12 * yy;
-                nb_mask[k3] = (unsigned)((169 * img + PITCH * yy + xx) * ROWB + 16 * (ln & 7));
+                const int Pc = P < MAPS * MHW ? P : MAPS * MHW - 1;            // (lanes past the tile's maps: a duplicate, never stored)
+                const int img = Pc / MHW, pl = Pc - MHW * img, yy = pl / MW, xx = pl - MW * yy;
+                nb_mask[k3] = (unsigned)((IMG * img + PITCH * yy + xx) * ROWB + 16 * (ln & 7)) | (P < MAPS * MHW ? 0u : 0x80000000u);
             }
             return;
         }
         if constexpr (DWM == 3) {      // one item: output pixel P of the tile's 2 x 36; its window starts at input (2 oy, 2 ox)
             const int P = min((ln >> 3) + 8 * wave, 71);
             const int img = P >= 36 ? 1 : 0, pl = P - 36 * img, oy = pl / 6, ox = pl - 6 * oy;
-            nb_mask[0] = (unsigned)((1 + PITCH + 169 * img + PITCH * 2 * oy + 2 * ox) * ROWB + 16 * (ln & 7));
+            nb_mask[0] = (unsigned)((1 + PITCH + IMG * img + PITCH * 2 * oy + 2 * ox) * ROWB + 16 * (ln & 7));
             return;
         }
         const int H = dw.HW / dw.W;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             for (int t = 0; t < 9; ++t) {
                 f32x4 v;
                 if constexpr (BORDERED) {
-                    v = *(const f32x4*)(cb + nb_mask[k3] + ((t / 3) * PITCH + t % 3) * ROWB);
+                    v = *(const f32x4*)(cb + (nb_mask[k3] & 0x7FFFFFFFu) + ((t / 3) * PITCH + t % 3) * ROWB);
                 } else {
                     const int row = ((nb_mask[k3] >> t) & 1u) ? P + (t / 3 - 1) * dw.W + (t % 3 - 1) : CB_ZROW;
                     v = *(const f32x4*)(cb + row * ROWB + 16 * q);
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
             const u32x4 out = odd ? u32x4{recv.x, recv.y, lb.x, lb.y} : u32x4{hb.x, hb.y, recv.x, recv.y};
             // (stride 2: lanes past the tile's 72 output pixels computed a duplicate of pixel 71; an out-of-range offset drops their store)
-            const bool drop = (DWM == 3 && P >= 72) || (DWM == 1 && !(nb_mask[k3] >> 16));
+            const bool drop = (DWM == 3 && P >= 72) || (DWM == 1 && !(nb_mask[k3] >> 16)) || (DWM == 2 && (nb_mask[k3] >> 31));
             const unsigned ovoff = drop ? 0x80000000u : (unsigned)P * (unsigned)Cout * 4u + (unsigned)c * 128u + 16u * unit;
             bstore16_welded(__builtin_bit_cast(f32x4, out), ro, ovoff, 0u);
         }
@@ -331,8 +334,8 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                         // the zero cells of the bordered layout (the stage still holds the last step's operands): every row that is
                         // not a pixel -- row 0, the border rows, cell 12 of every image row
                         for (int r = (wave - 8) * 8 + (lane >> 3); r < CB_ROWS; r += 32) {
-                            const int rr = r - 1 - PITCH, i2 = rr >= 169 ? 1 : 0, r2 = rr - 169 * i2;
-                            const bool pixel = rr >= 0 && r2 < 12 * PITCH && r2 % PITCH != 12;
+                            const int rr = r - 1 - PITCH, i2 = rr >= 0 ? rr / IMG : 0, r2 = rr - IMG * i2;
+                            const bool pixel = rr >= 0 && r2 < MW * PITCH && r2 % PITCH != MW;
                             if (!pixel) *(f32x4*)(cb + r * ROWB + 16 * (lane & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
                     } else if constexpr (DWM == 1) {
@@ -473,11 +476,12 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                             for (int nb = 0; nb < 2; ++nb)
                             {
                                 int row = wm * 16 * MB + 16 * mb + l16;
-                                if constexpr (BORDERED) {        // (MB == 9: wave row wm is image wm of the tile)
-                                    const int pl = 16 * mb + l16, yy = pl / 12;
-                                    row = 1 + PITCH + 169 * wm + PITCH * yy + (pl - 12 * yy);
+                                if constexpr (BORDERED) {
+                                    const int pt = row < MAPS * MHW ? row : MAPS * MHW - 1;      // (rows past the maps: parked on the last pixel's cell... see below)
+                                    const int img = pt / MHW, pl = pt - MHW * img, yy = pl / MW;
+                                    row = row < MAPS * MHW ? 1 + PITCH + IMG * img + PITCH * yy + (pl - MW * yy) : -1;
                                 }
-                                *(f32x4*)(cb + row * ROWB + (16 * nb + 4 * lq) * 4) = acc[mb][nb];
+                                if (row >= 0) *(f32x4*)(cb + row * ROWB + (16 * nb + 4 * lq) * 4) = acc[mb][nb];      // (tile rows past its whole maps are not parked)
                             }
                     }
                     __syncthreads();
@@ -588,7 +592,7 @@ bool pwconv_ps_dw_supported(long long m, int k, int cout, int map_w, int map_hw,
            (dw_stride == 1 || (dw_stride == 2 && map_w == 12 && map_hw == 144));
 }
 
-template <int MB, int MODE>
+template <int MB, int MODE, int MW = 12>
 static int launch_psdw_relu6(const void* xs, const void* wsplit, const float* descale, const float* shift, long long m, int k, int cout,
                              PsDwParams dw, hipStream_t s) {
     const long long tiles_m = (m + dw.tile_rows - 1) / dw.tile_rows;
@@ -596,7 +600,7 @@ static int launch_psdw_relu6(const void* xs, const void* wsplit, const float* de
     const long long total = tiles_m * tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_dw: too many tiles");
     const unsigned g = (unsigned)(total < 256 ? total : 256);
-    hipLaunchKernelGGL((pwconv_ps_kernel<MB, HSEFR_ACT_RELU6, MODE>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k,
+    hipLaunchKernelGGL((pwconv_ps_kernel<MB, HSEFR_ACT_RELU6, MODE, MW>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k,
                        cout, tiles_n, (unsigned)total, sweep_reverse(), dw);
     return launch_status("pwconv_presplit_dw");
 }
@@ -612,9 +616,11 @@ int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale
     const int mb = (map_w == 12 && map_hw == 144) || act != HSEFR_ACT_RELU6 ? 9 : dw_tile_mb(map_hw);
     PsDwParams dw{dwc, ys, map_w, map_hw, 6.f * (float)(1 << out_log2), (32 * mb / map_hw) * map_hw};
     if (act == HSEFR_ACT_RELU6) {
-        const bool bordered = map_w == 12 && map_hw == 144 && g_psdw_mode != 1;      // the zero-bordered chunk buffer (12 x 12 maps)
+        const bool square = map_hw == map_w * map_w && g_psdw_mode != 1;      // the zero-bordered chunk buffer: 12 x 12, 14 x 14, 7 x 7 maps
         if (dw_stride == 2) return launch_psdw_relu6<9, 3>(xs, wsplit, descale, shift, m, k, cout, dw, s);
-        if (bordered) return launch_psdw_relu6<9, 2>(xs, wsplit, descale, shift, m, k, cout, dw, s);
+        if (square && map_w == 12) return launch_psdw_relu6<9, 2, 12>(xs, wsplit, descale, shift, m, k, cout, dw, s);
+        if (square && map_w == 14 && mb == 7) return launch_psdw_relu6<7, 2, 14>(xs, wsplit, descale, shift, m, k, cout, dw, s);
+        if (square && map_w == 7 && mb == 8) return launch_psdw_relu6<8, 2, 7>(xs, wsplit, descale, shift, m, k, cout, dw, s);
         if (mb == 7) return launch_psdw_relu6<7, 1>(xs, wsplit, descale, shift, m, k, cout, dw, s);
         if (mb == 8) return launch_psdw_relu6<8, 1>(xs, wsplit, descale, shift, m, k, cout, dw, s);
         return launch_psdw_relu6<9, 1>(xs, wsplit, descale, shift, m, k, cout, dw, s);
