@@ -155,9 +155,10 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             }
             return;
         }
-        if constexpr (DWM == 3) {      // one item: output pixel P of the tile's 2 x 36; its window starts at input (2 oy, 2 ox)
-            const int P = min((ln >> 3) + 8 * wave, 71);
-            const int img = P >= 36 ? 1 : 0, pl = P - 36 * img, oy = pl / 6, ox = pl - 6 * oy;
+        if constexpr (DWM == 3) {      // one item: output pixel P of the tile's MAPS x (MW / 2)^2; its window starts at input (2 oy, 2 ox)
+            constexpr int OW2 = MW / 2, OHW = OW2 * OW2;
+            const int P = min((ln >> 3) + 8 * wave, MAPS * OHW - 1);
+            const int img = P / OHW, pl = P - OHW * img, oy = pl / OW2, ox = pl - OW2 * oy;
             nb_mask[0] = (unsigned)((1 + PITCH + IMG * img + PITCH * 2 * oy + 2 * ox) * ROWB + 16 * (ln & 7));
             return;
         }
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
             const u32x4 out = odd ? u32x4{recv.x, recv.y, lb.x, lb.y} : u32x4{hb.x, hb.y, recv.x, recv.y};
             // (stride 2: lanes past the tile's 72 output pixels computed a duplicate of pixel 71; an out-of-range offset drops their store)
-            const bool drop = (DWM == 3 && P >= 72) || (DWM == 1 && !(nb_mask[k3] >> 16)) || (DWM == 2 && (nb_mask[k3] >> 31));
+            const bool drop = (DWM == 3 && P >= MAPS * (MW / 2) * (MW / 2)) || (DWM == 1 && !(nb_mask[k3] >> 16)) || (DWM == 2 && (nb_mask[k3] >> 31));
             const unsigned ovoff = drop ? 0x80000000u : (unsigned)P * (unsigned)Cout * 4u + (unsigned)c * 128u + 16u * unit;
             bstore16_welded(__builtin_bit_cast(f32x4, out), ro, ovoff, 0u);
         }
@@ -587,9 +588,9 @@ static int dw_tile_mb(int map_hw) {
 }
 
 bool pwconv_ps_dw_supported(long long m, int k, int cout, int map_w, int map_hw, int dw_stride) {
-    // 3 x 3 / SAME; stride 1 on any map of at most 288 pixels (square or not), stride 2 on 12 x 12 maps
+    // 3 x 3 / SAME; stride 1 on any map of at most 288 pixels (square or not), stride 2 on 12 x 12 and 14 x 14 maps
     return pwconv_ps_supported(m, k, cout) && map_w > 0 && map_hw > 0 && map_hw % map_w == 0 && map_hw <= 288 && m % map_hw == 0 &&
-           (dw_stride == 1 || (dw_stride == 2 && map_w == 12 && map_hw == 144));
+           (dw_stride == 1 || (dw_stride == 2 && (map_w == 12 || map_w == 14) && map_hw == map_w * map_w));
 }
 
 template <int MB, int MODE, int MW = 12>
@@ -613,11 +614,12 @@ int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale
     HSEFR_REQUIRE(dw_stride == 1 || act == HSEFR_ACT_RELU6, HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_dw: the stride-2 epilogue is built for ReLU6");
     HSEFR_REQUIRE(out_log2 >= 1 && out_log2 <= 12, HSEFR_ERR_INVALID, "pwconv_presplit_dw: out_log2=%d", out_log2);
     if (m == 0) return HSEFR_OK;
-    const int mb = (map_w == 12 && map_hw == 144) || act != HSEFR_ACT_RELU6 ? 9 : dw_tile_mb(map_hw);
+    const int mb = (map_w == 12 && map_hw == 144) || act != HSEFR_ACT_RELU6 ? 9 : dw_tile_mb(map_hw);      // (14 x 14 -> 7, 7 x 7 -> 8)
     PsDwParams dw{dwc, ys, map_w, map_hw, 6.f * (float)(1 << out_log2), (32 * mb / map_hw) * map_hw};
     if (act == HSEFR_ACT_RELU6) {
         const bool square = map_hw == map_w * map_w && g_psdw_mode != 1;      // the zero-bordered chunk buffer: 12 x 12, 14 x 14, 7 x 7 maps
-        if (dw_stride == 2) return launch_psdw_relu6<9, 3>(xs, wsplit, descale, shift, m, k, cout, dw, s);
+        if (dw_stride == 2 && map_w == 14) return launch_psdw_relu6<7, 3, 14>(xs, wsplit, descale, shift, m, k, cout, dw, s);
+        if (dw_stride == 2) return launch_psdw_relu6<9, 3, 12>(xs, wsplit, descale, shift, m, k, cout, dw, s);
         if (square && map_w == 12) return launch_psdw_relu6<9, 2, 12>(xs, wsplit, descale, shift, m, k, cout, dw, s);
         if (square && map_w == 14 && mb == 7) return launch_psdw_relu6<7, 2, 14>(xs, wsplit, descale, shift, m, k, cout, dw, s);
         if (square && map_w == 7 && mb == 8) return launch_psdw_relu6<8, 2, 7>(xs, wsplit, descale, shift, m, k, cout, dw, s);

@@ -997,8 +997,9 @@ def pwdw_fusable(pw: Layer, dw: Layer) -> bool:
         return False
     if dw.stride == 1:
         return dw.pad_t == 1 and dw.pad_l == 1 and dw.out_shape == dw.in_shape
-    # stride 2: the 12x12 -> 6x6 layer (TF SAME on an even map pads bottom / right only); the GEMM's own activation must be ReLU6
-    return dw.stride == 2 and (h, w) == (12, 12) and (dw.pad_t, dw.pad_l) == (0, 0) and dw.out_shape[:2] == (6, 6) and pw.act == ACT_RELU6
+    # stride 2: the 12x12 -> 6x6 / 14x14 -> 7x7 layer (TF SAME on an even map pads bottom / right only); the GEMM's own activation must be ReLU6
+    return (dw.stride == 2 and (h, w) in ((12, 12), (14, 14)) and (dw.pad_t, dw.pad_l) == (0, 0) and dw.out_shape[:2] == (h // 2, w // 2) and
+            pw.act == ACT_RELU6)
 
 
 def fuse_pwgap(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:

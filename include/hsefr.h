@@ -107,7 +107,7 @@ typedef enum hsefr_op_kind {
                                   reserved = pool_pad_t | pool_pad_l << 4, each 0 or 1; blob operands as STEM7X7_BF16    */
     HSEFR_OP_PWCONV_PS_DW = 21, /* PWCONV_PS + the NEXT block's depthwise 3x3 (stride 1, SAME) + scale + shift + ReLU6 in the GEMM's epilogue,
                                   output = that depthwise layer's split rows (csrc/pwconv_ps.hip): h * w <= 288; stride = the depthwise's
-                                  (1, or 2 on 12 x 12 maps with pad 0), oh / ow = its output size.
+                                  (1, or 2 on 12 x 12 / 14 x 14 maps with pad 0), oh / ow = its output size.
                                   w2_off = [11][cout] fp32: taps 0..8, scale * 2^out_log2, shift * 2^out_log2;
                                   reserved = a_log2 | out_log2 << 8                                                         */
     HSEFR_OP_PWCONV_PS_GAP = 22, /* PWCONV_PS + the global average pool behind it in the GEMM's epilogue: output [1,1,cout] fp32 per image
@@ -274,7 +274,7 @@ int hsefr_pwconv1x1_presplit_gap(const void* x_split, const void* w_split, const
 
 /* hsefr_pwconv1x1_presplit with the next block's depthwise 3x3 / SAME + scale + shift + ReLU6 fused into its epilogue: the result
  * leaves as that depthwise layer's split rows y_split (scaled by 2^out_log2; m / dw_stride^2 pixels).  The m rows are maps of
- * map_hw = map_h * map_w <= 288 pixels (whole maps per GEMM tile); dw_stride 1, or 2 on 12 x 12 maps (TF SAME on an even map: no top / left
+ * map_hw = map_h * map_w <= 288 pixels (whole maps per GEMM tile); dw_stride 1, or 2 on 12 x 12 / 14 x 14 maps (TF SAME on an even map: no top / left
  * padding).  dw_consts = [11][cout] floats: the depthwise taps (row-major 3x3), then its scale and shift, the last two already
  * multiplied by 2^out_log2. */
 int hsefr_pwconv1x1_presplit_dw(const void* x_split, const void* w_split, const float* descale, const float* shift, const float* dw_consts,

@@ -164,7 +164,7 @@ def test_whole_network_presplit_vs_fp32_tensors(env):
 
 @pytest.mark.parametrize("n,h,w,k,cout,act,s", [(2, 12, 12, 512, 512, 2, 1), (5, 12, 12, 256, 512, 2, 1), (8, 6, 6, 512, 1024, 2, 1), (19, 6, 6, 1024, 1024, 2, 1),
                                                 (3, 3, 3, 256, 128, 2, 1), (4, 4, 3, 256, 256, 1, 1), (1, 12, 12, 288, 384, 0, 1),
-                                                (2, 12, 12, 512, 512, 2, 2), (7, 12, 12, 256, 384, 2, 2),
+                                                (2, 12, 12, 512, 512, 2, 2), (7, 12, 12, 256, 384, 2, 2), (5, 14, 14, 512, 512, 2, 2),
                                                 (3, 14, 14, 512, 512, 2, 1), (11, 7, 7, 1024, 1024, 2, 1), (4, 10, 10, 256, 256, 2, 1), (2, 16, 18, 256, 128, 2, 1)])
 def test_pointwise_with_depthwise_epilogue_vs_oracle(n, h, w, k, cout, act, s):
     """csrc/pwconv_ps.hip with DW = true: pointwise on split rows + the next block's depthwise 3x3 / 1 / SAME + scale + shift + ReLU6
