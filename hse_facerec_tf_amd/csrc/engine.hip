@@ -214,9 +214,22 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                 return HSEFR_ERR_UNSUPPORTED;
         }
     }
-    for (int s = 0; s < HSEFR_N_OUTPUT_SLOTS; ++s)
+    for (int s = 0; s < HSEFR_N_OUTPUT_SLOTS; ++s) {
         HSEFR_REQUIRE(h.out_buffer[s] == HSEFR_BUF_NONE || (h.out_buffer[s] >= 0 && h.out_buffer[s] < (int)h.n_buffers),
                       HSEFR_ERR_INVALID, "plan: output slot %d names buffer %d", s, h.out_buffer[s]);
+        if (h.out_buffer[s] == HSEFR_BUF_NONE) continue;
+        // hsefr_engine_forward lets the producing kernel write the CALLER's [n, out_elems] tensor in place of this buffer:
+        // that is only sound if the buffer has exactly one producer (never recycled for another tensor) and holds exactly
+        // out_elems fp32 values per image -- a hand-made plan that breaks either would overrun the caller's memory.
+        const int b = h.out_buffer[s];
+        uint32_t producers = 0;
+        for (uint32_t i = 0; i < h.n_ops; ++i) producers += (ops[i].out_buf == b);
+        HSEFR_REQUIRE(producers == 1, HSEFR_ERR_INVALID, "plan: output slot %d: buffer %d has %u producing ops (must be exactly 1)", s, b,
+                      producers);
+        HSEFR_REQUIRE((uint64_t)bufs[b].elems_per_image * bufs[b].elem_bytes == (uint64_t)h.out_elems[s] * 4, HSEFR_ERR_INVALID,
+                      "plan: output slot %d: buffer %d holds %llu x %u bytes per image, the slot declares %u fp32 elements", s, b,
+                      (unsigned long long)bufs[b].elems_per_image, (unsigned)bufs[b].elem_bytes, h.out_elems[s]);
+    }
     return HSEFR_OK;
 }
 
@@ -609,20 +622,24 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
     } else {
         // Output buffers are pinned by the lowering (one producer, never recycled, distinct per slot), so the caller's
         // pointer can stand in for the whole forward.  A buffer serving two slots is written once and copied once.
+        // The kernels store 16 bytes per lane: a caller pointer that is not 16-byte aligned (the ABI does not require it) keeps
+        // the engine's own buffer for that slot and is served by a copy, like a slot that shares its buffer with another.
         std::vector<void*> tab(e->d_bufs);
-        int first_slot_of[HSEFR_N_OUTPUT_SLOTS];
+        const void* src_of[HSEFR_N_OUTPUT_SLOTS] = {nullptr, nullptr, nullptr};
         for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl) {
-            first_slot_of[sl] = sl;
             if (!outs[sl]) continue;
-            for (int t = 0; t < sl; ++t)
-                if (outs[t] && e->hdr.out_buffer[t] == e->hdr.out_buffer[sl]) { first_slot_of[sl] = t; break; }
-            if (first_slot_of[sl] == sl) tab[e->hdr.out_buffer[sl]] = outs[sl];
+            const int b = e->hdr.out_buffer[sl];
+            if (tab[b] != e->d_bufs[b]) { src_of[sl] = tab[b]; continue; }             // an earlier slot already redirected this buffer
+            if (((uintptr_t)outs[sl] & 15) == 0) tab[b] = outs[sl];                  // written in place by its producer
+            else src_of[sl] = e->d_bufs[b];
         }
+        for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl)                             // an unaligned slot ahead of an aligned one of the same buffer
+            if (outs[sl] && src_of[sl] == e->d_bufs[e->hdr.out_buffer[sl]]) src_of[sl] = tab[e->hdr.out_buffer[sl]];
         const int rc = run_ops(e, tab, d_input, n, needed, s, prof ? pev : nullptr);
         if (rc != HSEFR_OK) return rc;
         for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl)
-            if (outs[sl] && first_slot_of[sl] != sl)
-                HSEFR_HIP_CHECK(hipMemcpyAsync(outs[sl], outs[first_slot_of[sl]], (size_t)e->hdr.out_elems[sl] * sizeof(float) * n,
+            if (outs[sl] && src_of[sl])
+                HSEFR_HIP_CHECK(hipMemcpyAsync(outs[sl], src_of[sl], (size_t)e->hdr.out_elems[sl] * sizeof(float) * n,
                                                hipMemcpyDeviceToDevice, s));
     }
     if (prof) e->prof_calls++;

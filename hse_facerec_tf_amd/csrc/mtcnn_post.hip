@@ -72,9 +72,13 @@ __device__ void nms_sorted(PostLds& L, int n, double thr, bool use_min) {
     __syncthreads();
 }
 
+// Sort key: ascending key = descending score, and among bit-equal scores DESCENDING index -- what the reference's own
+// `I = np.argsort(s)` + "pick I[-1]" does on its usual list sizes (NumPy's introsort finishes lists of <= 16 elements with a
+// stable insertion sort, facial_analysis.py:398-403), made the rule for every size so the order is deterministic.
 __device__ __forceinline__ unsigned long long make_key(float score, unsigned idx) {
-    return ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(score)) << 32) | idx;
+    return ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(score)) << 32) | (0xFFFFFFFFu - idx);
 }
+__device__ __forceinline__ unsigned key_idx(unsigned long long key) { return 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull); }
 __device__ __forceinline__ int np2_of(int n) {
     int p = 2;
     while (p < n) p <<= 1;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(NT) void stage1_level_kernel(const float* __restric
     __syncthreads();
     sort_keys(L, p2);
     for (int i = tid; i < n; i += NT) {
-        const unsigned idx = (unsigned)(L.key[i] & 0xFFFFFFFFull);
+        const unsigned idx = key_idx(L.key[i]);
         const int xi = (int)(idx / (unsigned)h), yi = (int)(idx - (unsigned)xi * (unsigned)h);
         L.x1[i] = dfix((double)(2 * xi + 1) / scale);
         L.y1[i] = dfix((double)(2 * yi + 1) / scale);
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(NT) void stage1_level_kernel(const float* __restric
     if (base + nk > CAP) { if (tid == 0) counters[4] = 1; return; }
     for (int k = tid; k < nk; k += NT) {
         const int i = L.keep_pos[k];
-        const unsigned idx = (unsigned)(L.key[i] & 0xFFFFFFFFull);
+        const unsigned idx = key_idx(L.key[i]);
         const int xi = (int)(idx / (unsigned)h), yi = (int)(idx - (unsigned)xi * (unsigned)h);
         // the reference reads the regression maps flipped when exactly one cell fires (facial_analysis.py:383-387)
         const int rxi = n == 1 ? w - 1 - xi : xi;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(NT) void stage1_finish_kernel(const double* __restr
     __syncthreads();
     sort_keys(L, p2);
     for (int i = tid; i < n; i += NT) {
-        const double* b = found + (size_t)(L.key[i] & 0xFFFFFFFFull) * 9;
+        const double* b = found + (size_t)key_idx(L.key[i]) * 9;
         L.x1[i] = b[0]; L.y1[i] = b[1]; L.x2[i] = b[2]; L.y2[i] = b[3];
         L.area[i] = __dmul_rn(b[2] - b[0] + 1.0, b[3] - b[1] + 1.0);
     }
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(NT) void stage1_finish_kernel(const double* __restr
     nms_sorted(L, n, 0.7, false);
     const int nk = L.nkeep;
     for (int k = tid; k < nk; k += NT) {
-        const double* b = found + (size_t)(L.key[L.keep_pos[k]] & 0xFFFFFFFFull) * 9;
+        const double* b = found + (size_t)key_idx(L.key[L.keep_pos[k]]) * 9;
         const double rw = b[2] - b[0], rh = b[3] - b[1];
         double x1 = mad_sep(b[0], b[5], rw), y1 = mad_sep(b[1], b[6], rh), x2 = mad_sep(b[2], b[7], rw), y2 = mad_sep(b[3], b[8], rh);
         square_box(x1, y1, x2, y2);
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(NT) void stage23_finish_kernel(const double* __rest
     __syncthreads();
     sort_keys(L, p2);
     for (int i = tid; i < m; i += NT) {
-        const unsigned src = (unsigned)(L.key[i] & 0xFFFFFFFFull);
+        const unsigned src = key_idx(L.key[i]);
         const double* b = boxes_in + (size_t)src * 5;
         double x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
         if (STAGE == 3) {      // bbreg before the NMS
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(NT) void stage23_finish_kernel(const double* __rest
     const int nk = L.nkeep;
     for (int k = tid; k < nk; k += NT) {
         const int i = L.keep_pos[k];
-        const unsigned src = (unsigned)(L.key[i] & 0xFFFFFFFFull);
+        const unsigned src = key_idx(L.key[i]);
         const float score = prob[2 * src + 1];
         double* o = boxes_out + (size_t)k * 5;
         if (STAGE == 2) {
@@ -272,13 +276,13 @@ __global__ __launch_bounds__(NT) void nms_kernel(const double* __restrict__ boxe
     __syncthreads();
     sort_keys(L, p2);
     for (int i = tid; i < n; i += NT) {
-        const double* b = boxes + (size_t)(L.key[i] & 0xFFFFFFFFull) * 5;
+        const double* b = boxes + (size_t)key_idx(L.key[i]) * 5;
         L.x1[i] = b[0]; L.y1[i] = b[1]; L.x2[i] = b[2]; L.y2[i] = b[3];
         L.area[i] = __dmul_rn(b[2] - b[0] + 1.0, b[3] - b[1] + 1.0);
     }
     __syncthreads();
     nms_sorted(L, n, thr, use_min != 0);
-    for (int k = tid; k < L.nkeep; k += NT) keep[k] = (int)(L.key[L.keep_pos[k]] & 0xFFFFFFFFull);
+    for (int k = tid; k < L.nkeep; k += NT) keep[k] = (int)key_idx(L.key[L.keep_pos[k]]);
     if (tid == 0) *n_keep = L.nkeep;
 }
 

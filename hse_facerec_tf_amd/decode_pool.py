@@ -1,0 +1,228 @@
+"""Worker PROCESSES that decode image files straight into shared, page-locked staging memory -- the host side of
+``TensorFlowInference.extract_files`` (the loop of facerec_test.py:394 at gallery scale).
+
+Why processes: ``Image.open`` / ``convert`` / ``np.asarray`` hold the GIL for most of a 250x250 JPEG, so a thread pool of
+PIL decoders tops out at ~1.5x one core (3.1 k img/s on 32 threads where one thread does 0.84 k).
+Each worker here is a plain Python process (spawned, never forked from a process that holds a HIP context; it imports
+PIL + NumPy only, no torch, no GPU) that receives (paths, region) tasks, decodes exactly as ``preprocess.imread_rgb``
+does (``misc.imread(path, mode='RGB')``, facerec_test.py:83,91) and packs the pixels back to back into its region of a
+``multiprocessing.shared_memory`` block.  The parent registers that block with the HIP runtime (``hipHostRegister``), so
+the upload is an asynchronous DMA out of the very bytes the decoder wrote: no pickling of pixels, no copy into a second
+pinned buffer, no per-(H, W) staging buffers (staging is a flat byte pool per slot, sized by capacity).
+
+The pool is persistent (workers start once per extractor, ~0.3 s) and is closed by ``close_session()``.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def default_workers() -> int:
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 32))
+
+
+def _worker_main(shm_name: str, tasks, results) -> None:
+    """Runs in the worker process.  task = (task_id, [paths], byte offset, byte capacity) or None to stop.
+    result = (task_id, [(offset, H, W) | None per image], spill, error): images that did not fit the region are returned
+    pickled in ``spill`` {position: ndarray}; ``error`` = (exception type name, message) of the first failing file."""
+    import signal
+    from multiprocessing import shared_memory
+    signal.signal(signal.SIGINT, signal.SIG_IGN)          # the parent decides when the pool stops
+    from PIL import Image
+    shm = shared_memory.SharedMemory(name=shm_name)
+    buf = np.frombuffer(shm.buf, dtype=np.uint8)
+    try:
+        while True:
+            task = tasks.get()
+            if task is None:
+                break
+            tid, paths, off, cap = task
+            metas, spill, err = [], {}, None
+            end = off + cap
+            for k, p in enumerate(paths):
+                try:
+                    with Image.open(p) as im:             # == preprocess.imread_rgb
+                        a = np.asarray(im.convert("RGB"))
+                except Exception as e:                    # reported to the parent, which raises it (first failing file)
+                    err = (type(e).__name__, "%s" % (e,), p)
+                    break
+                nb = a.size
+                if off + nb <= end:
+                    buf[off:off + nb] = a.reshape(-1)
+                    metas.append((off, a.shape[0], a.shape[1]))
+                    off += nb
+                else:
+                    metas.append(None)
+                    spill[k] = a
+            results.put((tid, metas, spill, err))
+    finally:
+        del buf
+        shm.close()
+
+
+class DecodePool:
+    """``slots`` staging slots of ``slot_bytes`` each in one shared block; a chunk of files is decoded into one slot by
+    tasks of ``task_files`` files, each task owning a fixed sub-region (so workers never contend for space)."""
+
+    def __init__(self, workers: Optional[int] = None, slot_bytes: int = 64 << 20, slots: int = 3, task_files: int = 8):
+        import multiprocessing as mp
+        from multiprocessing import shared_memory
+        self.workers = int(workers or default_workers())
+        self.slot_bytes, self.slots, self.task_files = int(slot_bytes), int(slots), int(task_files)
+        self._ctx = mp.get_context("spawn")
+        self._shm = shared_memory.SharedMemory(create=True, size=self.slot_bytes * self.slots)
+        self._np = np.frombuffer(self._shm.buf, dtype=np.uint8)
+        self._tasks = self._ctx.Queue()
+        self._results = self._ctx.Queue()
+        self._procs = []
+        # spawn re-imports __main__ in the child when it has a file (multiprocessing's "main path" fix-up): keep a heavy main
+        # module (bench.py, pytest) out of the decoders -- they need this module only
+        main = sys.modules.get("__main__")
+        saved = getattr(main, "__file__", None), getattr(main, "__spec__", None)
+        try:
+            if main is not None:
+                if saved[0] is not None:
+                    del main.__file__
+                main.__spec__ = None
+            for _ in range(self.workers):
+                p = self._ctx.Process(target=_worker_main, args=(self._shm.name, self._tasks, self._results), daemon=True)
+                p.start()
+                self._procs.append(p)
+        finally:
+            if main is not None:
+                if saved[0] is not None:
+                    main.__file__ = saved[0]
+                main.__spec__ = saved[1]
+        self._pinned = False
+        self._tensor = None
+        self._next_tid = 0
+        self._open = {}            # chunk key -> {"tasks": {tid: (first file position, n files)}, "done": {tid: result}}
+        self._stash = {}           # results that arrived for another chunk
+
+    # -- staging memory as a torch tensor (page-locked when the runtime lets us) -------------------------------------
+    def tensor(self):
+        """uint8 CPU tensor over the whole shared block; registered with the HIP runtime once (hipHostRegister) so
+        ``.to(device, non_blocking=True)`` from it is a true asynchronous copy."""
+        if self._tensor is None:
+            import torch
+            self._tensor = torch.frombuffer(self._shm.buf, dtype=torch.uint8)
+            try:
+                rc = torch.cuda.cudart().cudaHostRegister(self._tensor.data_ptr(), self._tensor.numel(), 0)
+                self._pinned = (int(rc) == 0)
+            except Exception:
+                self._pinned = False
+        return self._tensor
+
+    @property
+    def pinned(self) -> bool:
+        return self._pinned
+
+    # -- chunks ----------------------------------------------------------------------------------------------------
+    def submit(self, key, paths: Sequence[str], slot: int) -> None:
+        """Queue the decode of ``paths`` into staging slot ``slot``; collect with ``collect(key)``."""
+        n = len(paths)
+        ntask = max(1, -(-n // self.task_files))
+        region = (self.slot_bytes // ntask) & ~63
+        base = slot * self.slot_bytes
+        tasks = {}
+        for t in range(ntask):
+            lo, hi = t * self.task_files, min((t + 1) * self.task_files, n)
+            tid = self._next_tid
+            self._next_tid += 1
+            tasks[tid] = (lo, hi - lo)
+            self._tasks.put((tid, list(paths[lo:hi]), base + t * region, region))
+        self._open[key] = {"tasks": tasks, "n": n}
+
+    def collect(self, key) -> List[Tuple[int, Optional[Tuple[int, int, int]], Optional[np.ndarray]]]:
+        """Blocks until every task of the chunk is done.  Returns one (position, (offset, H, W) | None, spilled array | None)
+        per file, in file order; raises the first decoding error as the exception type the serial path would raise."""
+        import queue
+        ch = self._open.pop(key)
+        want = dict(ch["tasks"])
+        done = {}
+        for tid in list(want):
+            if tid in self._stash:
+                done[tid] = self._stash.pop(tid)
+        while len(done) < len(want):
+            try:
+                res = self._results.get(timeout=5.0)
+            except queue.Empty:
+                dead = [p for p in self._procs if not p.is_alive()]
+                if dead:
+                    raise RuntimeError("a decoder process died (exit code %r)" % dead[0].exitcode)
+                continue
+            if res[0] in want:
+                done[res[0]] = res
+            else:
+                self._stash[res[0]] = res
+        out = []
+        first_err = None
+        for tid in sorted(want):
+            lo, cnt = want[tid]
+            _, metas, spill, err = done[tid]
+            if err is not None and first_err is None:
+                first_err = err
+            for k, m in enumerate(metas):
+                out.append((lo + k, m, spill.get(k)))
+        if first_err is not None:
+            name, msg, path = first_err
+            import builtins
+            exc = getattr(builtins, name, None)
+            if not (isinstance(exc, type) and issubclass(exc, Exception)):
+                exc = RuntimeError
+                msg = "%s: %s" % (name, msg)
+            if exc is FileNotFoundError:
+                raise FileNotFoundError(2, "No such file or directory", path)
+            raise exc(msg)
+        return out
+
+    def close(self) -> None:
+        if self._shm is None:
+            return
+        for _ in self._procs:
+            try:
+                self._tasks.put(None)
+            except Exception:
+                pass
+        for p in self._procs:
+            p.join(timeout=5.0)
+            if p.is_alive():
+                p.terminate()
+        self._procs = []
+        if self._tensor is not None and self._pinned:
+            try:
+                import torch
+                torch.cuda.cudart().cudaHostUnregister(self._tensor.data_ptr())
+            except Exception:
+                pass
+        self._tensor = None
+        self._np = None
+        for q in (self._tasks, self._results):
+            try:
+                q.close()
+                q.join_thread()
+            except Exception:
+                pass
+        try:
+            self._shm.close()
+        except BufferError:       # a view is still alive somewhere: the block is unlinked anyway and dies with the process
+            pass
+        try:
+            self._shm.unlink()
+        except FileNotFoundError:
+            pass
+        self._shm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -59,11 +59,11 @@ def extract_sharded(extract_fn: Callable, items: Sequence, dim: int, device, gro
         t1 = _sync(device)
         timings["extract_s"] = t1 - t0
         timings["shard"] = (lo, hi)
-    if world == 1:
+    if not distributed:                       # no process group: nothing to exchange
         if timings is not None:
             timings["allgather_s"] = 0.0
         return local[:n]
-    full = all_gather_rows(local, group)
+    full = all_gather_rows(local, group)      # also with ONE rank in the group: the collective still runs (a world-1 communicator)
     if timings is not None:
         timings["allgather_s"] = _sync(device) - t1
         timings["allgather_bytes_per_rank"] = int(local.numel() * 4)

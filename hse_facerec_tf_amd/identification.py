@@ -32,19 +32,20 @@ def stratified_half_split(y: np.ndarray, random_state: int = 0) -> Tuple[np.ndar
 
 
 def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np.ndarray]] = None,
-                          pca_components: Optional[int] = None, timings: Optional[dict] = None) -> Dict:
+                          pca_components: Optional[int] = None, timings: Optional[dict] = None, device=None) -> Dict:
     """The protocol of facerec_test.py:401-432: 'k-NN' (pca_components=None) or 'k-NN+PCA'
     (pca_components=128, the Pipeline of :421 -- PCA is fitted on the gallery half by scikit-learn on
     the host, exactly as the reference does, and the projected vectors go back to the device for the search).
 
-    X: [N, D] float32 embeddings, CUDA tensor or NumPy array (uploaded); y: [N] labels.
+    X: [N, D] float32 embeddings, CUDA tensor or NumPy array (uploaded to ``device``, default: the current one); y: [N] labels.
     Returns accuracy, the split, predictions and nearest-gallery indices.  ``timings`` (optional dict) receives the
-    device-synchronised wall seconds of each phase: normalize_s, host_split_s, select_s, nn1_s."""
+    device-synchronised wall seconds of each phase: normalize_s, host_split_s, select_s, nn1_s, readback_s (indices and
+    distances back to the host + the label comparison)."""
     import time
     from . import _lib, ops
     torch = _lib.require_gpu()
     if isinstance(X, np.ndarray):
-        X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).cuda()
+        X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(_lib.cuda_device(device))
 
     def lap(key, t_prev):
         if timings is None:
@@ -75,24 +76,26 @@ def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np
         gal, qry = proj(gal), proj(qry)
     nn_idx, nn_d2 = ops.nn1(qry, gal)
     t = lap("nn1_s", t)
+    nn_idx_h = nn_idx.cpu().numpy()
+    nn_dist_h = np.sqrt(nn_d2.cpu().numpy())
+    y_pred = y_enc[train][nn_idx_h]
+    acc = float((y_pred == y_enc[test]).mean()) if len(test) else float("nan")
+    t = lap("readback_s", t)
     if timings is not None:
         timings.pop("_start", None)
         timings["nn1_shape"] = (int(qry.shape[0]), int(gal.shape[0]), int(qry.shape[1]))
-    nn_idx_h = nn_idx.cpu().numpy()
-    y_pred = y_enc[train][nn_idx_h]
-    acc = float((y_pred == y_enc[test]).mean()) if len(test) else float("nan")
     return {"accuracy": acc, "indices": indices, "y": y_enc, "train": train, "test": test, "y_pred": y_pred,
-            "nn_index": nn_idx_h, "nn_dist": np.sqrt(nn_d2.cpu().numpy()), "num_classes": int(y_enc.max() + 1) if len(y_enc) else 0}
+            "nn_index": nn_idx_h, "nn_dist": nn_dist_h, "num_classes": int(y_enc.max() + 1) if len(y_enc) else 0}
 
 
-def feature_distance_matrix(features, born_years=None, photo_years=None) -> np.ndarray:
+def feature_distance_matrix(features, born_years=None, photo_years=None, device=None) -> np.ndarray:
     """The dist_matrix of process_photos.perform_clustering (process_photos.py:45-60): Euclidean distance
     between facial features (on the GPU) plus 0.1 x the age term (cur_age_i - cur_age_j)^2 / (cur_age_i +
     cur_age_j), cur_age = max(year_i, year_j) - born_year, clipped at 0.  Returns a host float64 matrix as the
     clustering code (facial_clustering.get_facial_clusters) expects."""
     from . import _lib, ops
     torch = _lib.require_gpu()
-    f = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).cuda() if isinstance(features, np.ndarray) \
+    f = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(_lib.cuda_device(device)) if isinstance(features, np.ndarray) \
         else features.float().contiguous()
     dist = ops.pairwise_distances(f).cpu().numpy().astype(np.float64)
     if born_years is not None:

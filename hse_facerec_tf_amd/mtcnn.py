@@ -167,9 +167,11 @@ def _iou_suppress(boxes: np.ndarray, threshold: float, use_min: bool) -> np.ndar
         return np.empty((0,), np.int64)
     x1, y1, x2, y2, score = (boxes[:, i] for i in range(5))
     area = (x2 - x1 + 1) * (y2 - y1 + 1)
-    # descending score, ties by ascending index (np.argsort's default order among ties is unspecified; the device kernel
-    # csrc/mtcnn_post.hip uses the same explicit rule)
-    order = np.argsort(-score.astype(np.float32), kind="stable")[::-1]
+    # the reference: `I = np.argsort(s)`, pick I[-1] (facial_analysis.py:398-403).  Among bit-equal scores (softmax saturated
+    # to 1.0f on clear faces) NumPy's default sort leaves lists of <= 16 elements -- the usual R-/O-Net list -- in ascending
+    # index order, so the HIGHEST index is picked first.  A stable sort makes that the rule for every list size; the device
+    # kernel (csrc/mtcnn_post.hip make_key) uses the same rule.
+    order = np.argsort(score.astype(np.float32), kind="stable")
     keep = []
     while order.size:
         top, rest = order[-1], order[:-1]
@@ -247,7 +249,7 @@ class MTCNNDetector:
         if self.device_boxes and not device_resize:
             raise ValueError("device_boxes needs device_resize (the crops are cut from the frame on the device)")
         self.host_fallbacks = 0            # frames redone on the host because a candidate list overflowed
-        self._frame = None                 # the uint8 frame on the device (device_resize)
+        self._work = None                  # cap-sized work tensors of the device box logic, allocated once (_detect_device)
         self.device = _lib.cuda_device(device)
         self.net = _DeviceNet(read_graph(mtcnn_pb or MTCNN_PB), self.device)
 
@@ -274,16 +276,17 @@ class MTCNNDetector:
     def _to_device(self, a: np.ndarray):
         return self._torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
-    def _level_device(self, h: int, w: int, hs: int, ws: int):
-        """One pyramid level of the uploaded frame, normalised and transposed: CUDA float32 [1, ws, hs, 3]."""
+    def _level_device(self, frame, h: int, w: int, hs: int, ws: int):
+        """One pyramid level of the uploaded frame (``frame``: CUDA uint8 [h, w, 3] -- an argument, not detector state, so one
+        detector can serve several threads), normalised and transposed: CUDA float32 [1, ws, hs, 3]."""
         torch = self._torch
         out = torch.empty((1, ws, hs, 3), dtype=torch.float32, device=self.device)
         with _lib.on_device(out):
-            _lib.check(_lib.lib().hsefr_mtcnn_pyramid_level(self._frame.data_ptr(), out.data_ptr(), h, w, hs, ws,
+            _lib.check(_lib.lib().hsefr_mtcnn_pyramid_level(frame.data_ptr(), out.data_ptr(), h, w, hs, ws,
                                                             _lib.current_stream_ptr()), "hsefr_mtcnn_pyramid_level")
         return out
 
-    def _stage1(self, img: np.ndarray) -> np.ndarray:
+    def _stage1(self, img: np.ndarray, frame=None) -> np.ndarray:
         h, w = img.shape[:2]
         found = [np.empty((0, 9))]
         scales = self.pyramid_scales(h, w)
@@ -291,7 +294,7 @@ class MTCNNDetector:
         for scale in scales:                                         # launch every level first ...
             hs, ws = int(np.ceil(h * scale)), int(np.ceil(w * scale))
             if self.device_resize:
-                x = self._level_device(h, w, hs, ws)
+                x = self._level_device(frame, h, w, hs, ws)
             else:
                 level = (preprocess.resize_area(img, ws, hs) - 127.5) * 0.0078125
                 x = self._to_device(np.transpose(level, (1, 0, 2))[None])           # nets see (W, H)
@@ -312,7 +315,7 @@ class MTCNNDetector:
                 found.append(boxes[keep])
         return np.concatenate(found, axis=0)
 
-    def _crops(self, img: np.ndarray, boxes: np.ndarray, size: int):
+    def _crops(self, img: np.ndarray, boxes: np.ndarray, size: int, frame=None):
         h, w = img.shape[:2]
         bw, bh, x1, y1, x2, y2, tx1, ty1, tx2, ty2 = _crop_windows(boxes, w, h)
         if self.device_resize:
@@ -322,7 +325,7 @@ class MTCNNDetector:
             d_tab = torch.from_numpy(np.ascontiguousarray(tab)).to(self.device)
             out = torch.empty((n, size, size, 3), dtype=torch.float32, device=self.device)
             with _lib.on_device(out):
-                _lib.check(_lib.lib().hsefr_mtcnn_crops(self._frame.data_ptr(), d_tab.data_ptr(), out.data_ptr(), h, w, n, size,
+                _lib.check(_lib.lib().hsefr_mtcnn_crops(frame.data_ptr(), d_tab.data_ptr(), out.data_ptr(), h, w, n, size,
                                                         _lib.current_stream_ptr()), "hsefr_mtcnn_crops")
             return out
         out = np.zeros((boxes.shape[0], size, size, 3))
@@ -334,22 +337,37 @@ class MTCNNDetector:
         return self._to_device(np.transpose(out, (0, 2, 1, 3)))      # [n, W, H, 3]
 
     # ---- the cascade with its box logic on the device (csrc/mtcnn_post.hip) ------------------------------------------------
-    def _detect_device(self, img: np.ndarray):
+    def _work_tensors(self, cap: int):
+        """The cap-sized lists of the device box logic, allocated once per detector and thread (work on one stream is ordered,
+        so a frame may overwrite what the previous frame of the same thread left)."""
+        import threading
+        torch, dev = self._torch, self.device
+        if self._work is None:
+            self._work = threading.local()
+        wk = self._work
+        if getattr(wk, "cap", None) != cap:
+            wk.cap = cap
+            wk.found = torch.empty((cap, 9), dtype=torch.float64, device=dev)
+            wk.boxes = [torch.empty((cap, 5), dtype=torch.float64, device=dev) for _ in range(3)]
+            wk.tab = torch.empty((cap, 8), dtype=torch.int32, device=dev)
+            wk.points = torch.empty((cap, 10), dtype=torch.float32, device=dev)
+        return wk
+
+    def _detect_device(self, img: np.ndarray, frame):
         """Returns (boxes, points), or None when a candidate list overflowed the device capacity (caller falls back)."""
         torch, L = self._torch, _lib.lib()
         h, w = img.shape[:2]
         cap = int(L.hsefr_mtcnn_post_capacity())
         dev = self.device
-        with _lib.on_device(self._frame):
+        with _lib.on_device(frame):
             st = _lib.current_stream_ptr()
+            wk = self._work_tensors(cap)
             counters = torch.zeros(8, dtype=torch.int32, device=dev)
-            found = torch.empty((cap, 9), dtype=torch.float64, device=dev)
-            boxes1 = torch.empty((cap, 5), dtype=torch.float64, device=dev)
-            tab = torch.empty((cap, 8), dtype=torch.int32, device=dev)
+            found, (boxes1, boxes2, boxes3), tab, points3 = wk.found, wk.boxes, wk.tab, wk.points
             thr = [float(np.float32(t)) for t in self.THRESHOLDS]
             for scale in self.pyramid_scales(h, w):
                 hs, ws = int(np.ceil(h * scale)), int(np.ceil(w * scale))
-                reg_t, prob_t = self.pnet(self._level_device(h, w, hs, ws))
+                reg_t, prob_t = self.pnet(self._level_device(frame, h, w, hs, ws))
                 reg_t, prob_t = reg_t.contiguous(), prob_t.contiguous()
                 _lib.check(L.hsefr_mtcnn_stage1_level(prob_t.data_ptr(), reg_t.data_ptr(), int(prob_t.shape[1]), int(prob_t.shape[2]),
                                                       float(scale), thr[0], found.data_ptr(), counters.data_ptr(), st), "hsefr_mtcnn_stage1_level")
@@ -362,21 +380,18 @@ class MTCNNDetector:
             if n1 == 0:
                 return np.empty((0, 9)), np.array([])
             crops = torch.empty((n1, 24, 24, 3), dtype=torch.float32, device=dev)
-            _lib.check(L.hsefr_mtcnn_crops(self._frame.data_ptr(), tab.data_ptr(), crops.data_ptr(), h, w, n1, 24, st), "hsefr_mtcnn_crops")
+            _lib.check(L.hsefr_mtcnn_crops(frame.data_ptr(), tab.data_ptr(), crops.data_ptr(), h, w, n1, 24, st), "hsefr_mtcnn_crops")
             reg_t, prob_t = self.rnet(crops)
             reg_t, prob_t = reg_t.contiguous(), prob_t.contiguous()
-            boxes2 = torch.empty((cap, 5), dtype=torch.float64, device=dev)
             _lib.check(L.hsefr_mtcnn_stage_finish(2, boxes1.data_ptr(), n1, prob_t.data_ptr(), reg_t.data_ptr(), None, thr[1], boxes2.data_ptr(),
                                                   tab.data_ptr(), None, counters.data_ptr(), w, h, st), "hsefr_mtcnn_stage_finish")
             n2 = int(counters.cpu().numpy()[2])
             if n2 == 0:
                 return np.empty((0, 5)), np.array([])
             crops = torch.empty((n2, 48, 48, 3), dtype=torch.float32, device=dev)
-            _lib.check(L.hsefr_mtcnn_crops(self._frame.data_ptr(), tab.data_ptr(), crops.data_ptr(), h, w, n2, 48, st), "hsefr_mtcnn_crops")
+            _lib.check(L.hsefr_mtcnn_crops(frame.data_ptr(), tab.data_ptr(), crops.data_ptr(), h, w, n2, 48, st), "hsefr_mtcnn_crops")
             reg_t, pts_t, prob_t = self.onet(crops)
             reg_t, pts_t, prob_t = reg_t.contiguous(), pts_t.contiguous(), prob_t.contiguous()
-            boxes3 = torch.empty((cap, 5), dtype=torch.float64, device=dev)
-            points3 = torch.empty((cap, 10), dtype=torch.float32, device=dev)
             _lib.check(L.hsefr_mtcnn_stage_finish(3, boxes2.data_ptr(), n2, prob_t.data_ptr(), reg_t.data_ptr(), pts_t.data_ptr(), thr[2],
                                                   boxes3.data_ptr(), None, points3.data_ptr(), counters.data_ptr(), w, h, st), "hsefr_mtcnn_stage_finish")
             n3 = int(counters.cpu().numpy()[3])
@@ -386,17 +401,21 @@ class MTCNNDetector:
 
     def __call__(self, img: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         img = np.asarray(img)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("the detector takes an RGB frame [H, W, 3]")
+        frame = None
         if self.device_resize:
-            if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
-                raise ValueError("the detector takes a uint8 RGB frame [H, W, 3]")
-            self._frame = self._torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
+            if img.dtype != np.uint8:      # the device resampler is OpenCV's 8-bit path; float frames: MTCNNDetector(device_resize=False)
+                raise ValueError("device_resize takes a uint8 RGB frame [H, W, 3]; construct the detector with device_resize=False "
+                                 "for %s frames" % img.dtype)
+            frame = self._torch.from_numpy(np.ascontiguousarray(img)).to(self.device)     # local: no per-frame detector state
         if self.device_boxes:
-            res = self._detect_device(img)
+            res = self._detect_device(img, frame)
             if res is not None:
                 return res
             self.host_fallbacks += 1
         points = np.array([])
-        boxes = self._stage1(img)
+        boxes = self._stage1(img, frame)
         if boxes.shape[0]:
             boxes = boxes[_iou_suppress(boxes, 0.7, False)]
             rw, rh = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
@@ -405,7 +424,7 @@ class MTCNNDetector:
             boxes = _square(boxes)
             boxes[:, 0:4] = np.fix(boxes[:, 0:4]).astype(np.int32)
         if boxes.shape[0]:
-            reg_t, prob_t = self.rnet(self._crops(img, boxes, 24))
+            reg_t, prob_t = self.rnet(self._crops(img, boxes, 24, frame))
             score = prob_t[:, 1].cpu().numpy()
             reg = reg_t.cpu().numpy()
             ok = np.nonzero(score > self.THRESHOLDS[1])[0]
@@ -416,7 +435,7 @@ class MTCNNDetector:
                 boxes = _square(_regress(boxes[keep], reg[keep]))
         if boxes.shape[0]:
             boxes = np.fix(boxes).astype(np.int32)
-            reg_t, pts_t, prob_t = self.onet(self._crops(img, boxes, 48))
+            reg_t, pts_t, prob_t = self.onet(self._crops(img, boxes, 48, frame))
             score = prob_t[:, 1].cpu().numpy()
             ok = np.nonzero(score > self.THRESHOLDS[2])[0]
             points = pts_t.cpu().numpy()[ok].T                       # [10, n]

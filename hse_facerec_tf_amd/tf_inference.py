@@ -75,9 +75,14 @@ class TensorFlowInference:
         # they cover the graph, else bf16.  self.dtype names what was chosen ('f32', 'f32g' = general fp32, 'bf16').
         # input_bound: what preprocess_image guarantees about the values this class feeds -- uint8 pixels minus a BGR mean lie
         # in [-131.1, 151.1], the non-BGR branch in [-1, 1] (facerec_test.py:93-110): |x| < 256.  The fused stem uses it
-        # (csrc/stem3_fused.hip) and CHECKS it on the device; extract_batch with values outside it raises.  None = no
-        # assumption about extract_batch's input (exact-fp32 first convolution).
+        # (csrc/stem3_fused.hip) and CHECKS it on the device.  extract_batch with values outside it raises: at once for NumPy
+        # input; for a CUDA tensor (asynchronous) at the next call into this object after that forward has finished, at
+        # check_input_bound() or at close_session() -- never silently.  None = no assumption about extract_batch's input
+        # (exact-fp32 first convolution).
         self.input_bound = input_bound
+        self._ovf_host = None              # pinned int32 ring the device-side bound flag is copied into (CUDA-tensor callers)
+        self._ovf_pending = []             # [(event, slot)] in stream order
+        self._ovf_next = 0
         from .lowering import LoweringError
         if dtype == "auto":
             try:
@@ -123,16 +128,68 @@ class TensorFlowInference:
             raise ValueError("input values reach %g: outside the bound %g this extractor was built for (preprocess_image's output "
                              "is; pass input_bound=None or a larger bound for other data)" % (float(np.abs(x_np).max()), self.input_bound))
 
+    def _bound_check_queue(self) -> None:
+        """After a forward on caller-supplied CUDA values: queue an asynchronous read-and-clear of the device's bound flag."""
+        if self.input_bound is None:
+            return
+        torch = _lib.require_gpu()
+        if self._ovf_host is None:
+            self._ovf_host = torch.zeros(32, dtype=torch.int32).pin_memory()
+        if len(self._ovf_pending) >= self._ovf_host.numel():
+            self._bound_check_poll(wait_oldest=True)
+        slot = self._ovf_next
+        self._ovf_next = (slot + 1) % self._ovf_host.numel()
+        self.engine.input_overflow_async(self._ovf_host.data_ptr() + 4 * slot)
+        with torch.cuda.device(self.engine.device):
+            ev = torch.cuda.Event()
+            ev.record()
+        self._ovf_pending.append((ev, slot))
+
+    def _bound_check_poll(self, wait: bool = False, wait_oldest: bool = False) -> None:
+        """Raise for any finished forward that fed values outside input_bound (the features it returned are meaningless)."""
+        bad = False
+        while self._ovf_pending:
+            ev, slot = self._ovf_pending[0]
+            if wait or wait_oldest:
+                ev.synchronize()
+                wait_oldest = False
+            elif not ev.query():
+                break
+            self._ovf_pending.pop(0)
+            if int(self._ovf_host[slot]):
+                self._ovf_host[slot] = 0
+                bad = True
+        if bad:
+            raise ValueError("an earlier extract_batch on a CUDA tensor fed values outside the bound %g this extractor was built "
+                             "for: the features it returned are meaningless (pass input_bound=None or a larger bound for such data)"
+                             % self.input_bound)
+
+    def check_input_bound(self) -> None:
+        """Synchronisation point for CUDA-tensor callers of extract_batch: waits for the queued forwards and raises
+        ValueError if any of them violated ``input_bound``."""
+        self._bound_check_poll(wait=True)
+
     def close_session(self):                 # facerec_test.py:124-125
-        self.engine.close()
+        try:
+            if getattr(self.engine, "_h", None):
+                self._bound_check_poll(wait=True)
+        finally:
+            pool = getattr(self, "_decode_pool", None)
+            if pool is not None:
+                pool.close()
+                self._decode_pool = None
+            self.engine.close()
 
     # ---- batched entries (new) ------------------------------------------------------------------
     def extract_batch(self, x):
         """x: float32 [n, h, w, 3] NHWC, preprocessed as preprocess_image leaves it; a CUDA tensor
         (returned: CUDA tensor [n, D], asynchronous) or a NumPy array (returned: NumPy array).  Values must respect
-        ``input_bound`` (NumPy input is checked here; for a CUDA tensor the device-side check is read with
-        ``self.engine.input_overflow()``)."""
+        ``input_bound``: NumPy input is checked here and raises ValueError at once; a CUDA tensor is checked ON THE DEVICE by
+        the first kernel, the flag comes back asynchronously and the ValueError is raised by the next call into this object
+        after that forward has finished, by ``check_input_bound()`` (waits) or by ``close_session()`` -- read features only
+        after one of them when the data's range is not known."""
         torch = _lib.require_gpu()
+        self._bound_check_poll()
         if isinstance(x, np.ndarray):
             self._check_bound(x)
             out = []
@@ -140,7 +197,9 @@ class TensorFlowInference:
                 xd = torch.from_numpy(np.ascontiguousarray(x[i:i + self.engine.max_batch], dtype=np.float32))
                 out.append(self.engine.forward(xd.to(self.engine.device), (OUT_FEATURES,))["features"].cpu().numpy())
             return np.concatenate(out) if out else np.zeros((0, self.feature_dim), np.float32)
-        return self.engine.forward(x, (OUT_FEATURES,))["features"]
+        out = self.engine.forward(x, (OUT_FEATURES,))["features"]
+        self._bound_check_queue()
+        return out
 
     def extract_images(self, imgs_u8):
         """Decoded RGB uint8 images [n,H,W,3] (same size; NumPy or CUDA) -> CUDA features [n,D]: the resize +
@@ -154,10 +213,10 @@ class TensorFlowInference:
                       device_preprocess: bool = True, workers: Optional[int] = None, stats: Optional[dict] = None) -> np.ndarray:
         """The loop of facerec_test.py:394 with the per-image sess.run replaced by batched forwards.
 
-        device_preprocess (default): a PIPELINE -- `workers` host threads decode the files (PIL releases the GIL inside its
-        decoders; default: the cores this process may use, at most 32), decoded same-size images are packed into pinned
-        staging buffers, copied to the device on a copy stream (double-buffered) and resized + mean-subtracted + run through
-        the network on the compute stream while the next chunk decodes and uploads; features come back through pinned
+        device_preprocess (default): a PIPELINE -- `workers` decoder PROCESSES (decode_pool.py; default: the cores this
+        process may use, at most 32; started once per extractor) write the decoded pixels straight into shared page-locked
+        staging slots, two chunks ahead; the slot is copied to the device on a copy stream and resized + mean-subtracted +
+        run through the network on the compute stream while the next chunks decode; features come back through pinned
         memory.  The resize is integer arithmetic and a forward does not depend on how images are batched: results are
         bit-identical to the serial per-image path (tests/test_pipeline_gpu.py).
         crop_center or device_preprocess=False: the host does the reference's own preprocessing, image by image.
@@ -171,77 +230,97 @@ class TensorFlowInference:
             return np.concatenate(feats) if feats else np.zeros((0, self.feature_dim), np.float32)
         return self._extract_files_pipelined(list(paths), batch, workers, stats)
 
+    def _get_decode_pool(self, workers: Optional[int]):
+        from .decode_pool import DecodePool, default_workers
+        workers = int(workers or default_workers())
+        pool = getattr(self, "_decode_pool", None)
+        if pool is not None and pool.workers != workers:
+            pool.close()
+            pool = None
+        if pool is None:
+            # one flat byte pool per slot, sized by capacity (256 KiB per image of the largest batch: a 295x295 RGB photo;
+            # larger ones spill through the result queue), never one buffer per (H, W)
+            pool = self._decode_pool = DecodePool(workers, slot_bytes=max(8 << 20, self.engine.max_batch * (256 << 10)), slots=3)
+        return pool
+
     def _extract_files_pipelined(self, paths: List[str], batch: int, workers: Optional[int], stats: Optional[dict]) -> np.ndarray:
         import time
-        from concurrent.futures import ThreadPoolExecutor
         from . import preprocess_device
         torch = _lib.require_gpu()
         n = len(paths)
-        out_host = torch.empty((n, self.feature_dim), dtype=torch.float32).pin_memory() if n else torch.empty((0, self.feature_dim))
         if n == 0:
-            return out_host.numpy()
-        if workers is None:
-            try:
-                workers = len(os.sched_getaffinity(0))
-            except AttributeError:
-                workers = os.cpu_count() or 1
-            workers = max(1, min(workers, 32))
+            return np.zeros((0, self.feature_dim), np.float32)
+        out_host = torch.empty((n, self.feature_dim), dtype=torch.float32).pin_memory()
         dev = self.engine.device
         t0 = time.perf_counter()
+        pool = self._get_decode_pool(workers)
+        staging = pool.tensor()
         chunks = [(i, min(i + batch, n)) for i in range(0, n, batch)]
-        with torch.cuda.device(dev), ThreadPoolExecutor(max_workers=workers) as pool:
+        LOOK = pool.slots - 1                                 # chunks decoding ahead of the one being uploaded
+        uploaded = [None] * pool.slots                        # event: the copy stream has read staging slot k
+        with torch.cuda.device(dev):
             compute = torch.cuda.current_stream(dev)
             copy = torch.cuda.Stream(device=dev)
-            LOOK = 2                                          # chunks decoding ahead of the one on the GPU
-            futs = {}
 
             def submit(ci):
-                if ci < len(chunks) and ci not in futs:
+                if ci < len(chunks):
+                    slot = ci % pool.slots
+                    if uploaded[slot] is not None:
+                        uploaded[slot].synchronize()          # (chunk ci - slots: long done) the slot's bytes are free again
                     lo, hi = chunks[ci]
-                    futs[ci] = [pool.submit(preprocess.imread_rgb, p) for p in paths[lo:hi]]
-            for ci in range(min(LOOK, len(chunks))):
-                submit(ci)
-            staging = {}                                      # (slot, H, W) -> pinned uint8 buffer [batch, H, W, 3]
-            slot_done = [None, None]                          # event: the GPU has consumed staging slot k
-            for ci, (lo, hi) in enumerate(chunks):
-                submit(ci + LOOK)
-                imgs = [f.result() for f in futs.pop(ci)]
-                slot = ci & 1
-                if slot_done[slot] is not None:
-                    slot_done[slot].synchronize()             # its uploads have been consumed: the pinned buffers are free
-                groups = {}
-                for j, im in enumerate(imgs):
-                    groups.setdefault(im.shape[:2], []).append(j)
-                for (H, W), idx in groups.items():
-                    key = (slot, H, W)
-                    buf = staging.get(key)
-                    if buf is None:
-                        buf = staging[key] = torch.empty((batch, H, W, 3), dtype=torch.uint8).pin_memory()
-                    hb = buf.numpy()
-                    for k, j in enumerate(idx):
-                        hb[k] = imgs[j]
+                    pool.submit(ci, paths[lo:hi], slot)
+            try:
+                for ci in range(min(LOOK, len(chunks))):
+                    submit(ci)
+                for ci, (lo, hi) in enumerate(chunks):
+                    metas = pool.collect(ci)                  # [(position, (offset, H, W) | None, spilled array | None)]
+                    groups = {}                               # (H, W) -> positions, in file order
+                    for pos, m, sp in metas:
+                        groups.setdefault((m[1], m[2]) if m is not None else sp.shape[:2], []).append(pos)
+                    meta_of = {pos: (m, sp) for pos, m, sp in metas}
+                    pending = []
                     with torch.cuda.stream(copy):
-                        d_u8 = buf[:len(idx)].to(dev, non_blocking=True)
+                        for (H, W), idx in groups.items():
+                            nb = H * W * 3
+                            d_u8 = torch.empty((len(idx), H, W, 3), dtype=torch.uint8, device=dev)
+                            flat = d_u8.view(-1)
+                            k = 0
+                            while k < len(idx):               # runs of images that are consecutive in staging too -> ONE copy each
+                                m, sp = meta_of[idx[k]]
+                                if m is None:                 # did not fit its task's region: came back through the queue
+                                    flat[k * nb:(k + 1) * nb].copy_(torch.from_numpy(np.ascontiguousarray(sp)).view(-1))
+                                    k += 1
+                                    continue
+                                r = k + 1
+                                while r < len(idx) and meta_of[idx[r]][0] is not None and meta_of[idx[r]][0][0] == m[0] + (r - k) * nb:
+                                    r += 1
+                                flat[k * nb:r * nb].copy_(staging[m[0]:m[0] + (r - k) * nb], non_blocking=True)
+                                k = r
+                            pending.append((idx, d_u8))
                         up = torch.cuda.Event()
                         up.record(copy)
+                    uploaded[ci % pool.slots] = up
                     compute.wait_event(up)
-                    d_u8.record_stream(compute)
-                    x = preprocess_device.preprocess_pil(d_u8, (self.w, self.h), self.convert2BGR, self.imageNetUtilsMean)
-                    f = self.engine.forward(x, (OUT_FEATURES,))["features"]
-                    rows = torch.as_tensor(idx, dtype=torch.int64) + lo
-                    if len(idx) == hi - lo:                   # the usual case: one size per chunk -> one contiguous copy back
-                        out_host[lo:hi].copy_(f, non_blocking=True)
-                    else:
-                        tmp = f.cpu()
-                        out_host[rows] = tmp
-                ev = torch.cuda.Event()
-                ev.record(compute)
-                slot_done[slot] = ev
-            compute.synchronize()
+                    for idx, d_u8 in pending:
+                        d_u8.record_stream(compute)
+                        x = preprocess_device.preprocess_pil(d_u8, (self.w, self.h), self.convert2BGR, self.imageNetUtilsMean)
+                        f = self.engine.forward(x, (OUT_FEATURES,))["features"]
+                        if len(idx) == hi - lo:               # the usual case: one size per chunk -> one contiguous copy back
+                            out_host[lo:hi].copy_(f, non_blocking=True)
+                        else:
+                            out_host[torch.as_tensor(idx, dtype=torch.int64) + lo] = f.cpu()
+                    submit(ci + LOOK)
+                compute.synchronize()
+            except BaseException:
+                # leave no half-collected chunk behind: the pool is cheap to restart, stale results are not worth tracking
+                pool.close()
+                self._decode_pool = None
+                raise
         if stats is not None:
             stats["seconds"] = time.perf_counter() - t0
             stats["chunks"] = len(chunks)
-            stats["workers"] = workers
+            stats["workers"] = pool.workers
+            stats["pinned_staging"] = pool.pinned
         return out_host.numpy().copy()
 
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define HSEFR_VERSION 100 /* 0.1.0 */
+#define HSEFR_VERSION 110 /* 0.1.1: round-3 ABI (exports added/removed since 100, plan-op `reserved` carries more; see git log) */
 
 typedef enum hsefr_status {
     HSEFR_OK = 0,
@@ -196,13 +196,18 @@ int hsefr_engine_max_batch(const hsefr_engine* e);
 /* One pass of the hot path over `n` preprocessed images (d_input: [n,in_h,in_w,in_c] fp32 NHWC,
  * BGR mean-subtracted exactly as facerec_test.py:95-106 leaves it).  Any output pointer may be
  * NULL; a non-NULL pointer for an output the plan does not produce is HSEFR_ERR_INVALID.
- * d_features [n,D] fp32, d_age_probs [n,100] fp32, d_gender [n,1] fp32.
+ * d_features [n,D] fp32, d_age_probs [n,100] fp32, d_gender [n,1] fp32.  A 16-byte-aligned output pointer is written IN
+ * PLACE by the kernel that produces it (no copy; the engine's own buffer of that output is then not written by this
+ * forward); any other alignment is served by a device-to-device copy out of the engine's buffer.
  * Replaces tf_sess.run (facerec_test.py:120; facial_analysis.py:109). */
 int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_features,
                          void* d_age_probs, void* d_gender, hsefr_stream_t stream);
 
-/* Device pointer of an intermediate activation buffer (valid until the next forward);
- * used by the per-layer parity tests.  NULL if `buffer` is out of range. */
+/* Device pointer of an intermediate activation buffer (contents valid until the next forward); used by the per-layer
+ * parity tests.  NULL if `buffer` is out of range.  NOT for the buffers behind the plan's OUTPUT slots: a forward that
+ * was given an aligned output pointer writes that tensor into the caller's memory instead, and the engine's buffer keeps
+ * whatever an earlier forward left there (run the forward with all three output pointers NULL to have every op write the
+ * engine's own buffers -- what Engine.forward_all_layers does). */
 void* hsefr_engine_buffer(hsefr_engine* e, int buffer);
 /* Asynchronous device-to-device copy of the first `bytes` of an activation buffer into d_dst. */
 int hsefr_engine_copy_buffer(hsefr_engine* e, int buffer, void* d_dst, size_t bytes, hsefr_stream_t stream);

@@ -149,12 +149,16 @@ def generate_bounding_box(imap, reg, scale, t):               # :369-396
     return np.hstack([q1, q2, score[:, None], reg]), reg
 
 
-def nms(boxes, threshold, method):                            # :398-431
+def nms(boxes, threshold, method, argsort=np.argsort):        # :398-431
+    """``argsort``: the reference calls np.argsort(s).  Its order among EQUAL scores is whatever the installed NumPy does:
+    the NumPy of the reference's time (<= 1.24) finishes lists of <= 16 elements with a stable insertion sort (ascending index
+    among ties), NumPy >= 1.25 on AVX-512/AVX2 hosts uses a SIMD sort with another tie order.  Tests that pin the tie rule
+    pass ``lambda s: np.argsort(s, kind="stable")`` = the old behaviour on the list sizes that occur."""
     if boxes.size == 0:
         return np.empty((0, 3))
     x1, y1, x2, y2, s = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3], boxes[:, 4]
     area = (x2 - x1 + 1) * (y2 - y1 + 1)
-    order = np.argsort(s)
+    order = argsort(s)
     pick = []
     while order.size > 0:
         i = order[-1]

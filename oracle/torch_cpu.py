@@ -136,3 +136,108 @@ def time_reference_loop(graph_path: str, output_tensor: str, x_nhwc: np.ndarray,
         if el >= budget_s:
             break
     return done / el, done
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The same graph FUSED for the CPU: what a tuned CPU deployment of this network would run --
+# per-channel scales folded into the kernels, bias added by the convolution, Relu -> Minimum(6) -> Maximum(0) as ONE
+# in-place clamp, channels_last throughout.  Built by walking the chain of the frozen graph (MobileNet is a chain), not
+# by importing anything from the product.  Reported NEXT TO the op-by-op figure in bench.py, both kind "port".
+# ----------------------------------------------------------------------------------------------------------------
+class FusedChainCPU:
+    def __init__(self, graph_path: str, output_tensor: str, input_tensor: str = "input_1:0"):
+        g = TorchGraphOracle(graph_path)
+        out_name, in_name = output_tensor.split(":")[0], input_tensor.split(":")[0]
+        chain, cur = [], g.nodes[out_name]
+        while cur.name != in_name:
+            chain.append(cur)
+            cur = g.nodes[cur.inputs[0].split(":")[0].lstrip("^")]
+        chain.reverse()
+
+        def const(ref):
+            v = g.run(ref, {})
+            return np.asarray(v.numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
+        self.stages = []
+        i = 0
+        while i < len(chain):
+            nd = chain[i]
+            if nd.op in ("Conv2D", "DepthwiseConv2dNative"):
+                k = const(nd.inputs[1])
+                s = nd.attr["strides"].list_i
+                dw = nd.op != "Conv2D"
+                w = k.transpose(2, 3, 0, 1) if dw else k.transpose(3, 2, 0, 1)          # -> [O, I/groups, kh, kw]
+                w = np.ascontiguousarray(w).astype(np.float32)
+                bias = np.zeros(w.shape[0], np.float32)
+                same = nd.attr["padding"].s == b"SAME"
+                i += 1
+                clamp = False
+                while i < len(chain) and chain[i].op in ("Mul", "Add", "AddV2", "BiasAdd", "Relu", "Minimum", "Maximum", "Relu6"):
+                    f = chain[i]
+                    if f.op == "Mul":
+                        sc = const(f.inputs[1]).reshape(-1)
+                        w *= sc[:, None, None, None]
+                        bias *= sc
+                    elif f.op in ("Add", "AddV2", "BiasAdd"):
+                        bias += const(f.inputs[1]).reshape(-1)
+                    elif f.op == "Minimum":
+                        assert float(const(f.inputs[1]).reshape(-1)[0]) == 6.0
+                        clamp = True
+                    elif f.op == "Maximum":
+                        assert float(const(f.inputs[1]).reshape(-1)[0]) == 0.0
+                    elif f.op == "Relu6":
+                        clamp = True
+                    i += 1
+                wt = torch.from_numpy(w)
+                if not dw:
+                    wt = wt.contiguous(memory_format=torch.channels_last)
+                self.stages.append(("conv", wt, torch.from_numpy(bias), (int(s[1]), int(s[2])), same, w.shape[0] if dw else 1,
+                                    (w.shape[2], w.shape[3]), clamp))
+                continue
+            if nd.op == "Mean":
+                axes = [int(a) for a in const(nd.inputs[1]).reshape(-1)]
+                self.stages.append(("mean", axes))
+            elif nd.op in ("Reshape", "Identity"):
+                pass
+            else:
+                raise NotImplementedError("fused CPU chain: op %r" % nd.op)
+            i += 1
+
+    def run(self, x_nhwc: np.ndarray) -> np.ndarray:
+        with torch.no_grad():
+            x = torch.from_numpy(np.ascontiguousarray(x_nhwc, dtype=np.float32)).permute(0, 3, 1, 2)   # channels_last view
+            for st in self.stages:
+                if st[0] == "conv":
+                    _, w, b, stride, same, groups, (kh, kw), clamp = st
+                    if same:
+                        _, pt, pb = same_pad(x.shape[2], kh, stride[0])
+                        _, pl, pr = same_pad(x.shape[3], kw, stride[1])
+                        if pt == pb and pl == pr:
+                            x = F.conv2d(x, w, b, stride=stride, padding=(pt, pl), groups=groups)
+                        else:
+                            x = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, b, stride=stride, groups=groups)
+                    else:
+                        x = F.conv2d(x, w, b, stride=stride, groups=groups)
+                    if clamp:
+                        x = x.clamp_(0.0, 6.0)
+                else:
+                    x = x.mean(dim=[{0: 0, 1: 2, 2: 3, 3: 1}[a] for a in st[1]])          # NHWC axes -> NCHW dims
+            return x.reshape(x.shape[0], -1).numpy()
+
+
+def time_fused_loop(graph_path: str, output_tensor: str, x_nhwc: np.ndarray, threads: int, budget_s: float = 10.0, batch: int = 1):
+    """time_reference_loop for the fused chain: (faces_per_s, n_images_timed)."""
+    import time
+    torch.set_num_threads(threads)
+    m = FusedChainCPU(graph_path, output_tensor)
+    m.run(x_nhwc[:batch])
+    m.run(x_nhwc[:batch])
+    done, i, t0 = 0, 0, time.perf_counter()
+    while True:
+        lo = (i * batch) % max(1, x_nhwc.shape[0] - batch + 1)
+        m.run(x_nhwc[lo:lo + batch])
+        done += batch
+        i += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return done / el, done

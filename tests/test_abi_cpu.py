@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libhsefr.so does not export %s" % name
     # and the binding table covers the header one-to-one
     assert sorted(_lib.SIGNATURES) == declared_functions()
-    assert L.hsefr_version() == 100
+    assert L.hsefr_version() == 110
 
 
 def test_code_object_targets_gfx950_only():
@@ -138,3 +138,41 @@ def test_product_library_exports_the_documented_surface_only():
     assert [x for x in syms if "debug" in x] == []
     extra = [x for x in syms if x not in declared_functions() and not x.startswith(("_init", "_fini"))]
     assert extra == [], extra
+
+
+def test_plan_validation_guards_the_in_place_outputs():
+    """forward() lets the producing kernel write the caller's [n, out_elems] tensor in place of the plan's output
+    buffer, so engine_create must reject a plan whose output buffer has two producers or another size (validated before any
+    device is touched)."""
+    import copy
+    from conftest import MODEL_PB
+    from hse_facerec_tf_amd import _lib, graphdef, lowering
+    L = _lib.lib()
+    plan = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0", {0: "global_pooling/Mean:0", 1: "age_pred/Softmax:0",
+                                                                             2: "gender_pred/Sigmoid:0"}, (96, 96))
+
+    def create(p):
+        blob = p.serialize()
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        h = ctypes.c_void_p()
+        rc = L.hsefr_engine_create(ctypes.cast(buf, ctypes.c_void_p), len(blob), 2, ctypes.byref(h))
+        if rc == 0:
+            L.hsefr_engine_destroy(h)
+        return rc, _lib.last_error()
+    out_layer = plan.outputs[0][0]
+    out_buf = plan.layers[out_layer].out_buf
+    # (a) a second op writing the output buffer
+    bad = copy.deepcopy(plan)
+    victim = next(i for i, l in enumerate(bad.layers) if i != out_layer and l.out_buf != out_buf
+                  and l.out_bytes <= bad.buffers[out_buf])
+    bad.layers[victim].out_buf = out_buf
+    rc, msg = create(bad)
+    assert rc == _lib.ERR_INVALID and "producing ops" in msg, (rc, msg)
+    # (b) a slot that declares fewer elements than its buffer holds
+    bad = copy.deepcopy(plan)
+    bad.outputs[0] = (out_layer, plan.outputs[0][1] // 2)
+    rc, msg = create(bad)
+    assert rc == _lib.ERR_INVALID and "the slot declares" in msg, (rc, msg)
+    # the untouched plan passes validation (and then fails, or not, only for lack of a GPU)
+    rc, msg = create(plan)
+    assert rc == 0 or "producing ops" not in msg and "the slot declares" not in msg

@@ -53,6 +53,10 @@ def test_bench_line_contract_and_small_config5():
     dw = line["roofline_depthwise"]
     assert "STANDALONE" in dw["covers"] and len(dw["inside_fused_kernels"]) >= 1
     _check_config5(line["config5"], 700, 1)
+    assert abs(line["config5"]["unaccounted_ms"]) < 0.25 * line["config5"]["total_ms"]
+    lat = line["latency_batch1"]
+    assert "error" not in lat and lat["age_gender_fun"]["median_ms"] > 0 and lat["extract_features"]["median_ms"] > 0
+    assert lat["reference_published"]["age_gender_fun_ms"] == 4.97 and lat["mtcnn_process_image"]["faces"] == 4
 
 
 def test_bench_two_self_launched_ranks_share_the_gpu_over_gloo():

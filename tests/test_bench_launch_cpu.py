@@ -27,6 +27,15 @@ def test_bench_self_launches_its_ranks():
     assert line == {"dry_run": True, "n_gpus": 2, "gathered_first_column": [0.0, 0.0, 1.0, 1.0], "self_launched": True}
 
 
+def test_a_failing_rank_fails_the_self_launched_job_with_its_stderr():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSEFR_BENCH_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "rank 1: injected failure" in r.stderr and "the launched job failed" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]          # no JSON line from a failed job
+
+
 def test_bench_prelaunched_by_torchrun_does_not_relaunch():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",

@@ -1,0 +1,81 @@
+"""CPU suite: the decoder-process pool behind extract_files (decode_pool.py) -- same pixels as the serial
+``preprocess.imread_rgb`` (misc.imread(mode='RGB'), facerec_test.py:83), packing, spills, error propagation, clean shutdown."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from hse_facerec_tf_amd import preprocess
+from hse_facerec_tf_amd.decode_pool import DecodePool
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("imgs")
+    rs = np.random.RandomState(11)
+    paths = []
+    for i in range(37):
+        hw = (90, 70) if i % 5 else (64, 128)
+        mode_gray = (i == 9)                                     # a grayscale file: convert('RGB') must triple it
+        a = rs.randint(0, 256, hw if mode_gray else hw + (3,), dtype=np.uint8)
+        p = str(d / ("%02d.%s" % (i, "png" if i % 2 else "jpg")))
+        Image.fromarray(a).save(p)
+        paths.append(p)
+    return paths
+
+
+def _pixels(pool, m, sp):
+    if m is None:
+        return sp
+    buf = np.frombuffer(pool._shm.buf, dtype=np.uint8)
+    return buf[m[0]:m[0] + m[1] * m[2] * 3].reshape(m[1], m[2], 3).copy()
+
+
+def test_pool_decodes_what_imread_rgb_decodes_and_packs_back_to_back(files):
+    pool = DecodePool(2, slot_bytes=4 << 20, slots=2, task_files=8)
+    try:
+        pool.submit("a", files, 0)
+        pool.submit("b", files[::-1], 1)                         # two chunks in flight, collected out of order
+        rb = pool.collect("b")
+        ra = pool.collect("a")
+        for res, paths, slot in ((ra, files, 0), (rb, files[::-1], 1)):
+            assert [pos for pos, _, _ in res] == list(range(len(paths)))
+            for pos, m, sp in res:
+                assert m is not None and slot * (4 << 20) <= m[0] < (slot + 1) * (4 << 20)
+                assert np.array_equal(_pixels(pool, m, sp), preprocess.imread_rgb(paths[pos])), paths[pos]
+            # inside a task (8 files) the images are contiguous: a same-size run is ONE upload
+            for t in range(0, len(paths), 8):
+                offs = [res[k][1] for k in range(t, min(t + 8, len(paths)))]
+                for (o0, h0, w0), (o1, _, _) in zip(offs, offs[1:]):
+                    assert o1 == o0 + h0 * w0 * 3
+    finally:
+        pool.close()
+    assert pool._shm is None
+
+
+def test_images_that_do_not_fit_come_back_through_the_queue_and_errors_propagate(files, tmp_path):
+    pool = DecodePool(2, slot_bytes=64 << 10, slots=1, task_files=8)       # 64 KiB per slot: most images spill
+    try:
+        pool.submit(0, files[:16], 0)
+        res = pool.collect(0)
+        assert sum(m is None for _, m, _ in res) > 0 and sum(m is not None for _, m, _ in res) > 0
+        for pos, m, sp in res:
+            assert np.array_equal(_pixels(pool, m, sp), preprocess.imread_rgb(files[pos]))
+        pool.submit(1, files[:3] + [str(tmp_path / "nope.jpg")], 0)
+        with pytest.raises(FileNotFoundError):
+            pool.collect(1)
+        bad = tmp_path / "broken.jpg"
+        bad.write_bytes(b"not an image")
+        pool.submit(2, [str(bad)], 0)
+        with pytest.raises(Exception) as ei:
+            pool.collect(2)
+        try:
+            preprocess.imread_rgb(str(bad))
+        except Exception as e:
+            assert type(ei.value).__name__ in (type(e).__name__, "RuntimeError")
+        pool.submit(3, files[:5], 0)                                        # still alive after errors
+        assert len(pool.collect(3)) == 5
+    finally:
+        pool.close()
+    pool.close()                                                            # idempotent

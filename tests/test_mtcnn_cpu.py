@@ -38,6 +38,23 @@ def test_box_utilities_match_reference_semantics(seed):
     assert pm._iou_suppress(np.empty((0, 9)), 0.5, False).size == 0
 
 
+@pytest.mark.parametrize("n", [2, 5, 9, 16])
+def test_nms_score_ties_follow_the_references_own_argsort(n):
+    """bit-equal scores (softmax saturated to 1.0f).  The reference calls np.argsort(s) and picks I[-1]; on lists of
+    <= 16 elements (the usual R-/O-Net list) the NumPy of the reference's time sorts with a stable insertion sort, so the
+    HIGHEST index among equals goes first (NumPy >= 1.25 with SIMD sorts orders ties differently: oracle.mtcnn.nms takes the
+    argsort to use).  The product's rule -- descending index among ties, for every list size -- must reproduce that."""
+    old_numpy_argsort = lambda s: np.argsort(s, kind="stable")
+    rs = np.random.RandomState(n)
+    for trial in range(20):
+        b = random_boxes(rs, n, 200, 200)
+        b[:, 4] = np.float32(1.0)                                  # every score equal
+        if trial % 2:
+            b[rs.randint(0, n), 4] = np.float32(0.99)              # ... or all but one
+        for thr, method, use_min in ((0.5, 'Union', False), (0.7, 'Min', True)):
+            assert list(pm._iou_suppress(b, thr, use_min)) == list(om.nms(b.copy(), thr, method, argsort=old_numpy_argsort))
+
+
 @pytest.mark.parametrize("H,W,dh,dw,dt", [(588, 784, 221, 294, np.uint8), (100, 90, 24, 24, np.float64), (30, 41, 24, 24, np.float64),
                                           (20, 20, 24, 24, np.float64), (20, 30, 24, 24, np.uint8), (96, 96, 48, 48, np.uint8),
                                           (96, 64, 32, 32, np.uint8), (60, 60, 20, 20, np.float64), (48, 48, 48, 48, np.float64)])

@@ -48,20 +48,65 @@ def test_pipelined_extract_files_is_bit_identical_to_the_serial_path(jpegs):
 
 
 def test_pipeline_keeps_up_with_the_decoders(jpegs):
-    """Files-inclusive throughput is bounded by the host's JPEG decoders; the pipeline must stay within 2x of the aggregate
-    decode rate of the same thread pool (the GPU side is two orders of magnitude faster)."""
-    from concurrent.futures import ThreadPoolExecutor
-    from hse_facerec_tf_amd import TensorFlowInference, preprocess
+    """Files-inclusive throughput is bounded by the host's JPEG decoders; the pipeline must stay within 2x of the decode-only
+    time of the same pool of decoder processes (the GPU side is two orders of magnitude faster)."""
+    from hse_facerec_tf_amd import TensorFlowInference
+    from hse_facerec_tf_amd.decode_pool import DecodePool, default_workers
     paths = jpegs * 4
-    workers = max(1, min(len(os.sched_getaffinity(0)), 32))
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        list(pool.map(preprocess.imread_rgb, paths[:64]))
+    pool = DecodePool(default_workers(), slot_bytes=64 << 20, slots=3)
+    try:
+        pool.submit(-1, paths[:64], 0)
+        pool.collect(-1)
+        chunks = [paths[i:i + 256] for i in range(0, len(paths), 256)]
         t0 = time.perf_counter()
-        list(pool.map(preprocess.imread_rgb, paths))
+        for ci, ch in enumerate(chunks):
+            pool.submit(ci, ch, ci % 3)
+            if ci >= 2:
+                pool.collect(ci - 2)
+        for ci in range(max(0, len(chunks) - 2), len(chunks)):
+            pool.collect(ci)
         t_dec = time.perf_counter() - t0
+    finally:
+        pool.close()
     tfi = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(192, 192), max_batch=256)
-    tfi.extract_files(paths[:256], batch=256)          # warm-up
+    tfi.extract_files(paths[:256], batch=256)          # warm-up (starts the extractor's decoder processes)
     st = {}
     tfi.extract_files(paths, batch=256, stats=st)
     tfi.close_session()
     assert st["seconds"] < 2.0 * t_dec + 0.25, (st, t_dec)
+
+
+def test_decoder_errors_and_oversized_images_through_the_pool(tmp_path):
+    """A missing file raises what the serial path raises; an image larger than its staging share comes back through the
+    result queue and gives the same features; the CUDA-tensor bound check of extract_batch raises at the next sync point."""
+    import torch
+    from PIL import Image
+    from hse_facerec_tf_amd import TensorFlowInference
+    rs = np.random.RandomState(3)
+    paths = []
+    for i in range(20):
+        hw = (1700, 1700) if i in (4, 11) else (120, 100)        # 8.7 MB decoded: over this pool's 8 MiB slot -> spills
+        p = str(tmp_path / ("%02d.png" % i))
+        Image.fromarray(rs.randint(0, 256, hw + (3,), dtype=np.uint8)).save(p)
+        paths.append(p)
+    tfi = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(96, 96), max_batch=8)
+    X = tfi.extract_files(paths, batch=8, workers=2)
+    for i in (0, 4, 11, 19):
+        assert np.array_equal(tfi.extract_features(paths[i]), X[i]), i
+    with pytest.raises(FileNotFoundError):
+        tfi.extract_files(paths[:3] + [str(tmp_path / "missing.jpg")] + paths[3:], batch=8, workers=2)
+    assert np.array_equal(tfi.extract_files(paths, batch=8, workers=2), X)     # the pool restarts after an error
+    # ---- ADVICE r2: extract_batch on a CUDA tensor outside input_bound must not return garbage silently
+    x = torch.zeros((2, 96, 96, 3), device="cuda")
+    tfi.extract_batch(x)
+    tfi.check_input_bound()                                      # in range: nothing raised
+    x[1, 5, 5, 1] = 300.0
+    tfi.extract_batch(x)
+    with pytest.raises(ValueError, match="outside the bound"):
+        tfi.check_input_bound()
+    tfi.extract_batch(x)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="outside the bound"):
+        tfi.extract_batch(torch.zeros((1, 96, 96, 3), device="cuda"))   # the next call into the object raises
+    tfi.check_input_bound()                                      # ... once
+    tfi.close_session()
