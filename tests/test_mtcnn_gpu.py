@@ -83,11 +83,11 @@ def test_device_pyramid_levels_are_the_host_restatement(det):
     from hse_facerec_tf_amd import preprocess
     img = opl.imread_rgb(TEST_IMAGE)
     h, w = img.shape[:2]
-    det._frame = torch.from_numpy(np.ascontiguousarray(img)).to(det.device)
+    frame = torch.from_numpy(np.ascontiguousarray(img)).to(det.device)
     sizes = [(int(np.ceil(h * s)), int(np.ceil(w * s))) for s in det.pyramid_scales(h, w)]
     sizes += [(h // 2, w // 2), (h // 3, w // 3 + (1 if w % 3 else 0)), (h, w), (h + 40, w + 25), (h // 2, w + 10)]
     for hs, ws in sizes:
-        got = det._level_device(h, w, hs, ws)[0].cpu().numpy()
+        got = det._level_device(frame, h, w, hs, ws)[0].cpu().numpy()
         want = np.transpose((preprocess.resize_area(img, ws, hs) - 127.5) * 0.0078125, (1, 0, 2)).astype(np.float32)
         assert got.shape == want.shape == (ws, hs, 3)
         diff = np.abs(got - want)
@@ -110,8 +110,8 @@ def test_device_crops_match_the_host_restatement(det):
     boxes = np.asarray(boxes, np.float64)
     for size in (24, 48):
         det.device_resize = True
-        det._frame = torch.from_numpy(np.ascontiguousarray(img)).to(det.device)
-        got = det._crops(img, boxes, size).cpu().numpy()
+        frame = torch.from_numpy(np.ascontiguousarray(img)).to(det.device)
+        got = det._crops(img, boxes, size, frame).cpu().numpy()
         det.device_resize = False
         want = det._crops(img, boxes, size).cpu().numpy()
         det.device_resize = True
