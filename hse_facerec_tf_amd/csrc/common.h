@@ -219,6 +219,11 @@ int launch_stem3_fused(const float* x, const void* cw_split, const float* cdesca
                        int cpad_t, int cpad_l, int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int in_log2, int a_log2,
                        int act, hipStream_t s);
 bool stem3_fused_supported(int cin, int c1, int c2, int conv_stride, int dw1_stride, int dw2_stride, int kh, int kw);
+int launch_stem4_fused(const void* x, int x_is_u8, const void* cw4, const float* cdescale, const float* cshift, const float* wd1,
+                       const float* d1scale, const float* d1shift, const void* wsplit, const float* descale, const float* pshift,
+                       const float* wd2, const float* d2scale, const float* d2shift, float* y, int* overflow, int n, int h, int w,
+                       int in_log2, int a_log2, int act, hipStream_t s);
+bool stem4_fused_supported(int cin, int c1, int c2, int conv_stride, int dw1_stride, int dw2_stride, int kh, int kw, int h, int w);
 bool stem2_fused_supported(int cin, int c1, int c2, int conv_stride, int dw1_stride, int dw2_stride, int kh, int kw);
 bool stem_fused_supported(int cin, int cmid, int cout, int conv_stride, int dw_stride, int kh, int kw);
 int read_pws_stamps(void* host_out, size_t bytes);

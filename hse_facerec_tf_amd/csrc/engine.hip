@@ -174,9 +174,9 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                 break;
             case HSEFR_OP_STEM3_F16S:
                 HSEFR_REQUIRE(stem3_fused_supported(o.cin, 32, o.cout, o.stride, 1, 2, o.kh, o.kw & 15) && (o.reserved & 255) > 0 &&
-                                  (o.reserved & 255) <= 12 && (o.reserved >> 8) >= 64 - 8 && (o.reserved >> 8) <= 64 + 14 &&
+                                  (o.reserved & 255) <= 12 && ((o.reserved >> 8) & 255) >= 64 - 8 && ((o.reserved >> 8) & 255) <= 64 + 14 &&
                                   o.w_off != HSEFR_NO_OFFSET && o.w2_off != HSEFR_NO_OFFSET && o.shift2_off != HSEFR_NO_OFFSET &&
-                                  o.w_off + 3008 * 4 <= h.blob_bytes && o.w2_off + 64 * 128 <= h.blob_bytes &&
+                                  o.w_off + 7264 * 4 <= h.blob_bytes && o.w2_off + 64 * 128 <= h.blob_bytes &&
                                   o.shift2_off + 128 * 4 <= h.blob_bytes && o.in_buf == HSEFR_BUF_INPUT,
                               HSEFR_ERR_UNSUPPORTED, "plan op %u: bounded fused stem cin=%d cout=%d stride=%d not covered", i, o.cin, o.cout, o.stride);
                 break;
@@ -258,6 +258,7 @@ int sweep_reverse() { return g_sweep_reverse; }
 void set_sweep_reverse(int v) { g_sweep_reverse = v; }
 }  // namespace hsefr
 HSEFR_KNOB(g_sweep_alternate, 1);   // dev builds: 0 turns the alternation off (A/B timing)
+HSEFR_KNOB(g_stem4, 1);             // dev builds: 0 = stem3_fused.hip also where stem4_fused.hip covers the shape (A/B timing)
 
 #pragma GCC visibility push(default)   // the library is built with -fvisibility=hidden: the C ABI below is ALL it exports
 extern "C" {
@@ -415,7 +416,7 @@ int hsefr_engine_op_times_ms(hsefr_engine* e, int slot, float* ms, int n_ops) {
 
 // Launch the needed ops of the plan for a batch of n on stream s (plain launches: also what a graph capture records).
 static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d_input, int n, const std::vector<char>& needed,
-                   hipStream_t s, hipEvent_t* pev) {
+                   hipStream_t s, hipEvent_t* pev, bool input_u8 = false) {
     const bool prof = pev != nullptr;
     if (prof) HSEFR_HIP_CHECK(hipEventRecord(pev[0], s));
     for (size_t i = 0; i < e->ops.size(); ++i) {
@@ -517,10 +518,25 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                 const float* pk = (const float*)blob_ptr(e, o.w_off);
                 const float* ds2 = (const float*)blob_ptr(e, o.shift2_off);
                 const int h1 = (o.h + 1) / 2, w1 = (o.w + 1) / 2;
+                // pack: [0, 1952) the fp32 constants of stem2, [1952, 3008) conv1 split rows + descale for stem3_fused.hip,
+                // [3008, 5056) conv1 in the two-step K layout of stem4_fused.hip, [5056, 7104) the same channel-reversed for uint8
+                // RGB input, [7104, 7232) its four mean-folded shift vectors, [7232, 7264) its descale
+                if (input_u8) {
+                    rc = launch_stem4_fused(in, 1, pk + 5056, pk + 7232, pk + 7104, pk + 896, pk + 1184, pk + 1216, blob_ptr(e, o.w2_off), ds2,
+                                            ds2 + 64, pk + 1248, pk + 1824, pk + 1888, (float*)out, nullptr, n, o.h, o.w, 0, o.reserved & 255,
+                                            o.act, s);
+                    break;
+                }
+                if (g_stem4 && stem4_fused_supported(o.cin, 32, o.cout, o.stride, 1, 2, o.kh, o.kw & 15, o.h, o.w)) {
+                    rc = launch_stem4_fused(in, 0, pk + 3008, pk + 1952 + 1024, pk + 864, pk + 896, pk + 1184, pk + 1216, blob_ptr(e, o.w2_off),
+                                            ds2, ds2 + 64, pk + 1248, pk + 1824, pk + 1888, (float*)out, e->d_overflow, n, o.h, o.w,
+                                            ((o.reserved >> 8) & 255) - 64, o.reserved & 255, o.act, s);
+                    break;
+                }
                 rc = launch_stem3_fused((const float*)in, pk + 1952, pk + 1952 + 1024, pk + 864, pk + 896, pk + 1184, pk + 1216,
                                         blob_ptr(e, o.w2_off), ds2, ds2 + 64, pk + 1248, pk + 1824, pk + 1888, (float*)out, e->d_overflow, n,
                                         o.h, o.w, o.pad_t, o.pad_l, h1, w1, (o.kw >> 4) & 1, (o.kw >> 5) & 1, o.oh, o.ow,
-                                        (o.reserved >> 8) - 64, o.reserved & 255, o.act, s);
+                                        ((o.reserved >> 8) & 255) - 64, o.reserved & 255, o.act, s);
                 break;
             }
             case HSEFR_OP_STEM2_F16S: {
@@ -558,8 +574,32 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
     return HSEFR_OK;
 }
 
+static int engine_forward(hsefr_engine* e, const void* d_input, bool input_u8, int n, void* d_features, void* d_age_probs,
+                          void* d_gender, hsefr_stream_t stream);
+
 int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_features, void* d_age_probs,
                          void* d_gender, hsefr_stream_t stream) {
+    return engine_forward(e, d_input, false, n, d_features, d_age_probs, d_gender, stream);
+}
+
+int hsefr_engine_accepts_u8(const hsefr_engine* e) {
+    if (!e || e->ops.empty()) return 0;
+    const hsefr_plan_op& o = e->ops[0];
+    return o.kind == HSEFR_OP_STEM3_F16S && o.in_buf == HSEFR_BUF_INPUT && ((o.reserved >> 16) & 1) &&
+           stem4_fused_supported(o.cin, 32, o.cout, o.stride, 1, 2, o.kh, o.kw & 15, o.h, o.w);
+}
+
+int hsefr_engine_forward_u8(hsefr_engine* e, const void* d_input_u8, int n, void* d_features, void* d_age_probs,
+                            void* d_gender, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(e, HSEFR_ERR_INVALID, "forward_u8: null engine");
+    HSEFR_REQUIRE(hsefr_engine_accepts_u8(e), HSEFR_ERR_UNSUPPORTED,
+                  "forward_u8: this plan takes no uint8 input (it needs the fused stem lowered with a BGR mean and an input whose "
+                  "edges are multiples of 4)");
+    return engine_forward(e, d_input_u8, true, n, d_features, d_age_probs, d_gender, stream);
+}
+
+static int engine_forward(hsefr_engine* e, const void* d_input, bool input_u8, int n, void* d_features, void* d_age_probs,
+                          void* d_gender, hsefr_stream_t stream) {
     HSEFR_REQUIRE(e, HSEFR_ERR_INVALID, "forward: null engine");
     HSEFR_REQUIRE(d_input || n == 0, HSEFR_ERR_INVALID, "forward: null input");
     HSEFR_REQUIRE(n >= 0 && n <= e->max_batch, HSEFR_ERR_SHAPE, "forward: batch %d outside [0, %d]", n, e->max_batch);
@@ -590,7 +630,7 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
     }
     // ---- small batches: replay a captured graph (see hsefr_engine::graph_max_n) ----
     const int mask = (d_features ? 1 : 0) | (d_age_probs ? 2 : 0) | (d_gender ? 4 : 0);
-    if (!prof && mask != 0 && n <= e->graph_max_n && e->ops.size() > 0 && e->ops[0].in_buf == HSEFR_BUF_INPUT) {
+    if (!prof && !input_u8 && mask != 0 && n <= e->graph_max_n && e->ops.size() > 0 && e->ops[0].in_buf == HSEFR_BUF_INPUT) {
         const size_t in_bytes = (size_t)e->hdr.in_h * e->hdr.in_w * e->hdr.in_c * sizeof(float);
         if (!e->d_in_stage) {
             HSEFR_HIP_CHECK(hipMalloc(&e->d_in_stage, in_bytes * e->graph_max_n));
@@ -635,7 +675,7 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
         }
         for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl)                             // an unaligned slot ahead of an aligned one of the same buffer
             if (outs[sl] && src_of[sl] == e->d_bufs[e->hdr.out_buffer[sl]]) src_of[sl] = tab[e->hdr.out_buffer[sl]];
-        const int rc = run_ops(e, tab, d_input, n, needed, s, prof ? pev : nullptr);
+        const int rc = run_ops(e, tab, d_input, n, needed, s, prof ? pev : nullptr, input_u8);
         if (rc != HSEFR_OK) return rc;
         for (int sl = 0; sl < HSEFR_N_OUTPUT_SLOTS; ++sl)
             if (outs[sl] && src_of[sl])
@@ -758,6 +798,16 @@ int hsefr_stem3_fused(const float* x, const void* cw_split, const float* cdescal
                              d2scale && d2shift && y), HSEFR_ERR_INVALID, "stem3_fused: null pointer");
     return launch_stem3_fused(x, cw_split, cdescale, conv_shift, wd1, d1scale, d1shift, w_split, descale, pshift, wd2, d2scale, d2shift, y,
                               d_overflow, n, h, w, cpad_t, cpad_l, h1, w1, pad_t2, pad_l2, oh2, ow2, in_log2, a_log2, act, (hipStream_t)stream);
+}
+
+int hsefr_stem4_fused(const void* x, int x_is_u8, const void* cw4, const float* cdescale, const float* conv_shift, const float* wd1,
+                      const float* d1scale, const float* d1shift, const void* w_split, const float* descale, const float* pshift,
+                      const float* wd2, const float* d2scale, const float* d2shift, float* y, int* d_overflow, int n, int h, int w,
+                      int in_log2, int a_log2, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && cw4 && cdescale && conv_shift && wd1 && d1scale && d1shift && w_split && descale && pshift && wd2 &&
+                             d2scale && d2shift && y), HSEFR_ERR_INVALID, "stem4_fused: null pointer");
+    return launch_stem4_fused(x, x_is_u8, cw4, cdescale, conv_shift, wd1, d1scale, d1shift, w_split, descale, pshift, wd2, d2scale, d2shift, y,
+                              d_overflow, n, h, w, in_log2, a_log2, act, (hipStream_t)stream);
 }
 
 int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd, const float* dscale,

@@ -40,7 +40,9 @@ __global__ __launch_bounds__(256) void pil_resample_h_kernel(const unsigned char
 }
 
 // mode: 0 = BGR - mean in float64 then cast (facerec_test.py:95-106), 1 = RGB x/127.5 - 1 (:108-110),
-//       2 = BGR - mean in float32 (facial_analysis.py:101-107)
+//       2 = BGR - mean in float32 (facial_analysis.py:101-107), 3 = no colour step: `out` receives the resized RGB BYTES
+//       [n,oh,ow,3] (a quarter of the fp32 tensor) for hsefr_engine_forward_u8, whose first kernel folds conversion, reversal
+//       and mean into its window load
 __device__ __forceinline__ void emit(float* dst, int r, int g, int b, int mode, float m0, float m1, float m2, double d0, double d1,
                                      double d2) {
     if (mode == 0) {
@@ -81,7 +83,13 @@ __global__ __launch_bounds__(256) void pil_resample_v_kernel(const unsigned char
         s1 += p[1] * w;
         s2 += p[2] * w;
     }
-    emit(out + i * 3, min(max(s0 >> 22, 0), 255), min(max(s1 >> 22, 0), 255), min(max(s2 >> 22, 0), 255), mode, m0, m1, m2, d0, d1, d2);
+    const int r = min(max(s0 >> 22, 0), 255), g = min(max(s1 >> 22, 0), 255), b = min(max(s2 >> 22, 0), 255);
+    if (mode == 3) {       // the resized bytes themselves, RGB: the network's first kernel takes them as they are (stem4_fused.hip)
+        unsigned char* d = (unsigned char*)out + i * 3;
+        d[0] = (unsigned char)r; d[1] = (unsigned char)g; d[2] = (unsigned char)b;
+        return;
+    }
+    emit(out + i * 3, r, g, b, mode, m0, m1, m2, d0, d1, d2);
 }
 
 // cv2.resize INTER_LINEAR (8-bit): taps/weights per axis from the host (OpenCV's float32 coordinate
@@ -108,6 +116,11 @@ __global__ __launch_bounds__(256) void cv_resize_linear_kernel(const unsigned ch
         const int s1 = r1[x0[xx] * 3 + c] * a0 + r1[x1[xx] * 3 + c] * a1;
         v[c] = min(max((((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2, 0), 255);
     }
+    if (mode == 3) {
+        unsigned char* d = (unsigned char*)out + i * 3;
+        d[0] = (unsigned char)v[0]; d[1] = (unsigned char)v[1]; d[2] = (unsigned char)v[2];
+        return;
+    }
     emit(out + i * 3, v[0], v[1], v[2], mode, m0, m1, m2, d0, d1, d2);
 }
 
@@ -116,6 +129,11 @@ __global__ __launch_bounds__(256) void u8_to_input_kernel(const unsigned char* _
                                                           int mode, float m0, float m1, float m2, double d0, double d1, double d2) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
+    if (mode == 3) {
+        unsigned char* d = (unsigned char*)out + i * 3;
+        d[0] = in[i * 3]; d[1] = in[i * 3 + 1]; d[2] = in[i * 3 + 2];
+        return;
+    }
     emit(out + i * 3, in[i * 3], in[i * 3 + 1], in[i * 3 + 2], mode, m0, m1, m2, d0, d1, d2);
 }
 
@@ -127,7 +145,7 @@ int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, i
                       const int* xcnt, const int* xcoef, int xk, const int* ymin, const int* ycnt, const int* ycoef, int yk,
                       int mode, const double* mean, hipStream_t s) {
     HSEFR_REQUIRE(n >= 0 && H > 0 && W > 0 && oh > 0 && ow > 0, HSEFR_ERR_INVALID, "pil_resize: bad shape");
-    HSEFR_REQUIRE(mode >= 0 && mode <= 2, HSEFR_ERR_INVALID, "preprocess: mode %d", mode);
+    HSEFR_REQUIRE(mode >= 0 && mode <= 3, HSEFR_ERR_INVALID, "preprocess: mode %d", mode);
     if (n == 0) return HSEFR_OK;
     const long long t1 = (long long)n * H * ow, t2 = (long long)n * oh * ow;
     HSEFR_REQUIRE(t1 < (1ll << 39) && t2 < (1ll << 39), HSEFR_ERR_UNSUPPORTED, "pil_resize: too large");
@@ -140,7 +158,7 @@ int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, i
 int launch_cv_resize(const unsigned char* in, float* out, int n, int H, int W, int oh, int ow, const int* x0, const int* x1,
                      const int* wx1, const int* y0, const int* y1, const int* wy1, int mode, const double* mean, hipStream_t s) {
     HSEFR_REQUIRE(n >= 0 && H > 0 && W > 0 && oh > 0 && ow > 0, HSEFR_ERR_INVALID, "cv_resize: bad shape");
-    HSEFR_REQUIRE(mode >= 0 && mode <= 2, HSEFR_ERR_INVALID, "preprocess: mode %d", mode);
+    HSEFR_REQUIRE(mode >= 0 && mode <= 3, HSEFR_ERR_INVALID, "preprocess: mode %d", mode);
     if (n == 0) return HSEFR_OK;
     const long long t = (long long)n * oh * ow;
     if (H == oh && W == ow)

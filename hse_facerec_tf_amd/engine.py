@@ -76,6 +76,37 @@ class Engine:
                                                        _lib.current_stream_ptr()), "hsefr_engine_forward")
         return outs
 
+    @property
+    def accepts_u8(self) -> bool:
+        """True if forward_u8 works on this plan (fused stem lowered with a BGR mean, input edges multiples of 4)."""
+        return bool(self._h) and bool(_lib.lib().hsefr_engine_accepts_u8(self._h))
+
+    def forward_u8(self, x_u8, want: Sequence[int] = (OUT_FEATURES,)) -> Dict[str, "object"]:
+        """forward() on the RESIZED image bytes: x_u8 CUDA uint8 [n, h, w, 3], RGB as the decoder / resizer left them.  Float
+        conversion, channel reversal and mean subtraction (facerec_test.py:95-106) happen inside the first kernel."""
+        torch = self._torch
+        if self._h is None:
+            raise RuntimeError("Attempted to use a closed Session.")
+        h, w, c = self.in_hwc
+        if x_u8.dim() != 4 or tuple(x_u8.shape[1:]) != (h, w, c):
+            raise ValueError("Cannot feed value of shape %r for Tensor which has shape '(?, %d, %d, %d)'" % (tuple(x_u8.shape), h, w, c))
+        if x_u8.dtype != torch.uint8 or not x_u8.is_cuda or not x_u8.is_contiguous():
+            raise ValueError("forward_u8 takes a contiguous uint8 CUDA tensor")
+        if x_u8.device != self.device:
+            raise ValueError("engine input is on %s but the engine was created on %s" % (x_u8.device, self.device))
+        n = int(x_u8.shape[0])
+        outs, ptrs = {}, [None, None, None]
+        for slot in want:
+            if slot not in self.out_elems:
+                raise KeyError("the plan has no output %r" % _SLOT_NAMES[slot])
+            t = torch.empty((n, self.out_elems[slot]), dtype=torch.float32, device=x_u8.device)
+            outs[_SLOT_NAMES[slot]] = t
+            ptrs[slot] = t.data_ptr()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().hsefr_engine_forward_u8(self._h, x_u8.data_ptr(), n, ptrs[0], ptrs[1], ptrs[2],
+                                                          _lib.current_stream_ptr()), "hsefr_engine_forward_u8")
+        return outs
+
     def forward_all_layers(self, x) -> None:
         """Run every op (no fetch pruning); intermediate buffers can then be read with layer_output."""
         if x.device != self.device:

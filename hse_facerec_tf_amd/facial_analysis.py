@@ -71,7 +71,10 @@ class FacialImageProcessing:
         _, w, h, _ = graph.placeholder_shape(in_node.name)
         self.w, self.h = int(w), int(h)
         # the preprocessing of facial_analysis.py:95-107 (uint8 pixels minus the ImageNet-Caffe BGR mean) bounds the input: |x| < 256
-        self.plan = lower_graph(graph, 'input_1:0', outs, (self.w, self.h), input_bound=256.0)
+        # ... and lets the engine take the RESIZED BYTES themselves (Engine.forward_u8): the float32 conversion, the channel
+        # reversal and the float32 mean of :98-107 are folded into the first kernel's constants
+        mean32 = tuple(float(np.float32(m)) for m in preprocess.IMAGENET_CAFFE_BGR_MEAN)
+        self.plan = lower_graph(graph, 'input_1:0', outs, (self.w, self.h), input_bound=256.0, u8_mean_bgr=mean32)
         self.sess = Engine(self.plan, max_batch=max_batch, device=device)
 
         def age_gender_fun(img):
@@ -94,13 +97,18 @@ class FacialImageProcessing:
         mb = self.sess.max_batch
         for i in range(0, len(faces_rgb_u8), mb):
             chunk = faces_rgb_u8[i:i + mb]
-            if self.device_preprocess:      # cv2.resize + BGR + mean on the GPU (integer resize: same bits)
+            if self.device_preprocess and self.sess.accepts_u8:      # cv2.resize on the GPU (integer: same bits), bytes into the net
                 from . import preprocess_device
-                xd = preprocess_device.preprocess_faces_cv(chunk, (self.h, self.w), device=self.sess.device)
+                x8 = preprocess_device.preprocess_faces_cv(chunk, (self.h, self.w), device=self.sess.device, raw_u8=True)
+                r = self.sess.forward_u8(x8, (OUT_FEATURES, OUT_AGE, OUT_GENDER))
             else:
-                x = np.stack([self.preprocess_face(f) for f in chunk])
-                xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.sess.device)
-            r = self.sess.forward(xd, (OUT_FEATURES, OUT_AGE, OUT_GENDER))
+                if self.device_preprocess:  # cv2.resize + BGR + mean on the GPU
+                    from . import preprocess_device
+                    xd = preprocess_device.preprocess_faces_cv(chunk, (self.h, self.w), device=self.sess.device)
+                else:
+                    x = np.stack([self.preprocess_face(f) for f in chunk])
+                    xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.sess.device)
+                r = self.sess.forward(xd, (OUT_FEATURES, OUT_AGE, OUT_GENDER))
             age_p = r["age_probs"].cpu().numpy()
             gen = r["gender"].cpu().numpy()
             fea = r["features"].cpu().numpy()

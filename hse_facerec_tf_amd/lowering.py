@@ -112,6 +112,39 @@ def split_pointwise_weights(w_t: np.ndarray, a_log2: int = F16S_ACT_LOG2_RELU6) 
     return img, descale
 
 
+def stem4_conv_image(w_hwio: np.ndarray, in_log2: int, reverse_channels: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """The first convolution [3,3,3,32] (TF HWIO) as csrc/stem4_fused.hip contracts it: TWO 32-deep K steps whose 8-value lane
+    slices are contiguous runs of a window row -- step 0, slice dy: values j = dx*3 + ci = 0..7 of kernel row dy; step 1,
+    slice dy: value j = 8 of kernel row dy in its first element; everything else zero.  Returns (uint16 [2][32][64] split rows
+    per step, descale [32]) -- split_pointwise_weights' format, channel n's scaling shared by both steps.
+    reverse_channels: the image arrives as RGB while the kernel was trained on BGR (facerec_test.py:97-98): ci -> 2 - ci."""
+    w = np.asarray(w_hwio, dtype=np.float32).reshape(3, 3, 3, 32)
+    if reverse_channels:
+        w = w[:, :, ::-1, :]
+    w = w.reshape(3, 9, 32)                                   # [dy][j][n]
+    full = np.zeros((32, 64), np.float32)
+    for dy in range(3):
+        full[:, 8 * dy:8 * dy + 8] = w[dy, :8, :].T
+        full[:, 32 + 8 * dy] = w[dy, 8, :]
+    img, ds = split_pointwise_weights(full, in_log2)          # [32][2][64]
+    return np.ascontiguousarray(img.transpose(1, 0, 2)), ds
+
+
+def stem4_u8_shifts(w_hwio: np.ndarray, shift: np.ndarray, mean_bgr) -> np.ndarray:
+    """conv1(u8 - mean) = sum_valid w * u8 - sum_valid w * mean: the second sum for the four cases of csrc/stem4_fused.hip
+    (SAME padding of a stride-2 3x3 on an even input pads only the bottom row / right column: kernel row dy = 2 / column dx = 2
+    fall on it for the last conv row / column), folded into the layer's shift.  float64 -> float32 [4][32], case =
+    (last row ? 2 : 0) + (last column ? 1 : 0).  The kernel's channel axis is BGR, like the mean."""
+    w = np.asarray(w_hwio, dtype=np.float64).reshape(3, 3, 3, 32)
+    m = np.asarray(mean_bgr, dtype=np.float64).reshape(1, 1, 3, 1)
+    out = np.zeros((4, 32), np.float64)
+    for case in range(4):
+        rows = 2 if case & 2 else 3
+        cols = 2 if case & 1 else 3
+        out[case] = np.asarray(shift, np.float64) - (w[:rows, :cols] * m).sum(axis=(0, 1, 2))
+    return out.astype(np.float32)
+
+
 def unsplit_pointwise_weights(img: np.ndarray, descale: np.ndarray, a_log2: int) -> np.ndarray:
     """Inverse view used by the CPU plan checker: the effective fp64 weights [cout, k] a split image stands for."""
     cout, kt, _ = img.shape
@@ -153,6 +186,7 @@ class Layer:
     shift3: Optional[np.ndarray] = None
     pad3: Tuple[int, int] = (0, 0)
     in_log2: int = 0                                   # STEM3_F16S: the input is pre-scaled by 2^in_log2 for its f16 split (|x| < 2^(15 - in_log2))
+    u8_mean_bgr: Optional[Tuple[float, float, float]] = None   # STEM3_F16S: BGR mean folded into the uint8-input constants (None: no uint8 entry)
     out_split: int = 0                                 # DWCONV3X3: > 0 = output stored as split rows scaled by 2^out_split
     in_split: bool = False                             # PWCONV: the input buffer holds split rows (wire kind OP_PWCONV_PS)
     out_buf: int = BUF_NONE
@@ -212,10 +246,23 @@ class Plan:
                     cimg, cds = split_pointwise_weights(cw_t, L.in_log2)
                     w = np.concatenate([w, np.ascontiguousarray(cimg).reshape(-1).view(np.float32), cds.astype(np.float32)])
                     assert w.size == 3008
+                    # ... and in the two-step K layout of csrc/stem4_fused.hip (inputs whose edges are multiples of 4), for fp32
+                    # input and -- channel-reversed, with the mean folded into four shift vectors -- for uint8 RGB input
+                    img4, ds4 = stem4_conv_image(L.w0, L.in_log2)
+                    assert np.array_equal(ds4, cds)
+                    u8_ok = L.u8_mean_bgr is not None
+                    if u8_ok:
+                        img8, ds8 = stem4_conv_image(L.w0, 0, reverse_channels=True)
+                        sh8 = stem4_u8_shifts(L.w0, L.shift0, L.u8_mean_bgr)
+                    else:
+                        img8, ds8, sh8 = np.zeros_like(img4), np.zeros(32, np.float32), np.zeros((4, 32), np.float32)
+                    w = np.concatenate([w, img4.reshape(-1).view(np.float32), img8.reshape(-1).view(np.float32),
+                                        sh8.reshape(-1).astype(np.float32), ds8.astype(np.float32)])
+                    assert w.size == 7264
                 scale = None
                 w2, descale = split_pointwise_weights(w2, L.a_log2)
                 shift2 = np.concatenate([descale, L.shift2.astype(np.float32)])
-                aux = L.a_log2 if L.kind == OP_STEM2_F16S else (L.a_log2 | ((L.in_log2 + 64) << 8))
+                aux = L.a_log2 if L.kind == OP_STEM2_F16S else (L.a_log2 | ((L.in_log2 + 64) << 8) | ((1 << 16) if L.u8_mean_bgr is not None else 0))
                 kw_field = 3 + 16 * L.pad3[0] + 32 * L.pad3[1]
             if L.kind == OP_STEM7X7_POOL_BF16:
                 aux = L.pad3[0] | (L.pad3[1] << 4)
@@ -1071,7 +1118,7 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
                 feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32",
                 pw_math: Optional[str] = None, fuse_stem_block: Optional[bool] = None, stem_fusion: Optional[str] = None,
                 block_fusion: Optional[str] = None, presplit: Optional[str] = None, input_bound: Optional[float] = None,
-                pwdw_fusion: Optional[str] = None) -> Plan:
+                pwdw_fusion: Optional[str] = None, u8_mean_bgr: Optional[Sequence[float]] = None) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase.
     fuse: merge depthwise -> pointwise pairs into one kernel where a fused kernel covers the shape.  stem_fusion:
     'stem2' (default; env HSEFR_FUSE_STEM=0|1only|1 changes the default) = conv1 + block 1 + the depthwise of block 2 in one
@@ -1084,6 +1131,10 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
     input_bound: a bound the CALLER guarantees on |input| (the reference's preprocessing yields pixels minus a mean:
     < 256; facerec_test.py:93-110).  With it the fused stem forms conv1's products on the f16 MFMA too (csrc/stem3_fused.hip)
     and checks the bound on the device (Engine.input_overflow()); None = no assumption, exact-fp32 conv1.
+    u8_mean_bgr (with input_bound): the BGR mean the caller's preprocessing subtracts from its uint8 pixels after reversing the
+    channels (facerec_test.py:97-106).  The plan then ALSO takes the resized RGB bytes themselves (Engine.forward_u8):
+    conversion, reversal and mean are folded into the fused stem's constants (csrc/stem4_fused.hip; inputs whose edges are
+    multiples of 4).
     presplit: 'auto' (default; env HSEFR_PRESPLIT=auto|none) = depthwise layers feeding a split-f16 pointwise layer store
     their result pre-split and the GEMM stages both operands by LDS-DMA (presplit_activations); 'none' = fp32 tensors.
     pwdw_fusion: 'auto' (default; env HSEFR_FUSE_PWDW=auto|none) = a pre-split pointwise layer followed only by a stride-1
@@ -1165,6 +1216,12 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
                 for L in layers:
                     if L.kind == OP_STEM2_F16S:
                         L.kind, L.in_log2 = OP_STEM3_F16S, in_log2
+                        if u8_mean_bgr is not None:
+                            if len(u8_mean_bgr) != 3 or not all(0.0 <= float(m) <= 255.0 for m in u8_mean_bgr):
+                                raise ValueError("u8_mean_bgr must be three means in [0, 255], not %r" % (u8_mean_bgr,))
+                            if float(input_bound) < 256.0:
+                                raise ValueError("uint8 input needs input_bound >= 256 (pixels minus a mean), not %r" % (input_bound,))
+                            L.u8_mean_bgr = tuple(float(m) for m in u8_mean_bgr)
     if fuse and dtype == "bf16":      # ResNet stem: conv1 + pool1 in one kernel
         layers, remap = fuse_stem_pool(layers, [li for li, _ in out_layers.values()])
         out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}

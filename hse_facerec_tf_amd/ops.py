@@ -303,6 +303,47 @@ def stem3_fused(x, conv_w, conv_shift, w1_hwc, d1scale, d1shift, wp_t, pshift, w
 
 
 @_device_guarded
+def stem4_fused(x, conv_w, conv_shift, w1_hwc, d1scale, d1shift, wp_t, pshift, w2_hwc, d2scale, d2shift, act: int = ACT_RELU6,
+                a_log2: int = 12, in_log2: int = 7, prepared=None, overflow=None, u8_mean_bgr=None):
+    """stem3_fused for inputs whose edges are multiples of 4 (csrc/stem4_fused.hip): no im2col, conv1's operands straight from
+    the f16 window.  x float32 [n,h,w,3] within the declared bound -- or, with u8_mean_bgr, the RESIZED image as uint8 RGB
+    [n,h,w,3]: float conversion, channel reversal and the BGR mean are folded into the constants (in_log2 is then 0)."""
+    torch = _lib.require_gpu()
+    from . import lowering
+    for t, nm in ((conv_shift, "conv_shift"), (w1_hwc, "w1"), (d1scale, "d1scale"), (d1shift, "d1shift"),
+                  (pshift, "pshift"), (w2_hwc, "w2"), (d2scale, "d2scale"), (d2shift, "d2shift")):
+        _f32c(t, nm)
+    u8 = u8_mean_bgr is not None
+    if u8:
+        if x.dtype != torch.uint8 or not x.is_cuda or not x.is_contiguous():
+            raise ValueError("x: expected a contiguous uint8 CUDA tensor")
+    else:
+        _f32c(x, "x")
+    d_img, d_ds = prepared if prepared is not None else split_weights_device(wp_t, x.device, a_log2)
+    n, h, w, c = x.shape
+    cw = conv_w.detach().cpu().numpy() if hasattr(conv_w, "detach") else np.asarray(conv_w)
+    if c != 3 or tuple(cw.shape) != (3, 3, 3, 32) or tuple(w1_hwc.shape) != (3, 3, 32) or d_img.shape[0] != 64 or tuple(w2_hwc.shape) != (3, 3, 64):
+        raise NotImplementedError("stem4_fused covers 3 -> 32 -> 64 channels")
+    if u8:
+        img4, ds4 = lowering.stem4_conv_image(cw, 0, reverse_channels=True)
+        sh = lowering.stem4_u8_shifts(cw, conv_shift.detach().cpu().numpy(), u8_mean_bgr)
+        d_sh = torch.from_numpy(sh).to(x.device)
+        in_log2 = 0
+    else:
+        img4, ds4 = lowering.stem4_conv_image(cw, in_log2)
+        d_sh = conv_shift
+    d_cimg = torch.from_numpy(img4.view(np.int16)).to(x.device)
+    d_cds = torch.from_numpy(ds4).to(x.device)
+    y = torch.empty((n, h // 4, w // 4, 64), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_stem4_fused(x.data_ptr(), 1 if u8 else 0, d_cimg.data_ptr(), d_cds.data_ptr(), d_sh.data_ptr(), w1_hwc.data_ptr(),
+                                            d1scale.data_ptr(), d1shift.data_ptr(), d_img.data_ptr(), d_ds.data_ptr(), pshift.data_ptr(),
+                                            w2_hwc.data_ptr(), d2scale.data_ptr(), d2shift.data_ptr(), y.data_ptr(),
+                                            None if overflow is None else overflow.data_ptr(), n, h, w, in_log2, a_log2, act,
+                                            _lib.current_stream_ptr()), "hsefr_stem4_fused")
+    return y
+
+
+@_device_guarded
 def dwpw_fused(x, w_hwc, dscale, dshift, wp_t, pshift, stride: int = 1):
     """One early MobileNet block in one kernel: depthwise 3x3 SAME + scale + shift + ReLU6 -> pointwise 1x1 + shift +
     ReLU6 (graph nodes #35-#49).  c in {32, 64}, cout in {64, 128}; wp_t is the pointwise kernel transposed [cout, c]."""

@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from .preprocess import IMAGENET_CAFFE_BGR_MEAN, VGGFACE2_BGR_MEAN
 
-COLOR_BGR_MEAN_F64, COLOR_RGB_UNIT, COLOR_BGR_MEAN_F32 = 0, 1, 2
+COLOR_BGR_MEAN_F64, COLOR_RGB_UNIT, COLOR_BGR_MEAN_F32, COLOR_NONE_U8 = 0, 1, 2, 3
 _PRECISION_BITS = 32 - 8 - 2      # Pillow: Resample.c
 
 
@@ -99,17 +99,22 @@ def _as_u8_cuda(imgs, device=None):
     return imgs.contiguous()
 
 
-def preprocess_pil(imgs, out_hw: Tuple[int, int], convert2BGR: bool = True, imageNetUtilsMean: bool = True, device=None):
+def preprocess_pil(imgs, out_hw: Tuple[int, int], convert2BGR: bool = True, imageNetUtilsMean: bool = True, device=None,
+                   raw_u8: bool = False):
     """facerec_test.py:93-110 for a batch of same-size decoded RGB images -> CUDA float32 [n,oh,ow,3].
-    A NumPy batch is uploaded to ``device`` (default: the current one); a CUDA batch stays where it is."""
+    A NumPy batch is uploaded to ``device`` (default: the current one); a CUDA batch stays where it is.
+    raw_u8: stop after misc.imresize (:93) -- CUDA uint8 [n,oh,ow,3], RGB, for Engine.forward_u8, whose first kernel does the
+    float conversion, channel reversal and mean subtraction (:95-106) inside its window load."""
     torch = _lib.require_gpu()
     x = _as_u8_cuda(imgs, device)
     n, H, W, _ = x.shape
     oh, ow = int(out_hw[0]), int(out_hw[1])
+    if raw_u8 and (H, W) == (oh, ow):
+        return x                      # Pillow's resize to the same size is the identity (coefficients 1.0)
     xm, xc, xk, xks, ym, yc, yk, yks = _pil_tables_dev(H, W, oh, ow, x.device.index or 0)
     tmp = torch.empty((n, H, ow, 3), dtype=torch.uint8, device=x.device)
-    out = torch.empty((n, oh, ow, 3), dtype=torch.float32, device=x.device)
-    mode = COLOR_BGR_MEAN_F64 if convert2BGR else COLOR_RGB_UNIT
+    out = torch.empty((n, oh, ow, 3), dtype=torch.uint8 if raw_u8 else torch.float32, device=x.device)
+    mode = COLOR_NONE_U8 if raw_u8 else (COLOR_BGR_MEAN_F64 if convert2BGR else COLOR_RGB_UNIT)
     with _lib.on_device(x):
         _lib.check(_lib.lib().hsefr_preprocess_pil_u8(x.data_ptr(), tmp.data_ptr(), out.data_ptr(), n, H, W, oh, ow, xm.data_ptr(),
                                                       xc.data_ptr(), xk.data_ptr(), xks, ym.data_ptr(), yc.data_ptr(), yk.data_ptr(),
@@ -118,34 +123,38 @@ def preprocess_pil(imgs, out_hw: Tuple[int, int], convert2BGR: bool = True, imag
     return out
 
 
-def preprocess_cv(imgs, out_hw: Tuple[int, int], device=None):
-    """facial_analysis.py:95-107 (cv2.resize -> float32 -> BGR -> ImageNet-Caffe mean) for a same-size batch."""
+def preprocess_cv(imgs, out_hw: Tuple[int, int], device=None, raw_u8: bool = False):
+    """facial_analysis.py:95-107 (cv2.resize -> float32 -> BGR -> ImageNet-Caffe mean) for a same-size batch.
+    raw_u8: stop after cv2.resize (:95) -- CUDA uint8 [n,oh,ow,3] RGB for Engine.forward_u8."""
     torch = _lib.require_gpu()
     x = _as_u8_cuda(imgs, device)
     n, H, W, _ = x.shape
     oh, ow = int(out_hw[0]), int(out_hw[1])
-    out = torch.empty((n, oh, ow, 3), dtype=torch.float32, device=x.device)
+    if raw_u8 and (H, W) == (oh, ow):
+        return x
+    out = torch.empty((n, oh, ow, 3), dtype=torch.uint8 if raw_u8 else torch.float32, device=x.device)
     if (H, W) == (oh, ow):
         tabs = [None] * 6
     else:
         tabs = [t.data_ptr() for t in _cv_tables_dev(H, W, oh, ow, x.device.index or 0)]
     with _lib.on_device(x):
-        _lib.check(_lib.lib().hsefr_preprocess_cv_u8(x.data_ptr(), out.data_ptr(), n, H, W, oh, ow, *tabs, COLOR_BGR_MEAN_F32,
+        _lib.check(_lib.lib().hsefr_preprocess_cv_u8(x.data_ptr(), out.data_ptr(), n, H, W, oh, ow, *tabs, COLOR_NONE_U8 if raw_u8 else COLOR_BGR_MEAN_F32,
                                                      _mean_array(True), _lib.current_stream_ptr()), "hsefr_preprocess_cv_u8")
     return out
 
 
-def preprocess_faces_cv(crops: Sequence[np.ndarray], out_hw: Tuple[int, int], device=None):
+def preprocess_faces_cv(crops: Sequence[np.ndarray], out_hw: Tuple[int, int], device=None, raw_u8: bool = False):
     """Variable-size face crops (process_image's per-box crops): grouped by size, one launch per group,
-    results returned in input order as one CUDA float32 [n,oh,ow,3] tensor on ``device``."""
+    results returned in input order as one CUDA float32 [n,oh,ow,3] tensor on ``device`` (raw_u8: the resized RGB bytes,
+    uint8, for Engine.forward_u8)."""
     torch = _lib.require_gpu()
     oh, ow = out_hw
     dev = _lib.cuda_device(device)
-    out = torch.empty((len(crops), oh, ow, 3), dtype=torch.float32, device=dev)
+    out = torch.empty((len(crops), oh, ow, 3), dtype=torch.uint8 if raw_u8 else torch.float32, device=dev)
     groups = {}
     for i, c in enumerate(crops):
         groups.setdefault(c.shape[:2], []).append(i)
     for (h, w), idx in groups.items():
         batch = np.stack([np.ascontiguousarray(crops[i], dtype=np.uint8) for i in idx])
-        out[torch.tensor(idx, device=dev)] = preprocess_cv(batch, out_hw, dev)
+        out[torch.tensor(idx, device=dev)] = preprocess_cv(batch, out_hw, dev, raw_u8=raw_u8)
     return out

@@ -84,10 +84,15 @@ class TensorFlowInference:
         self._ovf_pending = []             # [(event, slot)] in stream order
         self._ovf_next = 0
         from .lowering import LoweringError
+        # uint8 entry of the engine (Engine.forward_u8): the float conversion, channel reversal and mean of :95-106 folded into
+        # the first kernel -- extract_images / extract_files then hand the resized bytes over as they are
+        u8_mean = None
+        if convert2BGR and input_bound is not None and input_bound >= 256.0:
+            u8_mean = tuple(float(m) for m in (preprocess.IMAGENET_CAFFE_BGR_MEAN if imageNetUtilsMean else preprocess.VGGFACE2_BGR_MEAN))
         if dtype == "auto":
             try:
                 self.plan: Plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds,
-                                              input_bound=input_bound)
+                                              input_bound=input_bound, u8_mean_bgr=u8_mean)
                 dtype = "f32"
             except LoweringError:
                 self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype="bf16")
@@ -95,7 +100,7 @@ class TensorFlowInference:
         elif dtype == "f32":
             try:
                 self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds,
-                                        input_bound=input_bound)
+                                        input_bound=input_bound, u8_mean_bgr=u8_mean)
             except LoweringError:
                 self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype="f32g")
                 dtype = "f32g"
@@ -205,6 +210,9 @@ class TensorFlowInference:
         """Decoded RGB uint8 images [n,H,W,3] (same size; NumPy or CUDA) -> CUDA features [n,D]: the resize +
         BGR + mean of preprocess_image run on the device (bit-exact with the PIL path), then one forward."""
         from . import preprocess_device
+        if self.engine.accepts_u8:      # the resized bytes go straight into the first kernel (no fp32 image in between)
+            x8 = preprocess_device.preprocess_pil(imgs_u8, (self.w, self.h), device=self.engine.device, raw_u8=True)
+            return self.engine.forward_u8(x8, (OUT_FEATURES,))["features"]
         x = preprocess_device.preprocess_pil(imgs_u8, (self.w, self.h), self.convert2BGR, self.imageNetUtilsMean,
                                              device=self.engine.device)
         return self.engine.forward(x, (OUT_FEATURES,))["features"]
@@ -303,8 +311,7 @@ class TensorFlowInference:
                     compute.wait_event(up)
                     for idx, d_u8 in pending:
                         d_u8.record_stream(compute)
-                        x = preprocess_device.preprocess_pil(d_u8, (self.w, self.h), self.convert2BGR, self.imageNetUtilsMean)
-                        f = self.engine.forward(x, (OUT_FEATURES,))["features"]
+                        f = self.extract_images(d_u8)
                         if len(idx) == hi - lo:               # the usual case: one size per chunk -> one contiguous copy back
                             out_host[lo:hi].copy_(f, non_blocking=True)
                         else:

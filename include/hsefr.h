@@ -115,7 +115,11 @@ typedef enum hsefr_op_kind {
     HSEFR_OP_STEM3_F16S = 17,  /* STEM2_F16S for an input with a DECLARED BOUND |x| < 2^(15 - in_log2) (csrc/stem3_fused.hip): conv1's
                                   products are formed on the f16 MFMA from two-term splits like the pointwise layers'.
                                   w_off = the STEM2 fp32 pack (1952 floats) | conv1 split rows [32][64 f16] (1024 floats) |
-                                  conv1 descale [32]; `reserved` = a_log2 | (in_log2 + 64) << 8; the rest as STEM2_F16S.
+                                  conv1 descale [32] | the conv kernel in the two-step K layout of csrc/stem4_fused.hip (2048 floats)
+                                  | the same channel-reversed for uint8 RGB input (2048) | its four mean-folded shift vectors
+                                  [4][32] | its descale [32] = 7264 floats; `reserved` = a_log2 | (in_log2 + 64) << 8 |
+                                  (uint8 constants valid ? 1 << 16 : 0); the rest as STEM2_F16S.  Inputs whose edges are
+                                  multiples of 4 run stem4_fused.hip, the others stem3_fused.hip.
                                   An input value outside the bound raises the engine's overflow flag (see
                                   hsefr_engine_input_overflow) -- the results of that forward are then meaningless.   */
     HSEFR_OP_PWCONV_PS = 16,   /* PWCONV_F16S whose INPUT buffer holds pre-split activations ("split rows", written by a
@@ -202,6 +206,16 @@ int hsefr_engine_max_batch(const hsefr_engine* e);
  * Replaces tf_sess.run (facerec_test.py:120; facial_analysis.py:109). */
 int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_features,
                          void* d_age_probs, void* d_gender, hsefr_stream_t stream);
+
+/* hsefr_engine_forward for callers that hold DECODED, RESIZED images: d_input_u8 is [n,in_h,in_w,3] RGB bytes as the decoder /
+ * resizer left them (misc.imresize's output, facerec_test.py:93).  The conversion to float, the channel reversal and the mean
+ * subtraction (facerec_test.py:95-106) happen inside the first kernel's window load (csrc/stem4_fused.hip): no fp32 image is ever
+ * written.  Only for plans whose first op is the fused stem lowered WITH the mean (lower_graph(..., u8_mean_bgr=...)) on inputs
+ * whose edges are multiples of 4: hsefr_engine_accepts_u8 says so, HSEFR_ERR_UNSUPPORTED otherwise.  Results equal
+ * hsefr_engine_forward on the preprocessed floats to fp32 round-off (exact products, another summation order). */
+int hsefr_engine_accepts_u8(const hsefr_engine* e);
+int hsefr_engine_forward_u8(hsefr_engine* e, const void* d_input_u8, int n, void* d_features, void* d_age_probs, void* d_gender,
+                            hsefr_stream_t stream);
 
 /* Device pointer of an intermediate activation buffer (contents valid until the next forward); used by the per-layer
  * parity tests.  NULL if `buffer` is out of range.  NOT for the buffers behind the plan's OUTPUT slots: a forward that
@@ -320,6 +334,18 @@ int hsefr_stem3_fused(const float* x, const void* cw_split, const float* cdescal
                       int cpad_t, int cpad_l, int h1, int w1, int pad_t2, int pad_l2, int oh2, int ow2, int in_log2, int a_log2,
                       int act, hsefr_stream_t stream);
 
+/* The same four layers for inputs whose edges are multiples of 4 (csrc/stem4_fused.hip; hsefr_stem3_fused covers the rest): the
+ * input window is converted to f16 once and conv1's MFMA operands are read straight from it (no im2col).  x_is_u8 = 0: x is fp32
+ * [n,h,w,3] with the declared bound |x| < 2^(15 - in_log2), conv_shift [32].  x_is_u8 = 1 (in_log2 = 0): x is the RESIZED image as
+ * RGB bytes [n,h,w,3] -- the float conversion, channel reversal and mean subtraction of facerec_test.py:95-106 /
+ * facial_analysis.py:98-107 are folded into the constants: cw4 is packed channel-reversed and conv_shift is [4][32] =
+ * shift - sum over the VALID taps of w * mean, for (pixel in the last conv row ? 2 : 0) + (in the last conv column ? 1 : 0).
+ * cw4 / cdescale = the conv kernel in the two-step K layout [2][32][hi 32 | lo 32] f16 (hse_facerec_tf_amd.lowering.stem4_conv_image). */
+int hsefr_stem4_fused(const void* x, int x_is_u8, const void* cw4, const float* cdescale, const float* conv_shift, const float* wd1,
+                      const float* d1scale, const float* d1shift, const void* w_split, const float* descale, const float* pshift,
+                      const float* wd2, const float* d2scale, const float* d2shift, float* y, int* d_overflow, int n, int h, int w,
+                      int in_log2, int a_log2, int act, hsefr_stream_t stream);
+
 /* One whole early MobileNet block (graph nodes #35-#49) fused: depthwise 3x3 SAME (stride 1|2) + scale + shift + ReLU6
  * -> pointwise 1x1 + shift + ReLU6.  x [n,h,w,c], wd [3,3,c], wp_t [cout,c] (TF kernel transposed), y [n,oh,ow,cout];
  * c in {32,64}, cout in {64,128}; HSEFR_ERR_UNSUPPORTED otherwise (callers fall back to the two separate kernels). */
@@ -363,8 +389,11 @@ int hsefr_gap_bf16(const void* x, float* y, int n, int hw, int c, hsefr_stream_t
 
 /* colour/mean handling after the resize:
  * 0 = BGR - mean3 evaluated in float64 then cast (facerec_test.py:95-106 feeding a float32 placeholder),
- * 1 = RGB, x/127.5 - 1 (facerec_test.py:108-110), 2 = BGR - mean3 in float32 (facial_analysis.py:101-107). */
-typedef enum hsefr_color_mode { HSEFR_COLOR_BGR_MEAN_F64 = 0, HSEFR_COLOR_RGB_UNIT = 1, HSEFR_COLOR_BGR_MEAN_F32 = 2 } hsefr_color_mode;
+ * 1 = RGB, x/127.5 - 1 (facerec_test.py:108-110), 2 = BGR - mean3 in float32 (facial_analysis.py:101-107),
+ * 3 = none: d_out receives the resized RGB BYTES [n,oh,ow,3] (uint8, a quarter of the fp32 tensor) for
+ * hsefr_engine_forward_u8, whose first kernel folds conversion, channel reversal and mean into its window load. */
+typedef enum hsefr_color_mode { HSEFR_COLOR_BGR_MEAN_F64 = 0, HSEFR_COLOR_RGB_UNIT = 1, HSEFR_COLOR_BGR_MEAN_F32 = 2,
+                                HSEFR_COLOR_NONE_U8 = 3 } hsefr_color_mode;
 
 /* misc.imresize(img, (oh, ow), 'bilinear') (= PIL BILINEAR, antialiased, 8-bit fixed point) + colour handling.
  * d_in [n,H,W,3] u8 RGB, d_tmp [n,H,ow,3] u8 scratch, d_out [n,oh,ow,3] f32.  The per-axis coefficient tables are

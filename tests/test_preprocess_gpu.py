@@ -46,17 +46,20 @@ def test_reference_image_through_device_preprocessing_matches_golden(torch_):
     tfi = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(192, 192), max_batch=4)
     f_dev = tfi.extract_images(img[None]).cpu().numpy()[0]
     f_host = tfi.extract_features(TEST_IMAGE)
-    assert np.array_equal(f_dev, f_host)                                   # same bits as the host PIL path
+    # the resized bytes are Pillow's bit for bit (tests above); the engine takes them as bytes (forward_u8) where the host path
+    # feeds float32(bytes - mean): same features to fp32 round-off
+    assert float(np.abs(f_dev - f_host).max()) <= 2e-6 * float(np.abs(f_host).max())
     assert np.abs(f_dev - z["feat_192"]).max() / np.abs(z["feat_192"]).max() < 1e-4
     a = tfi.extract_files([TEST_IMAGE, TEST_IMAGE], device_preprocess=True)
     b = tfi.extract_files([TEST_IMAGE, TEST_IMAGE], device_preprocess=False)
-    assert np.array_equal(a, b)
+    assert float(np.abs(a - b).max()) <= 2e-6 * float(np.abs(b).max())
     tfi.close_session()
     dev = FacialImageProcessing(mtcnn_detector=False, device_preprocess=True)
     host = FacialImageProcessing(mtcnn_detector=False, device_preprocess=False)
     bgr = np.ascontiguousarray(img[..., ::-1])
     r1 = dev.process_image(bgr, bounding_boxes=z["boxes"])
     r2 = host.process_image(bgr, bounding_boxes=z["boxes"])
-    assert np.array_equal(np.asarray(r1[4]), np.asarray(r2[4])) and np.array_equal(np.asarray(r1[3]), np.asarray(r2[3]))
-    assert r1[2] == r2[2]
+    f1, f2 = np.asarray(r1[4]), np.asarray(r2[4])
+    assert float(np.abs(f1 - f2).max()) <= 2e-6 * float(np.abs(f2).max())
+    assert np.allclose(np.asarray(r1[3]), np.asarray(r2[3]), rtol=0, atol=2e-6) and np.allclose(r1[2], r2[2], rtol=0, atol=1e-3)
     dev.close(); host.close()
