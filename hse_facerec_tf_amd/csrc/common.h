@@ -244,6 +244,7 @@ unsigned long long* stamp_buffer(hipStream_t s);
 #define STEM_STAMP_FLUSH(buf, lane, wave) do { } while (0)
 #endif
 #ifdef HSEFR_DEV
+void set_stem4_grid(int v);
 void set_c11(int v);
 void set_dwpws_tw(int v);
 void set_dwpws_bn(int v);

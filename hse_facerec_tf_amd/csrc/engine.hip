@@ -279,6 +279,8 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "cd_off")) { set_cd_off(value); return HSEFR_OK; }
     if (!strcmp(key, "w3_off")) { set_w3_off(value); return HSEFR_OK; }
     if (!strcmp(key, "c11")) { set_c11(value); return HSEFR_OK; }
+    if (!strcmp(key, "stem4_grid")) { set_stem4_grid(value); return HSEFR_OK; }
+    if (!strcmp(key, "stem4")) { g_stem4 = value; return HSEFR_OK; }
     if (!strcmp(key, "dw_look")) { set_dw_look(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_look2")) { set_dw_look2(value); return HSEFR_OK; }
     if (!strcmp(key, "sweep_alternate")) { g_sweep_alternate = value; return HSEFR_OK; }

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void stem4_fused_kernel(Stem4Params p) {
             item_rq(k, row, q);
             const int ih = ih0 + row;
             const bool ok = row < RAWH && ih >= 0 && ih < p.H && q >= q_lo && q < q_hi;
-            const long long first = ((long long)(c.n * p.H + ih) * p.W + iw0) * 3 - WSHIFT + 4 * q;   // value index, = 0 (mod 4)
+            const int first = ((c.n * p.H + ih) * p.W + iw0) * 3 - WSHIFT + 4 * q;   // value index, = 0 (mod 4); < 2^29 (launcher)
             const unsigned voff = ok ? (unsigned)(first * VB) : 0x80000000u;
             if constexpr (U8) rawv[k] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff, 0, 0);
             else rawv[k] = bload16(rx, voff, 0);
@@ -294,29 +294,30 @@ __global__ __launch_bounds__(256, 2) void stem4_fused_kernel(Stem4Params p) {
         // depends on the parity of the wave only -- two unrolled variants, register indices all static
         auto conv_stage = [&](auto ODDC) __attribute__((always_inline)) {
             constexpr int ODD = decltype(ODDC)::value;
+            // all fragments of the wave's four row blocks first (one LDS round trip), then the MFMAs with the seven accumulators
+            // interleaved: consecutive MFMAs never depend on each other
+            f16x8 ah[2][4], al[2][4];
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const unsigned char* a0 = Wn + caddr[ri];
+                ah[0][ri] = ((const Frag4*)(a0))->v;
+                ah[1][ri] = ((const Frag4*)(a0 + 16))->v;
+                if constexpr (!U8) { al[0][ri] = ((const Frag4*)(a0 + WPLANE))->v; al[1][ri] = ((const Frag4*)(a0 + WPLANE + 16))->v; }
+            }
             f32x4 acc[7];
 #pragma unroll
             for (int i = 0; i < 7; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const unsigned char* a0 = Wn + caddr[ri];
-                const f16x8 ah0 = ((const Frag4*)(a0))->v, ah1 = ((const Frag4*)(a0 + 16))->v;
-                f16x8 al0, al1;
-                if constexpr (!U8) { al0 = ((const Frag4*)(a0 + WPLANE))->v; al1 = ((const Frag4*)(a0 + WPLANE + 16))->v; }
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int i = 2 * ri + nb - ODD;
-                    if (i < 0 || i >= 7) continue;
-                    // per K step the products in the order (wh*al, wl*ah, wh*ah) of the pointwise kernels; a byte has no lo term
-                    if constexpr (!U8) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwh[0][nb], al0, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwl[0][nb], ah0, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwh[0][nb], ah0, acc[i], 0, 0, 0);
-                    if constexpr (!U8) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwh[1][nb], al1, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwl[1][nb], ah1, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cwh[1][nb], ah1, acc[i], 0, 0, 0);
-                }
-            }
+                for (int pdt = U8 ? 1 : 0; pdt < 3; ++pdt)
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int ri = (i + ODD) >> 1, nb = (i + ODD) & 1;
+                        // per K step the products in the order (wh*al, wl*ah, wh*ah) of the pointwise kernels; a byte has no lo term
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pdt == 1 ? cwl[st][nb] : cwh[st][nb], pdt == 0 ? al[st][ri] : ah[st][ri], acc[i], 0, 0, 0);
+                    }
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 // lane: pixel m = 16 * rb + l16, channels nb*16 + 4*q4 + (0..3)   (operands swapped: weights first)
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(256, 2) void stem4_fused_kernel(Stem4Params p) {
         // and the piece registers are free before the depthwise's taps need them
         if (more) {
             park_window();
-            border_tables(nxt, tid);
+            const int ny = 2 * nxt.th * PH, nx = 2 * nxt.tw * PW;
+            if (!(ny - 1 >= 0 && nx - 1 >= 0 && ny - 1 + R0H <= p.H1 - (U8 ? 1 : 0) && nx - 1 + R0W <= p.W1 - (U8 ? 1 : 0))) border_tables(nxt, tid);
         }
         STEM_STAMP(1);
         // ---- stage E: depthwise 2 (stride 2) from LDS -> global; both output pixels of a thread in flight together ----
@@ -471,6 +473,11 @@ __global__ __launch_bounds__(256, 2) void stem4_fused_kernel(Stem4Params p) {
 
 }  // namespace
 
+HSEFR_KNOB(g_stem4_grid, 512);      // dev builds: persistent workgroups of the launch (256 = one per CU: latency experiments)
+#ifdef HSEFR_DEV
+void set_stem4_grid(int v) { g_stem4_grid = v; }
+#endif
+
 bool stem4_fused_supported(int cin, int c1, int c2, int conv_stride, int dw1_stride, int dw2_stride, int kh, int kw, int h, int w) {
     return cin == 3 && c1 == 32 && c2 == 64 && conv_stride == 2 && dw1_stride == 1 && dw2_stride == 2 && kh == 3 && kw == 3 &&
            h >= 4 && w >= 4 && h % 4 == 0 && w % 4 == 0;
@@ -504,7 +511,7 @@ int launch_stem4_fused(const void* x, int x_is_u8, const void* cw4, const float*
 #ifdef HSEFR_STEM_STAMPS
     p.stamps = stamp_buffer(s);
 #endif
-    const unsigned g = p.total < 512u ? p.total : 512u;      // 512 % 8 == 0: the kernel's incremental patch cursor relies on it
+    const unsigned g = p.total < (unsigned)g_stem4_grid ? p.total : (unsigned)g_stem4_grid;      // % 8 == 0: the kernel's incremental patch cursor relies on it
 #define HSEFR_STEM4(A)                                                                                   \
     do {                                                                                                 \
         if (x_is_u8) hipLaunchKernelGGL((stem4_fused_kernel<A, true>), dim3(g), dim3(256), 0, s, p);     \

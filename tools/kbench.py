@@ -312,11 +312,18 @@ def bench_stemstamps():
     d2sc = torch.rand((64,), device="cuda", generator=g) + 0.5
     d2sh = torch.randn((64,), device="cuda", generator=g) * 0.3
     which = os.environ.get("KB_STEM", "2")
+    if "KB_STEM4_GRID" in os.environ:
+        _lib.check(_lib.lib().hsefr_debug_set(b"stem4_grid", int(os.environ["KB_STEM4_GRID"])))
     for _ in range(4):
         if which == "1":
             ops.stem_fused(x, cw, csh, wd, dsc, dsh, w, sh)
         elif which == "3":
             ops.stem3_fused(x * 0.99, cw, csh, wd, dsc, dsh, w, sh, wd2, d2sc, d2sh)
+        elif which == "4":
+            ops.stem4_fused(x * 0.99, cw, csh, wd, dsc, dsh, w, sh, wd2, d2sc, d2sh)
+        elif which == "4u8":
+            ops.stem4_fused((x * 0.99 + 128).clamp(0, 255).to(torch.uint8), cw, csh, wd, dsc, dsh, w, sh, wd2, d2sc, d2sh,
+                            u8_mean_bgr=(103.939, 116.779, 123.68))
         else:
             ops.stem2_fused(x, cw, csh, wd, dsc, dsh, w, sh, wd2, d2sc, d2sh)
     torch.cuda.synchronize()
@@ -328,6 +335,9 @@ def bench_stemstamps():
     if which == "3":
         names = ["cursor", "A' im2col from the window", "barriers (+ park next window)", "B conv1 mfma + region write", "C depthwise 1", "D pointwise mfma (+ patch write)",
                  "E depthwise 2 + stores", "window loads issue"]
+    if which in ("4", "4u8"):
+        names = ["cursor", "park next window + border tables", "barriers", "B conv1 from the window + region write", "C depthwise 1 (+ next window loads issue)",
+                 "D pointwise mfma (+ patch write)", "E depthwise 2 + stores", "-"]
     print("%d waves, lifetime mean %.0f cycles, patches/wave %.1f -> %.0f cycles per patch" % (len(b), b[:, 8].mean(), b[:, 9].mean(), (b[:, 8] / b[:, 9]).mean()))
     for i, nm in enumerate(names):
         print("   %-26s %5.1f %%  %7.0f cycles per patch" % (nm, 100 * (b[:, i] / b[:, 8]).mean(), (b[:, i] / b[:, 9]).mean()))
