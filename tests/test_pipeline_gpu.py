@@ -11,10 +11,11 @@ from conftest import MODEL_PB
 pytestmark = pytest.mark.gpu
 
 
-def near(a, b, tol=2e-6):
+def near(a, b, tol=5e-6):
     """The batched paths hand the resized BYTES to the engine (Engine.forward_u8: conversion and mean folded into the first
     kernel, exact products, another summation order); the per-image reference path feeds float32(bytes - mean).  Same
-    features to fp32 round-off, not bit for bit."""
+    features to fp32 round-off, not bit for bit: each path sits ~2e-6 (of the feature scale) from the fp64 oracle
+    (tests/test_stem4_gpu.py checks both against it), so two of them may be 4-5e-6 apart."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return a.shape == b.shape and float(np.abs(a - b).max()) <= tol * max(float(np.abs(b).max()), 1e-30)
 

@@ -147,6 +147,23 @@ def test_engine_takes_resized_bytes_and_matches_the_float_entry(env):
             assert float((a[k] - b[k]).abs().max() / b[k].abs().max()) < 2e-6, k
         assert not eng.input_overflow()
         eng.close()
+    # both entries against the fp64 oracle of the whole graph (96 x 96 keeps the NumPy interpreter to seconds): the bytes-in
+    # entry must be as close to it as the floats-in entry (2e-6 of the feature scale measured; the north-star bar is 1e-4)
+    from oracle.tf_graph import GraphOracle
+    plan = lowering.lower_graph(g, "input_1:0", {0: fetch[0]}, (96, 96), input_bound=256.0, u8_mean_bgr=MEAN_BGR)
+    eng = Engine(plan, max_batch=3)
+    gen = torch.Generator(device="cuda").manual_seed(96)
+    rgb = torch.randint(0, 256, (3, 96, 96, 3), dtype=torch.uint8, device="cuda", generator=gen)
+    rgb[2] = torch.randint(0, 256, (1, 1, 3), dtype=torch.uint8, device="cuda", generator=gen) // 2 + rgb[2] // 2      # a lower-contrast image
+    x = (rgb.flip(-1).double() - torch.tensor(MEAN_BGR, dtype=torch.float64, device="cuda")).float().contiguous()
+    want = GraphOracle(MODEL_PB, np.float64).run(fetch[0], {"input_1:0": x.cpu().numpy()}).reshape(3, -1)
+    f8 = eng.forward_u8(rgb)["features"].cpu().numpy()
+    f32 = eng.forward(x)["features"].cpu().numpy()
+    scale = np.abs(want).max()
+    e8, e32 = float(np.abs(f8 - want).max() / scale), float(np.abs(f32 - want).max() / scale)
+    print("features vs the fp64 oracle: bytes-in entry %.2e, floats-in entry %.2e" % (e8, e32))
+    assert e8 < 1e-5 and e32 < 1e-5 and e8 < 3 * e32 + 2e-6
+    eng.close()
     plain = Engine(lowering.lower_graph(g, "input_1:0", {0: fetch[0]}, (96, 96), input_bound=256.0), max_batch=2)
     odd = Engine(lowering.lower_graph(g, "input_1:0", {0: fetch[0]}, (98, 98), input_bound=256.0, u8_mean_bgr=MEAN_BGR), max_batch=2)
     assert not plain.accepts_u8 and not odd.accepts_u8
