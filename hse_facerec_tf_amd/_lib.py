@@ -64,6 +64,7 @@ SIGNATURES = {
     "hsefr_l2_normalize": (c_int, [_fp, _fp, c_int, c_int, c_void_p]),
     "hsefr_conv2d_direct": (c_int, [_fp] * 5 + [c_int] * 12 + [c_void_p]),
     "hsefr_conv2d_f32": (c_int, [_fp] * 6 + [c_int] * 13 + [c_void_p]),
+    "hsefr_conv2d_f32_mfma": (c_int, [_fp] * 6 + [c_int] * 13 + [c_void_p]),
     "hsefr_maxpool_f32": (c_int, [_fp, _fp] + [c_int] * 10 + [c_void_p]),
     "hsefr_mtcnn_pyramid_level": (c_int, [_fp, _fp, c_int, c_int, c_int, c_int, c_void_p]),
     "hsefr_mtcnn_post_capacity": (c_int, []),

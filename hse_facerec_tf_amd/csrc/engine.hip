@@ -488,6 +488,12 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                       o.ow, o.cout, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.act, s);
                 break;
             case HSEFR_OP_CONV_F32:
+                if (conv_f32_mfma_supported(o.cin, o.cout)) {       // exact fp32 on the fp32 matrix pipe (csrc/conv_f32_mfma.hip)
+                    rc = launch_conv_f32_mfma((const float*)in, (const float*)blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
+                                              (const float*)blob_ptr(e, o.shift_off), o.res_buf >= 0 ? (const float*)tab[o.res_buf] : nullptr,
+                                              (float*)out, n, o.h, o.w, o.cin, o.oh, o.ow, o.cout, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.act, s);
+                    break;
+                }
                 rc = launch_conv2d_f32((const float*)in, (const float*)blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
                                        (const float*)blob_ptr(e, o.shift_off), o.res_buf >= 0 ? (const float*)tab[o.res_buf] : nullptr,
                                        (float*)out, n, o.h, o.w, o.cin, o.oh, o.ow, o.cout, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.act, s);
@@ -920,6 +926,13 @@ int hsefr_conv2d_direct(const float* x, const float* wgt, const float* bias, con
                         int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || (x && wgt && y), HSEFR_ERR_INVALID, "conv2d_direct: null pointer");
     return launch_conv2d_direct(x, wgt, bias, alpha, y, n, h, w, c, oh, ow, cout, kh, kw, stride, pad_t, pad_l, (hipStream_t)stream);
+}
+
+int hsefr_conv2d_f32_mfma(const float* x, const float* wgt, const float* scale, const float* shift, const float* res, float* y, int n, int h,
+                          int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act,
+                          hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wgt && y), HSEFR_ERR_INVALID, "conv2d_f32_mfma: null pointer");
+    return launch_conv_f32_mfma(x, wgt, scale, shift, res, y, n, h, w, c, oh, ow, cout, kh, kw, stride, pad_t, pad_l, act, (hipStream_t)stream);
 }
 
 int hsefr_conv2d_f32(const float* x, const float* wgt, const float* scale, const float* shift, const float* res, float* y, int n, int h,

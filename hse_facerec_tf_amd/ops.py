@@ -443,9 +443,11 @@ def conv2d_direct(x, w_hwio, bias=None, alpha=None, stride: int = 1, padding: st
 
 
 @_device_guarded
-def conv2d_f32(x, w_hwio, scale=None, shift=None, stride: int = 1, pad: int = 0, res=None, act: int = ACT_NONE):
+def conv2d_f32(x, w_hwio, scale=None, shift=None, stride: int = 1, pad: int = 0, res=None, act: int = ACT_NONE, mfma: bool = False):
     """General Conv2D in exact fp32 + per-channel scale / shift + optional residual + activation (the fp32-grade mode of the
-    ResNet-style graphs).  x [n,h,w,c], w_hwio [kh,kw,c,cout] with cout % 4 == 0, symmetric zero padding `pad`."""
+    ResNet-style graphs).  x [n,h,w,c], w_hwio [kh,kw,c,cout] with cout % 4 == 0, symmetric zero padding `pad`.
+    mfma: the implicit GEMM on the fp32 matrix pipe (csrc/conv_f32_mfma.hip, cout % 64 == 0; what the engine runs when it covers
+    the layer) instead of the vector-FMA direct convolution."""
     torch = _lib.require_gpu()
     _f32c(x, "x"), _f32c(w_hwio, "w")
     n, h, w, c = x.shape
@@ -461,7 +463,8 @@ def conv2d_f32(x, w_hwio, scale=None, shift=None, stride: int = 1, pad: int = 0,
     for v, name in ((scale, "scale"), (shift, "shift")):
         if v is not None and _f32c(v, name).numel() != cout:
             raise ValueError("%s has %d elements for %d output channels" % (name, v.numel(), cout))
-    _lib.check(_lib.lib().hsefr_conv2d_f32(x.data_ptr(), w_hwio.data_ptr(), None if scale is None else scale.data_ptr(),
+    fn = _lib.lib().hsefr_conv2d_f32_mfma if mfma else _lib.lib().hsefr_conv2d_f32
+    _lib.check(fn(x.data_ptr(), w_hwio.data_ptr(), None if scale is None else scale.data_ptr(),
                                            None if shift is None else shift.data_ptr(), None if res is None else res.data_ptr(),
                                            y.data_ptr(), n, h, w, c, oh, ow, cout, kh, kw, stride, pad, pad, act,
                                            _lib.current_stream_ptr()), "hsefr_conv2d_f32")

@@ -463,6 +463,13 @@ int hsefr_mtcnn_nms(const double* boxes, int n, double thr, int use_min, int* ke
 int hsefr_mtcnn_crops(const unsigned char* d_frame, const int* d_boxes, float* d_dst, int sh, int sw, int n, int size,
                       hsefr_stream_t stream);
 
+/* hsefr_conv2d_f32 as an implicit GEMM on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, 155 TFLOP/s):
+ * same arguments and results to fp32 round-off (another summation order); cout multiple of 64.  What HSEFR_OP_CONV_F32 runs
+ * when it covers the layer (csrc/conv_f32_mfma.hip): the fp32-grade mode of vgg2_resnet.pb (facerec_test.py:213). */
+int hsefr_conv2d_f32_mfma(const float* x, const float* wgt, const float* scale, const float* shift, const float* res, float* y, int n,
+                          int h, int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act,
+                          hsefr_stream_t stream);
+
 /* General Conv2D in exact fp32 (FMA chains) + per-channel scale (NULL = 1) + shift (NULL = 0) + optional residual + act:
  * x [n,h,w,c], wgt [kh,kw,c,cout] (TF HWIO), res / y [n,oh,ow,cout], cout multiple of 4.  The fp32-grade mode of the
  * ResNet-style graphs; an order of magnitude slower than hsefr_conv_bf16. */

@@ -216,6 +216,40 @@ def test_conv2d_f32_vs_oracle(env, n, hw, c, cout, k, stride, pad, res, act):
         ops.conv2d_f32(torch.from_numpy(x).cuda(), torch.from_numpy(kern[..., :cout - 1].copy()).cuda())      # cout % 4 != 0
 
 
+@pytest.mark.parametrize("n,h,w,c,cout,k,stride,pad,res,act", [
+    (2, 9, 11, 16, 64, 3, 1, 1, True, 1),        # 3x3, one K run per tap, BN = 64, ragged M (198 pixels = 1.5 tiles)
+    (1, 23, 23, 3, 64, 7, 2, 3, False, 1),       # the 7x7/2 stem: value-by-value gather, K = 147 -> 10 steps with a zero tail
+    (3, 7, 7, 64, 256, 1, 1, 0, True, 1),        # 1x1 "increase" + residual + ReLU, BN = 128, two N tiles
+    (2, 14, 14, 256, 128, 1, 2, 0, False, 0),    # stride-2 1x1 projection, linear
+    (1, 10, 6, 128, 128, 3, 2, 1, False, 2),     # 3x3 stride 2 (odd output), ReLU6
+    (5, 8, 8, 32, 192, 3, 1, 1, True, 0)])       # cout = 192 -> BN = 64 x 3
+def test_conv2d_f32_on_the_fp32_matrix_pipe(env, n, h, w, c, cout, k, stride, pad, res, act):
+    """csrc/conv_f32_mfma.hip (what OP_CONV_F32 runs for cout % 64 == 0) against the fp64 oracle at the direct kernel's bar, and
+    against the direct vector-FMA kernel itself; three launches bit-identical."""
+    torch, ops, resnet50 = env
+    rs = np.random.RandomState(h * 7 + c + cout)
+    x = rs.uniform(-3, 3, (n, h, w, c)).astype(np.float32)
+    kern = (rs.randn(k, k, c, cout) / np.sqrt(k * k * c)).astype(np.float32)
+    sc, sh = rs.uniform(0.5, 1.5, cout).astype(np.float32), rs.randn(cout).astype(np.float32)
+    want = tfo.conv2d(x.astype(np.float64), kern.astype(np.float64), (stride, stride), "", explicit_pads=(pad, pad, pad, pad)) * sc + sh
+    r = rs.randn(*want.shape).astype(np.float32) if res else None
+    if res:
+        want = want + r
+    want = np.maximum(want, 0) if act else want
+    want = np.minimum(want, 6) if act == 2 else want
+    args = (torch.from_numpy(x).cuda(), torch.from_numpy(kern).cuda(), torch.from_numpy(sc).cuda(), torch.from_numpy(sh).cuda())
+    kw = dict(stride=stride, pad=pad, res=None if r is None else torch.from_numpy(r).cuda(), act=act)
+    got = [ops.conv2d_f32(*args, mfma=True, **kw) for _ in range(3)]
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
+    g = got[0].cpu().numpy()
+    assert g.shape == want.shape
+    assert np.abs(g - want).max() < 2e-6 * max(np.abs(want).max(), 1.0)
+    direct = ops.conv2d_f32(*args, **kw).cpu().numpy()
+    assert np.abs(g - direct).max() < 2e-6 * max(np.abs(want).max(), 1.0)
+    with pytest.raises(NotImplementedError):
+        ops.conv2d_f32(args[0], torch.from_numpy(kern[..., :cout - 4].copy()).cuda(), mfma=True)      # cout % 64 != 0
+
+
 @pytest.mark.parametrize("size,pool,n", [(64, "caffe", 2), (224, "caffe", 1)])
 def test_resnet50_fp32_grade_mode_meets_the_1e4_bar(env, size, pool, n):
     """ResNet-50 in the fp32-grade mode against the exact (unrounded) oracle at the bar BASELINE states
