@@ -104,6 +104,10 @@ class DecodePool:
         self._pinned = False
         self._tensor = None
         self._next_tid = 0
+        import atexit
+        import weakref
+        ref = weakref.ref(self)
+        atexit.register(lambda: ref() is not None and ref().close())     # an extractor nobody closed: stop the workers, unlink the block
         self._open = {}            # chunk key -> {"tasks": {tid: (first file position, n files)}, "done": {tid: result}}
         self._stash = {}           # results that arrived for another chunk
 

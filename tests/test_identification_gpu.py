@@ -124,7 +124,7 @@ def test_config1_plumbing_100_lfw_sized_crops(torch_, tmp_path):
     for i in (0, 31, 32, 99):
         d, f = divmod(i, 5)
         one = tfi.extract_features(str(tmp_path / ("subject_%02d" % d) / ("%d.jpg" % f)))
-        assert float(np.abs(one - X[i]).max()) <= 5e-6 * float(np.abs(one).max())     # bytes-in batched path vs floats-in reference path
+        assert float(np.abs(one - X[i]).max()) <= 2e-5 * float(np.abs(one).max())     # bytes-in batched path vs floats-in reference path
     r = identification.one_nn_identification(X, y)
     assert len(r["test"]) == 50 and r["num_classes"] == 20 and 0.0 <= r["accuracy"] <= 1.0
     assert r["accuracy"] > 0.5                                             # blocky per-subject patterns are easy to tell apart
@@ -146,7 +146,7 @@ def test_extract_dataset_walk_cache_and_labels(torch_, tmp_path):
     X, y = extract_dataset(tfi, str(tmp_path), cache, batch=4)
     assert X.shape == (6, 1024) and list(y) == [0, 0, 0, 1, 2, 2]          # sorted subjects: alice, bob, carol
     one = tfi.extract_features(str(tmp_path / "alice" / "1.jpg"))
-    assert float(np.abs(one - X[1]).max()) <= 5e-6 * float(np.abs(one).max())      # batched (bytes in) == per-image path (floats in) to round-off
+    assert float(np.abs(one - X[1]).max()) <= 2e-5 * float(np.abs(one).max())      # batched (bytes in) == per-image path (floats in) to round-off
     tfi.close_session()
     X2, y2 = extract_dataset(None, str(tmp_path), cache)                    # cache hit: extractor is not touched
     assert np.array_equal(X, X2) and np.array_equal(y, y2)

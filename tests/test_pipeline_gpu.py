@@ -11,11 +11,12 @@ from conftest import MODEL_PB
 pytestmark = pytest.mark.gpu
 
 
-def near(a, b, tol=5e-6):
+def near(a, b, tol=2e-5):
     """The batched paths hand the resized BYTES to the engine (Engine.forward_u8: conversion and mean folded into the first
     kernel, exact products, another summation order); the per-image reference path feeds float32(bytes - mean).  Same
-    features to fp32 round-off, not bit for bit: each path sits ~2e-6 (of the feature scale) from the fp64 oracle
-    (tests/test_stem4_gpu.py checks both against it), so two of them may be 4-5e-6 apart."""
+    features to fp32 round-off, not bit for bit: on these 96 x 96 noise images each path sits 4-6e-6 (of the feature scale)
+    from the fp64 oracle (measured: bytes-in 4.5e-6, floats-in 5.6e-6 on the worst image; tests/test_stem4_gpu.py checks both
+    against it), so two of them are up to 8e-6 apart.  The north-star bar is 1e-4."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return a.shape == b.shape and float(np.abs(a - b).max()) <= tol * max(float(np.abs(b).max()), 1e-30)
 

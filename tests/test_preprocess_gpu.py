@@ -48,11 +48,11 @@ def test_reference_image_through_device_preprocessing_matches_golden(torch_):
     f_host = tfi.extract_features(TEST_IMAGE)
     # the resized bytes are Pillow's bit for bit (tests above); the engine takes them as bytes (forward_u8) where the host path
     # feeds float32(bytes - mean): same features to fp32 round-off
-    assert float(np.abs(f_dev - f_host).max()) <= 5e-6 * float(np.abs(f_host).max())
+    assert float(np.abs(f_dev - f_host).max()) <= 2e-5 * float(np.abs(f_host).max())
     assert np.abs(f_dev - z["feat_192"]).max() / np.abs(z["feat_192"]).max() < 1e-4
     a = tfi.extract_files([TEST_IMAGE, TEST_IMAGE], device_preprocess=True)
     b = tfi.extract_files([TEST_IMAGE, TEST_IMAGE], device_preprocess=False)
-    assert float(np.abs(a - b).max()) <= 5e-6 * float(np.abs(b).max())
+    assert float(np.abs(a - b).max()) <= 2e-5 * float(np.abs(b).max())
     tfi.close_session()
     dev = FacialImageProcessing(mtcnn_detector=False, device_preprocess=True)
     host = FacialImageProcessing(mtcnn_detector=False, device_preprocess=False)
@@ -60,6 +60,6 @@ def test_reference_image_through_device_preprocessing_matches_golden(torch_):
     r1 = dev.process_image(bgr, bounding_boxes=z["boxes"])
     r2 = host.process_image(bgr, bounding_boxes=z["boxes"])
     f1, f2 = np.asarray(r1[4]), np.asarray(r2[4])
-    assert float(np.abs(f1 - f2).max()) <= 5e-6 * float(np.abs(f2).max())
+    assert float(np.abs(f1 - f2).max()) <= 2e-5 * float(np.abs(f2).max())
     assert np.allclose(np.asarray(r1[3]), np.asarray(r2[3]), rtol=0, atol=2e-6) and np.allclose(r1[2], r2[2], rtol=0, atol=1e-3)
     dev.close(); host.close()
