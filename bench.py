@@ -436,11 +436,28 @@ def run_other_configs(args, dev):
         fl, by = resnet50.flops_per_image(plan), resnet50.activation_bytes_per_image(plan)
         wb = sum(int(np.asarray(L.w).size) * 2 for L in plan.layers if L.w is not None)
         t_hbm, t_mfma = (by * B + wb) / (HBM_PEAK_GBS * 1e9), fl * B / (MFMA_F16_PEAK_TF * 1e12)
+        # measured HBM bytes per forward from the committed PMC profile of this config (tools/gpu_pmc.sh over
+        # tools/bench_configs.py resnet50: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled): sum over its kernels
+        # of launches x bytes per launch, divided by the number of forwards (= launches of the once-per-forward stem kernel)
+        rn_traffic, rn_src, rn_stale = None, None, None
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_resnet50_traffic.json")))
+            if cands:
+                pj = json.load(open(cands[-1]))
+                ks = pj["kernels"]
+                fwd = max([v["launches"] for k, v in ks.items() if "stem7x7_pool" in k] or [0])
+                if fwd:
+                    rn_traffic = int(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks.values()) / fwd)
+                    rn_src, rn_stale = os.path.relpath(cands[-1], ROOT), pj.get("csrc_hash") != csrc_hash()
+        except Exception:
+            rn_traffic = None
         out.append({"config": "BASELINE configs[2]: ResNet-50 embeddings (2048-D), batch 128, 224x224x3, bf16 storage + bf16 MFMA, fp32 accumulate",
                     "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "dtype": "bf16",
                     "weights": "synthetic (seed 123)", "tflops": round(fl * B / dt / 1e12, 1),
                     "roofline": {"bound": "hbm", "achieved": round((by * B + wb) / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(t_hbm / dt, 4), "traffic": None,
+                                 "frac": round(t_hbm / dt, 4), "traffic": rn_traffic, "traffic_unit": "HBM bytes per forward (batch %d)" % B,
+                                 "traffic_source": rn_src, "traffic_stale": rn_stale, "algorithmic_bytes_per_forward": int(by * B + wb),
                                  "note": "layer-wise HBM floor %.3f ms vs bf16 MFMA floor %.3f ms per batch: the net is HBM-bound unless layers are fused"
                                          % (t_hbm * 1e3, t_mfma * 1e3)}})
         eng.close()
@@ -483,16 +500,17 @@ def run_other_configs(args, dev):
         out.append({"config": "BASELINE configs[1] pw_math=f32", "error": repr(e)})
     # -- configs[2] in the fp32-grade mode (exact-fp32 general kernels; the 1e-4 mode of a ResNet): a correctness mode, timed for the record
     try:
-        B = 32
+        B = 128
         plan = resnet50.build_plan(resnet50.synthetic_weights(123), (224, 224), "caffe", dtype="f32")
         eng = Engine(plan, max_batch=B, device=dev.index)
         dt = time_engine(eng, gen(B, 224), (0,), max(3, steps // 4), 1)
         fl = resnet50.flops_per_image(plan)
-        out.append({"config": "BASELINE configs[2] in the fp32-grade mode: ResNet-50 batch %d, exact fp32 FMA convolutions (dtype='f32')" % B,
+        out.append({"config": "BASELINE configs[2] in the fp32-grade mode: ResNet-50 batch %d, every convolution an exact-fp32 implicit GEMM on the "
+                              "fp32 matrix pipe (v_mfma_f32_32x32x2_f32; dtype='f32'; 1e-5 of the feature scale vs the fp64 oracle)" % B,
                     "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": max(3, steps // 4), "dtype": "f32",
                     "roofline": {"bound": "mfma", "achieved": round(fl * B / dt / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": round(fl * B / dt / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None,
-                                 "note": "vector-FMA direct convolution; a parity mode (1e-4 bar), not a throughput mode"}})
+                                 "note": "csrc/conv_f32_mfma.hip: the mode that meets the 1e-4 bar on a ResNet (the bf16 mode is at 5e-3)"}})
         eng.close()
     except Exception as e:
         out.append({"config": "BASELINE configs[2] fp32-grade mode", "error": repr(e)})
@@ -706,7 +724,7 @@ def main():
     traffic_by_class, mfma_by_class, traffic_src, traffic_stale = {}, {}, None, None
     try:
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
         if cands:
             traffic_src = os.path.relpath(cands[-1], ROOT)
             pj = json.load(open(cands[-1]))

@@ -43,7 +43,13 @@ class TensorFlowInference:
                  convert2BGR=True, imageNetUtilsMean=True, additional_input_value=0,
                  input_size: Optional[Tuple[int, int]] = None, max_batch: int = 256, device: Optional[int] = None,
                  dtype: str = "auto", input_bound: Optional[float] = 256.0):
-        graph = load_graph(frozen_graph_filename, '')
+        if str(frozen_graph_filename).lower().endswith((".h5", ".hdf5")):
+            # Keras weights of MobileNet-v1 (models/vgg2_mobilenet.h5, facerec_test.py:322-334: model.load_weights + the
+            # 'reshape_1' output) read without an HDF5 library and turned into the frozen graph of the same model
+            from .h5weights import keras_mobilenet_graph
+            graph = keras_mobilenet_graph(frozen_graph_filename, int((input_size or (192, 192))[0]))
+        else:
+            graph = load_graph(frozen_graph_filename, '')
         self.graph = graph
         # graph.get_tensor_by_name semantics: KeyError for unknown names (facerec_test.py:60-64)
         in_node, _ = graph.get_tensor_by_name(input_tensor)
@@ -366,6 +372,10 @@ def get_tf_face_recognizer(model: str = "age_gender", models_dir: Optional[str] 
                                    output_tensor='reshape_1/Reshape:0',
                                    learning_phase_tensor='conv1_bn/keras_learning_phase:0', convert2BGR=True,
                                    imageNetUtilsMean=True, **kw)
+    if model == "vgg2_mobilenet_h5":     # facerec_test.py:322-334: the same network from its Keras weight file (sz = 192)
+        kw.setdefault("input_size", (192, 192))
+        return TensorFlowInference(os.path.join(d, 'vgg2_mobilenet.h5'), input_tensor='input_1:0', output_tensor='reshape_1/Reshape:0',
+                                   convert2BGR=True, imageNetUtilsMean=True, **kw)
     if model == "vgg2_resnet":           # facerec_test.py:213
         return TensorFlowInference(os.path.join(d, 'vgg2_resnet.pb'), input_tensor='input:0',
                                    output_tensor='pool5_7x7_s1:0', convert2BGR=True, imageNetUtilsMean=False, **kw)

@@ -317,6 +317,23 @@ def test_vgg2_mobilenet_shaped_graph_through_the_reference_registry(torch_, tmp_
     tfi.close_session(), folded.close_session()
 
 
+def test_vgg2_mobilenet_keras_h5_through_the_registry(torch_, tmp_path):
+    """facerec_test.py:322-334 (model.load_weights('models/vgg2_mobilenet.h5'), output of 'reshape_1') without Keras or h5py:
+    a weight file of that layout (tests/h5_writer.py: what save_weights writes) holding the shipped trunk un-folded into Keras
+    layers -> get_tf_face_recognizer('vgg2_mobilenet_h5') -> the same embeddings as the shipped folded graph, on the GPU."""
+    import h5_writer
+    from test_h5weights_cpu import _keras_layers_of_the_shipped_trunk
+    from hse_facerec_tf_amd import get_tf_face_recognizer, TensorFlowInference
+    (tmp_path / "vgg2_mobilenet.h5").write_bytes(h5_writer.keras_save_weights(_keras_layers_of_the_shipped_trunk()))
+    tfi = get_tf_face_recognizer("vgg2_mobilenet_h5", models_dir=str(tmp_path), max_batch=8)
+    assert (tfi.w, tfi.h) == (192, 192) and tfi.feature_dim == 1024 and tfi.engine.accepts_u8
+    x = np.random.RandomState(333).uniform(-128, 128, (3, 192, 192, 3)).astype(np.float32)
+    folded = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(192, 192), max_batch=8)
+    assert rel(tfi.extract_batch(x), folded.extract_batch(x)) < 2e-5
+    assert rel(tfi.extract_features(TEST_IMAGE), folded.extract_features(TEST_IMAGE)) < 2e-5
+    tfi.close_session(), folded.close_session()
+
+
 def test_epilogue_fused_plan_is_deterministic_and_equals_the_unfused_plan(torch_):
     """The depthwise / pool epilogues of the pre-split GEMMs (lowering.fuse_pwdw / fuse_pwgap, on by default): 40 forwards of one
     batch are bit-identical (the epilogue hands tiles between waves through LDS: a missing barrier would show up as run-to-run

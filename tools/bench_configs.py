@@ -39,7 +39,7 @@ def run(eng, x, want, label, flops_per_img, bytes_per_img):
     eng.set_profiling(0)
     for i, L in enumerate(eng.plan.layers):
         oh, ow, co = L.out_shape
-        fl = 2.0 * oh * ow * co * L.kh * L.kw * L.in_shape[2] * n if L.kind in (1, 3, 5, 7, 10) else 0
+        fl = 2.0 * oh * ow * co * L.kh * L.kw * L.in_shape[2] * n if L.kind in (1, 3, 5, 7, 10, 18) else 0
         print("  %2d kind %2d %-26s %-16s -> %-16s %8.1f us %7.1f TF" % (i, L.kind, L.name[:26], L.in_shape, L.out_shape, per[i] * 1e3,
                                                                           fl / (per[i] * 1e-3) / 1e12 if per[i] > 0 else 0))
     return out
@@ -48,7 +48,13 @@ def run(eng, x, want, label, flops_per_img, bytes_per_img):
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
     rs = np.random.RandomState(123)
-    if what == "resnet50":
+    if what == "resnet50f32":
+        B = int(os.environ.get("BC_BATCH", "32"))
+        plan = resnet50.build_plan(resnet50.synthetic_weights(123), (224, 224), "caffe", dtype="f32")
+        eng = Engine(plan, max_batch=B)
+        x = torch.from_numpy(rs.uniform(-128, 128, (B, 224, 224, 3)).astype(np.float32)).cuda()
+        run(eng, x, (0,), "ResNet-50 fp32-grade batch %d" % B, resnet50.flops_per_image(plan), 2 * resnet50.activation_bytes_per_image(plan))
+    elif what == "resnet50":
         B = int(os.environ.get("BC_BATCH", "128"))
         plan = resnet50.build_plan(resnet50.synthetic_weights(123), (224, 224), "caffe")
         eng = Engine(plan, max_batch=B)
