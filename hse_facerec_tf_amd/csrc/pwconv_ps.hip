@@ -124,6 +124,14 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     //    from the chunk buffer and only [maps][128 channels] means leave the kernel
     constexpr bool DW = DWM != 0;
     constexpr bool BORDERED = DWM == 2 || DWM == 3;
+    // SWAP (round 3): in the depthwise / pool variants the MFMA operands trade places (activations first), so a lane holds ONE
+    // channel of FOUR consecutive pixels instead of four channels of one pixel.  Parking the tile in the chunk buffer is then 16
+    // consecutive dwords per pixel row and instruction (ds_write_b32, conflict-free up to the harmless 2-way of the two row
+    // groups) instead of a 16-byte column of 8 consecutive rows at a 128-byte pitch = 8 lanes on the same four banks (PMC r02:
+    // 30 % of this kernel's LDS cycles were bank conflicts, all from these ds_write_b128; 512 -> 512 + depthwise 71 -> 61 us).
+    // The four pixels of a lane lie in one image row when 4 divides the map width (bordered 12 x 12 maps; always in the
+    // unbordered layouts, whose rows are the pixel indices); on 14- and 7-pixel maps each pixel's cell is computed by itself.
+    constexpr bool SWAP = DW;
 
     // ---- DW epilogue, shared by both roles: the depthwise of one 32-channel chunk of the tile from the chunk buffer cb ----
     // cb layout: rows 0 .. BM-1 = the chunk's activated pointwise results [pixel][32 ch] fp32, two zero rows (taps outside the
@@ -403,6 +411,15 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     for (int i = 0; i < HB; ++i) h_ah[i] = h_al[i] = fzero;
     auto mfma_block = [&](int mb, const f16x8& xh, const f16x8& xl, const f16x8& wh0, const f16x8& wl0, const f16x8& wh1, const f16x8& wl1) {
         // per accumulator the products keep the order (wh*al, wl*ah, wh*ah) of pwconv_f16s.hip
+        if constexpr (SWAP) {      // lane (l16, lq) -> channel l16 of the block, pixels 4 lq .. 4 lq + 3
+            acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh0, acc[mb][0], 0, 0, 0);
+            acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh1, acc[mb][1], 0, 0, 0);
+            acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl0, acc[mb][0], 0, 0, 0);
+            acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl1, acc[mb][1], 0, 0, 0);
+            acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh0, acc[mb][0], 0, 0, 0);
+            acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh1, acc[mb][1], 0, 0, 0);
+            return;
+        }
         acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, xl, acc[mb][0], 0, 0, 0);
         acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, xl, acc[mb][1], 0, 0, 0);
         acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl0, xh, acc[mb][0], 0, 0, 0);
@@ -460,17 +477,64 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             }
             if constexpr (DW) {
                 // activated results in place, then chunk by chunk through LDS into the depthwise (all twelve waves)
+                if constexpr (SWAP) {      // one channel per lane: 16 nb + l16 of the wave's 32
+                    float s_ds[2], s_sh[2];
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
+                    for (int nb = 0; nb < 2; ++nb) {
+                        s_ds[nb] = *(const float*)(smem + E_OFF + (ci & 1u) * 2048 + (wn * 32 + 16 * nb + l16) * 4);
+                        s_sh[nb] = *(const float*)(smem + E_OFF + (ci & 1u) * 2048 + 1024 + 512 + (wn * 32 + 16 * nb + l16) * 4);
+                    }
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
+                    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[mb][nb][e] = apply_act<ACT>(fmaf(acc[mb][nb][e], e_ds[nb][e], e_sh[nb][e]));
+                        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[mb][nb][e] = apply_act<ACT>(fmaf(acc[mb][nb][e], s_ds[nb], s_sh[nb]));
+                } else {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[mb][nb][e] = apply_act<ACT>(fmaf(acc[mb][nb][e], e_ds[nb][e], e_sh[nb][e]));
+                }
                 unsigned char* cb = smem + (g % 3u) * STAGE;
                 dw_masks();
 #pragma unroll 1
                 for (int c = 0; c < 4; ++c) {
-                    if (wn == c) {
+                    if (SWAP && wn == c) {
+                        // pixels 16 mb + 4 lq + (0..3) of the wave's half: one image row (4 | MW), so their chunk-buffer rows are consecutive
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            const int p0 = wm * 16 * MB + 16 * mb + 4 * lq;
+                            if constexpr (BORDERED && MW % 4 != 0) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int pp = p0 + e;
+                                    if (pp < MAPS * MHW) {          // (tile rows past its whole maps are not parked)
+                                        const int img = pp / MHW, pl = pp - MHW * img, yy = pl / MW;
+                                        const int row = 1 + PITCH + IMG * img + PITCH * yy + (pl - MW * yy);
+#pragma unroll
+                                        for (int nb = 0; nb < 2; ++nb) *(float*)(cb + row * ROWB + (16 * nb + l16) * 4) = acc[mb][nb][e];
+                                    }
+                                }
+                            } else {
+                                int row = p0;
+                                if constexpr (BORDERED) {
+                                    const int pt = row < MAPS * MHW ? row : MAPS * MHW - 4;
+                                    const int img = pt / MHW, pl = pt - MHW * img, yy = pl / MW;
+                                    row = row < MAPS * MHW ? 1 + PITCH + IMG * img + PITCH * yy + (pl - MW * yy) : -1;
+                                }
+                                if (row >= 0) {
+#pragma unroll
+                                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) *(float*)(cb + (row + e) * ROWB + (16 * nb + l16) * 4) = acc[mb][nb][e];
+                                }
+                            }
+                        }
+                    }
+                    if (!SWAP && wn == c) {
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
