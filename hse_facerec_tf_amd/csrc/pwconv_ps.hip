@@ -130,8 +130,9 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     // groups) instead of a 16-byte column of 8 consecutive rows at a 128-byte pitch = 8 lanes on the same four banks (PMC r02:
     // 30 % of this kernel's LDS cycles were bank conflicts, all from these ds_write_b128; 512 -> 512 + depthwise 71 -> 61 us).
     // The four pixels of a lane lie in one image row when 4 divides the map width (bordered 12 x 12 maps; always in the
-    // unbordered layouts, whose rows are the pixel indices); on 14- and 7-pixel maps each pixel's cell is computed by itself.
-    constexpr bool SWAP = DW;
+    // unbordered layouts, whose rows are the pixel indices).  14- and 7-pixel maps keep the old orientation: with a cell
+    // computed per pixel (36 divisions per lane and tile) the 224 x 224 plan lost 3.5 % in a same-box A/B.
+    constexpr bool SWAP = DW && (!BORDERED || MW % 4 == 0);
 
     // ---- DW epilogue, shared by both roles: the depthwise of one 32-channel chunk of the tile from the chunk buffer cb ----
     // cb layout: rows 0 .. BM-1 = the chunk's activated pointwise results [pixel][32 ch] fp32, two zero rows (taps outside the
@@ -507,18 +508,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb) {
                             const int p0 = wm * 16 * MB + 16 * mb + 4 * lq;
-                            if constexpr (BORDERED && MW % 4 != 0) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const int pp = p0 + e;
-                                    if (pp < MAPS * MHW) {          // (tile rows past its whole maps are not parked)
-                                        const int img = pp / MHW, pl = pp - MHW * img, yy = pl / MW;
-                                        const int row = 1 + PITCH + IMG * img + PITCH * yy + (pl - MW * yy);
-#pragma unroll
-                                        for (int nb = 0; nb < 2; ++nb) *(float*)(cb + row * ROWB + (16 * nb + l16) * 4) = acc[mb][nb][e];
-                                    }
-                                }
-                            } else {
+                            {
                                 int row = p0;
                                 if constexpr (BORDERED) {
                                     const int pt = row < MAPS * MHW ? row : MAPS * MHW - 4;
