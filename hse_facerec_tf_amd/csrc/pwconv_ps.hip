@@ -539,9 +539,13 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                                 if (row >= 0) *(f32x4*)(cb + row * ROWB + (16 * nb + 4 * lq) * 4) = acc[mb][nb];      // (tile rows past its whole maps are not parked)
                             }
                     }
+                    PS_STAMP(4);                        // (diagnostic builds: 4 = parking, 5 = barrier waits, 2 = the depthwise itself)
                     __syncthreads();
+                    PS_STAMP(5);
                     dw_chunk(c, cb, m0, n0);
+                    PS_STAMP(2);
                     __syncthreads();                    // (the last one lets the loaders go on)
+                    PS_STAMP(5);
                 }
                 PS_STAMP(2);
             } else {

@@ -27,13 +27,22 @@ for hw, k, n in ((12, 512, 512), (6, 1024, 1024), (24, 128, 256)):
     sh = torch.randn((n,), device="cuda", generator=g)
     prep = ops.split_weights_device(w, x.device)
     xs = ops.split_rows_encode(x)
+    DWE = os.environ.get("PS_DW") == "1" and hw in (12, 6)
+    if DWE:          # the variant with the next depthwise in the epilogue (whole maps per tile)
+        xs6 = xs.reshape(B * (GRID or 256) // 256 if GRID else B, hw, hw, k // 32, 2, 32)
+        dw_w = torch.randn((3, 3, n), device="cuda", generator=g) / 3
+        dsc = torch.rand((n,), device="cuda", generator=g) + 0.5
+        dsh = torch.randn((n,), device="cuda", generator=g) * 0.3
     for _ in range(5):
-        ops.pwconv1x1_presplit(xs, None, sh, prepared=prep)
+        if DWE:
+            ops.pwconv1x1_presplit_dw(xs6, None, sh, dw_w, dsc, dsh, prepared=prep)
+        else:
+            ops.pwconv1x1_presplit(xs, None, sh, prepared=prep)
     torch.cuda.synchronize()
     buf = np.zeros((256, 12, 8), np.uint64)
     _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
     b = buf.astype(np.float64)
-    for role, sl, names in (("MFMA waves", slice(0, 8), ["ds_read + mfma issue", "step barrier", "epilogue", "tile barrier"]),
+    for role, sl, names in (("MFMA waves", slice(0, 8), ["ds_read + mfma issue", "step barrier", "epilogue (DW: the depthwise)", "tile barrier", "DW: parking", "DW: barrier waits"]),
                             ("loader waves", slice(8, 12), ["DMA issue", "vmcnt wait", "step barrier", "tile barrier"])):
         r = b[:, sl, :].reshape(-1, 8)
         r = r[r[:, 7] > 0]
