@@ -59,6 +59,36 @@ def test_detection_on_the_reference_image(det, z):
     assert empty_boxes.shape[0] == 0
 
 
+def test_one_detector_serves_two_threads(det):
+    """the uploaded frame is an argument of the stage methods, not detector state, and the work tensors of the
+    device box logic are per thread -- two threads (each on its own stream, as a threaded pipeline would run them) detecting
+    DIFFERENT frames through one detector get what a serial run gets."""
+    import threading
+    import torch
+    img = opl.imread_rgb(TEST_IMAGE)
+    frames = [img, np.ascontiguousarray(img[:, ::-1]), np.ascontiguousarray(img[40:500, 100:700]), np.ascontiguousarray(img[::-1])]
+    serial = [det(f) for f in frames]
+    out = [None] * len(frames)
+    errors = []
+
+    def work(ids):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):
+                    for i in ids:
+                        out[i] = det(frames[i])
+        except Exception as e:           # surfaced below: an exception in a thread must fail the test
+            errors.append(e)
+    ts = [threading.Thread(target=work, args=(ids,)) for ids in ((0, 2), (1, 3))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for (b0, p0), (b1, p1) in zip(serial, out):
+        assert np.array_equal(b0, b1) and np.array_equal(p0, p1)
+
+
 def test_process_image_full_dropin(z):
     """FacialImageProcessing(mtcnn_detector=True).process_image(bgr frame) as process_photos.py:33 calls it."""
     from hse_facerec_tf_amd import FacialImageProcessing
