@@ -139,6 +139,93 @@ __global__ __launch_bounds__(256) void u8_to_input_kernel(const unsigned char* _
 
 unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
 
+// Both PIL passes in ONE kernel for the byte-output mode (round 3: the resized bytes feed hsefr_engine_forward_u8, and the two
+// per-pixel kernels above -- byte loads and byte stores from global memory, ~170 us per 256 photos -- were what kept the
+// H2D-inclusive rate 12 % under the engine's).  A workgroup owns a band of TB output rows of one image: the input rows the
+// band needs are one contiguous byte range, staged into LDS with dword loads; the horizontal pass runs LDS -> LDS (bytes: an
+// output value mixes input columns with its own weights); the vertical pass is elementwise over a row, so a thread takes FOUR
+// consecutive bytes (one ds_read_b32 per tap row) and leaves with one coalesced dword store.  Same integer arithmetic, same two
+// roundings to uint8: bit-exact with the two-kernel path and with Pillow.
+__global__ __launch_bounds__(256) void pil_resize_u8_fused_kernel(const unsigned char* __restrict__ in, unsigned* __restrict__ out,
+                                                                  const int* __restrict__ xmin, const int* __restrict__ xcnt,
+                                                                  const int* __restrict__ xcoef, int xk, const int* __restrict__ ymin,
+                                                                  const int* __restrict__ ycnt, const int* __restrict__ ycoef, int yk,
+                                                                  int H, int W, int oh, int ow, int TB, int cap, int bands,
+                                                                  long long in_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
+    const int y0 = band * TB, y1 = min(y0 + TB, oh);
+    const int r_lo = ymin[y0];
+    const int nr = min(ymin[y1 - 1] + ycnt[y1 - 1] - r_lo, cap);           // (the launcher sized `cap` from the scale: never binding)
+    const int rowb = W * 3, orow = ow * 3, D = orow >> 2;
+    const long long g0 = ((long long)n * H + r_lo) * rowb;
+    const long long g0a = g0 & ~3ll;
+    const int phase = (int)(g0 - g0a);
+    unsigned char* lin = lds;                                               // [phase + nr * rowb] input bytes
+    unsigned char* tmp = lds + (((size_t)cap * rowb + 3 + 15) & ~(size_t)15); // [nr][orow] horizontally resampled rows
+    const int nd = (phase + nr * rowb + 3) >> 2;
+    for (int i = tid; i < nd; i += 256) {
+        const long long a = g0a + 4ll * i;
+        unsigned v;
+        if (a + 4 <= in_bytes) v = *(const unsigned*)(in + a);
+        else {                                                              // the tensor's last dword, cut short
+            v = 0;
+            for (int b = 0; b < 4; ++b)
+                if (a + b < in_bytes) v |= (unsigned)in[a + b] << (8 * b);
+        }
+        ((unsigned*)lin)[i] = v;
+    }
+    __syncthreads();
+    // the column tables once per workgroup in LDS ([ow][8] ints: byte offset of the first tap, tap count, up to six weights): every
+    // item of the horizontal pass would otherwise fetch them from global memory again
+    int* xt = (int*)(tmp + (size_t)cap * orow);
+    const bool xt_ok = xk <= 6;
+    if (xt_ok)
+        for (int i = tid; i < ow * 8; i += 256) {
+            const int xx = i >> 3, f = i & 7;
+            xt[i] = f == 0 ? xmin[xx] * 3 : (f == 1 ? xcnt[xx] : (f - 2 < xk ? xcoef[(long long)xx * xk + f - 2] : 0));
+        }
+    __syncthreads();
+    for (int item = tid; item < nr * ow; item += 256) {
+        const int r = item / ow, xx = item - r * ow;
+        const unsigned char* src = lin + phase + r * rowb + (xt_ok ? xt[8 * xx] : xmin[xx] * 3);
+        const int* k = xt_ok ? xt + 8 * xx + 2 : xcoef + (long long)xx * xk;
+        const int c = xt_ok ? xt[8 * xx + 1] : xcnt[xx];
+        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+        for (int x = 0; x < c; ++x) {
+            const int w = k[x];
+            s0 += src[x * 3 + 0] * w;
+            s1 += src[x * 3 + 1] * w;
+            s2 += src[x * 3 + 2] * w;
+        }
+        unsigned char* dst = tmp + r * orow + xx * 3;
+        dst[0] = (unsigned char)min(max(s0 >> 22, 0), 255);
+        dst[1] = (unsigned char)min(max(s1 >> 22, 0), 255);
+        dst[2] = (unsigned char)min(max(s2 >> 22, 0), 255);
+    }
+    __syncthreads();
+    for (int item = tid; item < (y1 - y0) * D; item += 256) {
+        const int yy = item / D, d = item - yy * D, y = y0 + yy;
+        const int* k = ycoef + (long long)y * yk;
+        const int rb = ymin[y] - r_lo;
+        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21, a3 = 1 << 21;
+        // all `yk` table entries (zero beyond the row's tap count: Pillow's table is zero-padded), rows clamped into the band: a
+        // uniform trip count keeps the loop a plain one
+        for (int t = 0; t < yk; ++t) {
+            const int w = k[t];
+            const unsigned u = ((const unsigned*)(tmp + min(rb + t, nr - 1) * orow))[d];
+            a0 += (int)(u & 255u) * w;
+            a1 += (int)((u >> 8) & 255u) * w;
+            a2 += (int)((u >> 16) & 255u) * w;
+            a3 += (int)(u >> 24) * w;
+        }
+        const unsigned o = (unsigned)min(max(a0 >> 22, 0), 255) | ((unsigned)min(max(a1 >> 22, 0), 255) << 8) |
+                           ((unsigned)min(max(a2 >> 22, 0), 255) << 16) | ((unsigned)min(max(a3 >> 22, 0), 255) << 24);
+        out[((long long)n * oh + y) * D + d] = o;
+    }
+}
+
 }  // namespace
 
 int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, int n, int H, int W, int oh, int ow, const int* xmin,
@@ -149,6 +236,19 @@ int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, i
     if (n == 0) return HSEFR_OK;
     const long long t1 = (long long)n * H * ow, t2 = (long long)n * oh * ow;
     HSEFR_REQUIRE(t1 < (1ll << 39) && t2 < (1ll << 39), HSEFR_ERR_UNSUPPORTED, "pil_resize: too large");
+    if (mode == 3 && ow % 4 == 0) {
+        // the fused byte-output kernel: a band of TB output rows needs at most TB * scale + 2 * support (+ rounding) input rows
+        constexpr int TB = 16;
+        const double scale = (double)H / oh, support = scale > 1.0 ? scale : 1.0;
+        const int cap = (int)(TB * scale + 2.0 * support) + 4;
+        const size_t lds_bytes = (((size_t)cap * W * 3 + 3 + 15) & ~(size_t)15) + (size_t)cap * ow * 3 + (size_t)ow * 32;
+        const int bands = (oh + TB - 1) / TB;
+        if (lds_bytes <= 60 * 1024 && (long long)n * bands < (1ll << 31)) {
+            hipLaunchKernelGGL(pil_resize_u8_fused_kernel, dim3((unsigned)(n * bands)), dim3(256), lds_bytes, s, in, (unsigned*)out, xmin, xcnt, xcoef, xk,
+                               ymin, ycnt, ycoef, yk, H, W, oh, ow, TB, cap, bands, (long long)n * H * W * 3);
+            return launch_status("pil_resize_fused");
+        }
+    }
     hipLaunchKernelGGL(pil_resample_h_kernel, dim3(blocks_for(t1)), dim3(256), 0, s, in, tmp, xmin, xcnt, xcoef, xk, H, W, ow, t1);
     hipLaunchKernelGGL(pil_resample_v_kernel, dim3(blocks_for(t2)), dim3(256), 0, s, tmp, out, ymin, ycnt, ycoef, yk, H, oh, ow, t2,
                        mode, (float)mean[0], (float)mean[1], (float)mean[2], mean[0], mean[1], mean[2]);

@@ -30,6 +30,23 @@ def test_pil_path_bit_exact(torch_, n, H, W, s, bgr, imagenet):
     assert got.dtype == np.float32 and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,H,W,oh,ow", [(3, 250, 250, 192, 192), (2, 250, 250, 224, 224), (1, 588, 784, 224, 224), (2, 100, 80, 192, 192),
+                                          (4, 192, 192, 192, 192), (5, 251, 249, 96, 96), (1, 33, 47, 64, 40), (2, 250, 250, 190, 190),
+                                          (1, 1200, 900, 192, 192), (7, 250, 250, 100, 96)])
+def test_raw_uint8_resize_is_pillows_bytes(torch_, n, H, W, oh, ow):
+    """preprocess_pil(raw_u8=True) -- what Engine.forward_u8 is fed -- against PIL.Image.resize(BILINEAR) itself, byte for byte:
+    the fused one-kernel form (ow % 4 == 0 and the band fits LDS), its fallbacks (ow % 4 != 0: 190; a band too large for LDS:
+    1200 x 900 -> 192), enlarging, odd sizes, the last image's rows running to the very end of the buffer."""
+    from hse_facerec_tf_amd import preprocess_device as pd
+    imgs = np.random.RandomState(H + ow).randint(0, 256, (n, H, W, 3)).astype(np.uint8)
+    got = pd.preprocess_pil(imgs, (oh, ow), raw_u8=True)
+    assert got.dtype == torch_.uint8 and tuple(got.shape) == (n, oh, ow, 3)
+    want = np.stack([np.asarray(Image.fromarray(im).resize((ow, oh), resample=Image.BILINEAR)) for im in imgs])
+    assert np.array_equal(got.cpu().numpy(), want)
+    again = pd.preprocess_pil(torch_.from_numpy(imgs).cuda(), (oh, ow), raw_u8=True)
+    assert torch_.equal(got, again)
+
+
 @pytest.mark.parametrize("H,W", [(37, 53), (300, 200), (224, 224), (588, 784), (64, 64)])
 def test_cv_path_bit_exact(torch_, H, W):
     from hse_facerec_tf_amd import preprocess_device as pd
