@@ -141,88 +141,120 @@ unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
 
 // Both PIL passes in ONE kernel for the byte-output mode (round 3: the resized bytes feed hsefr_engine_forward_u8, and the two
 // per-pixel kernels above -- byte loads and byte stores from global memory, ~170 us per 256 photos -- were what kept the
-// H2D-inclusive rate 12 % under the engine's).  A workgroup owns a band of TB output rows of one image: the input rows the
-// band needs are one contiguous byte range, staged into LDS with dword loads; the horizontal pass runs LDS -> LDS (bytes: an
-// output value mixes input columns with its own weights); the vertical pass is elementwise over a row, so a thread takes FOUR
-// consecutive bytes (one ds_read_b32 per tap row) and leaves with one coalesced dword store.  Same integer arithmetic, same two
-// roundings to uint8: bit-exact with the two-kernel path and with Pillow.
-__global__ __launch_bounds__(256) void pil_resize_u8_fused_kernel(const unsigned char* __restrict__ in, unsigned* __restrict__ out,
-                                                                  const int* __restrict__ xmin, const int* __restrict__ xcnt,
-                                                                  const int* __restrict__ xcoef, int xk, const int* __restrict__ ymin,
-                                                                  const int* __restrict__ ycnt, const int* __restrict__ ycoef, int yk,
-                                                                  int H, int W, int oh, int ow, int TB, int cap, int bands,
-                                                                  long long in_bytes) {
+// H2D-inclusive rate 12 % under the engine's).  A workgroup owns a band of TB output rows of one image:
+//   1. the input rows the band needs are one contiguous byte range: `buffer_load_dwordx4 ... lds` pieces of 1 KiB, all in flight at
+//      once (the first version's load -> wait -> ds_write loop paid one memory latency per 1 KiB), the raw-buffer bound returning
+//      zeros past the tensor; the column / row tables ([.][8] ints: first tap, up to seven weights, zero-padded as Pillow's are) go
+//      to LDS under the DMA;
+//   2. horizontal pass, LDS -> LDS: a wave takes input rows, a lane an output pixel whose K weights stay in registers over the
+//      rows; the 3K source bytes come as aligned dwords + v_alignbit (not 3K ds_read_u8), the products are v_mad_i32_i24 (a 32-bit
+//      v_mul_lo is quarter rate), and the three result bytes of four neighbouring lanes are packed through a quad DPP move into
+//      three ds_write_b32;
+//   3. vertical pass: elementwise over a row, so a lane takes FOUR consecutive bytes (one ds_read_b32 per tap row) and leaves with
+//      one coalesced dword store; the row's weights are wave-uniform.
+// Same integer arithmetic, same two roundings to uint8: bit-exact with the two-kernel path and with Pillow.  K = table width
+// (3 when enlarging, 5 up to 2x reduction, 7 up to 3x).
+__device__ __forceinline__ int u8_round(int acc) { return min(max(acc >> 22, 0), 255); }
+
+template <int K>
+__global__ __launch_bounds__(256) void pil_resize_u8_band_kernel(const unsigned char* __restrict__ in, unsigned* __restrict__ out,
+                                                                 const int* __restrict__ xmin, const int* __restrict__ xcoef, int xk,
+                                                                 const int* __restrict__ ymin, const int* __restrict__ ycnt,
+                                                                 const int* __restrict__ ycoef, int yk, int H, int W, int oh, int ow,
+                                                                 int TB, int cap, int bands, long long in_bytes, int lin_bytes) {
+    constexpr int NA = (3 * K + 3) / 4;                                     // dwords holding one pixel's 3K source bytes
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
     const int y0 = band * TB, y1 = min(y0 + TB, oh);
     const int r_lo = ymin[y0];
     const int nr = min(ymin[y1 - 1] + ycnt[y1 - 1] - r_lo, cap);           // (the launcher sized `cap` from the scale: never binding)
     const int rowb = W * 3, orow = ow * 3, D = orow >> 2;
-    const long long g0 = ((long long)n * H + r_lo) * rowb;
-    const long long g0a = g0 & ~3ll;
+    const long long g0 = ((long long)n * H + r_lo) * rowb, g0a = g0 & ~15ll;
     const int phase = (int)(g0 - g0a);
-    unsigned char* lin = lds;                                               // [phase + nr * rowb] input bytes
-    unsigned char* tmp = lds + (((size_t)cap * rowb + 3 + 15) & ~(size_t)15); // [nr][orow] horizontally resampled rows
-    const int nd = (phase + nr * rowb + 3) >> 2;
-    for (int i = tid; i < nd; i += 256) {
-        const long long a = g0a + 4ll * i;
-        unsigned v;
-        if (a + 4 <= in_bytes) v = *(const unsigned*)(in + a);
-        else {                                                              // the tensor's last dword, cut short
-            v = 0;
-            for (int b = 0; b < 4; ++b)
-                if (a + b < in_bytes) v |= (unsigned)in[a + b] << (8 * b);
+    unsigned char* tmp = lds + lin_bytes;                                   // [nr][orow] horizontally resampled rows
+    int* xt = (int*)(tmp + (((size_t)cap * orow + 15) & ~(size_t)15));      // [ow][8]
+    int* yt = xt + ow * 8;                                                  // [TB][8]
+    {
+        // (+3: the tensor's last dword may be cut short; the bytes behind it sit in the same aligned word, are never faulting, and
+        // only ever meet zero weights)
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(in + g0a, ((in_bytes + 3) & ~3ll) - g0a);
+        const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds;
+        const int npiece = (phase + nr * rowb + 1023) >> 10;
+        for (int p = wave; p < npiece; p += 4)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds0 + p * 1024),
+                         "v"(p * 1024 + lane * 16), "s"(r)
+                         : "memory");
+    }
+    for (int e0 = 0; e0 < ow * 8; e0 += 256 * 8) {                           // eight independent loads per thread, then the writes
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + u * 256 + tid, ow * 8 - 1), xx = e >> 3, f = e & 7;
+            v[u] = f == 0 ? xmin[xx] : xcoef[(long long)xx * xk + min(f - 1, xk - 1)];
         }
-        ((unsigned*)lin)[i] = v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256 + tid, f = e & 7;
+            if (e < ow * 8) xt[e] = f == 0 ? v[u] * 3 : (f - 1 < xk ? v[u] : 0);
+        }
+    }
+    if (tid < TB * 8) {
+        const int y = min(y0 + (tid >> 3), oh - 1), f = tid & 7;
+        yt[tid] = f == 0 ? ymin[y] - r_lo : (f - 1 < yk ? ycoef[(long long)y * yk + f - 1] : 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int xx0 = 0; xx0 < ow; xx0 += 64) {
+        const int xx = xx0 + lane;
+        const bool on = xx < ow;
+        const int4 t0 = *(const int4*)(xt + 8 * (on ? xx : ow - 1)), t1 = *(const int4*)(xt + 8 * (on ? xx : ow - 1) + 4);
+        const int w[7] = {t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        const int j = lane & 3;
+        for (int r = wave; r < nr; r += 4) {
+            const int a = phase + r * rowb + t0.x;
+            const unsigned* q = (const unsigned*)(lds + (a & ~3));
+            const int sh = (a & 3) * 8;
+            unsigned d[NA + 1], s[NA];
+#pragma unroll
+            for (int i = 0; i <= NA; ++i) d[i] = q[i];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) s[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
+            int acc[3] = {1 << 21, 1 << 21, 1 << 21};
+#pragma unroll
+            for (int t = 0; t < K; ++t)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int b = 3 * t + c;
+                    acc[c] += __mul24((int)((s[b >> 2] >> (8 * (b & 3))) & 255u), w[t]);
+                }
+            const unsigned p = (unsigned)u8_round(acc[0]) | ((unsigned)u8_round(acc[1]) << 8) | ((unsigned)u8_round(acc[2]) << 16);
+            const unsigned pn = (unsigned)__builtin_amdgcn_mov_dpp((int)p, 0xF9, 0xF, 0xF, true);   // quad_perm [1,2,3,3]: the next lane's pixel
+            // four pixels = twelve bytes = three dwords: lanes 0..2 of the quad write one each
+            const unsigned dw = (p >> (8 * j)) | (pn << (24 - 8 * j));
+            if (on && j < 3) ((unsigned*)(tmp + r * orow))[3 * (xx >> 2) + j] = dw;
+        }
     }
     __syncthreads();
-    // the column tables once per workgroup in LDS ([ow][8] ints: byte offset of the first tap, tap count, up to six weights): every
-    // item of the horizontal pass would otherwise fetch them from global memory again
-    int* xt = (int*)(tmp + (size_t)cap * orow);
-    const bool xt_ok = xk <= 6;
-    if (xt_ok)
-        for (int i = tid; i < ow * 8; i += 256) {
-            const int xx = i >> 3, f = i & 7;
-            xt[i] = f == 0 ? xmin[xx] * 3 : (f == 1 ? xcnt[xx] : (f - 2 < xk ? xcoef[(long long)xx * xk + f - 2] : 0));
+    const int nch = (D + 63) >> 6, rows = y1 - y0;
+    for (int c = wave; c < rows * nch; c += 4) {
+        const int yy = c / nch, d = (c - yy * nch) * 64 + lane;
+        const int4 t0 = *(const int4*)(yt + 8 * yy), t1 = *(const int4*)(yt + 8 * yy + 4);
+        const int w[7] = {t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        if (d < D) {
+            int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21, a3 = 1 << 21;
+            // all K table entries (zero beyond the row's tap count), rows clamped into the band: a uniform trip count
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const unsigned u = ((const unsigned*)(tmp + min(t0.x + t, nr - 1) * orow))[d];
+                a0 += __mul24((int)(u & 255u), w[t]);
+                a1 += __mul24((int)((u >> 8) & 255u), w[t]);
+                a2 += __mul24((int)((u >> 16) & 255u), w[t]);
+                a3 += __mul24((int)(u >> 24), w[t]);
+            }
+            out[((long long)n * oh + y0 + yy) * D + d] = (unsigned)u8_round(a0) | ((unsigned)u8_round(a1) << 8) |
+                                                         ((unsigned)u8_round(a2) << 16) | ((unsigned)u8_round(a3) << 24);
         }
-    __syncthreads();
-    for (int item = tid; item < nr * ow; item += 256) {
-        const int r = item / ow, xx = item - r * ow;
-        const unsigned char* src = lin + phase + r * rowb + (xt_ok ? xt[8 * xx] : xmin[xx] * 3);
-        const int* k = xt_ok ? xt + 8 * xx + 2 : xcoef + (long long)xx * xk;
-        const int c = xt_ok ? xt[8 * xx + 1] : xcnt[xx];
-        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
-        for (int x = 0; x < c; ++x) {
-            const int w = k[x];
-            s0 += src[x * 3 + 0] * w;
-            s1 += src[x * 3 + 1] * w;
-            s2 += src[x * 3 + 2] * w;
-        }
-        unsigned char* dst = tmp + r * orow + xx * 3;
-        dst[0] = (unsigned char)min(max(s0 >> 22, 0), 255);
-        dst[1] = (unsigned char)min(max(s1 >> 22, 0), 255);
-        dst[2] = (unsigned char)min(max(s2 >> 22, 0), 255);
-    }
-    __syncthreads();
-    for (int item = tid; item < (y1 - y0) * D; item += 256) {
-        const int yy = item / D, d = item - yy * D, y = y0 + yy;
-        const int* k = ycoef + (long long)y * yk;
-        const int rb = ymin[y] - r_lo;
-        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21, a3 = 1 << 21;
-        // all `yk` table entries (zero beyond the row's tap count: Pillow's table is zero-padded), rows clamped into the band: a
-        // uniform trip count keeps the loop a plain one
-        for (int t = 0; t < yk; ++t) {
-            const int w = k[t];
-            const unsigned u = ((const unsigned*)(tmp + min(rb + t, nr - 1) * orow))[d];
-            a0 += (int)(u & 255u) * w;
-            a1 += (int)((u >> 8) & 255u) * w;
-            a2 += (int)((u >> 16) & 255u) * w;
-            a3 += (int)(u >> 24) * w;
-        }
-        const unsigned o = (unsigned)min(max(a0 >> 22, 0), 255) | ((unsigned)min(max(a1 >> 22, 0), 255) << 8) |
-                           ((unsigned)min(max(a2 >> 22, 0), 255) << 16) | ((unsigned)min(max(a3 >> 22, 0), 255) << 24);
-        out[((long long)n * oh + y) * D + d] = o;
     }
 }
 
@@ -236,16 +268,26 @@ int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, i
     if (n == 0) return HSEFR_OK;
     const long long t1 = (long long)n * H * ow, t2 = (long long)n * oh * ow;
     HSEFR_REQUIRE(t1 < (1ll << 39) && t2 < (1ll << 39), HSEFR_ERR_UNSUPPORTED, "pil_resize: too large");
-    if (mode == 3 && ow % 4 == 0) {
-        // the fused byte-output kernel: a band of TB output rows needs at most TB * scale + 2 * support (+ rounding) input rows
+    if (mode == 3 && ow % 4 == 0 && xk <= 7 && yk <= 7) {
+        // the fused byte-output kernel.  Pillow's tables: first tap = (int)(centre - support + 0.5), one past the last =
+        // (int)(centre + support + 0.5) -> a band of TB output rows spans at most (TB - 1) * scale + 2 * support + 1 input rows
         constexpr int TB = 16;
         const double scale = (double)H / oh, support = scale > 1.0 ? scale : 1.0;
-        const int cap = (int)(TB * scale + 2.0 * support) + 4;
-        const size_t lds_bytes = (((size_t)cap * W * 3 + 3 + 15) & ~(size_t)15) + (size_t)cap * ow * 3 + (size_t)ow * 32;
+        const int cap = (int)((TB - 1) * scale + 2.0 * support) + 2;
+        const int kk = xk > yk ? xk : yk;
+        const int na = (3 * (kk <= 3 ? 3 : (kk <= 5 ? 5 : 7)) + 3) / 4;
+        // input window: 16-byte phase + whole 1 KiB DMA pieces + the over-read of the last pixel's aligned dwords
+        const size_t lin_bytes = (((size_t)15 + (size_t)cap * W * 3 + 4 * (na + 1)) + 1023) & ~(size_t)1023;
+        const size_t lds_bytes = lin_bytes + (((size_t)cap * ow * 3 + 15) & ~(size_t)15) + (size_t)ow * 32 + TB * 32;
         const int bands = (oh + TB - 1) / TB;
-        if (lds_bytes <= 60 * 1024 && (long long)n * bands < (1ll << 31)) {
-            hipLaunchKernelGGL(pil_resize_u8_fused_kernel, dim3((unsigned)(n * bands)), dim3(256), lds_bytes, s, in, (unsigned*)out, xmin, xcnt, xcoef, xk,
-                               ymin, ycnt, ycoef, yk, H, W, oh, ow, TB, cap, bands, (long long)n * H * W * 3);
+        if (lds_bytes <= 64 * 1024 && (long long)n * bands < (1ll << 31)) {
+#define HSEFR_BAND(K)                                                                                                                 \
+    hipLaunchKernelGGL(pil_resize_u8_band_kernel<K>, dim3((unsigned)(n * bands)), dim3(256), lds_bytes, s, in, (unsigned*)out, xmin, \
+                       xcoef, xk, ymin, ycnt, ycoef, yk, H, W, oh, ow, TB, cap, bands, (long long)n * H * W * 3, (int)lin_bytes)
+            if (kk <= 3) HSEFR_BAND(3);
+            else if (kk <= 5) HSEFR_BAND(5);
+            else HSEFR_BAND(7);
+#undef HSEFR_BAND
             return launch_status("pil_resize_fused");
         }
     }
