@@ -154,7 +154,14 @@ unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
 //      one coalesced dword store; the row's weights are wave-uniform.
 // Same integer arithmetic, same two roundings to uint8: bit-exact with the two-kernel path and with Pillow.  K = table width
 // (3 when enlarging, 5 up to 2x reduction, 7 up to 3x).
-__device__ __forceinline__ int u8_round(int acc) { return min(max(acc >> 22, 0), 255); }
+// (the clamp goes through an opaque v_med3_i32: left to itself hipcc fuses  sat_u8(a >> 22) | sat_u8(b >> 22) << 8  into gfx950's
+// v_ashr_pk_u8_i32, which writes only 16 bits of its destination, and then ORs the other two bytes into an upper half it takes
+// for zero -- tools/ashr_pk_probe.hip, profiles/r03_ashr_pk_probe.txt; tools/isa_lint.py refuses the instruction)
+__device__ __forceinline__ int u8_round(int acc) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(acc >> 22), "v"(255));
+    return r;
+}
 
 template <int K>
 __global__ __launch_bounds__(256) void pil_resize_u8_band_kernel(const unsigned char* __restrict__ in, unsigned* __restrict__ out,
@@ -239,14 +246,17 @@ __global__ __launch_bounds__(256) void pil_resize_u8_band_kernel(const unsigned 
     const int nch = (D + 63) >> 6, rows = y1 - y0;
     for (int c = wave; c < rows * nch; c += 4) {
         const int yy = c / nch, d = (c - yy * nch) * 64 + lane;
-        const int4 t0 = *(const int4*)(yt + 8 * yy), t1 = *(const int4*)(yt + 8 * yy + 4);
-        const int w[7] = {t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        // (wave-uniform: through readfirstlane the row offsets and weights are scalar operands, not per-lane arithmetic)
+        int w[7];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) w[t] = t < K ? __builtin_amdgcn_readfirstlane(yt[8 * yy + 1 + t]) : 0;
+        const int rb = __builtin_amdgcn_readfirstlane(yt[8 * yy]);
         if (d < D) {
             int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21, a3 = 1 << 21;
             // all K table entries (zero beyond the row's tap count), rows clamped into the band: a uniform trip count
 #pragma unroll
             for (int t = 0; t < K; ++t) {
-                const unsigned u = ((const unsigned*)(tmp + min(t0.x + t, nr - 1) * orow))[d];
+                const unsigned u = ((const unsigned*)(tmp + min(rb + t, nr - 1) * orow))[d];
                 a0 += __mul24((int)(u & 255u), w[t]);
                 a1 += __mul24((int)((u >> 8) & 255u), w[t]);
                 a2 += __mul24((int)((u >> 16) & 255u), w[t]);

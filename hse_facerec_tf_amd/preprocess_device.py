@@ -65,12 +65,19 @@ def cv_linear_taps(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray,
     return base.astype(np.int32), nxt.astype(np.int32), w1
 
 
+def _tight(xmin, cnt, coef, ksize):
+    """Pillow sizes its table rows for ceil(support) * 2 + 1 taps; the rows hold at most floor(2 * support) + 1 (250 -> 192:
+    three of five).  The device kernels loop over the table WIDTH (zero weights included), so hand them the tight table."""
+    k = max(1, int(cnt.max()))
+    return xmin, cnt, np.ascontiguousarray(coef[:, :k]), k
+
+
 @lru_cache(maxsize=64)
 def _pil_tables_dev(H: int, W: int, oh: int, ow: int, device_index: int):
     torch = _lib.require_gpu()
     dev = torch.device("cuda", device_index)
-    xm, xc, xk, xks = pil_bilinear_coeffs(W, ow)
-    ym, yc, yk, yks = pil_bilinear_coeffs(H, oh)
+    xm, xc, xk, xks = _tight(*pil_bilinear_coeffs(W, ow))
+    ym, yc, yk, yks = _tight(*pil_bilinear_coeffs(H, oh))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     return (t(xm), t(xc), t(xk), xks, t(ym), t(yc), t(yk), yks)
 

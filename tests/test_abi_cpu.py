@@ -120,6 +120,15 @@ def test_no_unguarded_store_data_hazard_in_the_device_code():
 """
     found = lint.scan_listing(numeric)
     assert len(found) == 1 and found[0][3] == [("v", 2), ("v", 3)]
+    # second rule: the 16-bit-writing pack instruction hipcc treats as a full-register write (profiles/r03_ashr_pk_probe.txt)
+    half = """
+0000000000004000 <kernel_d>:
+	v_ashr_pk_u8_i32 v5, v5, v7, 22                            // 000000004000: D2650005 025A0F05
+	v_or3_b32 v5, v5, v6, v1                                   // 000000004008: D1FF0005 04060D05
+	s_endpgm                                                   // 000000004010: BF810000
+"""
+    found = lint.scan_listing(half)
+    assert len(found) == 1 and "v_ashr_pk_u8_i32" in found[0][1]
     # and a library in which nothing could be scanned does not pass vacuously
     import subprocess, sys, tempfile
     with tempfile.NamedTemporaryFile(suffix=".so") as f:

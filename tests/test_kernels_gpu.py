@@ -441,3 +441,22 @@ def test_store_data_hazard_probe_still_says_two_wait_states(tmp_path):
     first = out.stdout.split("1 wait state")[0]                 # the zero-wait-state block of the SGPR-offset form
     wrong = [int(v) for line in first.splitlines() if "wrong dwords" in line for v in line.split("= [")[1].split("]")[0].split()]
     assert sum(wrong) > 0, "the hazard no longer reproduces on this device/driver: revisit tools/isa_lint.py"
+
+
+def test_ashr_pk_probe_still_shows_the_half_register_write(tmp_path):
+    """tools/ashr_pk_probe.hip on this GPU: v_ashr_pk_u8_i32 keeps the upper half of its destination, and hipcc's own code for
+    sat(a>>22) | sat(b>>22)<<8 | sat(c>>22)<<16 comes out wrong because of it (DESIGN.md lesson 36).  The day either line changes,
+    preprocess.hip's opaque clamp and the lint rule can go."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "probe")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", os.path.join(root, "tools", "ashr_pk_probe.hip"), "-o", exe],
+                   check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "low half  : 0xC84D" in out.stdout
+    assert "PRESERVED" in out.stdout, "the instruction now writes the whole register: revisit tools/isa_lint.py\n" + out.stdout

@@ -16,6 +16,13 @@ The lint disassembles every gfx950 code object embedded in the library and repor
 scratch, more than 64 bits of data) followed within TWO wait states by a vector write into its data registers.
 Exit status 1 if any is found.  `hse_facerec_tf_amd/csrc/build.sh` runs it after linking, tests/test_abi_cpu.py again.
 
+Second rule (round 3, tools/ashr_pk_probe.hip -> profiles/r03_ashr_pk_probe.txt, DESIGN.md lesson 36): `v_ashr_pk_u8_i32` /
+`v_ashr_pk_i8_i32` (new on gfx950) write the LOW 16 bits of their destination and keep the upper half, while hipcc (ROCm 7.2)
+selects them for  sat_u8(a >> n) | sat_u8(b >> n) << 8  and then ORs further bytes into bits 16..31 as if they were zero:
+the C expression  sat(a>>22) | sat(b>>22)<<8 | sat(c>>22)<<16  returns garbage in its upper half whenever the destination
+register held something before.  Any occurrence of these instructions fails the build (clamp through an opaque
+`v_med3_i32`, as preprocess.hip's u8_round does).
+
 usage: tools/isa_lint.py [path/to/libhsefr.so]
 """
 import os
@@ -94,6 +101,7 @@ def load_dest_regs(line):
     return set()
 
 
+HALF_WRITE_RE = re.compile(r"^\s*v_ashr_pk_[iu]8_i32\b")
 BRANCH_RE = re.compile(r"^\s*s_c?branch\w*\s+(\S+)")
 
 
@@ -138,6 +146,8 @@ def scan_listing(dis, counts=None):
     for si, (kernel, lines, labels) in enumerate(symbols):
         pending = []          # [store text, data registers, wait states still needed]
         for i, line in enumerate(lines):
+            if HALF_WRITE_RE.match(line):
+                findings.append((kernel, line, "(writes 16 bits of its destination; hipcc assumes the upper half is zero)", [], 0))
             pending = advance(pending, line, kernel, findings)
             m = STORE_RE.match(line)
             if m:
