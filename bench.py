@@ -907,11 +907,11 @@ def main():
                    "parallelism": "%d independent replicas, gallery sharded by image, one all-gather of embeddings" % world,
                    "backend": None if not grouped else ("RCCL (torch 'nccl')" if args.backend == "nccl" else "gloo"),
                    "process_group": bool(grouped),
-                   # the knobs that change WHAT is benchmarked: effective values, env overrides included
+                   # the knobs that change WHAT is benchmarked: effective values (keyword arguments only: the product reads
+                   # no plan option from the environment)
                    "pw_math": "f16split" if any(L.a_log2 for L in plan.layers) else "f32",
                    "input_bound": tfi.input_bound,
                    "plan_kinds": [int(L.kind) for L in plan.layers],
-                   "env_overrides": {k: os.environ[k] for k in ("HSEFR_PW_MATH", "HSEFR_FUSE_STEM", "HSEFR_FUSE_BLOCKS") if k in os.environ},
                    "op_events": "second pass of the same %d steps, HIP events on the forward stream" % args.steps if use_events else None},
         "per_rank_faces_per_s": [round(v, 1) for v in per_rank_fps],
         "ms_per_step_instrumented": None if instrumented_ms is None else round(instrumented_ms, 4),

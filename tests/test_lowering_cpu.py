@@ -29,7 +29,12 @@ def graph():
 def _structure_tests_without_pwdw(monkeypatch):
     """The layer-table tests below count depthwise / pointwise layers of the passes they are about; the pointwise -> depthwise
     epilogue fusion (fuse_pwdw, on by default) has its own test, which asks for it explicitly."""
-    monkeypatch.setenv("HSEFR_FUSE_PWDW", "none")
+    real = lowering.lower_graph
+
+    def without_pwdw(*args, **kwargs):
+        kwargs.setdefault("pwdw_fusion", "none")
+        return real(*args, **kwargs)
+    monkeypatch.setattr(lowering, "lower_graph", without_pwdw)
 
 
 def test_product_reader_agrees_with_oracle_reader(graph):
