@@ -34,11 +34,13 @@ def _sync(device) -> float:
 
 
 def extract_sharded(extract_fn: Callable, items: Sequence, dim: int, device, group=None, batch: int = 256,
-                    timings: Optional[dict] = None):
+                    timings: Optional[dict] = None, on_issued: Optional[Callable] = None):
     """extract_fn(list_of_items) -> float32 tensor [len, dim] on ``device``.  Returns the full
     [N, dim] tensor (on ``device``) on every rank.  Works un-initialised (world = 1) too.
     ``timings`` (optional dict) receives wall seconds of the two phases, device-synchronised:
-    'extract_s' (this rank's shard) and 'allgather_s' (the one collective)."""
+    'extract_s' (this rank's shard) and 'allgather_s' (the one collective).
+    ``on_issued`` (optional) is called once, after the last batch of this rank's shard has been ENQUEUED and before anything
+    waits for the device: the place to start host work that needs no features (identification.start_split)."""
     import torch
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
@@ -55,6 +57,8 @@ def extract_sharded(extract_fn: Callable, items: Sequence, dim: int, device, gro
         if tuple(out.shape) != (j - i, dim):
             raise ValueError("extract_fn returned %r for %d items of dim %d" % (tuple(out.shape), j - i, dim))
         local[i - lo:j - lo] = out
+    if on_issued is not None:
+        on_issued()
     if timings is not None:
         t1 = _sync(device)
         timings["extract_s"] = t1 - t0

@@ -31,13 +31,46 @@ def stratified_half_split(y: np.ndarray, random_state: int = 0) -> Tuple[np.ndar
     return train, test
 
 
-def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np.ndarray]] = None,
+class SplitJob:
+    """The host half of the protocol -- filter_classes + stratified_half_split, 6-9 ms of scikit-learn for LFW's 9164 labels --
+    running in a thread of its own.  It depends on the labels only, which the dataset walk yields before the first image is
+    decoded (facerec_test.py:377-392), so a caller can start it while the device is still extracting (gallery.extract_sharded's
+    ``on_issued`` hook) and hand it to one_nn_identification(split=job): same indices, same split, off the critical path."""
+
+    def __init__(self, y: np.ndarray, random_state: int = 0):
+        import threading
+        self._out = None
+        self._err = None
+
+        def work():
+            try:
+                indices, y_enc = filter_classes(y)
+                train, test = stratified_half_split(y_enc, random_state)
+                self._out = (indices, y_enc, train, test)
+            except BaseException as e:          # re-raised in the caller's thread
+                self._err = e
+        self._thread = threading.Thread(target=work, name="hsefr-split", daemon=True)
+        self._thread.start()
+
+    def result(self):
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+
+def start_split(y: np.ndarray, random_state: int = 0) -> SplitJob:
+    return SplitJob(np.asarray(y), random_state)
+
+
+def one_nn_identification(X, y: np.ndarray, split=None,
                           pca_components: Optional[int] = None, timings: Optional[dict] = None, device=None) -> Dict:
     """The protocol of facerec_test.py:401-432: 'k-NN' (pca_components=None) or 'k-NN+PCA'
     (pca_components=128, the Pipeline of :421 -- PCA is fitted on the gallery half by scikit-learn on
     the host, exactly as the reference does, and the projected vectors go back to the device for the search).
 
     X: [N, D] float32 embeddings, CUDA tensor or NumPy array (uploaded to ``device``, default: the current one); y: [N] labels.
+    split: None (compute it here), a (train, test) pair over the FILTERED samples, or a SplitJob started on the same labels.
     Returns accuracy, the split, predictions and nearest-gallery indices.  ``timings`` (optional dict) receives the
     device-synchronised wall seconds of each phase: normalize_s, host_split_s, select_s, nn1_s, readback_s (indices and
     distances back to the host + the label comparison)."""
@@ -58,8 +91,11 @@ def one_nn_identification(X, y: np.ndarray, split: Optional[Tuple[np.ndarray, np
     t = lap("_start", 0.0)
     Xn = ops.l2_normalize(X.contiguous())                       # :401
     t = lap("normalize_s", t)
-    indices, y_enc = filter_classes(y)                          # :407-412
-    train, test = split if split is not None else stratified_half_split(y_enc)
+    if isinstance(split, SplitJob):                             # started earlier on the same labels: wait for it
+        indices, y_enc, train, test = split.result()
+    else:
+        indices, y_enc = filter_classes(y)                      # :407-412
+        train, test = split if split is not None else stratified_half_split(y_enc)
     t = lap("host_split_s", t)
     Xn = Xn[torch.from_numpy(indices).to(Xn.device)].contiguous()   # :413
     gal = Xn[torch.from_numpy(train).to(Xn.device)].contiguous()

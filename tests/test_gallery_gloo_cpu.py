@@ -70,3 +70,13 @@ def test_shard_ranges_cover_lfw_exactly():
 def test_single_process_path_needs_no_process_group():
     full = gallery.extract_sharded(_fake_extract, list(range(5)), 4, torch.device("cpu"), batch=2)
     assert np.array_equal(full.numpy(), _fake_extract(list(range(5))).numpy())
+
+
+def test_on_issued_hook_runs_once_after_the_last_batch():
+    calls = []
+
+    def extract(ids):
+        calls.append(("batch", list(ids)))
+        return _fake_extract(ids)
+    gallery.extract_sharded(extract, list(range(5)), 4, torch.device("cpu"), batch=2, on_issued=lambda: calls.append(("issued",)))
+    assert calls == [("batch", [0, 1]), ("batch", [2, 3]), ("batch", [4]), ("issued",)]

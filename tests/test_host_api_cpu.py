@@ -108,3 +108,16 @@ def test_float32_face_preprocessing_matches_reference_arithmetic():
     got = preprocess.to_model_input(preprocess.resize_linear_u8(img, 224, 224), True, True, dtype=np.float32)
     want = opl.age_gender_preprocess(img, 224, 224)[0]
     assert got.dtype == np.float32 and np.array_equal(got, want)
+
+
+def test_split_job_gives_the_serial_split_and_reraises():
+    """identification.start_split: filter + StratifiedShuffleSplit in a thread (bench.py starts it under the extraction) --
+    the same four arrays as the serial calls; an exception inside the thread surfaces in result()."""
+    from hse_facerec_tf_amd import gallery, identification
+    y = gallery.lfw_like_labels(600, 110)
+    indices, y_enc = identification.filter_classes(y)
+    tr, te = identification.stratified_half_split(y_enc)
+    got = identification.start_split(y).result()
+    assert all(np.array_equal(a, b) for a, b in zip(got, (indices, y_enc, tr, te)))
+    with pytest.raises(ValueError):
+        identification.start_split(np.arange(10)).result()      # no class with two samples: scikit-learn refuses the split

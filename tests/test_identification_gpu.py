@@ -203,6 +203,9 @@ def test_nn1_at_full_lfw_size_vs_sklearn_fixture_and_fp64(torch_):
     r = identification.one_nn_identification(X, y, timings=tm)
     assert tm["nn1_shape"] == (4582, 4582, 1024) and r["num_classes"] == 1680 and len(r["indices"]) == 9164
     assert np.array_equal(r["train"], z["train"]) and np.array_equal(r["test"], z["test"])        # same split as scikit-learn
+    # the same protocol with the label work started beforehand in a thread (what bench.py's config-5 leg does)
+    r2 = identification.one_nn_identification(X, y, split=identification.start_split(y))
+    assert all(np.array_equal(r2[k], r[k]) for k in ("indices", "y", "train", "test", "y_pred", "nn_index")) and r2["accuracy"] == r["accuracy"]
     # fp64 brute force of all 21 M distances
     Xn = X.astype(np.float64)
     Xn /= np.linalg.norm(Xn, axis=1, keepdims=True)
