@@ -479,9 +479,10 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
                     for (int i = 0; i < 4; ++i) {
                         const int r = erow + 8 * i;
                         const f32x4 v = *(const f32x4*)(scr + r * 128 + 16 * (ech ^ (r & 7)));
+                        const f32x4 z = __builtin_elementwise_fma(v, ds, sh);
                         f32x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(fmaf(v[e], ds[e], sh[e]));
+                        for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(z[e]);
                         bstore16_welded(o, ry, sv[mi][i], __builtin_amdgcn_readfirstlane((unsigned)(ni * 32) * 4u));
                     }
                 }
