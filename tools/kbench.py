@@ -343,60 +343,6 @@ def bench_stemstamps():
         print("   %-26s %5.1f %%  %7.0f cycles per patch" % (nm, 100 * (b[:, i] / b[:, 8]).mean(), (b[:, i] / b[:, 9]).mean()))
 
 
-def bench_b3():
-    """Block + stride-2 depthwise: three kernels vs fused block + depthwise vs the one-kernel form (csrc/dwpwdw_f16s.hip)."""
-    g = torch.Generator(device="cuda").manual_seed(0)
-    for hw, c in ((48, 128), (56, 128)):
-        n = B if hw == 48 else B // 2
-        x = torch.rand((n, hw, hw, c), device="cuda", generator=g) * 6
-        kd = torch.randn((3, 3, c), device="cuda", generator=g) / 3
-        sc = torch.rand((c,), device="cuda", generator=g) + 0.5
-        sh = torch.randn((c,), device="cuda", generator=g) * 0.3
-        w = torch.randn((128, c), device="cuda", generator=g) / c ** 0.5
-        psh = torch.randn((128,), device="cuda", generator=g)
-        kd2 = torch.randn((3, 3, 128), device="cuda", generator=g) / 3
-        sc2 = torch.rand((128,), device="cuda", generator=g) + 0.5
-        sh2 = torch.randn((128,), device="cuda", generator=g) * 0.3
-        prep = ops.split_weights_device(w, x.device)
-        mid = ops.dwpw_f16split(x, kd, sc, sh, None, psh, 1, prepared=prep)
-        t_blk = timeit(lambda: ops.dwpw_f16split(x, kd, sc, sh, None, psh, 1, prepared=prep))[0]
-        t_dw2 = timeit(lambda: ops.dwconv3x3(mid, kd2, sc2, sh2, 2))[0]
-        t_one = timeit(lambda: ops.dwpwdw_f16split(x, kd, sc, sh, None, psh, kd2, sc2, sh2, prepared=prep))[0]
-        ok = torch.equal(ops.dwpwdw_f16split(x, kd, sc, sh, None, psh, kd2, sc2, sh2, prepared=prep), ops.dwconv3x3(mid, kd2, sc2, sh2, 2))
-        by = 4.0 * n * (hw * hw * c + (hw // 2) ** 2 * 128)
-        print("%d c%d n%d: fused block %.1f + depthwise/2 %.1f = %.1f us | one kernel %.1f us (%.0f GB/s algorithmic) | identical %s" %
-              (hw, c, n, t_blk, t_dw2, t_blk + t_dw2, t_one, by / t_one / 1e3, ok))
-
-
-def bench_b3stamps():
-    """Diagnostic build only (-DHSEFR_STEM_STAMPS): phases of the block + stride-2 depthwise kernel, both wave roles."""
-    import ctypes
-    g = torch.Generator(device="cuda").manual_seed(0)
-    hw, c = 48, 128
-    x = torch.rand((B, hw, hw, c), device="cuda", generator=g) * 6
-    kd = torch.randn((3, 3, c), device="cuda", generator=g) / 3
-    sc = torch.rand((c,), device="cuda", generator=g) + 0.5
-    sh = torch.randn((c,), device="cuda", generator=g) * 0.3
-    w = torch.randn((128, c), device="cuda", generator=g) / c ** 0.5
-    psh = torch.randn((128,), device="cuda", generator=g)
-    kd2 = torch.randn((3, 3, 128), device="cuda", generator=g) / 3
-    sc2 = torch.rand((128,), device="cuda", generator=g) + 0.5
-    sh2 = torch.randn((128,), device="cuda", generator=g) * 0.3
-    prep = ops.split_weights_device(w, x.device)
-    for _ in range(4):
-        ops.dwpwdw_f16split(x, kd, sc, sh, None, psh, kd2, sc2, sh2, prepared=prep)
-    torch.cuda.synchronize()
-    buf = np.zeros((512 * 4, 10), np.uint64)
-    _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
-    names = ["wait vmcnt", "DMA issue", "depthwise 1 (halo -> A tile)", "barrier", "MFMA", "depthwise 2 / region write"]
-    for role, rows in (("producers", buf[:1024]), ("consumers", buf[1024:])):
-        b = rows[rows[:, 9] > 0].astype(np.float64)
-        print("%s: %d waves, lifetime mean %.0f cycles, patches/wave %.1f -> %.0f cycles per patch" %
-              (role, len(b), b[:, 8].mean(), b[:, 9].mean(), (b[:, 8] / b[:, 9]).mean()))
-        for i, nm in enumerate(names):
-            print("   %-30s %5.1f %%  %7.0f cycles per patch" % (nm, 100 * (b[:, i] / b[:, 8]).mean(), (b[:, i] / b[:, 9]).mean()))
-
-
 def bench_blkstamps():
     """Diagnostic build only (-DHSEFR_STEM_STAMPS): where a wave of the v2 fused block spends its cycles."""
     import ctypes
@@ -472,4 +418,4 @@ def bench_clock():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["pw", "dw", "c3"]
     for w in what:
-        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd, "pws": bench_pws, "blk": bench_blk, "stamps": bench_stamps, "stem": bench_stem, "stemstamps": bench_stemstamps, "blkstamps": bench_blkstamps, "b3": bench_b3, "b3stamps": bench_b3stamps}[w]()
+        {"pw": bench_pw, "dw": bench_dw, "c3": bench_c3, "copy": bench_copy, "dwv": bench_dwv, "clock": bench_clock, "pwa": bench_pwa, "pwd": bench_pwd, "pws": bench_pws, "blk": bench_blk, "stamps": bench_stamps, "stem": bench_stem, "stemstamps": bench_stemstamps, "blkstamps": bench_blkstamps}[w]()
