@@ -147,6 +147,10 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     constexpr int CB_ROWS = BORDERED ? 1 + PITCH + MAPS * IMG : BM + 2;
     constexpr int CB_ZROW = BM;
     constexpr int CB_CONST = CB_ROWS * ROWB;
+    // 12 x 12 and 6 x 6 bordered maps: a lane takes three ADJACENT pixels of an image row (15 window reads + 9 tap reads per
+    // 32-channel chunk instead of 27 + 9: stamps with the reads knocked out put 16 % of the launch in them -- 1.3 MB of 16-byte
+    // LDS reads per tile at ~128 B/clk)
+    constexpr bool RUN3 = DWM == 2 && BORDERED && MW % 3 == 0;
     // per item of this lane: bit t = tap t lies inside the map.  Recomputed at every tile's epilogue from an OPAQUE copy of the lane
     // id: as loop invariants these three registers (and what hipcc hoisted with them) lived through the K loop and spilled there.
     unsigned nb_mask[3] = {0, 0, 0};   // (DWM == 2: the byte offset of the item's tap (-1, -1) in the chunk buffer instead)
@@ -154,6 +158,13 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
         int ln = lane;
         asm volatile("" : "+v"(ln));
         if constexpr (DWM == 4) return;
+        if constexpr (RUN3) {          // one run of three adjacent pixels of an image row per lane: the offset of its first pixel's tap (-1, -1)
+            const int P = 3 * ((ln >> 3) + 8 * wave);
+            const int Pc = P < MAPS * MHW ? P : MAPS * MHW - 3;
+            const int img = Pc / MHW, pl = Pc - MHW * img, yy = pl / MW, xx = pl - MW * yy;
+            nb_mask[0] = (unsigned)((IMG * img + PITCH * yy + xx) * ROWB + 16 * (ln & 7)) | (P < MAPS * MHW ? 0u : 0x80000000u);
+            return;
+        }
         if constexpr (DWM == 2) {
 #pragma unroll
             for (int k3 = 0; k3 < 3; ++k3) {
@@ -214,9 +225,10 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
         const int q = lane & 7;
         const unsigned char* cp = cb + CB_CONST + (32 * c + 4 * q) * 4;
         f32x4 tap[9];
+        if constexpr (!RUN3) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) tap[t] = *(const f32x4*)(cp + t * 512);
-        const f32x4 sc = *(const f32x4*)(cp + 9 * 512), sh = *(const f32x4*)(cp + 10 * 512);
+            for (int t = 0; t < 9; ++t) tap[t] = *(const f32x4*)(cp + t * 512);
+        }
         // split rows of the output: pixel m, 32-channel group -> 128 B; this lane stores the 16-byte unit q/2 of the hi half
         // (even quad) or of the lo half (odd quad) after swapping one 8-byte half with its neighbour lane (dwconv.hip)
         // (stride 2: a quarter of the pixels -- the tile's 288 input pixels are output pixels tm0 / 4 .. + 71)
@@ -224,6 +236,46 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
         const __amdgpu_buffer_rsrc_t ro = make_rsrc((char*)dw.ys + ((tm0 >> OSH) * Cout + tn0) * 4ll, (((M - tm0) >> OSH) * Cout - tn0) * 4ll);
         const bool odd = q & 1;
         const unsigned unit = odd ? 4u + (unsigned)(q >> 1) : (unsigned)(q >> 1);
+        if constexpr (RUN3) {
+            const unsigned char* wb = cb + (nb_mask[0] & 0x7FFFFFFFu);
+            f32x4 acc3[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                f32x4 v[5];
+#pragma unroll
+                for (int cidx = 0; cidx < 5; ++cidx) v[cidx] = *(const f32x4*)(wb + (r * PITCH + cidx) * ROWB);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) tap[3 * r + dx] = *(const f32x4*)(cp + (3 * r + dx) * 512);      // (one row of taps live at a time)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)             // (per output: taps in the order 0..8 of the one-pixel form -- same bits)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc3[j][e] = fmaf(v[j + dx][e], tap[3 * r + dx][e], acc3[j][e]);
+            }
+            const f32x4 sc = *(const f32x4*)(cp + 9 * 512), sh = *(const f32x4*)(cp + 10 * 512);
+            const int P0 = 3 * ((lane >> 3) + 8 * wave);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(fmaf(acc3[j][e], sc[e], sh[e]), 0.f), dw.clamp_hi);
+                const f16x4 hi = __builtin_convertvector(o, f16x4);
+                const f16x4 lo = __builtin_convertvector(o - __builtin_convertvector(hi, f32x4), f16x4);
+                const u32x2 hb = __builtin_bit_cast(u32x2, hi), lb = __builtin_bit_cast(u32x2, lo);
+                const u32x2 send = odd ? hb : lb;
+                u32x2 recv;
+                recv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);
+                recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
+                const u32x4 out = odd ? u32x4{recv.x, recv.y, lb.x, lb.y} : u32x4{hb.x, hb.y, recv.x, recv.y};
+                const unsigned ovoff = (nb_mask[0] >> 31) ? 0x80000000u : (unsigned)(P0 + j) * (unsigned)Cout * 4u + (unsigned)c * 128u + 16u * unit;
+                bstore16_welded(__builtin_bit_cast(f32x4, out), ro, ovoff, 0u);
+            }
+            return;
+        }
+        const f32x4 sc = *(const f32x4*)(cp + 9 * 512), sh = *(const f32x4*)(cp + 10 * 512);
 #pragma unroll
         for (int k3 = 0; k3 < (DWM == 3 ? 1 : 3); ++k3) {
             const int P = (lane >> 3) + 8 * wave + 96 * k3;
