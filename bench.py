@@ -480,7 +480,10 @@ def run_other_configs(args, dev):
         B = 512
         g = read_graph(AGE_GENDER_PB)
         fetch = {0: "global_pooling/Mean:0", 1: "age_pred/Softmax:0", 2: "gender_pred/Sigmoid:0"}
-        plan = lowering.lower_graph(g, "input_1:0", fetch)
+        # (input_bound: what the drop-in declares -- FacialImageProcessing feeds pixels minus a mean, |x| < 256,
+        # facial_analysis.py:95-107 -- and what the synthetic U(-128, 128) batch satisfies; without it the stem forms conv1's
+        # products in exact fp32 and this config ran the older stem2 kernel: 0.91 instead of 0.78 ms of a 3.8 ms step)
+        plan = lowering.lower_graph(g, "input_1:0", fetch, input_bound=256.0)
         eng = Engine(plan, max_batch=B, device=dev.index)
         dt = time_engine(eng, gen(B, 224), (0, 1, 2), steps, warm)
         by = 40.948e6 * B + 12.74e6          # unfused layer-wise bytes per face @224 + weights per batch

@@ -44,30 +44,88 @@ __global__ __launch_bounds__(256) void gap_kernel(const float4* __restrict__ x, 
     }
 }
 
-// Dense head: thread = output column, workgroup = DR rows of x staged in LDS; each weight is
-// read once per DR rows (coalesced over columns), x values are LDS broadcasts.
-constexpr int DR = 8;
+// Dense head: a workgroup = DR rows of x (staged in LDS) x 64 output columns, the contraction split over its four waves (each
+// takes a quarter of k; the partial sums meet in LDS and are added in wave order: deterministic).  Each weight is read once per
+// DR rows, coalesced over the 64 columns of a wave; x values are LDS broadcasts.  (Round 3: the first version gave a workgroup 256
+// columns and the whole of k -- 64 workgroups and 1024 serial steps per thread for the 512 x 1024 x 256 head of BASELINE config 4:
+// 122 us, 3 % of that step; this form fills the chip at every batch size and runs it in ~10 us.)
+constexpr int DR = 8, DCOLS = 64;
 __global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ y, int n,
                                                     int k, int cout, int act) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [DR][k]
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [DR][k], then the partial sums [4][DR][DCOLS]
     const int r0 = blockIdx.x * DR;
     const int rows = min(DR, n - r0);
-    for (int i = threadIdx.x; i < rows * k; i += 256) xs[i] = x[(size_t)r0 * k + i];
-    for (int i = rows * k + threadIdx.x; i < DR * k; i += 256) xs[i] = 0.f;
+    if ((k & 3) == 0) {                 // 16-byte loads, eight in flight per thread (a load -> LDS-write loop pays one latency per trip)
+        const float4* xg = (const float4*)(x + (size_t)r0 * k);
+        const int nq = rows * k / 4, tq = DR * k / 4;
+        for (int i0 = 0; i0 < tq; i0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256 + threadIdx.x;
+                v[u] = i < nq ? xg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256 + threadIdx.x;
+                if (i < tq) ((float4*)xs)[i] = v[u];
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < rows * k; i += 256) xs[i] = x[(size_t)r0 * k + i];
+        for (int i = rows * k + threadIdx.x; i < DR * k; i += 256) xs[i] = 0.f;
+    }
     __syncthreads();
-    const int col = blockIdx.y * 256 + threadIdx.x;
-    if (col >= cout) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.y * DCOLS + lane;
+    const int kq = (k + 3) >> 2, k0 = wave * kq, k1 = min(k, k0 + kq);
     float acc[DR];
 #pragma unroll
     for (int r = 0; r < DR; ++r) acc[r] = 0.f;
-    for (int kk = 0; kk < k; ++kk) {
-        const float wv = w[(size_t)kk * cout + col];
+    if (col < cout) {
+        int kk = k0;
+        if ((k & 3) == 0 && (kq & 3) == 0) {          // 16 steps at a time: sixteen weights in flight, one 16-byte LDS broadcast per row and 4 steps
+            for (; kk + 16 <= k1; kk += 16) {
+                float wv[16];
 #pragma unroll
-        for (int r = 0; r < DR; ++r) acc[r] = fmaf(xs[r * k + kk], wv, acc[r]);
+                for (int u = 0; u < 16; ++u) wv[u] = w[(size_t)(kk + u) * cout + col];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < DR; ++r) {
+                        const float4 xv = *(const float4*)(xs + r * k + kk + 4 * g);
+                        acc[r] = fmaf(xv.w, wv[4 * g + 3], fmaf(xv.z, wv[4 * g + 2], fmaf(xv.y, wv[4 * g + 1], fmaf(xv.x, wv[4 * g], acc[r]))));
+                    }
+            }
+            for (; kk + 4 <= k1; kk += 4) {
+                const float w0 = w[(size_t)kk * cout + col], w1 = w[(size_t)(kk + 1) * cout + col];
+                const float w2 = w[(size_t)(kk + 2) * cout + col], w3 = w[(size_t)(kk + 3) * cout + col];
+#pragma unroll
+                for (int r = 0; r < DR; ++r) {
+                    const float4 xv = *(const float4*)(xs + r * k + kk);
+                    acc[r] = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc[r]))));
+                }
+            }
+        }
+        for (; kk < k1; ++kk) {
+            const float wv = w[(size_t)kk * cout + col];
+#pragma unroll
+            for (int r = 0; r < DR; ++r) acc[r] = fmaf(xs[r * k + kk], wv, acc[r]);
+        }
     }
-    const float b = bias ? bias[col] : 0.f;
-    for (int r = 0; r < rows; ++r) y[(size_t)(r0 + r) * cout + col] = apply_act_rt(acc[r] + b, act);
+    float* part = xs + DR * k;
+#pragma unroll
+    for (int r = 0; r < DR; ++r) part[(wave * DR + r) * DCOLS + lane] = acc[r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < DR * DCOLS; o += 256) {
+        const int r = o / DCOLS, c = o - r * DCOLS, oc = blockIdx.y * DCOLS + c;
+        if (r < rows && oc < cout) {
+            const float sum = ((part[(0 * DR + r) * DCOLS + c] + part[(1 * DR + r) * DCOLS + c]) + part[(2 * DR + r) * DCOLS + c]) +
+                              part[(3 * DR + r) * DCOLS + c];
+            y[(size_t)(r0 + r) * cout + oc] = apply_act_rt(sum + (bias ? bias[oc] : 0.f), act);
+        }
+    }
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -128,8 +186,8 @@ int launch_dense(const float* x, const float* wgt, const float* bias, float* y, 
     HSEFR_REQUIRE(k > 0 && k <= 2048 && cout > 0, HSEFR_ERR_UNSUPPORTED, "dense: k=%d cout=%d", k, cout);
     HSEFR_REQUIRE(n >= 0, HSEFR_ERR_INVALID, "dense: n=%d", n);
     if (n == 0) return HSEFR_OK;
-    dim3 grid((n + DR - 1) / DR, (cout + 255) / 256), block(256);
-    const size_t lds = (size_t)DR * k * sizeof(float);
+    dim3 grid((n + DR - 1) / DR, (cout + DCOLS - 1) / DCOLS), block(256);
+    const size_t lds = ((size_t)DR * k + 4 * DR * DCOLS) * sizeof(float);
     hipLaunchKernelGGL(dense_kernel, grid, block, lds, s, x, wgt, bias, y, n, k, cout, act);
     return launch_status("dense");
 }

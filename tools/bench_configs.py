@@ -63,7 +63,7 @@ if __name__ == "__main__":
     else:
         B = int(os.environ.get("BC_BATCH", "512"))
         plan = lowering.lower_graph(read_graph(AGE_GENDER_PB), "input_1:0",
-                                    {0: "global_pooling/Mean:0", 1: "age_pred/Softmax:0", 2: "gender_pred/Sigmoid:0"})
+                                    {0: "global_pooling/Mean:0", 1: "age_pred/Softmax:0", 2: "gender_pred/Sigmoid:0"}, input_bound=256.0)
         eng = Engine(plan, max_batch=B)
         x = torch.from_numpy(rs.uniform(-128, 128, (B, 224, 224, 3)).astype(np.float32)).cuda()
         run(eng, x, (0, 1, 2), "age/gender MobileNet-224 batch %d (3 outputs)" % B, plan.flops_per_image(), plan.bytes_per_image())
