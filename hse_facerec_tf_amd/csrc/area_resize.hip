@@ -10,6 +10,8 @@
 //   crops         : per box, the box-sized tile of the frame (zero outside the frame) resized to S x S in float64 (the
 //                   reference resizes a float64 tile), normalised, written transposed [n, S, S, 3].
 // Arithmetic is kept un-contracted (explicit mul / add) so that the order of roundings is the restatement's.
+#include <cmath>
+
 #include "common.h"
 
 namespace hsefr {
@@ -115,6 +117,78 @@ __global__ __launch_bounds__(256) void area_level_kernel(const unsigned char* __
     for (int c = 0; c < 3; ++c) o[c] = (float)(((double)out[c] - 127.5) * 0.0078125);
 }
 
+// The general decimation case of area_level_kernel with the work laid out for the SMALL levels of the pyramid (round 3: a 19 x 14
+// level of a 784 x 588 frame gave 266 threads a 42 x 42 x 3 cell each, byte by byte, one channel at a time: 137 us per level, a
+// third of process_image's kernel time).  A workgroup owns one destination row: the column cells go to LDS once; the horizontal
+// sums of every source row of the row's cell are computed by all threads -- (source row, destination column) items, three
+// channels per pass over the bytes -- into LDS; then a thread per destination column adds them up in table order.  The same
+// float32 operations in the same order as the per-pixel kernel: identical results (OpenCV's own order, preprocess.py).
+struct XCell { int a, b, flags; float wl, wh, m; };
+
+__global__ __launch_bounds__(256) void area_level_rows_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int sh, int sw,
+                                                              int dh, int dw, int hoff) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    XCell* xc = (XCell*)lds;
+    float* hbuf = (float*)(lds + hoff);                                       // [rows of the cell][dw][3]
+    const int dy = blockIdx.x;
+    const double fx = (double)sw / dw, fy = (double)sh / dh;
+    for (int dx = threadIdx.x; dx < dw; dx += 256) {
+        int xa, xb;
+        double c, wl, wh;
+        bool hl, hh;
+        area_cell(dx, sw, fx, xa, xb, c, hl, wl, hh, wh);
+        xc[dx] = XCell{xa, xb, (hl ? 1 : 0) | (hh ? 2 : 0), (float)wl, (float)wh, (float)(1.0 / c)};
+    }
+    int ya, yb;
+    double yc, ywl, ywh;
+    bool yhl, yhh;
+    area_cell(dy, sh, fy, ya, yb, yc, yhl, ywl, yhh, ywh);
+    const float ym = (float)(1.0 / yc);
+    const int r_first = yhl ? ya - 1 : ya;
+    const int nrows = (yb - ya) + (yhl ? 1 : 0) + (yhh ? 1 : 0);
+    __syncthreads();
+    for (int item = threadIdx.x; item < nrows * dw; item += 256) {
+        const int rr = item / dw, dx = item - rr * dw;
+        const XCell c = xc[dx];
+        const unsigned char* row = src + (long long)(r_first + rr) * sw * 3;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        if (c.flags & 1) {
+            const unsigned char* q = row + (c.a - 1) * 3;
+            a0 = __fadd_rn(a0, __fmul_rn((float)q[0], c.wl)); a1 = __fadd_rn(a1, __fmul_rn((float)q[1], c.wl)); a2 = __fadd_rn(a2, __fmul_rn((float)q[2], c.wl));
+        }
+        for (int x = c.a; x < c.b; ++x) {
+            const unsigned char* q = row + x * 3;
+            a0 = __fadd_rn(a0, __fmul_rn((float)q[0], c.m)); a1 = __fadd_rn(a1, __fmul_rn((float)q[1], c.m)); a2 = __fadd_rn(a2, __fmul_rn((float)q[2], c.m));
+        }
+        if (c.flags & 2) {
+            const unsigned char* q = row + c.b * 3;
+            a0 = __fadd_rn(a0, __fmul_rn((float)q[0], c.wh)); a1 = __fadd_rn(a1, __fmul_rn((float)q[1], c.wh)); a2 = __fadd_rn(a2, __fmul_rn((float)q[2], c.wh));
+        }
+        float* h = hbuf + (long long)item * 3;
+        h[0] = a0; h[1] = a1; h[2] = a2;
+    }
+    __syncthreads();
+    for (int dx = threadIdx.x; dx < dw; dx += 256) {
+        float* o = dst + ((long long)dx * dh + dy) * 3;                        // transposed: the nets see (W, H)
+        for (int c = 0; c < 3; ++c) {
+            float acc = 0.f;
+            bool first = true;                                                  // vertical pass: first tap assigns, later taps add
+            int rr = 0;
+            auto vadd = [&](float w) {
+                const float term = __fmul_rn(hbuf[((long long)rr * dw + dx) * 3 + c], w);
+                acc = first ? term : __fadd_rn(acc, term);
+                first = false;
+                ++rr;
+            };
+            if (yhl) vadd((float)ywl);
+            for (int y = ya; y < yb; ++y) vadd(ym);
+            if (yhh) vadd((float)ywh);
+            const float out = fminf(fmaxf(rintf(acc), 0.f), 255.f);
+            o[c] = (float)(((double)out - 127.5) * 0.0078125);
+        }
+    }
+}
+
 // ---- crops: box k = {x1, y1, x2, y2 (1-based inclusive window inside the frame), tx1, ty1 (where it lands in the tile), bw, bh} ----
 __global__ __launch_bounds__(256) void area_crops_kernel(const unsigned char* __restrict__ src, const int* __restrict__ boxes,
                                                          float* __restrict__ dst, int sh, int sw, int n, int S) {
@@ -192,6 +266,18 @@ __global__ __launch_bounds__(256) void area_crops_kernel(const unsigned char* __
 
 int launch_area_level(const unsigned char* src, float* dst, int sh, int sw, int dh, int dw, hipStream_t s) {
     HSEFR_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0, HSEFR_ERR_INVALID, "area_level: bad shape");
+    // the general decimation case (both factors >= 1, not both integers: every level of MTCNN's 0.709 pyramid) row by row
+    const double fx = (double)sw / dw, fy = (double)sh / dh;
+    if (fx >= 1.0 && fy >= 1.0 && !(sh == dh && sw == dw)) {
+        const double eps = 2.220446049250313e-16;
+        const bool integer = std::fabs(fx - std::rint(fx)) < eps && std::fabs(fy - std::rint(fy)) < eps;
+        const size_t hoff = ((size_t)dw * sizeof(XCell) + 15) & ~(size_t)15;
+        const size_t lds = hoff + ((size_t)fy + 3) * (size_t)dw * 3 * sizeof(float);
+        if (!integer && lds <= 64 * 1024) {
+            hipLaunchKernelGGL(area_level_rows_kernel, dim3(dh), dim3(256), lds, s, src, dst, sh, sw, dh, dw, (int)hoff);
+            return launch_status("area_level_rows");
+        }
+    }
     hipLaunchKernelGGL(area_level_kernel, dim3((dh * dw + 255) / 256), dim3(256), 0, s, src, dst, sh, sw, dh, dw);
     return launch_status("area_level");
 }

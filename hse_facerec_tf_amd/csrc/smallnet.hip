@@ -33,7 +33,22 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restr
             if (iw < 0 || iw >= W) continue;
             const float* xp = xn + ((long long)ih * W + iw) * C;
             const float* wp = w + (long long)((kh * KW + kw) * C) * Cout + co;
-            for (int c = 0; c < C; ++c) acc = fmaf(xp[c], wp[(long long)c * Cout], acc);
+            // (same FMA chain, c ascending; the input values of four / two channels in one load, the weights of the group in flight together)
+            int c = 0;
+            if ((C & 3) == 0) {
+                for (; c < C; c += 4) {
+                    const float4 xv = *(const float4*)(xp + c);
+                    const float w0 = wp[(long long)c * Cout], w1 = wp[(long long)(c + 1) * Cout], w2 = wp[(long long)(c + 2) * Cout], w3 = wp[(long long)(c + 3) * Cout];
+                    acc = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc))));
+                }
+            } else if ((C & 1) == 0) {
+                for (; c < C; c += 2) {
+                    const float2 xv = *(const float2*)(xp + c);
+                    const float w0 = wp[(long long)c * Cout], w1 = wp[(long long)(c + 1) * Cout];
+                    acc = fmaf(xv.y, w1, fmaf(xv.x, w0, acc));
+                }
+            }
+            for (; c < C; ++c) acc = fmaf(xp[c], wp[(long long)c * Cout], acc);
         }
     }
     if (alpha) acc = acc > 0.f ? acc : alpha[co] * acc;
