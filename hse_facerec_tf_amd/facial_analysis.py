@@ -153,7 +153,11 @@ class FacialImageProcessing:
     def process_image(self, draw, bounding_boxes=None, points=None):
         """draw: BGR uint8 frame, as cv2.imread returns it (:225-226).  Detection runs unless
         ``bounding_boxes`` is supplied.  Returns (bboxes, points, ages, genders, facial_features)."""
-        img = np.ascontiguousarray(np.asarray(draw)[..., ::-1])      # cv2.cvtColor(draw, COLOR_BGR2RGB)
+        draw = np.asarray(draw)
+        # cv2.cvtColor(draw, COLOR_BGR2RGB): plane by plane (np.ascontiguousarray(draw[..., ::-1]) walks a 3-element inner loop with
+        # a negative stride: 1.2 ms for a 784x588 frame, a quarter of this call, against 0.3 ms)
+        img = np.empty(draw.shape, draw.dtype)
+        img[..., 0], img[..., 1], img[..., 2] = draw[..., 2], draw[..., 1], draw[..., 0]
         t = time.time()
         if bounding_boxes is None:
             bounding_boxes, points = self.detect_faces(img)
