@@ -132,20 +132,30 @@ def check(status: int, what: str = "") -> None:
     raise HsefrError(msg)
 
 
+_torch_gpu = None      # torch, once a GPU has been seen (torch.cuda.is_available() re-reads the environment on every call: the
+                       # small-net paths make ~100 launches per frame and spent a tenth of their host time asking)
+
+
 def require_gpu():
     """The product path runs on an MI355X or not at all."""
-    import torch
-    if not torch.cuda.is_available():
-        raise RuntimeError("hse_facerec_tf_amd needs a ROCm GPU (gfx950); torch.cuda.is_available() is False "
-                           "and there is no CPU fallback")
-    return torch
+    global _torch_gpu
+    if _torch_gpu is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("hse_facerec_tf_amd needs a ROCm GPU (gfx950); torch.cuda.is_available() is False "
+                               "and there is no CPU fallback")
+        _torch_gpu = torch
+    return _torch_gpu
 
 
 def current_stream_ptr() -> int:
     """The current torch stream OF THE CURRENT DEVICE: callers launch under ``on_device(tensor)`` so that the
     current device is the one that owns the pointers they pass."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    try:        # the raw handle without building a torch.cuda.Stream object (what torch's own compiled code paths call)
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:
+        return torch.cuda.current_stream().cuda_stream
 
 
 def cuda_device(device=None):
@@ -164,4 +174,21 @@ def on_device(t):
     stream handed to libhsefr and the HIP launch target match the pointers (a launch under device 0
     on device-1 pointers is a memory fault, not an exception)."""
     import torch
-    return torch.cuda.device(t.device if hasattr(t, "device") else t)
+    dev = t.device if hasattr(t, "device") else t
+    try:        # already current (the usual case): nothing to switch, nothing to restore
+        if isinstance(dev, torch.device) and dev.index is not None and dev.index == torch._C._cuda_getDevice():
+            return _NO_SWITCH
+    except AttributeError:
+        pass
+    return torch.cuda.device(dev)
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
