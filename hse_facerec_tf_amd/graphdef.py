@@ -203,6 +203,7 @@ class Graph:
         self.by_name: Dict[str, GraphNode] = {n.name: n for n in nodes}
         self._const: Dict[str, np.ndarray] = {}
         self._consumers: Optional[Dict[str, List[GraphNode]]] = None
+        self._data_inputs: Dict[str, Tuple[GraphNode, List[Tuple[GraphNode, int]]]] = {}
 
     def __contains__(self, name: str) -> bool:
         return name in self.by_name
@@ -228,11 +229,17 @@ class Graph:
         return self.by_name[name], idx
 
     def data_inputs(self, node: GraphNode) -> List[Tuple[GraphNode, int]]:
+        """(producer node, output index) of every data input, in order.  Memoised per node (the graph does not change after
+        loading; graph walkers such as mtcnn._DeviceNet ask ~450 times per frame) -- treat the list as read-only."""
+        cached = self._data_inputs.get(node.name)
+        if cached is not None and cached[0] is node:
+            return cached[1]
         out = []
         for ref in node.inputs:
             name, idx, ctrl = _parse_ref(ref)
             if not ctrl:
                 out.append((self.by_name[name], idx))
+        self._data_inputs[node.name] = (node, out)
         return out
 
     def consumers(self, name: str) -> List[GraphNode]:
