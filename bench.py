@@ -385,11 +385,16 @@ def run_latency_batch1(args, dev):
         tfi.engine.forward(x1)["features"].cpu()
     mf, _ = med(fwd)
     mh, _ = med(lambda: tfi.preprocess_image(photo, False))
+    from hse_facerec_tf_amd import preprocess as _pre
+    md, _ = med(lambda: _pre.imread_rgb(photo))
     out["extract_features"] = {"median_ms": m, "p95_ms": p95, "construct_s": round(t1 - t0, 4), "first_call_ms": round((t2 - t1) * 1e3, 3),
-                               "host_preprocess_median_ms": mh, "upload_forward_readback_median_ms": mf, "calls": reps,
-                               "what": "TensorFlowInference.extract_features(%dx%d JPEG path): PIL decode + PIL-bilinear resize + BGR/mean on "
-                                       "the host (the reference's own preprocessing), then upload + MobileNet-%d forward + read-back"
-                                       % (rgb.shape[1], rgb.shape[0], args.size)}
+                               "host_decode_median_ms": md, "host_preprocess_image_median_ms": mh,
+                               "upload_forward_readback_median_ms": mf, "calls": reps,
+                               "what": "TensorFlowInference.extract_features(%dx%d JPEG path): PIL decode on the host (host_decode), the decoded "
+                                       "bytes uploaded, misc.imresize + float conversion + BGR + mean on the device (bit-exact / 2e-6), "
+                                       "MobileNet-%d forward, read-back.  host_preprocess_image = the reference's whole preprocess_image on "
+                                       "the host (decode + PIL resize + float64 BGR/mean), which this call no longer runs; "
+                                       "upload_forward_readback = the fp32-input forward alone" % (rgb.shape[1], rgb.shape[0], args.size)}
     tfi.close_session()
     # ---- first MTCNN detection (ipynb:109)
     try:

@@ -128,6 +128,14 @@ class TensorFlowInference:
     # ---- facerec_test.py:114-122 ----------------------------------------------------------------
     def extract_features(self, img_filepath, crop_center=False):
         torch = _lib.require_gpu()
+        if self.engine.accepts_u8:
+            # bytes in: decode (+ the optional centre crop) on the host as the reference does, then misc.imresize on the device
+            # (bit-exact with Pillow: tests/test_preprocess_gpu.py) and float conversion / BGR / mean inside the first kernel --
+            # no float64 image on the host, a 4x smaller upload; same features to 2e-6 (tests/test_stem4_gpu.py)
+            img = preprocess.imread_rgb(img_filepath)
+            if crop_center:
+                img = preprocess.center_crop_250_128(img)
+            return self.extract_images(img[None]).cpu().numpy().reshape(-1)
         x = self.preprocess_image(img_filepath, crop_center)
         x = np.expand_dims(x, axis=0)
         xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.engine.device)
