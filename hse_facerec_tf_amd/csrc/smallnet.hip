@@ -5,26 +5,45 @@
 // (weight reads coalesce, the input pixel is a broadcast).  Fully-connected layers run as a VALID convolution
 // whose kernel covers the whole feature map.  PReLU is fused: y = v > 0 ? v : alpha[c] * v (the graph spells it
 // Relu(v) + alpha * -Relu(-v), nodes pnet/PReLU1/*).
+#include <cstdint>
+
 #include "common.h"
 
 namespace hsefr {
 
 namespace {
 
+// Thread = CO consecutive output channels of one output pixel (CO = 4 | 2 | 1, whichever divides Cout): the input value is one
+// (broadcast) load for CO FMAs and the CO weights one 16- / 8-byte load.  Every output's FMA chain runs kh, kw, c ascending
+// whatever CO is: the same bits as the one-channel form of rounds 1-2 (R-Net / O-Net on a few hundred crops spent 50-80 us per
+// layer in it: two loads per FMA, four times the threads).
+template <int CO>
 __global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, const float* __restrict__ alpha,
                                                             float* __restrict__ y, int H, int W, int C, int OH, int OW, int Cout,
                                                             int KH, int KW, int stride, int pad_t, int pad_l, long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    typedef float vco __attribute__((ext_vector_type(CO == 1 ? 2 : CO)));      // (CO == 1 reads scalars; the type is unused then)
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;              // index over pixels x (Cout / CO)
     if (i >= total) return;
-    const int co = (int)(i % Cout);
-    const long long p = i / Cout;
+    const int cg = Cout / CO;
+    const int co = (int)(i % cg) * CO;
+    const long long p = i / cg;
     const int ow = (int)(p % OW);
     const long long t = p / OW;
     const int oh = (int)(t % OH);
     const long long n = t / OH;
-    float acc = bias ? bias[co] : 0.f;
+    float acc[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) acc[j] = bias ? bias[co + j] : 0.f;
     const float* xn = x + n * (long long)H * W * C;
+    auto wld = [&](const float* q, float* out) __attribute__((always_inline)) {
+        if constexpr (CO == 1) out[0] = q[0];
+        else {
+            const vco v = *(const vco*)q;
+#pragma unroll
+            for (int j = 0; j < CO; ++j) out[j] = v[j];
+        }
+    };
     for (int kh = 0; kh < KH; ++kh) {
         const int ih = oh * stride - pad_t + kh;
         if (ih < 0 || ih >= H) continue;
@@ -33,26 +52,40 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restr
             if (iw < 0 || iw >= W) continue;
             const float* xp = xn + ((long long)ih * W + iw) * C;
             const float* wp = w + (long long)((kh * KW + kw) * C) * Cout + co;
-            // (same FMA chain, c ascending; the input values of four / two channels in one load, the weights of the group in flight together)
+            // (c ascending; the input values of four / two channels in one load, the weights of the group in flight together)
             int c = 0;
             if ((C & 3) == 0) {
                 for (; c < C; c += 4) {
                     const float4 xv = *(const float4*)(xp + c);
-                    const float w0 = wp[(long long)c * Cout], w1 = wp[(long long)(c + 1) * Cout], w2 = wp[(long long)(c + 2) * Cout], w3 = wp[(long long)(c + 3) * Cout];
-                    acc = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc))));
+                    float w0[CO], w1[CO], w2[CO], w3[CO];
+                    wld(wp + (long long)c * Cout, w0); wld(wp + (long long)(c + 1) * Cout, w1);
+                    wld(wp + (long long)(c + 2) * Cout, w2); wld(wp + (long long)(c + 3) * Cout, w3);
+#pragma unroll
+                    for (int j = 0; j < CO; ++j) acc[j] = fmaf(xv.w, w3[j], fmaf(xv.z, w2[j], fmaf(xv.y, w1[j], fmaf(xv.x, w0[j], acc[j]))));
                 }
             } else if ((C & 1) == 0) {
                 for (; c < C; c += 2) {
                     const float2 xv = *(const float2*)(xp + c);
-                    const float w0 = wp[(long long)c * Cout], w1 = wp[(long long)(c + 1) * Cout];
-                    acc = fmaf(xv.y, w1, fmaf(xv.x, w0, acc));
+                    float w0[CO], w1[CO];
+                    wld(wp + (long long)c * Cout, w0); wld(wp + (long long)(c + 1) * Cout, w1);
+#pragma unroll
+                    for (int j = 0; j < CO; ++j) acc[j] = fmaf(xv.y, w1[j], fmaf(xv.x, w0[j], acc[j]));
                 }
             }
-            for (; c < C; ++c) acc = fmaf(xp[c], wp[(long long)c * Cout], acc);
+            for (; c < C; ++c) {
+                float w0[CO];
+                wld(wp + (long long)c * Cout, w0);
+#pragma unroll
+                for (int j = 0; j < CO; ++j) acc[j] = fmaf(xp[c], w0[j], acc[j]);
+            }
         }
     }
-    if (alpha) acc = acc > 0.f ? acc : alpha[co] * acc;
-    y[i] = acc;
+#pragma unroll
+    for (int j = 0; j < CO; ++j) {
+        float a = acc[j];
+        if (alpha) a = a > 0.f ? a : alpha[co + j] * a;
+        y[p * Cout + co + j] = a;
+    }
 }
 
 // max-pool k x k / stride, windows clipped to the image (== TF's -inf padding for SAME)
@@ -145,10 +178,17 @@ int launch_conv2d_direct(const float* x, const float* w, const float* bias, cons
     HSEFR_REQUIRE(n >= 0 && h > 0 && wd > 0 && c > 0 && oh > 0 && ow > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0,
                   HSEFR_ERR_INVALID, "conv2d_direct: bad shape");
     if (n == 0) return HSEFR_OK;
-    const long long total = (long long)n * oh * ow * cout;
-    HSEFR_REQUIRE(total < (1ll << 39), HSEFR_ERR_UNSUPPORTED, "conv2d_direct: too large");
-    hipLaunchKernelGGL(conv2d_direct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, alpha, y, h, wd, c,
-                       oh, ow, cout, kh, kw, stride, pad_t, pad_l, total);
+    HSEFR_REQUIRE((long long)n * oh * ow * cout < (1ll << 39), HSEFR_ERR_UNSUPPORTED, "conv2d_direct: too large");
+    // output channels per thread: the widest vector the weight rows allow (rows of `cout` floats from a 16-byte aligned base)
+    const int co = (cout % 4 == 0 && ((uintptr_t)w & 15) == 0) ? 4 : ((cout % 2 == 0 && ((uintptr_t)w & 7) == 0) ? 2 : 1);
+    const long long total = (long long)n * oh * ow * (cout / co);
+#define HSEFR_CONV_DIRECT(CO)                                                                                                          \
+    hipLaunchKernelGGL(conv2d_direct_kernel<CO>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, alpha, y, h, wd, c, \
+                       oh, ow, cout, kh, kw, stride, pad_t, pad_l, total)
+    if (co == 4) HSEFR_CONV_DIRECT(4);
+    else if (co == 2) HSEFR_CONV_DIRECT(2);
+    else HSEFR_CONV_DIRECT(1);
+#undef HSEFR_CONV_DIRECT
     return launch_status("conv2d_direct");
 }
 
