@@ -39,6 +39,7 @@ class _DeviceNet:
         self._torch = torch
         self.device = _lib.cuda_device(device)
         self._const: Dict[str, object] = {}
+        self._programs: Dict[tuple, tuple] = {}
 
     def _dev(self, node: GraphNode, reshape=None):
         key = node.name + ("" if reshape is None else str(reshape))
@@ -104,18 +105,38 @@ class _DeviceNet:
         return x
 
     # -- evaluation ------------------------------------------------------------------------------------------
+    # The graph is walked ONCE per (fetches, input) pair: pattern matching, attribute parsing and constant uploads produce a linear
+    # program of (output name, callable, input names); every later run just executes it (round 3: the recursive interpreter of
+    # rounds 1-2 re-matched the PReLU / softmax sub-graphs on every call -- 0.5 ms of host time per frame for ~60 launches).
     def run(self, fetches: List[str], input_name: str, x):
-        memo: Dict[str, object] = {self.g.get_tensor_by_name(input_name)[0].name: x}
-        return [self._eval(self.g.get_tensor_by_name(f)[0], memo) for f in fetches]
+        key = (tuple(fetches), input_name)
+        prog = self._programs.get(key)
+        in_name = self.g.get_tensor_by_name(input_name)[0].name
+        if prog is None:
+            steps: List[Tuple[str, object, Tuple[str, ...]]] = []
+            done = {in_name}
+            outs = []
+            for f in fetches:
+                node = self.g.get_tensor_by_name(f)[0]
+                self._compile(node, steps, done)
+                outs.append(node.name)
+            prog = self._programs[key] = (steps, outs)
+        steps, outs = prog
+        vals: Dict[str, object] = {in_name: x}
+        for name, fn, ins in steps:
+            vals[name] = fn(*[vals[i] for i in ins])
+        return [vals[o] for o in outs]
 
-    def _eval(self, node: GraphNode, memo):
-        if node.name in memo:
-            return memo[node.name]
-        out = self._eval_uncached(node, memo)
-        memo[node.name] = out
-        return out
+    def _compile(self, node: GraphNode, steps, done) -> None:
+        if node.name in done:
+            return
+        fn, srcs = self._compile_node(node)
+        for sn in srcs:
+            self._compile(sn, steps, done)
+        steps.append((node.name, fn, tuple(sn.name for sn in srcs)))
+        done.add(node.name)
 
-    def _linear(self, node: GraphNode, memo, alpha_node: Optional[GraphNode]):
+    def _compile_linear(self, node: GraphNode, alpha_node: Optional[GraphNode]):
         """node = BiasAdd(Conv2D | MatMul) (or a bare Conv2D/MatMul): one fused kernel launch."""
         bias = None
         if node.op == "BiasAdd":
@@ -125,38 +146,40 @@ class _DeviceNet:
             lin = node
         alpha = None if alpha_node is None else self._dev(alpha_node)
         src, wnode = self._ins(lin)
-        xin = self._eval(src, memo)
         if lin.op == "Conv2D":
-            s = lin.attr_ints("strides")
-            return ops.conv2d_direct(xin, self._dev(wnode), bias, alpha, s[1], lin.attr_s("padding"))
+            stride, padding, wdev = lin.attr_ints("strides")[1], lin.attr_s("padding"), self._dev(wnode)
+            return (lambda xin: ops.conv2d_direct(xin, wdev, bias, alpha, stride, padding)), [src]
         if lin.op == "MatMul":
             w = self._const_np(wnode)
-            n = xin.shape[0]
-            flat = xin.reshape(n, 1, 1, -1).contiguous()
-            y = ops.conv2d_direct(flat, self._dev(wnode, (1, 1, w.shape[0], w.shape[1])), bias, alpha, 1, "VALID")
-            return y.reshape(n, w.shape[1])
+            cout = int(w.shape[1])
+            wdev = self._dev(wnode, (1, 1, w.shape[0], w.shape[1]))
+
+            def matmul(xin):
+                n = xin.shape[0]
+                flat = xin.reshape(n, 1, 1, -1).contiguous()
+                return ops.conv2d_direct(flat, wdev, bias, alpha, 1, "VALID").reshape(n, cout)
+            return matmul, [src]
         raise NotImplementedError("%s: op %s" % (lin.name, lin.op))
 
-    def _eval_uncached(self, node: GraphNode, memo):
+    def _compile_node(self, node: GraphNode):
+        """-> (callable(*input tensors), [input nodes])."""
         op = node.op
         pr = self._match_prelu(node)
         if pr is not None:
-            return self._linear(pr[0], memo, pr[1])
+            return self._compile_linear(pr[0], pr[1])
         sm = self._match_softmax(node)
         if sm is not None:
-            x = self._eval(sm, memo)
-            return ops.softmax(x.reshape(-1, x.shape[-1]).contiguous()).reshape(x.shape)
+            return (lambda x: ops.softmax(x.reshape(-1, x.shape[-1]).contiguous()).reshape(x.shape)), [sm]
         if op in ("BiasAdd", "Conv2D", "MatMul"):
-            return self._linear(node, memo, None)
+            return self._compile_linear(node, None)
         if op == "MaxPool":
-            k, s = node.attr_ints("ksize"), node.attr_ints("strides")
-            return ops.maxpool(self._eval(self._ins(node)[0], memo), k[1], s[1], node.attr_s("padding"))
+            k, st, padding = node.attr_ints("ksize")[1], node.attr_ints("strides")[1], node.attr_s("padding")
+            return (lambda x: ops.maxpool(x, k, st, padding)), [self._ins(node)[0]]
         if op == "Reshape":
-            x = self._eval(self._ins(node)[0], memo)
             shape = [int(d) for d in self._const_np(self._ins(node)[1]).reshape(-1)]
-            return x.reshape(shape).contiguous()
+            return (lambda x: x.reshape(shape).contiguous()), [self._ins(node)[0]]
         if op == "Identity":
-            return self._eval(self._ins(node)[0], memo)
+            return (lambda x: x), [self._ins(node)[0]]
         raise NotImplementedError("MTCNN graph walker: no kernel for op %s (%s)" % (op, node.name))
 
 
