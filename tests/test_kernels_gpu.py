@@ -460,3 +460,66 @@ def test_ashr_pk_probe_still_shows_the_half_register_write(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:]
     assert "low half  : 0xC84D" in out.stdout
     assert "PRESERVED" in out.stdout, "the instruction now writes the whole register: revisit tools/isa_lint.py\n" + out.stdout
+
+
+@pytest.mark.parametrize("n,k,cout,act", [(1, 1024, 256, 1), (512, 1024, 256, 1), (5, 256, 100, 0), (13, 256, 1, 3), (9, 37, 70, 0),
+                                           (3, 20, 5, 0), (17, 48, 64, 2), (8, 2048, 128, 0)])
+def test_dense_every_tiling_branch(env, n, k, cout, act):
+    """hsefr_dense after its round-3 re-tiling (64 columns per workgroup, the contraction split over four waves, 16 / 4 / 1 steps at a
+    time): the heads' own shapes, k % 16 != 0, k % 4 != 0 (scalar staging and loop), cout < 64 and not a multiple of 64, partial row
+    groups -- against a float64 product of the same float32 operands."""
+    torch, ops = env
+    g = torch.Generator(device="cuda").manual_seed(n * 1000 + k + cout)
+    x = torch.randn((n, k), device="cuda", generator=g)
+    w = torch.randn((k, cout), device="cuda", generator=g) / k ** 0.5
+    b = torch.randn((cout,), device="cuda", generator=g)
+    got = ops.dense(x, w, b, act).cpu().numpy().astype(np.float64)
+    ref = x.cpu().numpy().astype(np.float64) @ w.cpu().numpy().astype(np.float64) + b.cpu().numpy().astype(np.float64)
+    if act == 1:
+        ref = np.maximum(ref, 0.0)
+    elif act == 2:
+        ref = np.clip(ref, 0.0, 6.0)
+    elif act == 3:
+        ref = 1.0 / (1.0 + np.exp(-ref))
+    assert got.shape == (n, cout)
+    assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()) + 1e-6
+    assert torch.equal(ops.dense(x, w, b, act), ops.dense(x, w, b, act))          # fixed summation order: bit-identical run to run
+
+
+@pytest.mark.parametrize("c,cout,k,stride,padding", [(3, 10, 3, 1, "VALID"), (10, 16, 3, 1, "VALID"), (16, 32, 3, 1, "VALID"),
+                                                      (32, 2, 1, 1, "VALID"), (5, 7, 3, 2, "SAME"), (6, 6, 2, 1, "SAME"),
+                                                      (64, 128, 2, 1, "VALID"), (7, 12, 3, 1, "SAME")])
+def test_conv2d_direct_every_channel_grouping(env, c, cout, k, stride, padding):
+    """hsefr_conv2d_direct with 4 / 2 / 1 output channels per thread and input channels loaded 4 / 2 / 1 at a time (MTCNN's layer
+    shapes and odd ones, both paddings, stride 2): bias and PReLU fused; within 1e-5 of a float64 convolution of the same float32
+    operands (the bit-level statement -- the same FMA chain whatever the grouping -- is what tests/test_mtcnn_gpu.py holds the
+    whole cascade to)."""
+    torch, ops = env
+    g = torch.Generator(device="cuda").manual_seed(c * 100 + cout)
+    n, h, w = 3, 11, 9
+    x = torch.randn((n, h, w, c), device="cuda", generator=g)
+    wt = torch.randn((k, k, c, cout), device="cuda", generator=g) / (k * k * c) ** 0.5
+    b = torch.randn((cout,), device="cuda", generator=g)
+    al = torch.rand((cout,), device="cuda", generator=g)
+    got = ops.conv2d_direct(x, wt, b, al, stride, padding)
+    xn, wn = x.cpu().numpy().astype(np.float64), wt.cpu().numpy().astype(np.float64)
+    oh, ow = got.shape[1], got.shape[2]
+    if padding == "SAME":
+        pt = max((oh - 1) * stride + k - h, 0) // 2
+        pl = max((ow - 1) * stride + k - w, 0) // 2
+    else:
+        pt = pl = 0
+    ref = np.zeros((n, oh, ow, cout))
+    for kh in range(k):
+        for kw in range(k):
+            for y in range(oh):
+                ih = y * stride - pt + kh
+                if not 0 <= ih < h:
+                    continue
+                for xx in range(ow):
+                    iw = xx * stride - pl + kw
+                    if 0 <= iw < w:
+                        ref[:, y, xx, :] += xn[:, ih, iw, :] @ wn[kh, kw]
+    ref += b.cpu().numpy().astype(np.float64)
+    ref = np.where(ref > 0, ref, al.cpu().numpy().astype(np.float64) * ref)
+    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
