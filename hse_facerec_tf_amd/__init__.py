@@ -7,8 +7,8 @@ a gfx950 device, and fails loudly otherwise (there is no CPU path in this packag
 """
 from .graphdef import read_graph  # noqa: F401
 from .lowering import lower_graph, LoweringError  # noqa: F401
-from .tf_inference import (TensorFlowInference, extract_dataset, get_files, get_tf_face_recognizer,  # noqa: F401
-                           load_graph)
+from .tf_inference import (TensorFlowInference, extract_dataset, extract_gallery_probe, get_files,  # noqa: F401
+                           get_tf_face_recognizer, load_graph)
 from .facial_analysis import FacialImageProcessing  # noqa: F401
 
 __version__ = "0.1.0"

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import struct
 from dataclasses import dataclass, field
-from typing import Any, Dict, Iterator, List, Optional, Tuple
+from typing import Any, Dict, Iterator, List, Optional, Tuple, Sequence
 
 import numpy as np
 
@@ -265,6 +265,35 @@ class Graph:
             v = _tensor_to_numpy(node.attrs["value"]["tensor"])
             self._const[node.name] = v
         return v
+
+    def with_prefix(self, prefix: str) -> "Graph":
+        """What ``tf.import_graph_def(graph_def, name=prefix)`` does to names (facerec_test.py:46-47,
+        facial_analysis.py:328-332): every node becomes ``prefix/<name>`` and every input reference -- data or
+        ``^control`` -- follows.  ``''`` (the default of both reference loaders) leaves the graph as it is.  Attributes are
+        shared with this graph (constants are not copied)."""
+        if not prefix:
+            return self
+        p = prefix.rstrip("/") + "/"
+
+        def ref(r: str) -> str:
+            return "^" + p + r[1:] if r.startswith("^") else p + r
+        return Graph([GraphNode(p + n.name, n.op, [ref(r) for r in n.inputs], n.attrs) for n in self.nodes])
+
+    @staticmethod
+    def merged(graphs: Sequence["Graph"]) -> "Graph":
+        """Several imported graphs as ONE graph, the way facial_analysis.py:55-58 imports mtcnn.pb and the age / gender
+        file(s) into one ``full_graph`` behind one session.  A node name that two of them define raises ValueError, as
+        ``import_graph_def`` does for a name that is already in use."""
+        nodes: List[GraphNode] = []
+        seen: Dict[str, int] = {}
+        for gi, g in enumerate(graphs):
+            for n in g.nodes:
+                if n.name in seen:
+                    raise ValueError("node name %r is defined by graph %d and graph %d: import them under different prefixes"
+                                     % (n.name, seen[n.name], gi))
+                seen[n.name] = gi
+                nodes.append(n)
+        return Graph(nodes)
 
 
 def read_graph(path_or_bytes) -> Graph:

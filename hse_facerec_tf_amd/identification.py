@@ -124,6 +124,93 @@ def one_nn_identification(X, y: np.ndarray, split=None,
             "nn_index": nn_idx_h, "nn_dist": nn_dist_h, "num_classes": int(y_enc.max() + 1) if len(y_enc) else 0}
 
 
+def single_image_per_class_splits(y: np.ndarray, n_splits: int = 10, random_state: int = 0):
+    """get_single_image_per_class_cv (facerec_test.py:177-197), the protocol behind README.md:13's one-training-image rows:
+    ``n_splits`` splits; in each, every class's sample indices are shuffled and the FIRST one is the gallery image, the rest
+    are probes.  The reference seeds NumPy's global generator once (``np.random.seed(random_state)``) and shuffles class by
+    class in ``np.unique`` order, split after split; a private ``RandomState(random_state)`` draws the same stream without
+    touching the caller's global state -- the splits are bit-equal (tests/golden/single_image_splits.npz)."""
+    y = np.asarray(y)
+    inds = np.arange(len(y))
+    rs = np.random.RandomState(random_state)
+    classes = np.unique(y)
+    members = [inds[y == lbl] for lbl in classes]
+    res_cv = []
+    for _ in range(n_splits):
+        inds_train, inds_test = [], []
+        for m in members:
+            tmp = m.copy()
+            rs.shuffle(tmp)
+            inds_train.extend(tmp[:1])
+            inds_test.extend(tmp[1:])
+        res_cv.append((np.array(inds_train), np.array(inds_test)))
+    return res_cv
+
+
+def _nn1_predict(torch, ops, Xd, train, test, y):
+    gal = Xd[torch.from_numpy(np.asarray(train, dtype=np.int64)).to(Xd.device)].contiguous()
+    qry = Xd[torch.from_numpy(np.asarray(test, dtype=np.int64)).to(Xd.device)].contiguous()
+    nn_idx, nn_d2 = ops.nn1(qry, gal)
+    nn_idx_h = nn_idx.cpu().numpy()
+    return y[np.asarray(train)][nn_idx_h], nn_idx_h, np.sqrt(nn_d2.cpu().numpy())
+
+
+def cross_validated_1nn(X, y: np.ndarray, cv, normalize: bool = True, device=None) -> Dict:
+    """classifier_tester (facerec_test.py:199-207) for KNeighborsClassifier(n_neighbors=1, p=2) over an explicit list of
+    (train, test) index pairs -- e.g. single_image_per_class_splits(y) in place of the stratified half split (:200-201) --
+    with every search on the GPU.  Returns the per-split accuracies and their mean / std as the reference prints them."""
+    from . import _lib, ops
+    torch = _lib.require_gpu()
+    if isinstance(X, np.ndarray):
+        X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(_lib.cuda_device(device))
+    Xd = ops.l2_normalize(X.contiguous()) if normalize else X.contiguous()
+    y = np.asarray(y)
+    accs, preds = [], []
+    for train, test in cv:
+        y_pred, _, _ = _nn1_predict(torch, ops, Xd, train, test, y)
+        preds.append(y_pred)
+        accs.append(float((y_pred == y[np.asarray(test)]).mean()) if len(test) else float("nan"))
+    accs = np.asarray(accs)
+    return {"accuracies": accs, "mean": float(accs.mean()) if len(accs) else float("nan"),
+            "std": float(accs.std()) if len(accs) else float("nan"), "y_pred": preds}
+
+
+def gallery_probe_identification(X_train, y_train: np.ndarray, X_test, y_test: np.ndarray, normalize: bool = False,
+                                 pca_components: Optional[int] = None, device=None) -> Dict:
+    """The gallery / probe protocol of tf_train_test_recognition (facerec_test.py:260-288): the '1-NN' classifier (and
+    '1-NN+PCA' with ``pca_components``, 16 at :269) FITTED on the gallery features, every probe labelled by its nearest
+    gallery row; accuracy = share of probes whose label is right (:287).  NB the reference computes L2-normalised copies
+    (:262,265) and then fits / predicts on the UN-normalised ``X_train`` / ``X_test`` (:284-285): ``normalize=False`` is what
+    it runs, ``normalize=True`` what the copies suggest it meant.  The search runs on the GPU (hsefr_nn1: ties -> the lowest
+    gallery index, scikit-learn's own choice)."""
+    from . import _lib, ops
+    torch = _lib.require_gpu()
+    dev = _lib.cuda_device(device)
+
+    def up(a):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev) if isinstance(a, np.ndarray) else a.float()
+        return ops.l2_normalize(t.contiguous()) if normalize else t.contiguous()
+    gal, qry = up(X_train), up(X_test)
+    y_train, y_test = np.asarray(y_train), np.asarray(y_test)
+    if gal.shape[0] != len(y_train) or qry.shape[0] != len(y_test):
+        raise ValueError("features and labels differ in length: %d/%d gallery, %d/%d probe"
+                         % (gal.shape[0], len(y_train), qry.shape[0], len(y_test)))
+    if pca_components:
+        from sklearn.decomposition import PCA
+        pca = PCA(n_components=pca_components).fit(gal.cpu().numpy())
+        pad = (-pca_components) % 8
+
+        def proj(t):
+            z = pca.transform(t.cpu().numpy()).astype(np.float32)
+            return torch.from_numpy(np.pad(z, ((0, 0), (0, pad)))).to(dev).contiguous()
+        gal, qry = proj(gal), proj(qry)
+    nn_idx, nn_d2 = ops.nn1(qry, gal)
+    nn_idx_h = nn_idx.cpu().numpy()
+    y_pred = y_train[nn_idx_h]
+    acc = float((y_pred == y_test).mean()) if len(y_test) else float("nan")
+    return {"accuracy": acc, "y_pred": y_pred, "nn_index": nn_idx_h, "nn_dist": np.sqrt(nn_d2.cpu().numpy())}
+
+
 def feature_distance_matrix(features, born_years=None, photo_years=None, device=None) -> np.ndarray:
     """The dist_matrix of process_photos.perform_clustering (process_photos.py:45-60): Euclidean distance
     between facial features (on the GPU) plus 0.1 x the age term (cur_age_i - cur_age_j)^2 / (cur_age_i +

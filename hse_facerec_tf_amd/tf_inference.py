@@ -31,11 +31,10 @@ def get_files(db_dir):                       # facerec_test.py:38-39 (os.walk or
             for f in sorted(next(os.walk(os.path.join(db_dir, d)))[2]) if not f.startswith(".") and is_image(f)]
 
 
-def load_graph(frozen_graph_filename, prefix='') -> Graph:   # facerec_test.py:41-48
-    g = read_graph(frozen_graph_filename)
-    if prefix:
-        raise NotImplementedError("name prefixes are not needed by any caller of the hot path")
-    return g
+def load_graph(frozen_graph_filename, prefix='') -> Graph:   # facerec_test.py:41-48, facial_analysis.py:328-332
+    """``tf.import_graph_def(graph_def, name=prefix)``: with a prefix every node is addressed as ``prefix/<name>``
+    (the reference imports its separate age and gender files as 'age/...' and 'gender/...': facial_analysis.py:48-58)."""
+    return read_graph(frozen_graph_filename).with_prefix(prefix)
 
 
 class TensorFlowInference:
@@ -345,15 +344,25 @@ class TensorFlowInference:
         return out_host.numpy().copy()
 
 
+def get_files_of_subjects(db_dir, subjects_file):
+    """The 'LFW and YTF concatenation' branch of facerec_test.py:378-380 (README.md:13's LFW-and-YTF row): only the
+    sub-directories named in ``subjects_file`` (lfw_ytf_classes.txt: one subject per line), in the file's order."""
+    with open(subjects_file) as fh:
+        subjects = [line.rstrip('\n') for line in fh]
+    return [[d, os.path.join(d, f)] for d in subjects if d
+            for f in sorted(next(os.walk(os.path.join(db_dir, d)))[2]) if is_image(f)]
+
+
 def extract_dataset(tfInference, dataset_path: str, features_file: Optional[str] = None, batch: int = 256,
-                    crop_center: bool = False):
-    """The extract stage of facerec_test.py:377-401: walk ``dataset_path`` (one sub-directory per subject),
-    label-encode the directory names, extract every image, cache ``np.savez(features_file, x=X, y=y)`` and
-    reuse the cache when the file exists (:308,:399-401).  Returns (X [N,D] float32, y [N] int)."""
+                    crop_center: bool = False, subjects_file: Optional[str] = None):
+    """The extract stage of facerec_test.py:377-401: walk ``dataset_path`` (one sub-directory per subject; with
+    ``subjects_file`` only the subjects it lists, :378-380), label-encode the directory names, extract every image,
+    cache ``np.savez(features_file, x=X, y=y)`` and reuse the cache when the file exists (:308,:399-401).
+    Returns (X [N,D] float32, y [N] int)."""
     if features_file is not None and os.path.exists(features_file):
         data = np.load(features_file)
         return data['x'], data['y']
-    dirs_and_files = np.array(get_files(dataset_path))
+    dirs_and_files = np.array(get_files(dataset_path) if subjects_file is None else get_files_of_subjects(dataset_path, subjects_file))
     dirs = dirs_and_files[:, 0]
     files = dirs_and_files[:, 1]
     classes, y = np.unique(dirs, return_inverse=True)          # == LabelEncoder().fit(dirs).transform(dirs)
@@ -361,6 +370,31 @@ def extract_dataset(tfInference, dataset_path: str, features_file: Optional[str]
     if features_file is not None:
         np.savez(features_file, x=X, y=y)
     return X, y
+
+
+def extract_gallery_probe(tfInference, gallery_path: str, probe_path: str, features_file: Optional[str] = None,
+                          batch: int = 256, crop_center: bool = False):
+    """The extract stage of tf_train_test_recognition (facerec_test.py:220-258): separate Gallery and Probe trees, the label
+    encoder FITTED on the gallery's directory names and applied to the probe's (a probe subject the gallery does not have
+    raises ValueError, as LabelEncoder.transform does), both trees extracted, cached as
+    ``np.savez(features_file, x_train=, y_train=, x_test=, y_test=)`` (:258) and re-used when the file exists (:227).
+    Returns (X_train, y_train, X_test, y_test)."""
+    if features_file is not None and os.path.exists(features_file):
+        data = np.load(features_file)
+        return data['x_train'], data['y_train'], data['x_test'], data['y_test']
+    train = np.array(get_files(gallery_path))
+    classes, y_train = np.unique(train[:, 0], return_inverse=True)       # LabelEncoder().fit(train_dirs) / .transform (:235-237)
+    test = np.array(get_files(probe_path))
+    pos = np.searchsorted(classes, test[:, 0])
+    known = (pos < len(classes)) & (classes[np.minimum(pos, len(classes) - 1)] == test[:, 0])
+    if not known.all():
+        raise ValueError("y contains previously unseen labels: %r" % sorted(set(test[~known, 0]))[:5])     # :249
+    y_test = pos.astype(y_train.dtype)
+    X_train = tfInference.extract_files([os.path.join(gallery_path, f) for f in train[:, 1]], batch=batch, crop_center=crop_center)
+    X_test = tfInference.extract_files([os.path.join(probe_path, f) for f in test[:, 1]], batch=batch, crop_center=crop_center)
+    if features_file is not None:
+        np.savez(features_file, x_train=X_train, y_train=y_train, x_test=X_test, y_test=y_test)
+    return X_train, y_train, X_test, y_test
 
 
 _MODELS_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models")

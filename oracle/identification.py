@@ -81,3 +81,49 @@ def embeddings_for_labels(y: np.ndarray, dim: int = 1024, seed: int = 123, noise
         rows = np.nonzero(y == c)[0]
         X[rows] = np.maximum(cent[c] + noise * rs.randn(len(rows), dim).astype(np.float32), 0)
     return X
+
+
+def single_image_per_class_cv(y: np.ndarray, n_splits: int = 10, random_state: int = 0):
+    """facerec_test.py:177-197 as written there: NumPy's GLOBAL generator seeded once, then -- split after split, class
+    after class in np.unique order -- the class's indices shuffled in place, the first kept for training, the rest for
+    testing.  The caller's global generator state is put back afterwards (the only departure: an oracle must not disturb
+    the tests around it)."""
+    saved = np.random.get_state()
+    try:
+        res_cv = []
+        inds = np.arange(len(y))
+        np.random.seed(random_state)
+        for _ in range(n_splits):
+            inds_train, inds_test = [], []
+            for lbl in np.unique(y):
+                tmp_inds = inds[y == lbl]
+                np.random.shuffle(tmp_inds)
+                last_ind = 1
+                inds_train.extend(tmp_inds[:last_ind])
+                inds_test.extend(tmp_inds[last_ind:])
+            res_cv.append((np.array(inds_train), np.array(inds_test)))
+        return res_cv
+    finally:
+        np.random.set_state(saved)
+
+
+def cross_validate_1nn(X_norm: np.ndarray, y: np.ndarray, cv):
+    """classifier_tester (facerec_test.py:199-207) with the commented-in ``sss=get_single_image_per_class_cv(y)``:
+    scikit-learn's own cross_validate over explicit splits.  Returns the test accuracies."""
+    from sklearn import model_selection
+    from sklearn.neighbors import KNeighborsClassifier
+    scores = model_selection.cross_validate(KNeighborsClassifier(n_neighbors=1, p=2), X_norm, y, scoring="accuracy", cv=cv)
+    return scores["test_score"]
+
+
+def gallery_probe_1nn(X_train: np.ndarray, y_train: np.ndarray, X_test: np.ndarray, y_test: np.ndarray):
+    """facerec_test.py:271,282-288: KNeighborsClassifier(n_neighbors=1, p=2).fit(X_train, y_train).predict(X_test) --
+    on the features AS LOADED (the reference normalises into X_train_norm / X_test_norm at :262,265 and then does not use
+    them) -- accuracy in percent as printed there, plus the nearest gallery indices."""
+    from sklearn.neighbors import KNeighborsClassifier
+    clf = KNeighborsClassifier(n_neighbors=1, p=2)
+    clf.fit(X_train, y_train)
+    y_test_pred = clf.predict(X_test)
+    acc = 100.0 * (y_test == y_test_pred).sum() / len(y_test)
+    dist, idx = clf.kneighbors(X_test, n_neighbors=1)
+    return acc, y_test_pred, idx[:, 0], dist[:, 0]

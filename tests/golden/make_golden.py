@@ -153,6 +153,34 @@ def nn1_lfw():
     print("nn1_lfw: kept=%d acc=%.6f min d2 margin=%.3e" % (len(kept), acc, margin))
 
 
+def protocols():
+    """The two other identification protocols of facerec_test.py, frozen from NumPy / scikit-learn themselves:
+    get_single_image_per_class_cv (:177-197) -> cross_validate(KNeighborsClassifier(1)) (:199-207), and the gallery / probe
+    split of tf_train_test_recognition (:220-288)."""
+    X, y = oid.synthetic_gallery(n_classes=120, dim=256, seed=321, noise=1.5)
+    Xn, y2, kept = oid.filter_and_encode(X, y)
+    cv = oid.single_image_per_class_cv(y2, n_splits=10, random_state=0)
+    accs = oid.cross_validate_1nn(Xn, y2, cv)
+    # gallery / probe: even samples of every class are the gallery tree, odd ones the probe tree; features NOT normalised
+    Xk = X[kept]
+    order = np.argsort(y2, kind="stable")
+    pos_in_class = np.zeros(len(y2), dtype=np.int64)
+    for c in np.unique(y2):
+        m = order[y2[order] == c]
+        pos_in_class[m] = np.arange(len(m))
+    g, p = np.nonzero(pos_in_class % 2 == 0)[0], np.nonzero(pos_in_class % 2 == 1)[0]
+    acc_gp, pred_gp, idx_gp, dist_gp = oid.gallery_probe_1nn(Xk[g], y2[g], Xk[p], y2[p])
+    acc_gpn, pred_gpn, idx_gpn, _ = oid.gallery_probe_1nn(Xn[g], y2[g], Xn[p], y2[p])
+    out = {"n_classes": 120, "dim": 256, "seed": 321, "noise": 1.5, "y": y2, "accuracies": accs,
+           "gallery": g, "probe": p, "gp_accuracy_percent": acc_gp, "gp_pred": pred_gp, "gp_nn_index": idx_gp,
+           "gp_nn_dist": dist_gp.astype(np.float32), "gpn_accuracy_percent": acc_gpn, "gpn_pred": pred_gpn, "gpn_nn_index": idx_gpn}
+    for i, (tr, te) in enumerate(cv):
+        out["train_%d" % i], out["test_%d" % i] = tr, te
+    np.savez_compressed(os.path.join(HERE, "protocols.npz"), **out)
+    print("protocols: single-image accs mean %.4f std %.4f; gallery/probe %.2f %% (raw) %.2f %% (normalised)"
+          % (accs.mean(), accs.std(), acc_gp, acc_gpn))
+
+
 def mtcnn():
     """Oracle MTCNN cascade (fp32 graph interpreter + restated INTER_AREA) on the reference's demo image, then the
     oracle age/gender model on the detected faces exactly as process_image crops them (facial_analysis.py:233-271)."""
@@ -185,6 +213,6 @@ def mtcnn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["e2e_image", "e2e_synthetic", "kernels", "nn1", "nn1_lfw", "mtcnn"]
+    which = sys.argv[1:] or ["e2e_image", "e2e_synthetic", "kernels", "nn1", "nn1_lfw", "protocols", "mtcnn"]
     for w in which:
         globals()[w]()

@@ -121,3 +121,97 @@ def test_split_job_gives_the_serial_split_and_reraises():
     assert all(np.array_equal(a, b) for a, b in zip(got, (indices, y_enc, tr, te)))
     with pytest.raises(ValueError):
         identification.start_split(np.arange(10)).result()      # no class with two samples: scikit-learn refuses the split
+
+
+def test_single_image_per_class_splits_equal_numpy_seeded_reference_loop():
+    """facerec_test.py:177-197: bit-equal to the fixture frozen from NumPy's GLOBAL seeded generator (the reference's own
+    calls, restated in oracle/identification.py), without touching the caller's global state."""
+    z = np.load(os.path.join(GOLDEN, "protocols.npz"))
+    np.random.seed(77)
+    before = np.random.get_state()[1].copy()
+    cv = identification.single_image_per_class_splits(z["y"], n_splits=10, random_state=0)
+    assert np.array_equal(np.random.get_state()[1], before)
+    assert len(cv) == 10
+    for i, (tr, te) in enumerate(cv):
+        assert np.array_equal(tr, z["train_%d" % i]) and np.array_equal(te, z["test_%d" % i])
+        assert len(tr) == len(np.unique(z["y"])) and len(tr) + len(te) == len(z["y"])
+        assert np.array_equal(np.sort(z["y"][tr]), np.unique(z["y"]))          # exactly one gallery image per class
+    live = oid.single_image_per_class_cv(z["y"], 10, 0)                         # and the restatement run live agrees too
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(cv, live))
+    other = identification.single_image_per_class_splits(z["y"], n_splits=2, random_state=1)
+    assert not np.array_equal(other[0][0], cv[0][0])
+
+
+def test_load_graph_prefix_renames_like_import_graph_def():
+    """facerec_test.py:41-48 / facial_analysis.py:328-332: tf.import_graph_def(graph_def, name=prefix)."""
+    from hse_facerec_tf_amd import graphdef, lowering
+    g0 = tf_inference.load_graph(MODEL_PB)
+    g = tf_inference.load_graph(MODEL_PB, prefix="age")
+    assert len(g.nodes) == len(g0.nodes)
+    assert all(n.name == "age/" + m.name and n.op == m.op for n, m in zip(g.nodes, g0.nodes))
+    for n, m in zip(g.nodes, g0.nodes):
+        assert [r.lstrip("^") for r in n.inputs] == ["age/" + r.lstrip("^") for r in m.inputs]
+        assert [r.startswith("^") for r in n.inputs] == [r.startswith("^") for r in m.inputs]
+    g.get_tensor_by_name("age/input_1:0")
+    with pytest.raises(KeyError):
+        g.get_tensor_by_name("input_1:0")
+    assert tf_inference.load_graph(MODEL_PB, prefix="age/").node("age/input_1").op == "Placeholder"
+    # the prefixed graph lowers to the SAME plan bytes (names are not part of a plan)
+    a = lowering.lower_graph(g0, "input_1:0", {0: "global_pooling/Mean:0"}, (96, 96)).serialize()
+    b = lowering.lower_graph(g, "age/input_1:0", {0: "age/global_pooling/Mean:0"}, (96, 96)).serialize()
+    assert a == b
+    # several files behind one session (facial_analysis.py:55-58): one graph, disjoint prefixes; a clash raises
+    full = graphdef.Graph.merged([g, tf_inference.load_graph(MODEL_PB, prefix="gender")])
+    assert len(full.nodes) == 2 * len(g0.nodes)
+    full.get_tensor_by_name("gender/gender_pred/Sigmoid:0")
+    with pytest.raises(ValueError):
+        graphdef.Graph.merged([g0, g0])
+
+
+class _StubExtractor:
+    """extract_files of a TensorFlowInference without a device: the feature of a file is its size and its first byte."""
+    feature_dim = 2
+
+    def __init__(self):
+        self.calls = []
+
+    def extract_files(self, paths, batch=256, crop_center=False):
+        self.calls.append(list(paths))
+        return np.array([[os.path.getsize(p), open(p, "rb").read(1)[0]] for p in paths], dtype=np.float32).reshape(-1, 2)
+
+
+def test_extract_gallery_probe_labels_cache_and_unseen_subject(tmp_path):
+    """facerec_test.py:220-258: encoder fitted on the Gallery tree, applied to the Probe tree; x_train / y_train / x_test / y_test
+    cache; a probe subject the gallery lacks raises as LabelEncoder.transform does."""
+    for tree, subjects in (("Gallery", {"carol": 2, "alice": 1, "bob": 3}), ("Probe", {"bob": 2, "alice": 2})):
+        for s, k in subjects.items():
+            os.makedirs(tmp_path / tree / s)
+            for i in range(k):
+                (tmp_path / tree / s / ("%d.jpg" % i)).write_bytes(bytes([65 + i]) * (1 + i + len(s)))
+    stub = _StubExtractor()
+    cache = str(tmp_path / "feats.npz")
+    Xtr, ytr, Xte, yte = tf_inference.extract_gallery_probe(stub, str(tmp_path / "Gallery"), str(tmp_path / "Probe"), cache)
+    assert list(ytr) == [0, 1, 1, 1, 2, 2] and list(yte) == [0, 0, 1, 1]          # alice 0, bob 1, carol 2 (sorted walk)
+    assert Xtr.shape == (6, 2) and Xte.shape == (4, 2) and len(stub.calls) == 2
+    assert stub.calls[1][0].endswith(os.path.join("Probe", "alice", "0.jpg"))
+    z = np.load(cache)
+    assert sorted(z.files) == ["x_test", "x_train", "y_test", "y_train"]          # facerec_test.py:258
+    again = tf_inference.extract_gallery_probe(None, "/nonexistent", "/nonexistent", cache)     # :227 the cache short-circuits
+    assert all(np.array_equal(a, b) for a, b in zip(again, (Xtr, ytr, Xte, yte)))
+    os.makedirs(tmp_path / "Probe" / "dave")
+    (tmp_path / "Probe" / "dave" / "0.png").write_bytes(b"zz")
+    with pytest.raises(ValueError, match="unseen"):
+        tf_inference.extract_gallery_probe(stub, str(tmp_path / "Gallery"), str(tmp_path / "Probe"))
+
+
+def test_extract_dataset_subjects_file_variant(tmp_path):
+    """facerec_test.py:378-380: the LFW-and-YTF protocol walks only the subjects of lfw_ytf_classes.txt, in that order."""
+    for s in ("zed", "amy", "kim"):
+        os.makedirs(tmp_path / "db" / s)
+        (tmp_path / "db" / s / "a.jpg").write_bytes(s.encode())
+        (tmp_path / "db" / s / "b.txt").write_bytes(b"no")
+    (tmp_path / "classes.txt").write_text("zed\namy\n")
+    assert tf_inference.get_files_of_subjects(str(tmp_path / "db"), str(tmp_path / "classes.txt")) == \
+        [["zed", os.path.join("zed", "a.jpg")], ["amy", os.path.join("amy", "a.jpg")]]
+    X, y = tf_inference.extract_dataset(_StubExtractor(), str(tmp_path / "db"), subjects_file=str(tmp_path / "classes.txt"))
+    assert list(y) == [1, 0] and X.shape == (2, 2)                                # LabelEncoder order: amy 0, zed 1

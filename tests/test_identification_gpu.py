@@ -221,3 +221,56 @@ def test_nn1_at_full_lfw_size_vs_sklearn_fixture_and_fp64(torch_):
     assert abs(r["accuracy"] - float(z["accuracy"])) <= (~clear).sum() / 4582.0 + 1e-12
     if clear.all():
         assert r["accuracy"] == pytest.approx(float(z["accuracy"]), abs=1e-12)
+
+
+def _protocol_fixture():
+    z = np.load(os.path.join(GOLDEN, "protocols.npz"))
+    X, y = oid.synthetic_gallery(int(z["n_classes"]), int(z["dim"]), int(z["seed"]), float(z["noise"]))
+    Xn, y2, kept = oid.filter_and_encode(X, y)
+    assert np.array_equal(y2, z["y"])
+    return z, X[kept], Xn
+
+
+def _near_tie_only(A, probe, gallery, got_idx, want_idx, tol):
+    """Every probe whose nearest gallery row differs from the fixture's must be an fp tie in fp64 (distance gap <= tol)."""
+    bad = np.nonzero(got_idx != want_idx)[0]
+    A = A.astype(np.float64)
+    for b in bad:
+        d_got = ((A[probe[b]] - A[gallery[got_idx[b]]]) ** 2).sum()
+        d_want = ((A[probe[b]] - A[gallery[want_idx[b]]]) ** 2).sum()
+        assert abs(d_got - d_want) <= tol * max(d_want, 1.0), (b, d_got, d_want)
+    return len(bad)
+
+
+def test_gallery_probe_identification_matches_sklearn_fixture(torch_):
+    """facerec_test.py:260-288 on the GPU vs KNeighborsClassifier(1).fit(gallery).predict(probe) frozen from scikit-learn:
+    the reference's un-normalised call and the normalised variant."""
+    from hse_facerec_tf_amd import identification
+    z, Xraw, Xn = _protocol_fixture()
+    g, p = z["gallery"], z["probe"]
+    r = identification.gallery_probe_identification(Xraw[g], z["y"][g], Xraw[p], z["y"][p])
+    assert _near_tie_only(Xraw, p, g, r["nn_index"], z["gp_nn_index"], 1e-6) == 0          # margin 0.35 on d2 ~ 570: no ties
+    assert np.array_equal(r["y_pred"], z["gp_pred"])
+    assert 100.0 * r["accuracy"] == pytest.approx(float(z["gp_accuracy_percent"]), abs=1e-9)
+    assert np.abs(r["nn_dist"] - z["gp_nn_dist"]).max() < 1e-3 * float(z["gp_nn_dist"].max())
+    rn = identification.gallery_probe_identification(torch_.from_numpy(Xraw[g]).cuda(), z["y"][g], torch_.from_numpy(Xraw[p]).cuda(),
+                                                     z["y"][p], normalize=True)
+    ties = _near_tie_only(Xn, p, g, rn["nn_index"], z["gpn_nn_index"], 2e-6)
+    assert ties <= 2 and int((rn["y_pred"] != z["gpn_pred"]).sum()) <= ties
+    with pytest.raises(ValueError):
+        identification.gallery_probe_identification(Xraw[g], z["y"][g][:-1], Xraw[p], z["y"][p])
+
+
+def test_single_image_per_class_cross_validation_matches_sklearn_fixture(torch_):
+    """classifier_tester with sss = get_single_image_per_class_cv(y) (facerec_test.py:199-207, 177-197): ten splits, one
+    gallery image per class, accuracies vs scikit-learn's cross_validate."""
+    from hse_facerec_tf_amd import identification
+    z, Xraw, Xn = _protocol_fixture()
+    cv = identification.single_image_per_class_splits(z["y"], 10, 0)
+    r = identification.cross_validated_1nn(Xraw, z["y"], cv)                               # normalises on the device (:401)
+    assert r["accuracies"].shape == (10,)
+    # a near tie (fp64 gap 7e-6 in this fixture) may flip one probe of a split: at most one probe per split may differ
+    for i, (tr, te) in enumerate(cv):
+        assert abs(r["accuracies"][i] - z["accuracies"][i]) <= 1.0 / len(te) + 1e-12
+    assert int((np.abs(r["accuracies"] - z["accuracies"]) > 1e-12).sum()) <= 2
+    assert r["mean"] == pytest.approx(float(z["accuracies"].mean()), abs=2e-4)
