@@ -46,6 +46,7 @@ SIGNATURES = {
     "hsefr_engine_accepts_u8": (c_int, [c_void_p]),
     "hsefr_engine_forward_u8": (c_int, [c_void_p, _fp, c_int, _fp, _fp, _fp, c_void_p]),
     "hsefr_engine_input_overflow": (c_int, [c_void_p, POINTER(c_int), c_void_p]),
+    "hsefr_engine_input_overflow_async": (c_int, [c_void_p, POINTER(c_int), c_void_p]),
     "hsefr_stem_fused": (c_int, [_fp] * 6 + [c_void_p, _fp, _fp, _fp] + [c_int] * 9 + [c_void_p]),
     "hsefr_dwpw_f16split": (c_int, [_fp, _fp, _fp, _fp, c_void_p, _fp, _fp, _fp] + [c_int] * 12 + [c_void_p]),
     "hsefr_pwconv1x1_f16split": (c_int, [_fp, c_void_p, _fp, _fp, _fp, c_longlong, c_int, c_int, c_int, c_int, c_void_p]),

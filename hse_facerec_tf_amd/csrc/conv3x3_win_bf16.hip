@@ -117,7 +117,7 @@ __global__ __launch_bounds__(768, 1) void conv3x3_win_bf16_kernel(Win3Params p) 
         const int lw = wave - 8;
         auto piece = [&](const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(r)
-                         : "memory");
+                         : "memory", "m0");
         };
         const __amdgpu_buffer_rsrc_t rx = make_rsrc_sgpr(p.x, p.x_bytes);
         // weight pieces: rows lw * BPW * 8 .. of the tile's BN rows

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
         auto piece = [&](const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
                          "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff))
-                         : "memory");
+                         : "memory", "m0");
         };
         unsigned pf_i = 0, pf_step = 0;
         int pf_kt = 0, pf_tap = 0, pf_cs = 0, pf_kh = 0, pf_kw = 0, pf_n0 = 0;

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
     auto piece = [&](const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
                      "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff))
-                     : "memory");   // issued from asm so that hipcc does not drain vmcnt before every LDS read
+                     : "memory", "m0");   // issued from asm so that hipcc does not drain vmcnt before every LDS read
     };
     // halo DMA duty: producers.  (Measured both ways with in-kernel stamps: the patch time does not change, the waiting moves to
     // whichever waves issue the vector-memory instructions.  Neither did keeping all the weight rows of the 128-channel block

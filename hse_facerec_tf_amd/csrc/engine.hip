@@ -59,6 +59,14 @@ struct hsefr_engine {
     long long graph_launches = 0;
 };
 
+// stem4_fused.hip hard-codes TensorFlow's SAME geometry for inputs whose edges are multiples of 4 (conv1 and the stride-2
+// depthwise pad at the bottom / right only, H1 = h / 2, OH2 = h / 4) and its uint8 mean-folded shifts assume it too: an op with
+// any other padding (VALID, a hand-made plan) keeps stem3_fused.hip, which honours pad_t / pad_l / pad3 / oh / ow.
+static bool stem4_route(const hsefr_plan_op& o) {
+    return stem4_fused_supported(o.cin, 32, o.cout, o.stride, 1, 2, o.kh, o.kw & 15, o.h, o.w) && o.pad_t == 0 && o.pad_l == 0 &&
+           ((o.kw >> 4) & 3) == 0 && o.oh == o.h / 4 && o.ow == o.w / 4;
+}
+
 static const void* blob_ptr(const hsefr_engine* e, uint64_t off) {
     return off == HSEFR_NO_OFFSET ? nullptr : (const void*)(e->d_blob + off);
 }
@@ -535,7 +543,7 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                             o.act, s);
                     break;
                 }
-                if (g_stem4 && stem4_fused_supported(o.cin, 32, o.cout, o.stride, 1, 2, o.kh, o.kw & 15, o.h, o.w)) {
+                if (g_stem4 && stem4_route(o)) {
                     rc = launch_stem4_fused(in, 0, pk + 3008, pk + 1952 + 1024, pk + 864, pk + 896, pk + 1184, pk + 1216, blob_ptr(e, o.w2_off),
                                             ds2, ds2 + 64, pk + 1248, pk + 1824, pk + 1888, (float*)out, e->d_overflow, n, o.h, o.w,
                                             ((o.reserved >> 8) & 255) - 64, o.reserved & 255, o.act, s);
@@ -593,8 +601,7 @@ int hsefr_engine_forward(hsefr_engine* e, const void* d_input, int n, void* d_fe
 int hsefr_engine_accepts_u8(const hsefr_engine* e) {
     if (!e || e->ops.empty()) return 0;
     const hsefr_plan_op& o = e->ops[0];
-    return o.kind == HSEFR_OP_STEM3_F16S && o.in_buf == HSEFR_BUF_INPUT && ((o.reserved >> 16) & 1) &&
-           stem4_fused_supported(o.cin, 32, o.cout, o.stride, 1, 2, o.kh, o.kw & 15, o.h, o.w);
+    return o.kind == HSEFR_OP_STEM3_F16S && o.in_buf == HSEFR_BUF_INPUT && ((o.reserved >> 16) & 1) && stem4_route(o);
 }
 
 int hsefr_engine_forward_u8(hsefr_engine* e, const void* d_input_u8, int n, void* d_features, void* d_age_probs,
@@ -699,6 +706,15 @@ int hsefr_engine_input_overflow(hsefr_engine* e, int* host_flag, hsefr_stream_t 
     HSEFR_HIP_CHECK(hipMemcpyAsync(host_flag, e->d_overflow, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HSEFR_HIP_CHECK(hipMemsetAsync(e->d_overflow, 0, sizeof(int), (hipStream_t)stream));
     HSEFR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return HSEFR_OK;
+}
+
+int hsefr_engine_input_overflow_async(hsefr_engine* e, int* pinned_host_flag, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(e && pinned_host_flag, HSEFR_ERR_INVALID, "input_overflow_async: null argument");
+    // enqueue only: the copy and the clear are ordered on `stream` behind the forwards already queued there; the caller waits on
+    // an event of its own before it reads the (page-locked) int
+    HSEFR_HIP_CHECK(hipMemcpyAsync(pinned_host_flag, e->d_overflow, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HSEFR_HIP_CHECK(hipMemsetAsync(e->d_overflow, 0, sizeof(int), (hipStream_t)stream));
     return HSEFR_OK;
 }
 

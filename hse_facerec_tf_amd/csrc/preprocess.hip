@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void pil_resize_u8_band_kernel(const unsigned 
         for (int p = wave; p < npiece; p += 4)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds0 + p * 1024),
                          "v"(p * 1024 + lane * 16), "s"(r)
-                         : "memory");
+                         : "memory", "m0");
     }
     for (int e0 = 0; e0 < ow * 8; e0 += 256 * 8) {                           // eight independent loads per thread, then the writes
         int v[8];

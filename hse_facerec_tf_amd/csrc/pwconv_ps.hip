@@ -325,7 +325,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             // issued from asm: hipcc serialises builtin LDS-DMA against every later ds_read (DESIGN.md lesson 15b)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
                          "s"(r), "s"(__builtin_amdgcn_readfirstlane(soff))
-                         : "memory");
+                         : "memory", "m0");
         };
         __amdgpu_buffer_rsrc_t ra_rsrc, rb_rsrc;
         unsigned pf_i = 0, pf_step = 0;

@@ -21,7 +21,7 @@ template <int CO>
 __global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, const float* __restrict__ alpha,
                                                             float* __restrict__ y, int H, int W, int C, int OH, int OW, int Cout,
-                                                            int KH, int KW, int stride, int pad_t, int pad_l, long long total) {
+                                                            int KH, int KW, int stride, int pad_t, int pad_l, long long total, int xvec) {
     typedef float vco __attribute__((ext_vector_type(CO == 1 ? 2 : CO)));      // (CO == 1 reads scalars; the type is unused then)
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;              // index over pixels x (Cout / CO)
     if (i >= total) return;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restr
             const float* wp = w + (long long)((kh * KW + kw) * C) * Cout + co;
             // (c ascending; the input values of four / two channels in one load, the weights of the group in flight together)
             int c = 0;
-            if ((C & 3) == 0) {
+            if (xvec >= 4 && (C & 3) == 0) {        // xvec: what the ALIGNMENT of x allows (launcher), wave-uniform
                 for (; c < C; c += 4) {
                     const float4 xv = *(const float4*)(xp + c);
                     float w0[CO], w1[CO], w2[CO], w3[CO];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restr
 #pragma unroll
                     for (int j = 0; j < CO; ++j) acc[j] = fmaf(xv.w, w3[j], fmaf(xv.z, w2[j], fmaf(xv.y, w1[j], fmaf(xv.x, w0[j], acc[j]))));
                 }
-            } else if ((C & 1) == 0) {
+            } else if (xvec >= 2 && (C & 1) == 0) {
                 for (; c < C; c += 2) {
                     const float2 xv = *(const float2*)(xp + c);
                     float w0[CO], w1[CO];
@@ -182,9 +182,12 @@ int launch_conv2d_direct(const float* x, const float* w, const float* bias, cons
     // output channels per thread: the widest vector the weight rows allow (rows of `cout` floats from a 16-byte aligned base)
     const int co = (cout % 4 == 0 && ((uintptr_t)w & 15) == 0) ? 4 : ((cout % 2 == 0 && ((uintptr_t)w & 7) == 0) ? 2 : 1);
     const long long total = (long long)n * oh * ow * (cout / co);
+    // the input side loads four / two channels of a pixel at once: only from a base that is aligned for it (the ABI promises
+    // nothing about x; a pixel row is c floats, so c % 4 == 0 keeps every pixel as aligned as the base)
+    const int xvec = ((uintptr_t)x & 15) == 0 ? 4 : (((uintptr_t)x & 7) == 0 ? 2 : 1);
 #define HSEFR_CONV_DIRECT(CO)                                                                                                          \
     hipLaunchKernelGGL(conv2d_direct_kernel<CO>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, alpha, y, h, wd, c, \
-                       oh, ow, cout, kh, kw, stride, pad_t, pad_l, total)
+                       oh, ow, cout, kh, kw, stride, pad_t, pad_l, total, xvec)
     if (co == 4) HSEFR_CONV_DIRECT(4);
     else if (co == 2) HSEFR_CONV_DIRECT(2);
     else HSEFR_CONV_DIRECT(1);

@@ -16,17 +16,28 @@ from __future__ import annotations
 
 import os
 import sys
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
 
+_MAIN_PATCH_LOCK = threading.Lock()       # DecodePool.__init__ edits sys.modules['__main__'] for a moment: one thread at a time
+
+
 def default_workers() -> int:
+    """Decoder processes for ONE extractor: the cores this process may use, SHARED between the ranks of the node
+    (``LOCAL_WORLD_SIZE``, set by torchrun: eight ranks of a file-driven gallery job on one host get an eighth of the cores
+    each, not 32 decoders apiece), at most 32."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, 32))
+    try:
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local_world = 1
+    return max(1, min(n // local_world, 32))
 
 
 def _worker_main(shm_name: str, tasks, results) -> None:
@@ -52,7 +63,13 @@ def _worker_main(shm_name: str, tasks, results) -> None:
                     with Image.open(p) as im:             # == preprocess.imread_rgb
                         a = np.asarray(im.convert("RGB"))
                 except Exception as e:                    # reported to the parent, which raises it (first failing file)
-                    err = (type(e).__name__, "%s" % (e,), p)
+                    try:                                  # the exception OBJECT when it pickles (PIL.UnidentifiedImageError,
+                        import pickle                     # OSError with errno ...): the parent raises what the serial path raises
+                        blob = pickle.dumps(e)
+                        pickle.loads(blob)
+                    except Exception:
+                        blob = None
+                    err = (type(e).__name__, "%s" % (e,), p, blob)
                     break
                 nb = a.size
                 if off + nb <= end:
@@ -66,6 +83,30 @@ def _worker_main(shm_name: str, tasks, results) -> None:
     finally:
         del buf
         shm.close()
+
+
+def _rebuild_error(name: str, msg: str, path: str, blob: Optional[bytes]) -> BaseException:
+    """The worker's exception in the parent: the pickled object itself when it travelled (same type -- also non-builtin ones
+    such as PIL.UnidentifiedImageError, an OSError the serial imread_rgb raises -- same args, errno, filename); otherwise
+    a builtin of that name built from the message, and RuntimeError when even that constructor refuses one argument."""
+    if blob is not None:
+        try:
+            import pickle
+            e = pickle.loads(blob)
+            if isinstance(e, Exception):
+                return e
+        except Exception:
+            pass
+    import builtins
+    exc = getattr(builtins, name, None)
+    if exc is FileNotFoundError:
+        return FileNotFoundError(2, "No such file or directory", path)
+    if isinstance(exc, type) and issubclass(exc, Exception):
+        try:
+            return exc(msg)
+        except TypeError:               # e.g. UnicodeDecodeError: five positional arguments
+            pass
+    return RuntimeError("%s: %s (%s)" % (name, msg, path))
 
 
 class DecodePool:
@@ -85,22 +126,23 @@ class DecodePool:
         self._procs = []
         # spawn re-imports __main__ in the child when it has a file (multiprocessing's "main path" fix-up): keep a heavy main
         # module (bench.py, pytest) out of the decoders -- they need this module only
-        main = sys.modules.get("__main__")
-        saved = getattr(main, "__file__", None), getattr(main, "__spec__", None)
-        try:
-            if main is not None:
-                if saved[0] is not None:
-                    del main.__file__
-                main.__spec__ = None
-            for _ in range(self.workers):
-                p = self._ctx.Process(target=_worker_main, args=(self._shm.name, self._tasks, self._results), daemon=True)
-                p.start()
-                self._procs.append(p)
-        finally:
-            if main is not None:
-                if saved[0] is not None:
-                    main.__file__ = saved[0]
-                main.__spec__ = saved[1]
+        with _MAIN_PATCH_LOCK:
+            main = sys.modules.get("__main__")
+            saved = getattr(main, "__file__", None), getattr(main, "__spec__", None)
+            try:
+                if main is not None:
+                    if saved[0] is not None:
+                        del main.__file__
+                    main.__spec__ = None
+                for _ in range(self.workers):
+                    p = self._ctx.Process(target=_worker_main, args=(self._shm.name, self._tasks, self._results), daemon=True)
+                    p.start()
+                    self._procs.append(p)
+            finally:
+                if main is not None:
+                    if saved[0] is not None:
+                        main.__file__ = saved[0]
+                    main.__spec__ = saved[1]
         self._pinned = False
         self._tensor = None
         self._next_tid = 0
@@ -177,15 +219,7 @@ class DecodePool:
             for k, m in enumerate(metas):
                 out.append((lo + k, m, spill.get(k)))
         if first_err is not None:
-            name, msg, path = first_err
-            import builtins
-            exc = getattr(builtins, name, None)
-            if not (isinstance(exc, type) and issubclass(exc, Exception)):
-                exc = RuntimeError
-                msg = "%s: %s" % (name, msg)
-            if exc is FileNotFoundError:
-                raise FileNotFoundError(2, "No such file or directory", path)
-            raise exc(msg)
+            raise _rebuild_error(*first_err)
         return out
 
     def close(self) -> None:

@@ -143,10 +143,11 @@ class Engine:
 
     def input_overflow_async(self, pinned_host_int_ptr: int) -> None:
         """The same read-and-clear, asynchronous: the flag lands in a PINNED host int32 (address given) when the current
-        stream reaches this point; the caller waits on an event of its own before reading it."""
+        stream reaches this point; the caller waits on an event of its own before reading it.  Nothing here waits for the device
+        (hsefr_engine_input_overflow_async only enqueues the copy and the clear)."""
         with self._torch.cuda.device(self.device):
-            _lib.check(_lib.lib().hsefr_engine_input_overflow(self._h, ctypes.cast(ctypes.c_void_p(pinned_host_int_ptr), ctypes.POINTER(ctypes.c_int)),
-                                                              _lib.current_stream_ptr()), "hsefr_engine_input_overflow")
+            _lib.check(_lib.lib().hsefr_engine_input_overflow_async(self._h, ctypes.cast(ctypes.c_void_p(pinned_host_int_ptr), ctypes.POINTER(ctypes.c_int)),
+                                                                    _lib.current_stream_ptr()), "hsefr_engine_input_overflow_async")
 
     # -- small batches as one hipGraph launch ---------------------------------------------------
     def set_graph_batch(self, max_n: int) -> None:

@@ -238,6 +238,11 @@ int hsefr_engine_op_times_ms(hsefr_engine* e, int slot, float* ms, int n_ops);
  * the last call saw an input value outside the bound (its results are meaningless), else 0; the flag is then cleared.
  * Synchronises `stream`.  Always 0 for plans without a bound. */
 int hsefr_engine_input_overflow(hsefr_engine* e, int* host_flag, hsefr_stream_t stream);
+/* The same read-and-clear WITHOUT the synchronisation: both operations are only enqueued on `stream`; `pinned_host_flag` must be
+ * page-locked host memory (hipHostMalloc / hipHostRegister) that stays valid until the stream has passed this point -- the caller
+ * records an event behind the call and reads the int after that event.  For pipelined callers that hand device tensors to
+ * hsefr_engine_forward and must not block per batch (TensorFlowInference.extract_batch on a CUDA tensor). */
+int hsefr_engine_input_overflow_async(hsefr_engine* e, int* pinned_host_flag, hsefr_stream_t stream);
 int hsefr_engine_destroy(hsefr_engine* e); /* replaces tf_sess.close(), facerec_test.py:124-125 */
 
 /* ------------------------------------------------------------------------------------ */

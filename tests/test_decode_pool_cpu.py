@@ -70,12 +70,35 @@ def test_images_that_do_not_fit_come_back_through_the_queue_and_errors_propagate
         pool.submit(2, [str(bad)], 0)
         with pytest.raises(Exception) as ei:
             pool.collect(2)
-        try:
+        with pytest.raises(Exception) as serial:
             preprocess.imread_rgb(str(bad))
-        except Exception as e:
-            assert type(ei.value).__name__ in (type(e).__name__, "RuntimeError")
+        # the SAME exception type as the serial path (PIL.UnidentifiedImageError: not a builtin, an OSError callers may catch)
+        assert type(ei.value) is type(serial.value) and isinstance(ei.value, OSError)
         pool.submit(3, files[:5], 0)                                        # still alive after errors
         assert len(pool.collect(3)) == 5
     finally:
         pool.close()
     pool.close()                                                            # idempotent
+
+
+def test_worker_errors_rebuild_in_the_parent_and_workers_share_the_node(monkeypatch):
+    """non-builtin exception types and builtins whose constructors want several arguments must not turn into a
+    TypeError in collect(); VERDICT r3 #6: the default decoder count is divided between the ranks of a node."""
+    import pickle
+    from hse_facerec_tf_amd import decode_pool
+    from PIL import UnidentifiedImageError
+    e = decode_pool._rebuild_error("UnidentifiedImageError", "cannot identify image file 'x'", "x",
+                                   pickle.dumps(UnidentifiedImageError("cannot identify image file 'x'")))
+    assert type(e) is UnidentifiedImageError
+    e = decode_pool._rebuild_error("UnicodeDecodeError", "codec can't decode", "f.jpg", None)      # 5-argument constructor
+    assert type(e) is RuntimeError and "UnicodeDecodeError" in str(e) and "f.jpg" in str(e)
+    e = decode_pool._rebuild_error("FileNotFoundError", "gone", "/x/y.jpg", None)
+    assert type(e) is FileNotFoundError and e.filename == "/x/y.jpg"
+    assert type(decode_pool._rebuild_error("ValueError", "bad", "p", b"not a pickle")) is ValueError
+    monkeypatch.setattr(decode_pool.os, "sched_getaffinity", lambda _pid: set(range(64)), raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert decode_pool.default_workers() == 32
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert decode_pool.default_workers() == 8                               # 64 cores / 8 ranks: 64 decoders on the host, not 256
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "128")
+    assert decode_pool.default_workers() == 1

@@ -125,3 +125,33 @@ def test_decoder_errors_and_oversized_images_through_the_pool(tmp_path):
         tfi.extract_batch(torch.zeros((1, 96, 96, 3), device="cuda"))   # the next call into the object raises
     tfi.check_input_bound()                                      # ... once
     tfi.close_session()
+
+
+def test_extract_batch_on_a_cuda_tensor_does_not_wait_for_the_device():
+    """ADVICE r3: the bound flag of a CUDA-tensor forward comes back through hsefr_engine_input_overflow_async (enqueue only);
+    extract_batch must return while the stream is still busy -- and the flag must still arrive."""
+    import time
+    import torch
+    from hse_facerec_tf_amd.tf_inference import TensorFlowInference
+    tfi = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(192, 192), max_batch=256)
+    x = torch.rand((256, 192, 192, 3), device="cuda") * 200.0 - 100.0
+    for _ in range(3):
+        tfi.extract_batch(x)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+    t0 = time.perf_counter()
+    for _ in range(30):                          # ~35 ms of device work queued ...
+        out = tfi.extract_batch(x)
+    host_s = time.perf_counter() - t0
+    busy = not stream.query()                    # ... and the host is back long before it has run
+    torch.cuda.synchronize()
+    dev_s = time.perf_counter() - t0
+    assert busy, "extract_batch waited for the device (host %.1f ms, device %.1f ms)" % (host_s * 1e3, dev_s * 1e3)
+    assert host_s < 0.6 * dev_s
+    tfi.check_input_bound()
+    assert bool(torch.isfinite(out).all())
+    x[3, 7, 7, 0] = 1e4
+    tfi.extract_batch(x)
+    with pytest.raises(ValueError, match="outside the bound"):
+        tfi.check_input_bound()
+    tfi.close_session()
