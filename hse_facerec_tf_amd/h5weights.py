@@ -255,7 +255,16 @@ def _find(datasets: Dict[str, np.ndarray], layer: str, weight: str) -> np.ndarra
 def keras_mobilenet_graph(path_or_bytes, size: int = 192, bn_epsilon: float = 1e-3) -> Graph:
     """The graph of facerec_test.py:322-334 from its Keras weight file: input_1 [-1, size, size, 3] -> reshape_1/Reshape
     [-1, 1, 1, 1024].  ``size`` must be a multiple of 32: Keras pads its stride-2 convolutions ((0, 1), (0, 1)) + 'valid', which
-    is TensorFlow's SAME only on even maps."""
+    is TensorFlow's SAME only on even maps.
+
+    Padding assumption: a weight file does not record the architecture's padding.  This builds every convolution
+    with TensorFlow SAME padding -- what ``keras.applications.MobileNet`` is up to Keras 2.1.5 (``padding='same'`` throughout:
+    the shape of the reference's own shipped graph, trained with the same code in 2018: conv1 and every stride-2 depthwise
+    there are SAME with no Pad node) and again, on even maps, from keras_applications 1.0.4 on (((0, 1), (0, 1)) + 'valid').
+    Keras 2.1.6 / 2.2.0 built stride-2 layers as ``ZeroPadding2D((1, 1))`` + 'valid' (windows start one pixel EARLIER): a
+    model trained with those two releases needs its graph exported from Keras (the .pb route), not this importer.
+    Attributes the reader cannot decode (h5py >= 3 writes ``layer_names`` / ``weight_names`` as variable-length strings) are
+    skipped, not fatal: weights are found by dataset PATH."""
     if size % 32:
         raise ValueError("Keras MobileNet's explicit ((0, 1), (0, 1)) padding equals SAME only on even maps: size %d must be a "
                          "multiple of 32" % size)
