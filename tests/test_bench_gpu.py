@@ -54,6 +54,11 @@ def test_bench_line_contract_and_small_config5():
     assert "STANDALONE" in dw["covers"] and len(dw["inside_fused_kernels"]) >= 1
     _check_config5(line["config5"], 700, 1)
     assert abs(line["config5"]["unaccounted_ms"]) < 0.25 * line["config5"]["total_ms"]
+    su = line["sustained"]
+    assert su["seconds"] >= 2.0 and su["steps"] % 100 == 0 and su["window_faces_per_s_min"] <= su["value"] * 1.02 <= su["window_faces_per_s_max"] * 1.04
+    assert line["config"]["sustained_faces_per_s"] == su["value"] and line["config"]["config5_total_ms"] == line["config5"]["total_ms"]
+    fi = pl["file_inclusive"]
+    assert len(fi["host_decode_runs_faces_per_s"]) == 2 and fi["host_decode_faces_per_s"] == max(fi["host_decode_runs_faces_per_s"])
     lat = line["latency_batch1"]
     assert "error" not in lat and lat["age_gender_fun"]["median_ms"] > 0 and lat["extract_features"]["median_ms"] > 0
     assert lat["reference_published"]["age_gender_fun_ms"] == 4.97 and lat["mtcnn_process_image"]["faces"] == 4
@@ -68,3 +73,18 @@ def test_bench_two_self_launched_ranks_share_the_gpu_over_gloo():
     c5 = line["config5"]
     _check_config5(c5, 701, 2)
     assert c5["pad_rows"] == 1 and c5["allgather_bytes_per_rank"] == 351 * 1024 * 4
+    assert c5["gathered_rows"] == 701 and c5["gathered_rows_differing_from_single_rank_extraction"] == 0
+
+
+def test_bench_eight_ranks_lfw_shards_with_pad_rows_equal_the_single_rank_extraction():
+    """BASELINE configs[4] at its own size and world size -- 9164 photos over EIGHT ranks (S = 1146, the last
+    shard 1142 rows + 4 pad rows) -- with the ranks sharing this box's one GPU over gloo: every call site of the 8-GPU job
+    (torchrun env, shard ranges, the ONE all-gather, identification on every rank) and the gathered matrix row for row against
+    rank 0's single-rank extraction of all 9164 photos."""
+    line = _run(["--gpus", "8", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-op-events", "--no-sustained"], timeout=1500)
+    assert line["n_gpus"] == 8 and len(line["per_rank_faces_per_s"]) == 8
+    c5 = line["config5"]
+    _check_config5(c5, 9164, 8)
+    assert c5["shard_rows"] == 1146 and c5["pad_rows"] == 4 and c5["allgather_bytes_per_rank"] == 1146 * 1024 * 4
+    assert c5["gathered_rows"] == 9164 and c5["gathered_rows_differing_from_single_rank_extraction"] == 0
+    assert c5["gathered_shard_equals_local"] is True and c5["num_classes"] == 1680

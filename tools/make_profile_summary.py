@@ -37,6 +37,9 @@ for line in open(os.path.join(src, "summary.txt")):
         m = re.match(r"\s+(SQ_VALU_MFMA_BUSY_CYCLES|GRBM_GUI_ACTIVE|SQ_INSTS_MFMA|SQ_LDS_BANK_CONFLICT|SQ_LDS_IDX_ACTIVE)\s+n=\d+\s+avg=\s*([\d.]+)", line)
         if m and cur:
             traffic[cur][m.group(1)] = float(m.group(2))
+            mp = re.search(r"pass_us=([\d.]+)", line)
+            if mp and m.group(1) == "GRBM_GUI_ACTIVE":
+                traffic[cur]["pmc_pass_us"] = float(mp.group(1))      # duration of the kernel in the pass that counted its cycles
 for k, v in traffic.items():
     if "fetch_bytes_x2_corrected" in v and "write_bytes" in v:
         v["hbm_bytes_per_launch"] = v["fetch_bytes_x2_corrected"] + v["write_bytes"]
@@ -45,9 +48,18 @@ for k, v in traffic.items():
         # pipe cycles): busy / (1024 x kernel cycles) = share of the matrix pipes' cycles in use = fraction of the dense peak
         # at the clock the kernel actually ran at
         cyc = v["GRBM_GUI_ACTIVE"] / 8.0
-        v["mfma_util"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 4)
-        if v.get("avg_us") and v["avg_us"] >= 50:          # (short kernels: the counter window is longer than the kernel)
-            v["gfx_clock_ghz"] = round(cyc / (v["avg_us"] * 1e3), 3)
+        # the clock these cycles imply, over the duration the kernel had IN THE COUNTER PASS (the trace pass's duration is the
+        # fallback for profiles taken before the passes carried timestamps); a clock this part cannot run at means the counter
+        # window and the kernel do not match (short kernels: the window is longer than the kernel) -- such a kernel gets NO
+        # mfma_util, and says why (4.4 GHz was silently kept)
+        dur_us = v.get("pmc_pass_us") or v.get("avg_us")
+        clock = cyc / (dur_us * 1e3) if dur_us else None
+        if clock is not None and 1.2 <= clock <= 2.7:
+            v["mfma_util"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 4)
+            v["gfx_clock_ghz"] = round(clock, 3)
+        else:
+            v["mfma_util_rejected"] = ("implied clock %s GHz over %s us (%s) is outside 1.2-2.7 GHz: GRBM_GUI_ACTIVE does not bracket "
+                                       "this kernel" % ("%.2f" % clock if clock else "?", dur_us, "counter pass" if v.get("pmc_pass_us") else "trace pass"))
     if v.get("SQ_LDS_IDX_ACTIVE"):
         v["lds_conflict_share"] = round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"], 4)
 traffic = {k: v for k, v in traffic.items() if "hbm_bytes_per_launch" in v and not k.startswith("void at::") and not k.startswith("__amd")}

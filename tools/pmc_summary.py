@@ -27,16 +27,22 @@ def main():
         dirs = [d for d in dirs if d != match]
     counters = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [values per dispatch]
     durs = defaultdict(list)
+    pass_durs = defaultdict(lambda: defaultdict(list))  # counter -> kernel -> [us per dispatch IN THE PASS that collected the counter]
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             per_dispatch = defaultdict(float)
             names = {}
+            stamps = {}
             for row in csv.DictReader(open(f)):
                 key = (f, row["Dispatch_Id"], row["Counter_Name"])
                 per_dispatch[key] += float(row["Counter_Value"])
                 names[(f, row["Dispatch_Id"])] = row["Kernel_Name"]
+                if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                    stamps[(f, row["Dispatch_Id"])] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
             for (ff, did, cn), v in per_dispatch.items():
                 counters[short(names[(ff, did)])][cn].append(v)
+                if (ff, did) in stamps:
+                    pass_durs[cn][short(names[(ff, did)])].append(stamps[(ff, did)])
         for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 durs[short(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
@@ -56,6 +62,9 @@ def main():
                 extra = "  (KiB; x2-corrected = %.1f MB)" % (avg * 1024 * 2 / 1e6)
             if cn == "WRITE_SIZE":
                 extra = "  (KiB; = %.1f MB)" % (avg * 1024 / 1e6)
+            pd = pass_durs.get(cn, {}).get(k)
+            if pd:
+                extra += "  pass_us=%.2f" % (sum(pd) / len(pd))
             print("    %-34s n=%-5d avg=%16.1f%s" % (cn, len(vals), avg, extra))
 
 
