@@ -698,10 +698,14 @@ def main():
     # forward's stream.  Reported beside `value`, never instead of it.
     sustained = None
     if not args.no_sustained:
-        per = max(elapsed_local / args.steps, 1e-5)
-        for _ in range(int(args.sustained_warmup_s / per) + 1):
-            step()
-        n_win = max(2, int(args.sustained_s / (100 * per)) + 1)
+        tw, nw = time.perf_counter(), 0
+        while time.perf_counter() - tw < args.sustained_warmup_s:          # warm-up by the clock (also yields the per-step estimate)
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+            nw += 50
+        per = max((time.perf_counter() - tw) / nw, 1e-5)
+        n_win = max(2, int(args.sustained_s * 1.05 / (100 * per)) + 1)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
         barrier()
         t1 = time.perf_counter()
