@@ -43,6 +43,7 @@ SIGNATURES = {
     "hsefr_stem2_fused": (c_int, [_fp] * 6 + [c_void_p] + [_fp] * 6 + [c_int] * 13 + [c_void_p]),
     "hsefr_stem3_fused": (c_int, [_fp, c_void_p] + [_fp] * 5 + [c_void_p] + [_fp] * 7 + [c_int] * 14 + [c_void_p]),
     "hsefr_stem4_fused": (c_int, [_fp, c_int, c_void_p] + [_fp] * 5 + [c_void_p] + [_fp] * 7 + [c_int] * 6 + [c_void_p]),
+    "hsefr_stem5_stream": (c_int, [_fp, c_int, c_void_p] + [_fp] * 5 + [c_void_p] + [_fp] * 7 + [c_int] * 6 + [c_void_p]),
     "hsefr_engine_accepts_u8": (c_int, [c_void_p]),
     "hsefr_engine_forward_u8": (c_int, [c_void_p, _fp, c_int, _fp, _fp, _fp, c_void_p]),
     "hsefr_engine_input_overflow": (c_int, [c_void_p, POINTER(c_int), c_void_p]),

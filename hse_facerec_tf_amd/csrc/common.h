@@ -227,6 +227,11 @@ int launch_stem4_fused(const void* x, int x_is_u8, const void* cw4, const float*
                        const float* wd2, const float* d2scale, const float* d2shift, float* y, int* overflow, int n, int h, int w,
                        int in_log2, int a_log2, int act, hipStream_t s);
 bool stem4_fused_supported(int cin, int c1, int c2, int conv_stride, int dw1_stride, int dw2_stride, int kh, int kw, int h, int w);
+int launch_stem5_stream(const void* x, int x_is_u8, const void* cw4, const float* cdescale, const float* cshift, const float* wd1,
+                        const float* d1scale, const float* d1shift, const void* wsplit, const float* descale, const float* pshift,
+                        const float* wd2, const float* d2scale, const float* d2shift, float* y, int* overflow, int n, int h, int w,
+                        int in_log2, int a_log2, int act, hipStream_t s);
+bool stem5_stream_supported(int cin, int c1, int c2, int conv_stride, int dw1_stride, int dw2_stride, int kh, int kw, int h, int w);
 bool stem2_fused_supported(int cin, int c1, int c2, int conv_stride, int dw1_stride, int dw2_stride, int kh, int kw);
 bool stem_fused_supported(int cin, int cmid, int cout, int conv_stride, int dw_stride, int kh, int kw);
 int read_pws_stamps(void* host_out, size_t bytes);
@@ -248,6 +253,8 @@ unsigned long long* stamp_buffer(hipStream_t s);
 #endif
 #ifdef HSEFR_DEV
 void set_stem4_grid(int v);
+void set_stem5_grid(int v);
+void set_stem5_segs(int v);
 void set_c11(int v);
 void set_dwpws_tw(int v);
 void set_dwpws_bn(int v);

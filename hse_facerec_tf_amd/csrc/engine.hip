@@ -266,6 +266,7 @@ int sweep_reverse() { return g_sweep_reverse; }
 void set_sweep_reverse(int v) { g_sweep_reverse = v; }
 }  // namespace hsefr
 HSEFR_KNOB(g_sweep_alternate, 1);   // dev builds: 0 turns the alternation off (A/B timing)
+HSEFR_KNOB(g_stem5, 1);             // dev builds: 0 = stem4_fused.hip (round 3's patch kernel) where stem5_stream.hip covers the shape (A/B timing)
 HSEFR_KNOB(g_stem4, 1);             // dev builds: 0 = stem3_fused.hip also where stem4_fused.hip covers the shape (A/B timing)
 
 #pragma GCC visibility push(default)   // the library is built with -fvisibility=hidden: the C ABI below is ALL it exports
@@ -289,6 +290,9 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "c11")) { set_c11(value); return HSEFR_OK; }
     if (!strcmp(key, "stem4_grid")) { set_stem4_grid(value); return HSEFR_OK; }
     if (!strcmp(key, "stem4")) { g_stem4 = value; return HSEFR_OK; }
+    if (!strcmp(key, "stem5")) { g_stem5 = value; return HSEFR_OK; }
+    if (!strcmp(key, "stem5_grid")) { set_stem5_grid(value); return HSEFR_OK; }
+    if (!strcmp(key, "stem5_segs")) { set_stem5_segs(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_look")) { set_dw_look(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_look2")) { set_dw_look2(value); return HSEFR_OK; }
     if (!strcmp(key, "sweep_alternate")) { g_sweep_alternate = value; return HSEFR_OK; }
@@ -538,15 +542,16 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                 // [3008, 5056) conv1 in the two-step K layout of stem4_fused.hip, [5056, 7104) the same channel-reversed for uint8
                 // RGB input, [7104, 7232) its four mean-folded shift vectors, [7232, 7264) its descale
                 if (input_u8) {
-                    rc = launch_stem4_fused(in, 1, pk + 5056, pk + 7232, pk + 7104, pk + 896, pk + 1184, pk + 1216, blob_ptr(e, o.w2_off), ds2,
-                                            ds2 + 64, pk + 1248, pk + 1824, pk + 1888, (float*)out, nullptr, n, o.h, o.w, 0, o.reserved & 255,
-                                            o.act, s);
+                    rc = (g_stem5 ? launch_stem5_stream : launch_stem4_fused)(in, 1, pk + 5056, pk + 7232, pk + 7104, pk + 896, pk + 1184, pk + 1216,
+                                                                            blob_ptr(e, o.w2_off), ds2, ds2 + 64, pk + 1248, pk + 1824, pk + 1888,
+                                                                            (float*)out, nullptr, n, o.h, o.w, 0, o.reserved & 255, o.act, s);
                     break;
                 }
                 if (g_stem4 && stem4_route(o)) {
-                    rc = launch_stem4_fused(in, 0, pk + 3008, pk + 1952 + 1024, pk + 864, pk + 896, pk + 1184, pk + 1216, blob_ptr(e, o.w2_off),
-                                            ds2, ds2 + 64, pk + 1248, pk + 1824, pk + 1888, (float*)out, e->d_overflow, n, o.h, o.w,
-                                            ((o.reserved >> 8) & 255) - 64, o.reserved & 255, o.act, s);
+                    rc = (g_stem5 ? launch_stem5_stream : launch_stem4_fused)(in, 0, pk + 3008, pk + 1952 + 1024, pk + 864, pk + 896, pk + 1184, pk + 1216,
+                                                                            blob_ptr(e, o.w2_off), ds2, ds2 + 64, pk + 1248, pk + 1824, pk + 1888,
+                                                                            (float*)out, e->d_overflow, n, o.h, o.w, ((o.reserved >> 8) & 255) - 64,
+                                                                            o.reserved & 255, o.act, s);
                     break;
                 }
                 rc = launch_stem3_fused((const float*)in, pk + 1952, pk + 1952 + 1024, pk + 864, pk + 896, pk + 1184, pk + 1216,
@@ -832,6 +837,16 @@ int hsefr_stem4_fused(const void* x, int x_is_u8, const void* cw4, const float* 
                              d2scale && d2shift && y), HSEFR_ERR_INVALID, "stem4_fused: null pointer");
     return launch_stem4_fused(x, x_is_u8, cw4, cdescale, conv_shift, wd1, d1scale, d1shift, w_split, descale, pshift, wd2, d2scale, d2shift, y,
                               d_overflow, n, h, w, in_log2, a_log2, act, (hipStream_t)stream);
+}
+
+int hsefr_stem5_stream(const void* x, int x_is_u8, const void* cw4, const float* cdescale, const float* conv_shift, const float* wd1,
+                       const float* d1scale, const float* d1shift, const void* w_split, const float* descale, const float* pshift,
+                       const float* wd2, const float* d2scale, const float* d2shift, float* y, int* d_overflow, int n, int h, int w,
+                       int in_log2, int a_log2, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && cw4 && cdescale && conv_shift && wd1 && d1scale && d1shift && w_split && descale && pshift && wd2 &&
+                             d2scale && d2shift && y), HSEFR_ERR_INVALID, "stem5_stream: null pointer");
+    return launch_stem5_stream(x, x_is_u8, cw4, cdescale, conv_shift, wd1, d1scale, d1shift, w_split, descale, pshift, wd2, d2scale, d2shift, y,
+                               d_overflow, n, h, w, in_log2, a_log2, act, (hipStream_t)stream);
 }
 
 int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd, const float* dscale,

@@ -302,9 +302,14 @@ def stem3_fused(x, conv_w, conv_shift, w1_hwc, d1scale, d1shift, wp_t, pshift, w
     return y
 
 
+def stem5_stream(*args, **kw):
+    """stem4_fused's four layers, operands and bits as the streaming kernel of round 4 (csrc/stem5_stream.hip): same arguments."""
+    return stem4_fused(*args, _entry="hsefr_stem5_stream", **kw)
+
+
 @_device_guarded
 def stem4_fused(x, conv_w, conv_shift, w1_hwc, d1scale, d1shift, wp_t, pshift, w2_hwc, d2scale, d2shift, act: int = ACT_RELU6,
-                a_log2: int = 12, in_log2: int = 7, prepared=None, overflow=None, u8_mean_bgr=None):
+                a_log2: int = 12, in_log2: int = 7, prepared=None, overflow=None, u8_mean_bgr=None, _entry: str = "hsefr_stem4_fused"):
     """stem3_fused for inputs whose edges are multiples of 4 (csrc/stem4_fused.hip): no im2col, conv1's operands straight from
     the f16 window.  x float32 [n,h,w,3] within the declared bound -- or, with u8_mean_bgr, the RESIZED image as uint8 RGB
     [n,h,w,3]: float conversion, channel reversal and the BGR mean are folded into the constants (in_log2 is then 0)."""
@@ -335,11 +340,11 @@ def stem4_fused(x, conv_w, conv_shift, w1_hwc, d1scale, d1shift, wp_t, pshift, w
     d_cimg = torch.from_numpy(img4.view(np.int16)).to(x.device)
     d_cds = torch.from_numpy(ds4).to(x.device)
     y = torch.empty((n, h // 4, w // 4, 64), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().hsefr_stem4_fused(x.data_ptr(), 1 if u8 else 0, d_cimg.data_ptr(), d_cds.data_ptr(), d_sh.data_ptr(), w1_hwc.data_ptr(),
+    _lib.check(getattr(_lib.lib(), _entry)(x.data_ptr(), 1 if u8 else 0, d_cimg.data_ptr(), d_cds.data_ptr(), d_sh.data_ptr(), w1_hwc.data_ptr(),
                                             d1scale.data_ptr(), d1shift.data_ptr(), d_img.data_ptr(), d_ds.data_ptr(), pshift.data_ptr(),
                                             w2_hwc.data_ptr(), d2scale.data_ptr(), d2shift.data_ptr(), y.data_ptr(),
                                             None if overflow is None else overflow.data_ptr(), n, h, w, in_log2, a_log2, act,
-                                            _lib.current_stream_ptr()), "hsefr_stem4_fused")
+                                            _lib.current_stream_ptr()), _entry)
     return y
 
 
