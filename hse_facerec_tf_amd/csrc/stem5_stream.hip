@@ -10,7 +10,7 @@
 // What changed is the decomposition (PMC of stem4: vector ALU 42 % busy + LDS 48 % + matrix pipe 13 % = 100 %:
 // four waves in lock step through four barrier-separated stages use ONE unit at a time, 1.6x halo recompute on top):
 //
-//   * ONE WAVE = ONE STRIP.  A wave owns 4 output columns of one image and walks DOWN the image, one output row per step.
+//   * ONE WAVE = ONE STRIP.  A wave owns 6 output columns of one image and walks DOWN the image, one output row per step.
 //     It shares nothing with the other waves of its workgroup but the read-only constants: no barrier after the prologue,
 //     no lock step -- the twelve waves of a CU (3 workgroups x 4) drift apart and the matrix pipe, the vector ALU and the LDS
 //     work for different waves at the same time.
@@ -62,25 +62,36 @@ struct Stem5Params {
     long long x_bytes;
 };
 
-constexpr int KS = 4;                     // output columns of a strip
-constexpr int PXW = 2 * KS + 1;           // block-1 (depthwise 1 / pointwise) columns: 9
-constexpr int CXW = 2 * KS + 3;           // conv1 columns: 11
+#ifndef S5_KS
+#define S5_KS 6
+#endif
+constexpr int KS = S5_KS;                 // output columns of a strip (48 = 8 x 6: one strip per wave at batch 256 x 192)
+constexpr int PXW = 2 * KS + 1;           // block-1 (depthwise 1 / pointwise) columns: 13
+constexpr int CXW = 2 * KS + 3;           // conv1 columns: 15
 constexpr int WROWS = 5;                  // input rows of a step
-constexpr int WPIECES = 18;               // 4-value pieces per window row: 2 + 23 * 3 = 71 values -> 72
-constexpr int WRP = 160;                  // bytes per window row and plane: 72 f16 + 8 that stay zero
-constexpr int WPLANE = WROWS * WRP;       // 800
+constexpr int WPIECES = (2 + (4 * KS + 7) * 3 + 3) / 4;   // 4-value pieces per window row: 2 + 31 * 3 = 95 values -> 24
+constexpr int WDQ = WPIECES / 2;          // a lane converts two adjacent pieces
+static_assert(WPIECES % 2 == 0 && WROWS * WDQ <= 64, "one lane per pair of pieces");
+constexpr int WRP = WPIECES * 8 + 16;     // bytes per window row and plane: the pieces as f16 + 16 that stay zero
+constexpr int WPLANE = WROWS * WRP;
 constexpr int WSHIFT = 2;                 // a window row starts this many values into its first piece
 constexpr int COP = 36;                   // floats per conv1 pixel in LDS (32 + 4)
 constexpr int P1P = 68;                   // floats per pointwise pixel in LDS (64 + 4)
-constexpr int OFF_CO = 2 * WPLANE;                     // 1600
-constexpr int OFF_AS = OFF_CO + 2 * CXW * COP * 4;     // 4768
-constexpr int OFF_P1 = OFF_AS + 2 * PXW * 128;         // 7072: the A tile's rows 18..31 (read, never used) alias the first of these
-constexpr int WAVE_LDS = OFF_P1 + 2 * PXW * P1P * 4;   // 11968
+constexpr int CMB = (2 * CXW + 15) / 16;  // MFMA row blocks of the conv1 GEMM (2 x 15 pixels -> 2)
+constexpr int PMB = (2 * PXW + 15) / 16;  // ... of the pointwise GEMM (2 x 13 -> 2)
+constexpr int NR1 = (PXW + 7) / 8;        // depthwise-1 rounds: 8 columns x 8 channel quads per round
+constexpr int NR2 = (KS + 3) / 4;         // depthwise-2 rounds: 4 output columns x 16 channel quads per round
+constexpr int OFF_CO = 2 * WPLANE;
+constexpr int OFF_AS = OFF_CO + 2 * CXW * COP * 4;
+constexpr int OFF_P1 = OFF_AS + 2 * PXW * 128;         // the A tile's last rows (read, never used) alias the first of these
+constexpr int WAVE_LDS = OFF_P1 + 2 * PXW * P1P * 4;
 constexpr int WAVES = 4;
 #ifndef S5_WGS
 #define S5_WGS 2
 #endif
-static_assert(OFF_AS + 32 * 128 <= WAVE_LDS, "the A tile's over-read stays inside the wave's own region");
+static_assert(OFF_AS + PMB * 16 * 128 <= WAVE_LDS, "the A tile's over-read stays inside the wave's own region");
+static_assert(4 + 12 * (CXW - 1) + 32 <= WRP, "the second K step of a row's last pixel stays inside the row");
+static_assert(S5_WGS * (WAVES * WAVE_LDS + 6 * 1024) <= 160 * 1024, "S5_WGS workgroups per CU");
 
 __device__ __forceinline__ int swzb(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)); }
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
@@ -115,6 +126,7 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
     // the last 16 bytes of every window row (both planes) are written by no piece: zero, so that the second K step of a row's
     // last pixels meets finite bytes under its zero weights
     if (lane < 2 * WROWS) *(f32x4*)(L + lane * WRP + WRP - 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_assert(WPIECES * 8 == WRP - 16, "pieces fill a row up to its zero tail");
     __syncthreads();
     const float cap6 = 6.f * p.a_scale;
 
@@ -137,31 +149,31 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
     // ---- lane roles (the same for every strip) ----
     // conv1 GEMM, row block mb: pixel m = 16 mb + l16 of the 2 x 11 new conv pixels (pixels past the 22nd repeat the last one:
     // same operands, same result, same LDS address); K slice q4 = kernel row min(q4, 2)
-    int c_ry[2], c_rx[2];
-    unsigned caddr[2], coaddr[2];
+    int c_ry[CMB], c_rx[CMB];
+    unsigned caddr[CMB], coaddr[CMB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < CMB; ++mb) {
         const int m = min(16 * mb + l16, 2 * CXW - 1);
         c_ry[mb] = m >= CXW ? 1 : 0;
         c_rx[mb] = m - CXW * c_ry[mb];
         caddr[mb] = (unsigned)((2 * c_ry[mb] + min(q4, 2)) * WRP + 2 * WSHIFT + 12 * c_rx[mb]);
         coaddr[mb] = (unsigned)(OFF_CO + (c_ry[mb] * CXW + c_rx[mb]) * COP * 4 + 16 * q4);        // + 64 nb
     }
-    // pointwise GEMM, row block mb: pixel m = 16 mb + l16 of the 2 x 9 new block-1 pixels (m < 18)
-    int p_pr[2], p_x[2];
+    // pointwise GEMM, row block mb: pixel m = 16 mb + l16 of the 2 x PXW new block-1 pixels
+    int p_pr[PMB], p_x[PMB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < PMB; ++mb) {
         const int m = min(16 * mb + l16, 2 * PXW - 1);
         p_pr[mb] = m >= PXW ? 1 : 0;
         p_x[mb] = m - PXW * p_pr[mb];
     }
-    const bool p_store1 = l16 < 2 * PXW - 16;                    // row block 1 holds pixels 16, 17 only
-    // window pieces: lane = 9 row + dq loads pieces 2 dq and 2 dq + 1 of input row `row` (45 lanes)
-    const int wl_row = lane / 9, wl_dq = lane - 9 * wl_row;
-    const bool wl_on = lane < 9 * WROWS;
-    // depthwise 1: (column x, channel quad): round 0 covers x = 0..7, round 1 x = 8
+    const bool p_store_last = 16 * (PMB - 1) + l16 < 2 * PXW;      // the last row block is partly empty
+    // window pieces: lane = WDQ row + dq loads pieces 2 dq and 2 dq + 1 of input row `row`
+    const int wl_row = lane / WDQ, wl_dq = lane - WDQ * wl_row;
+    const bool wl_on = lane < WDQ * WROWS;
+    // depthwise 1: (column x, channel quad): round rd covers x = 8 rd .. 8 rd + 7
     const int d1_q = lane & 7, d1_x0 = lane >> 3;
-    // depthwise 2: (output column j, channel quad of 16)
+    // depthwise 2: (output column j, channel quad of 16): round rd covers j = 4 rd .. 4 rd + 3
     const int d2_q = lane & 15, d2_j = lane >> 4;
 
     typedef typename std::conditional<U8, unsigned, f32x4>::type raw_t;
@@ -181,13 +193,16 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
 
         // column validity (SAME padding: a pixel outside its map must read as zero downstream) and, U8, the column half of the
         // mean case of a conv pixel
-        float cval[2], pval[2];
-        int ccase[2];
+        float cval[CMB], pval[PMB];
+        int ccase[CMB];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < CMB; ++mb) {
             const int cx = cb0 + c_rx[mb];
             cval[mb] = (cx >= 0 && cx < p.W1) ? 1.f : 0.f;
             ccase[mb] = cx == p.W1 - 1 ? 1 : 0;
+        }
+#pragma unroll
+        for (int mb = 0; mb < PMB; ++mb) {
             const int px = xb + p_x[mb];
             pval[mb] = (px >= 0 && px < p.W1) ? 1.f : 0.f;
         }
@@ -217,10 +232,11 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
 
         // depthwise accumulators: rows in flight.  dw1: per round, Q = the row that has its first kernel row, R is built fresh;
         // dw2: the output row that has its first kernel row
-        f32x4 aQ[2], aR[2], aO;
+        f32x4 aQ[NR1], aR[NR1], aO[NR2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) { aQ[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; aR[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        aO = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < NR1; ++r) { aQ[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; aR[r] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int r = 0; r < NR2; ++r) aO[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         load_rows(i0 - 2);
         for (int s = i0 - 2; s < i1; ++s) {
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
                     if constexpr (!U8) csh[nb] = *(const f32x4*)(&Kz[32 + nb * 16 + 4 * q4]);
                 }
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {          // one row block at a time: 4 fragments + 2 accumulators live
+                for (int mb = 0; mb < CMB; ++mb) {          // one row block at a time: 4 fragments + 2 accumulators live
                     f16x8 ah[2], al[2];
                     const unsigned char* a0 = L + caddr[mb];
                     ah[0] = ((const Frag4*)(a0))->v;
@@ -318,8 +334,8 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
 #pragma unroll
                 for (int cr = 0; cr < 2; ++cr) {
 #pragma unroll
-                    for (int rd = 0; rd < 2; ++rd) {
-                        const int x = rd == 0 ? d1_x0 : PXW - 1;
+                    for (int rd = 0; rd < NR1; ++rd) {
+                        const int x = min(8 * rd + d1_x0, PXW - 1);          // (lanes past the last column repeat it and do not store)
                         const float* t = (const float*)(L + OFF_CO) + (cr * CXW + x) * COP + 4 * d1_q;
                         const f32x4 t0 = *(const f32x4*)(t), t1 = *(const f32x4*)(t + COP), t2 = *(const f32x4*)(t + 2 * COP);
                         f32x4 sP = aQ[rd];                 // the row that had kernel rows 0 and 1: this is its third -> complete
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
                         const f16x4 hi = __builtin_convertvector(v, f16x4);
                         const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
                         const int q = cr * PXW + x;
-                        if (rd == 0 || lane < 8) {
+                        if (8 * rd + 8 <= PXW || 8 * rd + d1_x0 < PXW) {
                             *(f16x4*)(L + OFF_AS + swzb(q, d1_q >> 1) + 8 * (d1_q & 1)) = hi;
                             *(f16x4*)(L + OFF_AS + swzb(q, 4 + (d1_q >> 1)) + 8 * (d1_q & 1)) = lo;
                         }
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) { pds[cb] = *(const f32x4*)(&Kz[128 + cb * 16 + 4 * q4]); psh[cb] = *(const f32x4*)(&Kz[192 + cb * 16 + 4 * q4]); }
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
+                for (int mb = 0; mb < PMB; ++mb) {
                     const f16x8 ah = *(const f16x8*)(L + OFF_AS + swzb(16 * mb + l16, q4));
                     const f16x8 al = *(const f16x8*)(L + OFF_AS + swzb(16 * mb + l16, 4 + q4));
                     f32x4 acc[4];
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
 #pragma unroll
                         for (int cb = 0; cb < 4; ++cb)
                             acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pdt == 1 ? bl[cb] : bh[cb], pdt == 0 ? al : ah, acc[cb], 0, 0, 0);
-                    if (mb == 0 || p_store1) {
+                    if (mb < PMB - 1 || p_store_last) {
                         const float vmul = pval[mb] * (p_pr[mb] ? rv1 : rv0);
 #pragma unroll
                         for (int cb = 0; cb < 4; ++cb) {
@@ -384,25 +400,32 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
 
             // ---- depthwise 2 (stride 2): output row s gets its second and third kernel rows, row s + 1 its first ----
             {
-                const float* t = (const float*)(L + OFF_P1) + (2 * d2_j) * P1P + 4 * d2_q;
-                const f32x4 a0 = *(const f32x4*)(t), a1 = *(const f32x4*)(t + P1P), a2 = *(const f32x4*)(t + 2 * P1P);
-                f32x4 sO = aO;
-                sO = vfma(a0, as_v(W2z[3 * 16 + d2_q]), sO); sO = vfma(a1, as_v(W2z[4 * 16 + d2_q]), sO); sO = vfma(a2, as_v(W2z[5 * 16 + d2_q]), sO);
-                const f32x4 b0 = *(const f32x4*)(t + PXW * P1P), b1 = *(const f32x4*)(t + (PXW + 1) * P1P), b2 = *(const f32x4*)(t + (PXW + 2) * P1P);
-                sO = vfma(b0, as_v(W2z[6 * 16 + d2_q]), sO); sO = vfma(b1, as_v(W2z[7 * 16 + d2_q]), sO); sO = vfma(b2, as_v(W2z[8 * 16 + d2_q]), sO);
-                f32x4 sN = (f32x4){0.f, 0.f, 0.f, 0.f};
-                sN = vfma(b0, as_v(W2z[0 * 16 + d2_q]), sN); sN = vfma(b1, as_v(W2z[1 * 16 + d2_q]), sN); sN = vfma(b2, as_v(W2z[2 * 16 + d2_q]), sN);
-                aO = sN;
-                if (s >= i0) {
-                    const f32x4 d2sc = *(const f32x4*)(&Kz[256 + 4 * d2_q]), d2sh = *(const f32x4*)(&Kz[320 + 4 * d2_q]);
-                    const f32x4 o = vfma(sO, d2sc, d2sh);
-                    f32x4 v;
-                    v[0] = apply_act<ACT>(o[0]); v[1] = apply_act<ACT>(o[1]); v[2] = apply_act<ACT>(o[2]); v[3] = apply_act<ACT>(o[3]);
-                    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + (size_t)n * p.OH2 * p.OW2 * 64, (long long)p.OH2 * p.OW2 * 256);
-                    const int ow = j0 + d2_j;
-                    // a column outside the map gets an offset beyond the resource and the store is dropped (no branch)
-                    const unsigned voff = ow < p.OW2 ? (unsigned)(s * p.OW2 + ow) * 256u + 16u * d2_q : 0x80000000u;
-                    bstore16(v, ry, voff, 0);
+                const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + (size_t)n * p.OH2 * p.OW2 * 64, (long long)p.OH2 * p.OW2 * 256);
+                const f32x4 d2sc = *(const f32x4*)(&Kz[256 + 4 * d2_q]), d2sh = *(const f32x4*)(&Kz[320 + 4 * d2_q]);
+                f32x4 w2[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) w2[k] = as_v(W2z[k * 16 + d2_q]);
+#pragma unroll
+                for (int rd = 0; rd < NR2; ++rd) {
+                    const int j = min(4 * rd + d2_j, KS - 1);          // (lanes past the last column repeat it and do not store)
+                    const float* t = (const float*)(L + OFF_P1) + (2 * j) * P1P + 4 * d2_q;
+                    const f32x4 a0 = *(const f32x4*)(t), a1 = *(const f32x4*)(t + P1P), a2 = *(const f32x4*)(t + 2 * P1P);
+                    const f32x4 b0 = *(const f32x4*)(t + PXW * P1P), b1 = *(const f32x4*)(t + (PXW + 1) * P1P), b2 = *(const f32x4*)(t + (PXW + 2) * P1P);
+                    f32x4 sO = aO[rd];
+                    sO = vfma(a0, w2[3], sO); sO = vfma(a1, w2[4], sO); sO = vfma(a2, w2[5], sO);
+                    sO = vfma(b0, w2[6], sO); sO = vfma(b1, w2[7], sO); sO = vfma(b2, w2[8], sO);
+                    f32x4 sN = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    sN = vfma(b0, w2[0], sN); sN = vfma(b1, w2[1], sN); sN = vfma(b2, w2[2], sN);
+                    aO[rd] = sN;
+                    if (s >= i0) {
+                        const f32x4 o = vfma(sO, d2sc, d2sh);
+                        f32x4 v;
+                        v[0] = apply_act<ACT>(o[0]); v[1] = apply_act<ACT>(o[1]); v[2] = apply_act<ACT>(o[2]); v[3] = apply_act<ACT>(o[3]);
+                        const int ow = j0 + 4 * rd + d2_j;
+                        // a column outside the strip or the map gets an offset beyond the resource and the store is dropped (no branch)
+                        const unsigned voff = (4 * rd + d2_j < KS && ow < p.OW2) ? (unsigned)(s * p.OW2 + ow) * 256u + 16u * d2_q : 0x80000000u;
+                        bstore16(v, ry, voff, 0);
+                    }
                 }
             }
             wave_order();
