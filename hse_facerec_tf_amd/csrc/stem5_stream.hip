@@ -91,7 +91,7 @@ constexpr int WAVES = 4;
 #endif
 static_assert(OFF_AS + PMB * 16 * 128 <= WAVE_LDS, "the A tile's over-read stays inside the wave's own region");
 static_assert(4 + 12 * (CXW - 1) + 32 <= WRP, "the second K step of a row's last pixel stays inside the row");
-static_assert(S5_WGS * (WAVES * WAVE_LDS + 6 * 1024) <= 160 * 1024, "S5_WGS workgroups per CU");
+static_assert(S5_WGS * (WAVES * WAVE_LDS + 14 * 1024) <= 160 * 1024, "S5_WGS workgroups per CU");
 
 __device__ __forceinline__ int swzb(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)); }
 __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
@@ -104,6 +104,7 @@ __device__ __forceinline__ void wave_order() { asm volatile("" ::: "memory"); }
 template <int ACT, bool U8>
 __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char Lw[WAVES * WAVE_LDS];
+    __shared__ __attribute__((aligned(16))) unsigned char Wp[64 * 128];   // the pointwise split rows (8 KB): read per step, see below
     __shared__ __attribute__((aligned(16))) float4 W2[9 * 16];
     __shared__ __attribute__((aligned(16))) float4 W1[9 * 8];
     __shared__ __attribute__((aligned(16))) float Kc[64 + 64 + 128 + 128];   // conv1 descale | shift, dw1 scale | shift (x 2^a), pointwise descale | shift, dw2 scale | shift
@@ -115,6 +116,8 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
     const int l16 = lane & 15, q4 = lane >> 4;
 
     // ---- constants, once per workgroup (the only barrier of the kernel) ----
+    ((f32x4*)Wp)[tid] = ((const f32x4*)p.wsplit)[tid];
+    ((f32x4*)Wp)[tid + 256] = ((const f32x4*)p.wsplit)[tid + 256];
     if (tid < 9 * 16) W2[tid] = p.wd2[tid];
     if (tid < 9 * 8) W1[tid] = p.wd1[tid];
     if (U8 && tid < 4 * 32) Ct[tid] = p.cshift[tid];
@@ -130,9 +133,11 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
     __syncthreads();
     const float cap6 = 6.f * p.a_scale;
 
-    // conv1 weights: lane (n = 16 nb + l16, k-slice q4), both K steps, both channel blocks; pointwise weights: all four
-    // channel blocks (a wave computes all 64 channels of its pixels)
-    f16x8 cwh[2][2], cwl[2][2], bh[4], bl[4];
+    // conv1 weights: lane (n = 16 nb + l16, k-slice q4), both K steps, both channel blocks, in registers for good.  The pointwise
+    // weights (all four channel blocks: a wave computes all 64 channels of its pixels) are READ FROM LDS in every step: held in
+    // registers too (32 more) the kernel spilled a dozen lane constants, and their reloads -- vector-memory operations queued
+    // behind the step's row requests -- made every step wait for HBM
+    f16x8 cwh[2][2], cwl[2][2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -140,11 +145,6 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
             cwh[st][nb] = *(const f16x8*)((const unsigned char*)p.cw4 + (size_t)(st * 32 + nb * 16 + l16) * 128 + 16 * q4);
             cwl[st][nb] = *(const f16x8*)((const unsigned char*)p.cw4 + (size_t)(st * 32 + nb * 16 + l16) * 128 + 64 + 16 * q4);
         }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        bh[cb] = *(const f16x8*)((const unsigned char*)p.wsplit + (size_t)(cb * 16 + l16) * 128 + 16 * q4);
-        bl[cb] = *(const f16x8*)((const unsigned char*)p.wsplit + (size_t)(cb * 16 + l16) * 128 + 64 + 16 * q4);
-    }
 
     // ---- lane roles (the same for every strip) ----
     // conv1 GEMM, row block mb: pixel m = 16 mb + l16 of the 2 x 11 new conv pixels (pixels past the 22nd repeat the last one:
@@ -357,7 +357,11 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
                             *(f16x4*)(L + OFF_AS + swzb(q, d1_q >> 1) + 8 * (d1_q & 1)) = hi;
                             *(f16x4*)(L + OFF_AS + swzb(q, 4 + (d1_q >> 1)) + 8 * (d1_q & 1)) = lo;
                         }
+                        wave_order();
                     }
+                    // (one conv row and one round at a time: with both in one scheduling region hipcc hoisted all twelve tap reads to the top and
+                    // spilled lane constants -- whose reloads, vector-memory operations behind the row requests, then waited for HBM)
+                    wave_order();
                 }
             }
             wave_order();
@@ -367,6 +371,12 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
                 // block-1 rows 2 s + 1 and 2 s + 2
                 const int pr0 = 2 * s + 1;
                 const float rv0 = (pr0 >= 0 && pr0 < p.H1) ? 1.f : 0.f, rv1 = (pr0 + 1 >= 0 && pr0 + 1 < p.H1) ? 1.f : 0.f;
+                f16x8 bh[4], bl[4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    bh[cb] = *(const f16x8*)(Wp + oz + (cb * 16 + l16) * 128 + 16 * q4);
+                    bl[cb] = *(const f16x8*)(Wp + oz + (cb * 16 + l16) * 128 + 64 + 16 * q4);
+                }
                 f32x4 pds[4], psh[4];
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) { pds[cb] = *(const f32x4*)(&Kz[128 + cb * 16 + 4 * q4]); psh[cb] = *(const f32x4*)(&Kz[192 + cb * 16 + 4 * q4]); }
@@ -426,6 +436,7 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
                         const unsigned voff = (4 * rd + d2_j < KS && ow < p.OW2) ? (unsigned)(s * p.OW2 + ow) * 256u + 16u * d2_q : 0x80000000u;
                         bstore16(v, ry, voff, 0);
                     }
+                    wave_order();          // (one round at a time, as in depthwise 1)
                 }
             }
             wave_order();
