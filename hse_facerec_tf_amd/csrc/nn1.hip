@@ -156,6 +156,108 @@ __global__ __launch_bounds__(256) void pairwise_dist_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Large searches (the LFW protocol: 4582 probes x 4582 gallery rows x 1024): the contraction on the split-f16
+// GEMM of pwconv_f16s.hip (three f16 MFMA products per fp32 product, error <= 3 * 2^-22 per product -- the arithmetic every
+// pointwise layer of the network runs on) instead of the fp32 matrix pipe (29 TFLOP/s in nn1_kernel):
+//   1. row norms |q|^2 and the largest |q| of the whole probe matrix (one device scalar: the probes are scaled by the power of
+//      two that brings them into [-1, 1], which is what the GEMM's fixed activation scale 2^12 assumes);
+//   2. the gallery as the GEMM's WEIGHTS: every row scaled by its own power of two into [8192, 16384), split hi / lo into
+//      "split rows" [row][k / 32][hi 32 x f16 | lo 32 x f16]; descale[g] = -2 * 2^(Eq - 12 - e_g), shift[g] = |g|^2 -- so
+//      the GEMM's own epilogue returns |g|^2 - 2 q.g; rows that pad the gallery to a multiple of 64 get descale 0 and a huge shift;
+//   3. the GEMM -> [nq, ng_pad] fp32 (84 MB for LFW: written and read once at HBM speed);
+//   4. row arg-min of max(|q|^2 + that, 0), ties to the lowest gallery index (the rule of nn1_kernel and of scikit-learn).
+__global__ __launch_bounds__(256) void nn1_prep_queries_kernel(const float* __restrict__ q, int nq, int d, float* __restrict__ qq,
+                                                               unsigned* __restrict__ qmax_bits) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nq) return;
+    const float* r = q + (size_t)row * d;
+    float ss = 0.f, mx = 0.f;
+    for (int j = lane; j < d; j += 64) { const float v = r[j]; ss = fmaf(v, v, ss); mx = fmaxf(mx, fabsf(v)); }
+    ss = wave_sum64(ss);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+    if (lane == 0) {
+        qq[row] = ss;
+        atomicMax(qmax_bits, __float_as_uint(mx));          // non-negative floats order like their bit patterns (a NaN row wins: results NaN, as before)
+    }
+}
+
+__device__ __forceinline__ int pow2_above(float mx) {      // e with mx * 2^-e in [0.5, 1)  (0 for mx = 0 / Inf / NaN)
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &e);
+    return e;
+}
+
+__global__ __launch_bounds__(256) void nn1_scale_queries_kernel(const float* __restrict__ q, float* __restrict__ qs, long long n4,
+                                                                const unsigned* __restrict__ qmax_bits) {
+    const float sc = ldexpf(1.f, -pow2_above(__uint_as_float(*qmax_bits)));
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) ((f32x4*)qs)[i] = ((const f32x4*)q)[i] * sc;
+}
+
+__global__ __launch_bounds__(256) void nn1_split_gallery_kernel(const float* __restrict__ g, int ng, int ng_pad, int d,
+                                                                unsigned short* __restrict__ wsplit, float* __restrict__ descale,
+                                                                float* __restrict__ shift, const unsigned* __restrict__ qmax_bits) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= ng_pad) return;
+    unsigned short* w = wsplit + (size_t)row * d * 2;
+    if (row >= ng) {
+        for (int j = lane; j < 2 * d; j += 64) w[j] = 0;
+        if (lane == 0) { descale[row] = 0.f; shift[row] = 3.0e38f; }
+        return;
+    }
+    const float* r = g + (size_t)row * d;
+    float ss = 0.f, mx = 0.f;
+    for (int j = lane; j < d; j += 64) { const float v = r[j]; ss = fmaf(v, v, ss); mx = fmaxf(mx, fabsf(v)); }
+    ss = wave_sum64(ss);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+    const int eg = 14 - pow2_above(mx);                      // mx * 2^eg in [8192, 16384)
+    const float sc = ldexpf(1.f, eg);
+    for (int j = lane; j < d; j += 64) {
+        const float v = r[j] * sc;                           // exact
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const int grp = j >> 5, k = j & 31;
+        w[grp * 64 + k] = __builtin_bit_cast(unsigned short, hi);
+        w[grp * 64 + 32 + k] = __builtin_bit_cast(unsigned short, lo);
+    }
+    if (lane == 0) {
+        const int eq = pow2_above(__uint_as_float(*qmax_bits));
+        descale[row] = -2.f * ldexpf(1.f, eq - 12 - eg);
+        shift[row] = ss;
+    }
+}
+
+__global__ __launch_bounds__(256) void nn1_row_argmin_kernel(const float* __restrict__ y, int nq, int ng, int ng_pad,
+                                                             const float* __restrict__ qq, int* __restrict__ nn_index,
+                                                             float* __restrict__ nn_dist2) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nq) return;
+    const float* r = y + (size_t)row * ng_pad;
+    const float qr = qq[row];
+    float bv = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < ng; j += 64) {
+        const float v = fmaxf(qr + r[j], 0.f);
+        if (better(v, j, bv, bi)) { bv = v; bi = j; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(bv, m);
+        const int oi = __shfl_xor(bi, m);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        nn_index[row] = bi;
+        if (nn_dist2) nn_dist2[row] = bv;
+    }
+}
+
 }  // namespace
 
 int launch_pairwise_dist(const float* x, const float* y, int n, int m, int d, float* out, hipStream_t s) {
@@ -179,6 +281,37 @@ int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_in
     HSEFR_REQUIRE(d > 0 && d % 8 == 0, HSEFR_ERR_UNSUPPORTED, "nn1: d=%d must be a multiple of 8", d);
     HSEFR_REQUIRE(nq >= 0 && ng > 0, HSEFR_ERR_INVALID, "nn1: nq=%d ng=%d", nq, ng);
     if (nq == 0) return HSEFR_OK;
+    if (d % 32 == 0 && (long long)nq * ng * d >= (1ll << 28)) {
+        // the split-f16 GEMM path; its workspace (scaled probes, split gallery, the [nq, ng_pad] matrix) is stream-ordered
+        const int ng_pad = (ng + 63) / 64 * 64;
+        const size_t b_qs = (size_t)nq * d * 4, b_w = (size_t)ng_pad * d * 4, b_y = (size_t)nq * ng_pad * 4;
+        const size_t b_small = ((size_t)nq + 2 * (size_t)ng_pad + 64) * 4;
+        char* ws = nullptr;
+        HSEFR_HIP_CHECK(hipMallocAsync((void**)&ws, b_qs + b_w + b_y + b_small, s));
+        float* qs = (float*)ws;
+        unsigned short* w = (unsigned short*)(ws + b_qs);
+        float* y = (float*)(ws + b_qs + b_w);
+        float* qq = (float*)(ws + b_qs + b_w + b_y);
+        float* descale = qq + nq;
+        float* shift = descale + ng_pad;
+        unsigned* qmax = (unsigned*)(shift + ng_pad);
+        int rc = HSEFR_OK;
+        if (hipMemsetAsync(qmax, 0, 4, s) != hipSuccess) rc = HSEFR_ERR_HIP;
+        if (rc == HSEFR_OK) {
+            hipLaunchKernelGGL(nn1_prep_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, q, nq, d, qq, qmax);
+            hipLaunchKernelGGL(nn1_split_gallery_kernel, dim3((ng_pad + 3) / 4), dim3(256), 0, s, g, ng, ng_pad, d, w, descale, shift, qmax);
+            const long long n4 = (long long)nq * d / 4;
+            hipLaunchKernelGGL(nn1_scale_queries_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, q, qs, n4, qmax);
+            rc = launch_status("nn1 (split-f16 preparation)");
+        }
+        if (rc == HSEFR_OK) rc = launch_pwconv_f16s(qs, w, descale, shift, y, nq, d, ng_pad, 12, HSEFR_ACT_NONE, s);
+        if (rc == HSEFR_OK) {
+            hipLaunchKernelGGL(nn1_row_argmin_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, y, nq, ng, ng_pad, qq, nn_index, nn_dist2);
+            rc = launch_status("nn1 (row arg-min)");
+        }
+        (void)hipFreeAsync(ws, s);
+        return rc;
+    }
     dim3 grid((nq + 31) / 32), block(256);
     hipLaunchKernelGGL(nn1_kernel, grid, block, 0, s, q, g, nq, ng, d, nn_index, nn_dist2);
     return launch_status("nn1");

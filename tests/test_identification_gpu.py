@@ -61,6 +61,33 @@ def test_nn1_vs_bruteforce(torch_, nq, ng, d):
     assert np.abs(dist.cpu().numpy() - best).max() < 1e-4
 
 
+@pytest.mark.parametrize("nq,ng,d,scale", [(300, 1000, 1024, 1.0), (513, 2049, 512, 37.5), (257, 4100, 256, 3e-4), (1100, 1000, 288 + 32, 1.0)])
+def test_nn1_split_f16_gemm_path_vs_fp64(torch_, nq, ng, d, scale):
+    """searches of nq * ng * d >= 2^28 run on the split-f16 GEMM (probes scaled by a power of two into [-1, 1],
+    the gallery split row by row, |g|^2 - 2 q.g out of the GEMM's epilogue, a row arg-min kernel): ragged gallery sizes (padded to
+    64 columns), UN-normalised rows of any magnitude (the gallery / probe protocol feeds raw features: facerec_test.py:284-285),
+    duplicated gallery rows (ties -> the lowest index) and a zero row."""
+    from hse_facerec_tf_amd import ops
+    assert nq * ng * d >= 1 << 28
+    rs = np.random.RandomState(nq + ng + d)
+    centres = rs.randn(50, d)
+    g = (centres[rs.randint(0, 50, ng)] + 0.7 * rs.randn(ng, d)).astype(np.float32) * np.float32(scale)
+    q = (centres[rs.randint(0, 50, nq)] + 0.7 * rs.randn(nq, d)).astype(np.float32) * np.float32(scale)
+    g[ng // 2] = g[3]                                        # an exact duplicate: the probe next to it must pick index 3
+    q[5] = g[3]
+    q[6] = 0.0
+    g[7] *= np.float32(1e-3)                                 # rows of very different magnitude get their own power of two
+    d2 = (q.astype(np.float64) ** 2).sum(1)[:, None] + (g.astype(np.float64) ** 2).sum(1)[None] - 2 * q.astype(np.float64) @ g.astype(np.float64).T
+    idx, dist = ops.nn1(torch_.from_numpy(q).cuda(), torch_.from_numpy(g).cuda())
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    best = d2.min(axis=1)
+    unit = float((np.abs(q).max() * np.abs(g).max()) * d) * 2.0 ** -20            # the fp32-grade error scale of a d-term product sum
+    assert np.all(d2[np.arange(nq), idx] <= best + unit)     # the chosen row is a nearest one
+    assert (idx == d2.argmin(axis=1)).mean() > 0.99 and idx[5] == 3
+    assert np.abs(dist - np.maximum(best, 0)).max() <= unit
+    assert 0 <= idx.min() and idx.max() < ng
+
+
 def test_nn1_ties_resolve_to_lowest_index(torch_):
     from hse_facerec_tf_amd import ops
     g = np.zeros((40, 8), np.float32)
