@@ -116,8 +116,10 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
     const int l16 = lane & 15, q4 = lane >> 4;
 
     // ---- constants, once per workgroup (the only barrier of the kernel) ----
-    ((f32x4*)Wp)[tid] = ((const f32x4*)p.wsplit)[tid];
-    ((f32x4*)Wp)[tid + 256] = ((const f32x4*)p.wsplit)[tid + 256];
+    // (16-byte chunk c of row r sits at chunk c ^ (r & 7): a fragment read -- 16 rows x one chunk column at a 128-byte pitch --
+    // would otherwise put four lanes of every read group on the same four banks)
+#pragma unroll
+    for (int i = tid; i < 512; i += 256) ((f32x4*)Wp)[(i & ~7) | ((i & 7) ^ ((i >> 3) & 7))] = ((const f32x4*)p.wsplit)[i];
     if (tid < 9 * 16) W2[tid] = p.wd2[tid];
     if (tid < 9 * 8) W1[tid] = p.wd1[tid];
     if (U8 && tid < 4 * 32) Ct[tid] = p.cshift[tid];
@@ -374,8 +376,8 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
                 f16x8 bh[4], bl[4];
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
-                    bh[cb] = *(const f16x8*)(Wp + oz + (cb * 16 + l16) * 128 + 16 * q4);
-                    bl[cb] = *(const f16x8*)(Wp + oz + (cb * 16 + l16) * 128 + 64 + 16 * q4);
+                    bh[cb] = *(const f16x8*)(Wp + oz + (cb * 16 + l16) * 128 + 16 * (q4 ^ (l16 & 7)));
+                    bl[cb] = *(const f16x8*)(Wp + oz + (cb * 16 + l16) * 128 + 16 * ((4 + q4) ^ (l16 & 7)));
                 }
                 f32x4 pds[4], psh[4];
 #pragma unroll
