@@ -224,11 +224,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
         }
         const int q = lane & 7;
         const unsigned char* cp = cb + CB_CONST + (32 * c + 4 * q) * 4;
-        f32x4 tap[9];
-        if constexpr (!RUN3) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) tap[t] = *(const f32x4*)(cp + t * 512);
-        }
+        f32x4 tap[9];          // (RUN3 only: one row of taps live at a time)
         // split rows of the output: pixel m, 32-channel group -> 128 B; this lane stores the 16-byte unit q/2 of the hi half
         // (even quad) or of the lo half (odd quad) after swapping one 8-byte half with its neighbour lane (dwconv.hip)
         // (stride 2: a quarter of the pixels -- the tile's 288 input pixels are output pixels tm0 / 4 .. + 71)
@@ -275,13 +271,19 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             }
             return;
         }
-        const f32x4 sc = *(const f32x4*)(cp + 9 * 512), sh = *(const f32x4*)(cp + 10 * 512);
+        // tap-outer order: ONE tap vector live at a time and NK accumulators (with all nine taps loaded up front -- 36 registers --
+        // the masked variant spilled 27 registers, and the reloads sat in the MFMA waves' K loop); per output the products are
+        // still added in tap order 0..8: same bits
+        constexpr int NK = DWM == 3 ? 1 : 3;
+        f32x4 a[NK];
 #pragma unroll
-        for (int k3 = 0; k3 < (DWM == 3 ? 1 : 3); ++k3) {
-            const int P = (lane >> 3) + 8 * wave + 96 * k3;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int k3 = 0; k3 < NK; ++k3) a[k3] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < 9; ++t) {
+            const f32x4 tp = *(const f32x4*)(cp + t * 512);
+#pragma unroll
+            for (int k3 = 0; k3 < NK; ++k3) {
+                const int P = (lane >> 3) + 8 * wave + 96 * k3;
                 f32x4 v;
                 if constexpr (BORDERED) {
                     v = *(const f32x4*)(cb + (nb_mask[k3] & 0x7FFFFFFFu) + ((t / 3) * PITCH + t % 3) * ROWB);
@@ -290,11 +292,16 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                     v = *(const f32x4*)(cb + row * ROWB + 16 * q);
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = fmaf(v[e], tap[t][e], a[e]);
+                for (int e = 0; e < 4; ++e) a[k3][e] = fmaf(v[e], tp[e], a[k3][e]);
             }
+        }
+        const f32x4 sc = *(const f32x4*)(cp + 9 * 512), sh = *(const f32x4*)(cp + 10 * 512);
+#pragma unroll
+        for (int k3 = 0; k3 < NK; ++k3) {
+            const int P = (lane >> 3) + 8 * wave + 96 * k3;
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(fmaf(a[e], sc[e], sh[e]), 0.f), dw.clamp_hi);
+            for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(fmaf(a[k3][e], sc[e], sh[e]), 0.f), dw.clamp_hi);
             const f16x4 hi = __builtin_convertvector(o, f16x4);
             const f16x4 lo = __builtin_convertvector(o - __builtin_convertvector(hi, f32x4), f16x4);
             const u32x2 hb = __builtin_bit_cast(u32x2, hi), lb = __builtin_bit_cast(u32x2, lo);
