@@ -806,7 +806,7 @@ def main():
             pj = json.load(open(cands[-1]))
             prof = pj["kernels"]
             traffic_stale = pj.get("csrc_hash") != csrc_hash()
-            prefixes = {"stem_conv1_dw_pw_dw_fused": ("stem2_fused_kernel", "stem3_"), "stem_conv1_dw_pw_fused": "stem_fused_kernel", "conv1_3x3x3_s2": "conv3x3_c3",
+            prefixes = {"stem_conv1_dw_pw_dw_fused": ("stem2_fused_kernel", "stem3_", "stem4_", "stem5_"), "stem_conv1_dw_pw_fused": "stem_fused_kernel", "conv1_3x3x3_s2": "conv3x3_c3",
                         "depthwise3x3": "dwconv3x3_kernel",
                         "pointwise1x1_f32mfma": "pwconv_f32_",
                         "pointwise1x1_f16split": lambda k: k.startswith("pwconv_f16s_kernel") or (k.startswith("pwconv_ps_") and k.rstrip().endswith(", 0>")),

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define HSEFR_VERSION 110 /* 0.1.1: round-3 ABI (exports added/removed since 100, plan-op `reserved` carries more; see git log) */
+#define HSEFR_VERSION 120 /* 0.1.2: round-4 ABI (added: hsefr_stem5_stream, hsefr_engine_input_overflow_async; 110 = round 3, 100 = round 1-2) */
 
 typedef enum hsefr_status {
     HSEFR_OK = 0,
