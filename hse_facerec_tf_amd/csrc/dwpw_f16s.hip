@@ -475,10 +475,18 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
                         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
                         *(f32x4*)(scr + li * 128 + 16 * ((2 * j + lh) ^ (li & 7))) = v;
                     }
+                    // (all four reads first: each store below is an asm statement that clobbers memory, and with a read per store
+                    // hipcc waited out one LDS round trip per 16 bytes -- 64 of them per patch and wave at BN = 256.  Going further --
+                    // parking and fetching block k + 1 before block k is stored -- measured no better)
+                    f32x4 rv[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = erow + 8 * i;
-                        const f32x4 v = *(const f32x4*)(scr + r * 128 + 16 * (ech ^ (r & 7)));
+                        rv[i] = *(const f32x4*)(scr + r * 128 + 16 * (ech ^ (r & 7)));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 v = rv[i];
                         const f32x4 z = __builtin_elementwise_fma(v, ds, sh);
                         f32x4 o;
 #pragma unroll
