@@ -263,16 +263,23 @@ __global__ __launch_bounds__(128 * WAVES_N, OCC) void pwconv_f16s_kernel(const f
                         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
                         *(f32x4*)(scr + li * 128 + 16 * ((2 * j + lh) ^ (li & 7))) = v;
                     }
+                    // (all four reads before the first store: the store's hazard guard is an asm statement the LDS reads do not cross,
+                    // and with a read per store the wave waited out one LDS round trip per 16 bytes)
+                    f32x4 rv[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = erow + 8 * i;
-                        const f32x4 v = *(const f32x4*)(scr + r * 128 + 16 * (ech ^ (r & 7)));
-                        f32x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = apply_act<ACT>(fmaf(v[e], ds[e], sh[e]));
-                        // rows beyond M fall outside the resource and are dropped by the hardware
-                        bstore16(o, ry, yvoff, (unsigned)(mi * 32 + 8 * i) * (unsigned)Cout * 4u + (unsigned)(ni * 32) * 4u);
+                        rv[i] = *(const f32x4*)(scr + r * 128 + 16 * (ech ^ (r & 7)));
                     }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rv[i][e] = apply_act<ACT>(fmaf(rv[i][e], ds[e], sh[e]));
+                    // (the four stores back to back, after all the arithmetic: no vector write lands in a store's data registers
+                    // inside its hazard window -- tools/isa_lint.py)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)   // rows beyond M fall outside the resource and are dropped by the hardware
+                        bstore16(rv[i], ry, yvoff, (unsigned)(mi * 32 + 8 * i) * (unsigned)Cout * 4u + (unsigned)(ni * 32) * 4u);
                 }
             }
             __syncthreads();   // the scratch is the stage the next step refills
