@@ -395,8 +395,14 @@ def run_latency_batch1(args, dev):
     out["age_gender_fun"] = {"median_ms": m, "p95_ms": p95, "construct_s": round(t1 - t0, 4), "first_call_ms": round((t2 - t1) * 1e3, 3),
                              "calls": reps, "what": "FacialImageProcessing.age_gender_fun(250x250 RGB uint8 crop) -> (age, gender, 1024 features) "
                                                     "on the host: upload + cv-resize + forward (3 outputs) + read-back + age decode",
-                             "vs_reference_published": round(4.97 / m, 2)}
+                             "vs_reference_published": round(4.97 / m, 2),
+                             "plan": "small-batch lowering (FacialImageProcessing's default for its per-face calls: latency_plan=True)"}
     fp.close()
+    fpb = FacialImageProcessing(mtcnn_detector=False, max_batch=8, device=dev.index, latency_plan=False)
+    fpb.age_gender_fun(face)
+    mb_, _ = med(lambda: fpb.age_gender_fun(face))
+    out["age_gender_fun"]["median_ms_bulk_plan"] = mb_        # the batch-256 plan on one face (what rounds 1-3 reported)
+    fpb.close()
     # ---- TensorFlowInference.extract_features(path): facerec_test.py:114-122 (decode + PIL resize on the host, as the reference)
     t0 = time.perf_counter()
     tfi = TensorFlowInference(AGE_GENDER_PB, input_tensor="input_1:0", output_tensor="global_pooling/Mean:0", convert2BGR=True,
@@ -416,12 +422,25 @@ def run_latency_batch1(args, dev):
     out["extract_features"] = {"median_ms": m, "p95_ms": p95, "construct_s": round(t1 - t0, 4), "first_call_ms": round((t2 - t1) * 1e3, 3),
                                "host_decode_median_ms": md, "host_preprocess_image_median_ms": mh,
                                "upload_forward_readback_median_ms": mf, "calls": reps,
+                               "plan": "the bulk plan (default: extract_files(paths) is [extract_features(p) for p in paths] bit for bit)",
                                "what": "TensorFlowInference.extract_features(%dx%d JPEG path): PIL decode on the host (host_decode), the decoded "
                                        "bytes uploaded, misc.imresize + float conversion + BGR + mean on the device (bit-exact / 2e-6), "
                                        "MobileNet-%d forward, read-back.  host_preprocess_image = the reference's whole preprocess_image on "
                                        "the host (decode + PIL resize + float64 BGR/mean), which this call no longer runs; "
                                        "upload_forward_readback = the fp32-input forward alone" % (rgb.shape[1], rgb.shape[0], args.size)}
     tfi.close_session()
+    # the same call on an extractor built with latency_plan=True (small-batch lowering for the one-image calls; 3e-7 from the bulk plan)
+    tfl = TensorFlowInference(AGE_GENDER_PB, input_tensor="input_1:0", output_tensor="global_pooling/Mean:0", convert2BGR=True,
+                              imageNetUtilsMean=True, input_size=(args.size, args.size), max_batch=8, device=dev.index, latency_plan=True)
+    tfl.extract_features(photo)
+    ml, _ = med(lambda: tfl.extract_features(photo))
+
+    def fwd_l():
+        tfl.engine.forward(x1, latency=True)["features"].cpu()
+    mfl, _ = med(fwd_l)
+    out["extract_features"]["latency_plan"] = {"median_ms": ml, "upload_forward_readback_median_ms": mfl,
+                                               "what": "TensorFlowInference(..., latency_plan=True): the small-batch lowering for one-image calls"}
+    tfl.close_session()
     # ---- first MTCNN detection (ipynb:109)
     try:
         bgr = np.ascontiguousarray(rgb[..., ::-1])

@@ -14,25 +14,54 @@ from .lowering import OUT_AGE, OUT_FEATURES, OUT_GENDER, Plan
 _SLOT_NAMES = {OUT_FEATURES: "features", OUT_AGE: "age_probs", OUT_GENDER: "gender"}
 
 
+SMALL_BATCH = 32      # forward(..., latency=True) of at most this many images runs the small-batch plan, when the caller lowered one
+
+
 class Engine:
-    def __init__(self, plan: Plan, max_batch: int = 256, device: Optional[int] = None):
+    def __init__(self, plan: Plan, max_batch: int = 256, device: Optional[int] = None, small_plan: Optional[Plan] = None,
+                 small_batch: int = SMALL_BATCH):
+        """small_plan: a second lowering of the SAME graph for forwards of at most small_batch images -- the reference calls
+        its session once per image (facerec_test.py:114-122, facial_analysis.py:93-129), and a plan tuned for 256 images per launch
+        (GEMM tiles of 288 rows with the next depthwise in their epilogue: one tile, 4 of 256 CUs, 28 us per layer whatever the
+        batch) is not the fastest one for that: lowered with presplit='none' (plain GEMMs + standalone depthwise kernels) one
+        image takes 0.17 ms instead of 0.26, 32 images 0.34 instead of 0.36, and from 48 up the default plan wins.  Both plans
+        are fp32-grade restatements of the same graph (each is tested against the oracle at the same tolerance); their results
+        differ by summation order (3e-7 relative) -- which is why the choice is the CALLER's, per call (latency=True), and never
+        made from the batch size alone: the bulk paths (extract_batch / extract_files / config 5's shards) promise that an image's
+        embedding does not depend on how the images were batched, and keep the one plan for every batch size."""
         torch = _lib.require_gpu()
         self._torch = torch
         self.plan = plan
         self.device = _lib.cuda_device(device)
         self.max_batch = int(max_batch)
-        blob = plan.serialize()
-        handle = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            buf = ctypes.create_string_buffer(blob, len(blob))
-            _lib.check(_lib.lib().hsefr_engine_create(ctypes.cast(buf, ctypes.c_void_p), len(blob), self.max_batch,
-                                                      ctypes.byref(handle)), "hsefr_engine_create")
-        self._h = handle
+        self._h = self._create(plan, self.max_batch)
         self.in_hwc = plan.in_hwc
         self.out_elems = {slot: elems for slot, (_, elems) in plan.outputs.items()}
+        self.small_plan, self.small_batch, self._hs, self._last = None, 0, None, None
+        if small_plan is not None and small_batch > 0:
+            if small_plan.in_hwc != plan.in_hwc or {s_: e for s_, (_, e) in small_plan.outputs.items()} != self.out_elems:
+                raise ValueError("small_plan must be a lowering of the same graph: same input and outputs")
+            self.small_plan, self.small_batch = small_plan, min(int(small_batch), self.max_batch)
+            self._hs = self._create(small_plan, self.small_batch)
+
+    def _create(self, plan: Plan, max_batch: int):
+        blob = plan.serialize()
+        handle = ctypes.c_void_p()
+        with self._torch.cuda.device(self.device):
+            buf = ctypes.create_string_buffer(blob, len(blob))
+            _lib.check(_lib.lib().hsefr_engine_create(ctypes.cast(buf, ctypes.c_void_p), len(blob), int(max_batch),
+                                                      ctypes.byref(handle)), "hsefr_engine_create")
+        return handle
+
+    def _handle_for(self, n: int, latency: bool):
+        self._last = self._hs if latency and self._hs is not None and n <= self.small_batch else self._h
+        return self._last
 
     # -- lifecycle ---------------------------------------------------------------------------
     def close(self) -> None:
+        if getattr(self, "_hs", None):
+            _lib.lib().hsefr_engine_destroy(self._hs)
+            self._hs = None
         if getattr(self, "_h", None):
             _lib.lib().hsefr_engine_destroy(self._h)
             self._h = None
@@ -45,12 +74,14 @@ class Engine:
 
     @property
     def device_bytes(self) -> int:
-        return int(_lib.lib().hsefr_engine_workspace_bytes(self._h))
+        return int(_lib.lib().hsefr_engine_workspace_bytes(self._h)) + (int(_lib.lib().hsefr_engine_workspace_bytes(self._hs)) if self._hs else 0)
 
     # -- forward -----------------------------------------------------------------------------
-    def forward(self, x, want: Sequence[int] = (OUT_FEATURES,)) -> Dict[str, "object"]:
+    def forward(self, x, want: Sequence[int] = (OUT_FEATURES,), latency: bool = False) -> Dict[str, "object"]:
         """x: CUDA float32 tensor [n, h, w, c] NHWC contiguous (already preprocessed).  Returns
-        {'features'|'age_probs'|'gender': CUDA tensor}.  Asynchronous on the current stream."""
+        {'features'|'age_probs'|'gender': CUDA tensor}.  Asynchronous on the current stream.
+        latency=True: a call of the reference's one-image-per-run kind -- at most small_batch images take the small-batch
+        plan if the engine has one (__init__)."""
         torch = self._torch
         if self._h is None:
             raise RuntimeError("Attempted to use a closed Session.")   # TF's message for a closed session
@@ -72,7 +103,7 @@ class Engine:
             outs[_SLOT_NAMES[slot]] = t
             ptrs[slot] = t.data_ptr()
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().hsefr_engine_forward(self._h, x.data_ptr(), n, ptrs[0], ptrs[1], ptrs[2],
+            _lib.check(_lib.lib().hsefr_engine_forward(self._handle_for(n, latency), x.data_ptr(), n, ptrs[0], ptrs[1], ptrs[2],
                                                        _lib.current_stream_ptr()), "hsefr_engine_forward")
         return outs
 
@@ -81,7 +112,7 @@ class Engine:
         """True if forward_u8 works on this plan (fused stem lowered with a BGR mean, input edges multiples of 4)."""
         return bool(self._h) and bool(_lib.lib().hsefr_engine_accepts_u8(self._h))
 
-    def forward_u8(self, x_u8, want: Sequence[int] = (OUT_FEATURES,)) -> Dict[str, "object"]:
+    def forward_u8(self, x_u8, want: Sequence[int] = (OUT_FEATURES,), latency: bool = False) -> Dict[str, "object"]:
         """forward() on the RESIZED image bytes: x_u8 CUDA uint8 [n, h, w, 3], RGB as the decoder / resizer left them.  Float
         conversion, channel reversal and mean subtraction (facerec_test.py:95-106) happen inside the first kernel."""
         torch = self._torch
@@ -103,7 +134,7 @@ class Engine:
             outs[_SLOT_NAMES[slot]] = t
             ptrs[slot] = t.data_ptr()
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().hsefr_engine_forward_u8(self._h, x_u8.data_ptr(), n, ptrs[0], ptrs[1], ptrs[2],
+            _lib.check(_lib.lib().hsefr_engine_forward_u8(self._handle_for(n, latency), x_u8.data_ptr(), n, ptrs[0], ptrs[1], ptrs[2],
                                                           _lib.current_stream_ptr()), "hsefr_engine_forward_u8")
         return outs
 
@@ -135,27 +166,36 @@ class Engine:
     def input_overflow(self) -> bool:
         """True if any forward since the last call fed a value outside the plan's declared input bound (lower_graph
         input_bound; the results of such a forward are meaningless).  Synchronises the current stream and clears the flag."""
-        flag = ctypes.c_int(0)
+        any_set = False
         with self._torch.cuda.device(self.device):
-            _lib.check(_lib.lib().hsefr_engine_input_overflow(self._h, ctypes.byref(flag), _lib.current_stream_ptr()),
-                       "hsefr_engine_input_overflow")
-        return bool(flag.value)
+            for h in (self._h, self._hs):
+                if h:
+                    flag = ctypes.c_int(0)
+                    _lib.check(_lib.lib().hsefr_engine_input_overflow(h, ctypes.byref(flag), _lib.current_stream_ptr()),
+                               "hsefr_engine_input_overflow")
+                    any_set = any_set or bool(flag.value)
+        return any_set
 
     def input_overflow_async(self, pinned_host_int_ptr: int) -> None:
         """The same read-and-clear, asynchronous: the flag lands in a PINNED host int32 (address given) when the current
         stream reaches this point; the caller waits on an event of its own before reading it.  Nothing here waits for the device
         (hsefr_engine_input_overflow_async only enqueues the copy and the clear)."""
+        # (the flag of the engine the LAST forward ran on: callers pair every forward with one read; input_overflow() reads both)
         with self._torch.cuda.device(self.device):
-            _lib.check(_lib.lib().hsefr_engine_input_overflow_async(self._h, ctypes.cast(ctypes.c_void_p(pinned_host_int_ptr), ctypes.POINTER(ctypes.c_int)),
+            _lib.check(_lib.lib().hsefr_engine_input_overflow_async(self._last or self._h, ctypes.cast(ctypes.c_void_p(pinned_host_int_ptr), ctypes.POINTER(ctypes.c_int)),
                                                                     _lib.current_stream_ptr()), "hsefr_engine_input_overflow_async")
 
     # -- small batches as one hipGraph launch ---------------------------------------------------
     def set_graph_batch(self, max_n: int) -> None:
-        """Forwards of at most max_n images replay a captured hipGraph (default 0 = off: no faster on the device)."""
-        _lib.check(_lib.lib().hsefr_engine_set_graph_batch(self._h, int(max_n)))
+        """Forwards of at most max_n images replay a captured hipGraph (default 0 = off: no faster on the device).  With a
+        small-batch plan the graphs belong to it (max_n is then capped at small_batch)."""
+        if self._hs:
+            _lib.check(_lib.lib().hsefr_engine_set_graph_batch(self._hs, min(int(max_n), self.small_batch)))
+        else:
+            _lib.check(_lib.lib().hsefr_engine_set_graph_batch(self._h, int(max_n)))
 
     def graph_launches(self) -> int:
-        return int(_lib.lib().hsefr_engine_graph_launches(self._h))
+        return int(_lib.lib().hsefr_engine_graph_launches(self._hs or self._h))
 
     # -- profiling -----------------------------------------------------------------------------
     def set_profiling(self, depth: int) -> None:

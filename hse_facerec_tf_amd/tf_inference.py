@@ -41,7 +41,7 @@ class TensorFlowInference:
     def __init__(self, frozen_graph_filename, input_tensor, output_tensor, learning_phase_tensor=None,
                  convert2BGR=True, imageNetUtilsMean=True, additional_input_value=0,
                  input_size: Optional[Tuple[int, int]] = None, max_batch: int = 256, device: Optional[int] = None,
-                 dtype: str = "auto", input_bound: Optional[float] = 256.0):
+                 dtype: str = "auto", input_bound: Optional[float] = 256.0, latency_plan: bool = False):
         if str(frozen_graph_filename).lower().endswith((".h5", ".hdf5")):
             # Keras weights of MobileNet-v1 (models/vgg2_mobilenet.h5, facerec_test.py:322-334: model.load_weights + the
             # 'reshape_1' output) read without an HDF5 library and turned into the frozen graph of the same model
@@ -112,7 +112,16 @@ class TensorFlowInference:
         else:
             self.plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds, dtype=dtype)
         self.dtype = dtype
-        self.engine = Engine(self.plan, max_batch=max_batch, device=device)
+        small_plan = None
+        self.latency_plan = bool(latency_plan) and dtype == "f32"
+        if self.latency_plan:
+            # latency_plan=True: extract_features -- the reference's one-image-per-run call (facerec_test.py:114-122) -- runs a
+            # second lowering of the same graph whose kernels do not need hundreds of images to fill the chip (Engine.__init__:
+            # 0.17 instead of 0.26 ms per image on the device).  OFF by default: its results differ from the bulk paths' in the
+            # last bits (3e-7), and by default extract_files(paths) IS [extract_features(p) for p in paths], bit for bit.
+            small_plan = lower_graph(graph, input_tensor, {OUT_FEATURES: output_tensor}, (self.w, self.h), feeds,
+                                     input_bound=input_bound, u8_mean_bgr=u8_mean, presplit="none")
+        self.engine = Engine(self.plan, max_batch=max_batch, device=device, small_plan=small_plan)
         self.tf_sess = self.engine           # attribute name kept for callers that poke at it
         self.feature_dim = self.engine.out_elems[OUT_FEATURES]
 
@@ -134,11 +143,11 @@ class TensorFlowInference:
             img = preprocess.imread_rgb(img_filepath)
             if crop_center:
                 img = preprocess.center_crop_250_128(img)
-            return self.extract_images(img[None]).cpu().numpy().reshape(-1)
+            return self.extract_images(img[None], latency=self.latency_plan).cpu().numpy().reshape(-1)
         x = self.preprocess_image(img_filepath, crop_center)
         x = np.expand_dims(x, axis=0)
         xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.engine.device)
-        preds = self.engine.forward(xd, (OUT_FEATURES,))["features"]
+        preds = self.engine.forward(xd, (OUT_FEATURES,), latency=self.latency_plan)["features"]
         return preds.cpu().numpy().reshape(-1)
 
     def _check_bound(self, x_np) -> None:
@@ -219,16 +228,17 @@ class TensorFlowInference:
         self._bound_check_queue()
         return out
 
-    def extract_images(self, imgs_u8):
+    def extract_images(self, imgs_u8, latency: bool = False):
         """Decoded RGB uint8 images [n,H,W,3] (same size; NumPy or CUDA) -> CUDA features [n,D]: the resize +
-        BGR + mean of preprocess_image run on the device (bit-exact with the PIL path), then one forward."""
+        BGR + mean of preprocess_image run on the device (bit-exact with the PIL path), then one forward.
+        latency: see Engine.forward (extract_features passes it when the extractor was built with latency_plan=True)."""
         from . import preprocess_device
         if self.engine.accepts_u8:      # the resized bytes go straight into the first kernel (no fp32 image in between)
             x8 = preprocess_device.preprocess_pil(imgs_u8, (self.w, self.h), device=self.engine.device, raw_u8=True)
-            return self.engine.forward_u8(x8, (OUT_FEATURES,))["features"]
+            return self.engine.forward_u8(x8, (OUT_FEATURES,), latency=latency)["features"]
         x = preprocess_device.preprocess_pil(imgs_u8, (self.w, self.h), self.convert2BGR, self.imageNetUtilsMean,
                                              device=self.engine.device)
-        return self.engine.forward(x, (OUT_FEATURES,))["features"]
+        return self.engine.forward(x, (OUT_FEATURES,), latency=latency)["features"]
 
     def extract_files(self, paths: Sequence[str], batch: int = 256, crop_center: bool = False,
                       device_preprocess: bool = True, workers: Optional[int] = None, stats: Optional[dict] = None) -> np.ndarray:
