@@ -119,9 +119,10 @@ class FacialImageProcessing:
                     x = np.stack([self.preprocess_face(f) for f in chunk])
                     xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.sess.device)
                 r = self.sess.forward(xd, (OUT_FEATURES, OUT_AGE, OUT_GENDER), latency=latency)
-            age_p = r["age_probs"].cpu().numpy()
-            gen = r["gender"].cpu().numpy()
-            fea = r["features"].cpu().numpy()
+            # one read-back (three small device-to-host copies are three synchronisations)
+            packed = torch.cat([r["age_probs"], r["gender"], r["features"]], dim=1).cpu().numpy()
+            na, ng = r["age_probs"].shape[1], r["gender"].shape[1]
+            age_p, gen, fea = packed[:, :na], packed[:, na:na + ng].copy(), packed[:, na + ng:].copy()
             for j in range(len(chunk)):
                 ages.append(decode_age(age_p[j])[0])
                 genders.append(gen[j])

@@ -157,10 +157,12 @@ def preprocess_faces_cv(crops: Sequence[np.ndarray], out_hw: Tuple[int, int], de
     torch = _lib.require_gpu()
     oh, ow = out_hw
     dev = _lib.cuda_device(device)
-    out = torch.empty((len(crops), oh, ow, 3), dtype=torch.uint8 if raw_u8 else torch.float32, device=dev)
     groups = {}
     for i, c in enumerate(crops):
         groups.setdefault(c.shape[:2], []).append(i)
+    if len(groups) == 1:       # one face, or faces of one size: the resize kernel's own output, no scatter (two launches and an index upload less)
+        return preprocess_cv(np.stack([np.ascontiguousarray(c, dtype=np.uint8) for c in crops]), out_hw, dev, raw_u8=raw_u8)
+    out = torch.empty((len(crops), oh, ow, 3), dtype=torch.uint8 if raw_u8 else torch.float32, device=dev)
     for (h, w), idx in groups.items():
         batch = np.stack([np.ascontiguousarray(crops[i], dtype=np.uint8) for i in idx])
         out[torch.tensor(idx, device=dev)] = preprocess_cv(batch, out_hw, dev, raw_u8=raw_u8)
