@@ -472,9 +472,22 @@ int launch_stem5_stream(const void* x, int x_is_u8, const void* cw4, const float
                   "stem5_stream: %dx%d input (both edges must be multiples of 4; other sizes take stem3_fused)", h, w);
     HSEFR_REQUIRE(a_log2 > 0 && a_log2 <= 12, HSEFR_ERR_INVALID, "stem5_stream: a_log2=%d", a_log2);
     HSEFR_REQUIRE(x_is_u8 ? in_log2 == 0 : (in_log2 >= -8 && in_log2 <= 14), HSEFR_ERR_INVALID, "stem5_stream: in_log2=%d", in_log2);
-    HSEFR_REQUIRE((long long)n * h * w * 12 < (1ll << 31) - 64, HSEFR_ERR_UNSUPPORTED,
-                  "stem5_stream: the input batch must stay below 2 GB (its offsets travel in 32 bits, 2^31 marks a masked piece)");
+    // input offsets travel in 32 bits and 2^31 marks a masked piece: a launch takes at most 2 GB of (fp32-sized) input -- 4 850
+    // images of 192 x 192; a larger batch goes as several launches over ranges of images
+    const long long per_img = (long long)h * w * 12;
+    HSEFR_REQUIRE(per_img < (1ll << 31) - 64, HSEFR_ERR_UNSUPPORTED, "stem5_stream: one %dx%d image exceeds the 2 GB a launch addresses", h, w);
     if (n == 0) return HSEFR_OK;
+    const long long n_max = ((1ll << 31) - 64 - 1) / per_img;
+    if (n > n_max) {
+        for (long long i0 = 0; i0 < n; i0 += n_max) {
+            const int m = (int)(n - i0 < n_max ? n - i0 : n_max);
+            const int rc = launch_stem5_stream((const char*)x + i0 * h * w * 3 * (x_is_u8 ? 1 : 4), x_is_u8, cw4, cdescale, cshift, wd1, d1scale, d1shift,
+                                               wsplit, descale, pshift, wd2, d2scale, d2shift, y + i0 * (h / 4) * (w / 4) * 64, overflow, m, h, w,
+                                               in_log2, a_log2, act, s);
+            if (rc != HSEFR_OK) return rc;
+        }
+        return HSEFR_OK;
+    }
     Stem5Params p;
     p.x = x; p.cw4 = cw4; p.cdescale = cdescale; p.cshift = cshift; p.wd1 = (const float4*)wd1; p.d1scale = (const float4*)d1scale;
     p.d1shift = (const float4*)d1shift; p.wsplit = (const float*)wsplit; p.descale = descale; p.pshift = pshift;

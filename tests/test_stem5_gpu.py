@@ -103,3 +103,19 @@ def test_stem5_checks_the_declared_bound_and_rejects_other_shapes(env):
     for hw in ((50, 48), (48, 46), (33, 33)):
         with pytest.raises(ValueError):
             ops.stem5_stream(pixels(torch, (1,) + hw + (3,), 2), cw, csh, k1, sc1, sh1, kp, psh, k2, sc2, sh2)
+
+
+def test_stem5_batch_beyond_one_launch_goes_as_ranges_of_images(env):
+    """A launch addresses 2 GB of (fp32-sized) input: 11 651 images of 64 x 64 x 3 x 4 B.  A larger batch is split into ranges of
+    images by the launcher -- same bits as the ranges run one by one."""
+    torch, ops = env
+    n, h, w = 12000, 64, 64
+    cw, csh, k1, sc1, sh1, kp, psh, k2, sc2, sh2 = weights(torch, 77)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rgb = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+    prep = ops.split_weights_device(kp, rgb.device)
+    y = ops.stem5_stream(rgb, cw, csh, k1, sc1, sh1, None, psh, k2, sc2, sh2, prepared=prep, u8_mean_bgr=MEAN_BGR)
+    assert tuple(y.shape) == (n, 16, 16, 64)
+    for a, b in ((0, 3000), (11000, 12000), (11600, 11700)):          # ranges on both sides of the launcher's cut at image 11 651
+        part = ops.stem5_stream(rgb[a:b].contiguous(), cw, csh, k1, sc1, sh1, None, psh, k2, sc2, sh2, prepared=prep, u8_mean_bgr=MEAN_BGR)
+        assert torch.equal(y[a:b], part), (a, b)
