@@ -113,3 +113,19 @@ def test_age_gender_fun_takes_the_latency_plan_by_default(torch_):
     assert np.array_equal(feats_l[0], xl) and ages_l[0] == al
     fl.close()
     fb.close()
+
+
+def test_a_batch_of_5000_images_is_the_same_bits_as_batches_of_256(torch_):
+    """The bulk plan at a batch no launch-size limit was tuned for (the streaming stem addresses 4 850 images of 192 x 192 per launch and
+    splits the rest off; 32-bit offsets elsewhere are per tile): every image's embedding equals the one a batch of 256 gives."""
+    from hse_facerec_tf_amd import TensorFlowInference
+    n = 5000
+    tfi = TensorFlowInference(MODEL_PB, input_tensor="input_1:0", output_tensor=FETCH[0], input_size=(192, 192), max_batch=n)
+    g = torch_.Generator(device="cuda")
+    g.manual_seed(1)
+    x = (torch_.rand((n, 192, 192, 3), device="cuda", generator=g) * 256 - 128).contiguous()
+    big = tfi.engine.forward(x)["features"]
+    for a in (0, 2400, 4700, n - 256):
+        assert torch_.equal(tfi.engine.forward(x[a:a + 256].contiguous())["features"], big[a:a + 256]), a
+    assert tfi.engine.input_overflow() is False
+    tfi.close_session()
