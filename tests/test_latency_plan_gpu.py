@@ -116,11 +116,13 @@ def test_age_gender_fun_takes_the_latency_plan_by_default(torch_):
 
 
 def test_a_batch_of_5000_images_is_the_same_bits_as_batches_of_256(torch_):
-    """The bulk plan at a batch no launch-size limit was tuned for (the streaming stem addresses 4 850 images of 192 x 192 per launch and
-    splits the rest off; 32-bit offsets elsewhere are per tile): every image's embedding equals the one a batch of 256 gives."""
+    """A batch far beyond what the plan was tuned for goes through the network in chunks of engine.BULK_CHUNK images (consecutive
+    layers meet in the caches; the workspace is one chunk's): every image's embedding equals the one a batch of 256 gives."""
     from hse_facerec_tf_amd import TensorFlowInference
     n = 5000
     tfi = TensorFlowInference(MODEL_PB, input_tensor="input_1:0", output_tensor=FETCH[0], input_size=(192, 192), max_batch=n)
+    from hse_facerec_tf_amd.engine import BULK_CHUNK
+    assert tfi.engine.chunk == BULK_CHUNK and tfi.engine.device_bytes < 2.5e9      # the workspace is one chunk's (5000 images in one piece: 12 GB)
     g = torch_.Generator(device="cuda")
     g.manual_seed(1)
     x = (torch_.rand((n, 192, 192, 3), device="cuda", generator=g) * 256 - 128).contiguous()
@@ -129,3 +131,27 @@ def test_a_batch_of_5000_images_is_the_same_bits_as_batches_of_256(torch_):
         assert torch_.equal(tfi.engine.forward(x[a:a + 256].contiguous())["features"], big[a:a + 256]), a
     assert tfi.engine.input_overflow() is False
     tfi.close_session()
+
+
+def test_chunked_and_unchunked_engines_agree_bit_for_bit_in_both_input_forms(torch_):
+    """Engine(bulk_chunk=...) against bulk_chunk=0 (one piece; the streaming stem then splits its own launch beyond 2 GB of input),
+    three outputs, float and uint8 entries, a ragged last chunk; more than max_batch still raises."""
+    from hse_facerec_tf_amd import engine, graphdef, lowering
+    g = graphdef.read_graph(MODEL_PB)
+    outs = {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]}
+    plan = lowering.lower_graph(g, "input_1:0", outs, (96, 96), input_bound=256.0, u8_mean_bgr=(103.939, 116.779, 123.68))
+    a, b = engine.Engine(plan, max_batch=300, bulk_chunk=64), engine.Engine(plan, max_batch=300, bulk_chunk=0)
+    assert a.chunk == 64 and b.chunk == 300 and a.device_bytes < b.device_bytes
+    gen = torch_.Generator(device="cuda")
+    gen.manual_seed(9)
+    x = (torch_.rand((203, 96, 96, 3), device="cuda", generator=gen) * 256 - 128).contiguous()
+    u8 = torch_.randint(0, 256, (203, 96, 96, 3), dtype=torch_.uint8, device="cuda", generator=gen)
+    ra, rb = a.forward(x, (0, 1, 2)), b.forward(x, (0, 1, 2))
+    ua, ub = a.forward_u8(u8, (0, 2)), b.forward_u8(u8, (0, 2))
+    for k in ("features", "age_probs", "gender"):
+        assert torch_.equal(ra[k], rb[k]), k
+    assert torch_.equal(ua["features"], ub["features"]) and torch_.equal(ua["gender"], ub["gender"])
+    with pytest.raises(ValueError):
+        a.forward(torch_.zeros((301, 96, 96, 3), device="cuda"))
+    a.close()
+    b.close()
