@@ -170,6 +170,11 @@ bool conv3x3_win_forced();
 bool conv3x3_win_bf16_supported(long long n, int h, int w, int c, int cout);
 int launch_conv3x3_win_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
                             int w, int c, int cout, int act, hipStream_t s);
+bool conv3x3_w2_forced();
+bool conv3x3_w2_bf16_supported(long long n, int h, int w, int c, int cout);
+bool conv3x3_w2_bf16_preferred(int h, int w, int cout);
+int launch_conv3x3_w2_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
+                           int w, int c, int cout, int act, hipStream_t s);
 bool conv_dma_forced();
 bool conv_dma_bf16_supported(long long n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw);
 int launch_conv_dma_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
@@ -265,6 +270,8 @@ void set_ps_grid(int v);
 void set_psdw_mode(int v);
 void set_cd_rb(int v);
 void set_w3_off(int v);
+void set_w2_off(int v);
+int read_w2_stamps(void* host_out, size_t bytes);
 int read_w3_stamps(void* host_out, size_t bytes);
 int read_cd_stamps(void* host_out, size_t bytes);
 void set_cd_off(int v);

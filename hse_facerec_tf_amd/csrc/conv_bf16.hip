@@ -454,6 +454,10 @@ int launch_conv_bf16(const void* x, const void* wt, const float* scale, const fl
     if (n == 0) return HSEFR_OK;
     const long long P = (long long)n * oh * ow;
     HSEFR_REQUIRE(P < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv_bf16: too many output pixels");
+    // 3x3 / stride 1 / pad 1, window resident in LDS, four wide MFMA waves (conv3x3_w2_bf16.hip, round 5): the 56 / 28 / 14-pixel maps
+    if (kh == 3 && kw == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && oh == h && ow == w && conv3x3_w2_bf16_supported(n, h, w, c, cout) &&
+        (conv3x3_w2_bf16_preferred(h, w, cout) || conv3x3_w2_forced()))
+        return launch_conv3x3_w2_bf16(x, wt, scale, shift, res, y, n, h, w, c, cout, act, s);
     // 3x3 / stride 1 / pad 1 with the input window resident in LDS (conv3x3_win_bf16.hip): wide maps, W >= 40 (56x56x64 at batch 128:
     // 54 us against 80 register-staged and 84 im2col-by-DMA); on the smaller maps it ties with conv_dma_bf16.hip, which stays there
     if (kh == 3 && kw == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && oh == h && ow == w && (w >= 40 || conv3x3_win_forced()) &&

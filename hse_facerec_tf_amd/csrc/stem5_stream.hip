@@ -10,16 +10,16 @@
 // What changed is the decomposition (PMC of stem4: vector ALU 42 % busy + LDS 48 % + matrix pipe 13 % = 100 %:
 // four waves in lock step through four barrier-separated stages use ONE unit at a time, 1.6x halo recompute on top):
 //
-//   * ONE WAVE = ONE STRIP.  A wave owns 6 output columns of one image and walks DOWN the image, one output row per step.
+//   * ONE WAVE = ONE STRIP.  A wave owns KS = 6 output columns of one image and walks DOWN the image, one output row per step.
 //     It shares nothing with the other waves of its workgroup but the read-only constants: no barrier after the prologue,
-//     no lock step -- the twelve waves of a CU (3 workgroups x 4) drift apart and the matrix pipe, the vector ALU and the LDS
-//     work for different waves at the same time.
+//     no lock step -- the eight waves of a CU (S5_WGS = 2 workgroups x 4) drift apart and the matrix pipe, the vector ALU and
+//     the LDS work for different waves at the same time.
 //   * NO VERTICAL HALO.  A step brings in 4 new input rows (+ the one it shares with the previous step), computes the TWO new
 //     conv1 rows, and every depthwise output is accumulated IN REGISTERS as its three input rows arrive: a conv1 row is read
 //     from LDS once (3 taps per output column) and added into the three depthwise rows it belongs to; a pointwise row likewise
-//     feeds the stride-2 depthwise row above and below it.  LDS holds line buffers of two rows, not patches: 12 KB per wave.
-//     conv1 is computed on 11 / 8 = 1.38x the pixels (horizontal halo only; the 4 x 8 patches of stem4: 1.63x), depthwise 1
-//     and the pointwise on 9 / 8 (1.20x).
+//     feeds the stride-2 depthwise row above and below it.  LDS holds line buffers of two rows, not patches: 16.8 KB per wave.
+//     conv1 is computed on CXW / 2 KS = 15 / 12 = 1.25x the pixels (horizontal halo only; the 4 x 8 patches of stem4: 1.63x),
+//     depthwise 1 and the pointwise on PXW / 2 KS = 13 / 12 (1.08x).
 //   * Two start-up steps per strip (their output row is dropped) fill the accumulators: 50 steps for 48 output rows.
 //
 // Shapes: H % 4 == 0 and W % 4 == 0 (SAME padding then pads bottom / right only in both stride-2 layers), as stem4.
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
             wave_order();
             if (s + 1 < i1) load_rows(s + 1);        // in flight for the whole step
 
-            // ---- conv1: the two new rows (2 s + 2, 2 s + 3) x 11 columns, straight from the window ----
+            // ---- conv1: the two new rows (2 s + 2, 2 s + 3) x CXW = 15 columns, straight from the window ----
             const int cr0 = 2 * s + 2;
             // rows of this step that lie outside their maps (SAME padding: they must read as zero downstream)
             {
@@ -476,6 +476,9 @@ int launch_stem5_stream(const void* x, int x_is_u8, const void* cw4, const float
     // images of 192 x 192; a larger batch goes as several launches over ranges of images
     const long long per_img = (long long)h * w * 12;
     HSEFR_REQUIRE(per_img < (1ll << 31) - 64, HSEFR_ERR_UNSUPPORTED, "stem5_stream: one %dx%d image exceeds the 2 GB a launch addresses", h, w);
+    // the OUTPUT is addressed through one buffer resource per image (OH2 x OW2 x 256 B = h w 16 B) with the same 2^31 marker for
+    // masked stores: an image whose map reaches 2 GB would put the marker INSIDE the resource
+    HSEFR_REQUIRE((long long)h * w * 16 < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "stem5_stream: the %dx%d image's output map exceeds 2 GB", h, w);
     if (n == 0) return HSEFR_OK;
     const long long n_max = ((1ll << 31) - 64 - 1) / per_img;
     if (n > n_max) {

@@ -156,9 +156,14 @@ class Engine:
         return outs
 
     def forward_all_layers(self, x) -> None:
-        """Run every op (no fetch pruning); intermediate buffers can then be read with layer_output."""
+        """Run every op of the BULK plan (no fetch pruning); intermediate buffers can then be read with layer_output.  A debug
+        entry: the activation workspace holds one chunk (bulk_chunk), so at most `self.chunk` images -- more would need the
+        layer buffers of several chunks at once."""
         if x.device != self.device:
             raise ValueError("engine input is on %s but the engine was created on %s" % (x.device, self.device))
+        if int(x.shape[0]) > self.chunk:
+            raise ValueError("forward_all_layers: batch %d outside [0, %d] (the workspace holds one chunk of bulk_chunk images; "
+                             "create the engine with a larger bulk_chunk to inspect more)" % (int(x.shape[0]), self.chunk))
         with self._torch.cuda.device(self.device):
             _lib.check(_lib.lib().hsefr_engine_forward(self._h, x.data_ptr(), int(x.shape[0]), None, None, None,
                                                        _lib.current_stream_ptr()), "hsefr_engine_forward")
@@ -168,6 +173,8 @@ class Engine:
         right after the op ran and before a later op recycled the buffer.  A layer whose result is stored as split
         rows for the GEMM behind it (Layer.out_split) is decoded back to fp32 values."""
         torch = self._torch
+        if not 0 <= int(n) <= self.chunk:
+            raise ValueError("layer_output: n = %d outside [0, %d] (one chunk of bulk_chunk images)" % (int(n), self.chunk))
         L = self.plan.layers[layer_index]
         out = torch.empty((n,) + tuple(L.out_shape), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
@@ -197,33 +204,44 @@ class Engine:
         """The same read-and-clear, asynchronous: the flag lands in a PINNED host int32 (address given) when the current
         stream reaches this point; the caller waits on an event of its own before reading it.  Nothing here waits for the device
         (hsefr_engine_input_overflow_async only enqueues the copy and the clear)."""
-        # (the flag of the engine the LAST forward ran on: callers pair every forward with one read; input_overflow() reads both)
+        # (the flag of the engine the LAST forward ran on: callers pair every forward with one read, and a forward runs on one
+        # handle only -- chunked forwards never take the small plan; input_overflow() reads both.  A flag left on the OTHER handle
+        # by an unpaired earlier forward stays there until that handle's next read: it is never lost, only late)
         with self._torch.cuda.device(self.device):
             _lib.check(_lib.lib().hsefr_engine_input_overflow_async(self._last or self._h, ctypes.cast(ctypes.c_void_p(pinned_host_int_ptr), ctypes.POINTER(ctypes.c_int)),
                                                                     _lib.current_stream_ptr()), "hsefr_engine_input_overflow_async")
 
     # -- small batches as one hipGraph launch ---------------------------------------------------
     def set_graph_batch(self, max_n: int) -> None:
-        """Forwards of at most max_n images replay a captured hipGraph (default 0 = off: no faster on the device).  With a
-        small-batch plan the graphs belong to it (max_n is then capped at small_batch)."""
+        """Forwards of at most max_n images replay a captured hipGraph (default 0 = off: no faster on the device).  The setting
+        goes to BOTH plans (each capped at what its handle was created for: one chunk / small_batch), so a forward replays
+        graphs whichever plan its `latency` flag selects."""
+        max_n = int(max_n)
+        if max_n < 0:
+            raise ValueError("set_graph_batch: max_n = %d" % max_n)
+        _lib.check(_lib.lib().hsefr_engine_set_graph_batch(self._h, min(max_n, self.chunk)))
         if self._hs:
-            _lib.check(_lib.lib().hsefr_engine_set_graph_batch(self._hs, min(int(max_n), self.small_batch)))
-        else:
-            _lib.check(_lib.lib().hsefr_engine_set_graph_batch(self._h, int(max_n)))
+            _lib.check(_lib.lib().hsefr_engine_set_graph_batch(self._hs, min(max_n, self.small_batch)))
 
     def graph_launches(self) -> int:
-        return int(_lib.lib().hsefr_engine_graph_launches(self._hs or self._h))
+        """Graph replays so far, both plans together."""
+        return int(_lib.lib().hsefr_engine_graph_launches(self._h)) + (int(_lib.lib().hsefr_engine_graph_launches(self._hs)) if self._hs else 0)
 
     # -- profiling -----------------------------------------------------------------------------
     def set_profiling(self, depth: int) -> None:
-        """depth > 0: keep HIP-event timings of the last `depth` forwards (ring); 0: off."""
+        """depth > 0: keep HIP-event timings of the last `depth` forwards (ring) of EACH plan; 0: off.  A forward of more than
+        bulk_chunk images is several C forwards: one ring slot per chunk."""
         _lib.check(_lib.lib().hsefr_engine_set_profiling(self._h, int(depth)))
+        if self._hs:
+            _lib.check(_lib.lib().hsefr_engine_set_profiling(self._hs, int(depth)))
 
-    def profiled_calls(self) -> int:
-        return int(_lib.lib().hsefr_engine_profiled_calls(self._h))
+    def profiled_calls(self, small: bool = False) -> int:
+        return int(_lib.lib().hsefr_engine_profiled_calls(self._hs if small and self._hs else self._h))
 
-    def op_times_ms(self, slot: int = 0) -> List[float]:
-        n = len(self.plan.layers)
+    def op_times_ms(self, slot: int = 0, small: bool = False) -> List[float]:
+        """Per-op times of ring slot `slot`: of the bulk plan, or (small=True) of the small-batch plan's own layer list."""
+        h, plan = (self._hs, self.small_plan) if small and self._hs else (self._h, self.plan)
+        n = len(plan.layers)
         arr = (ctypes.c_float * n)()
-        _lib.check(_lib.lib().hsefr_engine_op_times_ms(self._h, int(slot), arr, n))
+        _lib.check(_lib.lib().hsefr_engine_op_times_ms(h, int(slot), arr, n))
         return list(arr)

@@ -129,7 +129,8 @@ def single_image_per_class_splits(y: np.ndarray, n_splits: int = 10, random_stat
     ``n_splits`` splits; in each, every class's sample indices are shuffled and the FIRST one is the gallery image, the rest
     are probes.  The reference seeds NumPy's global generator once (``np.random.seed(random_state)``) and shuffles class by
     class in ``np.unique`` order, split after split; a private ``RandomState(random_state)`` draws the same stream without
-    touching the caller's global state -- the splits are bit-equal (tests/golden/single_image_splits.npz)."""
+    touching the caller's global state -- the splits are bit-equal (tests/golden/protocols.npz, written by
+    tests/golden/make_golden.py from the reference's literal globally seeded loop)."""
     y = np.asarray(y)
     inds = np.arange(len(y))
     rs = np.random.RandomState(random_state)

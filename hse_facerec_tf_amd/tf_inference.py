@@ -356,7 +356,10 @@ class TensorFlowInference:
 
 def get_files_of_subjects(db_dir, subjects_file):
     """The 'LFW and YTF concatenation' branch of facerec_test.py:378-380 (README.md:13's LFW-and-YTF row): only the
-    sub-directories named in ``subjects_file`` (lfw_ytf_classes.txt: one subject per line), in the file's order."""
+    sub-directories named in ``subjects_file`` (lfw_ytf_classes.txt: one subject per line), in the file's order.  Inside a
+    subject the file names are SORTED, deliberately (as in get_files): the reference takes them in os.walk order, which is the
+    directory's on-disk order and differs from machine to machine.  The rows of X / y can therefore be ordered differently from a
+    features_file cache the reference wrote on another file system; the labels travel with the rows, so every accuracy is unaffected."""
     with open(subjects_file) as fh:
         subjects = [line.rstrip('\n') for line in fh]
     return [[d, os.path.join(d, f)] for d in subjects if d

@@ -351,7 +351,7 @@ int hsefr_stem4_fused(const void* x, int x_is_u8, const void* cw4, const float* 
                       const float* wd2, const float* d2scale, const float* d2shift, float* y, int* d_overflow, int n, int h, int w,
                       int in_log2, int a_log2, int act, hsefr_stream_t stream);
 /* The same four layers, same operands, same arithmetic (the same bits as hsefr_stem4_fused) as a STREAMING kernel (csrc/stem5_stream.hip,
- * round 4): a wave owns 4 output columns of an image and walks down it one output row per step, every depthwise output accumulated in
+ * round 4): a wave owns 6 output columns of an image and walks down it one output row per step, every depthwise output accumulated in
  * registers as its input rows arrive -- no vertical halo, no barriers, twelve independent waves per CU.  What the engine runs for
  * HSEFR_OP_STEM3_F16S on inputs whose edges are multiples of 4. */
 int hsefr_stem5_stream(const void* x, int x_is_u8, const void* cw4, const float* cdescale, const float* conv_shift, const float* wd1,

@@ -1,5 +1,6 @@
 """GPU parity, end to end: the engine behind the reference's API vs golden vectors and the live
-oracle.  Bar (north_star): embeddings within 1e-4 relative, fp32.  `rel` is max|a-b| / max|b|."""
+oracle.  Bar (north_star): embeddings within 1e-4 relative, fp32 -- asserted ELEMENT-WISE by `fp32_grade` on every element
+above 1e-3 of the tensor's maximum, next to a max-norm bar of 1e-5 (`rel` is max|a-b| / max|b|; observed 2e-6 .. 6e-6)."""
 import os
 
 import numpy as np
@@ -12,12 +13,27 @@ from conftest import GOLDEN, MODEL_PB, TEST_IMAGE
 
 pytestmark = pytest.mark.gpu
 
-BAR = 1e-4
+BAR = 1e-4            # north_star: within 1e-4 relative -- per element (fp32_grade)
+BAR_MAXNORM = 1e-5    # max|a-b| / max|b| of the fp32-grade modes (a regression of one decade shows)
 FETCH = ["global_pooling/Mean:0", "age_pred/Softmax:0", "gender_pred/Sigmoid:0"]
 
 
 def rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+def fp32_grade(a, b, what=""):
+    """The bar as BASELINE.json words it: every element above 1e-3 of the maximum within 1e-4 RELATIVE of the oracle's, and the
+    whole tensor within 1e-5 of its scale (elements below 1e-3 of the maximum are covered by the max-norm only: their relative
+    error is their absolute error over a near-zero value)."""
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = np.abs(b).max() + 1e-30
+    err = np.abs(a - b)
+    assert err.max() / scale < BAR_MAXNORM, "%s: max-norm error %.3g" % (what, err.max() / scale)
+    big = np.abs(b) > 1e-3 * scale
+    worst = float((err[big] / np.abs(b)[big]).max())
+    assert worst < BAR, "%s: element-wise relative error %.3g" % (what, worst)
 
 
 @pytest.fixture(scope="module")
@@ -47,9 +63,9 @@ def test_engine_matches_golden_for_every_stem_fusion(torch_, size, stem_fusion):
     eng = engine.Engine(plan, max_batch=4)
     x = np.random.RandomState(123).uniform(-128, 128, (n, size, size, 3)).astype(np.float32)
     out = eng.forward(torch_.from_numpy(x).cuda(), (0, 1, 2))
-    assert rel(out["features"].cpu().numpy(), z["feat_%d" % size]) < BAR
-    assert rel(out["age_probs"].cpu().numpy(), z["age_%d" % size]) < BAR
-    assert rel(out["gender"].cpu().numpy(), z["gender_%d" % size]) < BAR
+    fp32_grade(out["features"].cpu().numpy(), z["feat_%d" % size], "features %d" % size)
+    fp32_grade(out["age_probs"].cpu().numpy(), z["age_%d" % size], "age_probs %d" % size)
+    fp32_grade(out["gender"].cpu().numpy(), z["gender_%d" % size], "gender %d" % size)
     eng.close()
 
 
@@ -74,7 +90,7 @@ def test_block_fusion_is_bit_identical_to_the_unfused_plan(torch_, size):
         eng = engine.Engine(plan, max_batch=4)
         outs[mode] = {k: v.clone() for k, v in eng.forward(x, (0, 1, 2)).items()}
         eng.close()
-        assert rel(outs[mode]["features"].cpu().numpy(), z["feat_%d" % size]) < BAR
+        fp32_grade(outs[mode]["features"].cpu().numpy(), z["feat_%d" % size], "features %d" % size)
     for mode in ("auto", "all"):
         for k in outs["none"]:
             assert torch_.equal(outs[mode][k], outs["none"][k]), (mode, k)
@@ -83,7 +99,7 @@ def test_block_fusion_is_bit_identical_to_the_unfused_plan(torch_, size):
     assert any(L.in_split for L in plan.layers)
     eng = engine.Engine(plan, max_batch=4)
     dflt = eng.forward(x, (0, 1, 2))
-    assert rel(dflt["features"].cpu().numpy(), z["feat_%d" % size]) < BAR
+    fp32_grade(dflt["features"].cpu().numpy(), z["feat_%d" % size], "features %d" % size)
     for k in outs["none"]:
         assert rel(dflt[k].cpu().numpy(), outs["none"][k].cpu().numpy()) < 1e-5, k
     eng.close()
@@ -102,13 +118,9 @@ def test_engine_matches_golden_synthetic(torch_, size, fuse, pw_math):
     eng = engine.Engine(plan, max_batch=4)
     x = np.random.RandomState(123).uniform(-128, 128, (n, size, size, 3)).astype(np.float32)
     out = eng.forward(torch_.from_numpy(x).cuda(), (0, 1, 2))
-    assert rel(out["features"].cpu().numpy(), z["feat_%d" % size]) < BAR
-    assert rel(out["age_probs"].cpu().numpy(), z["age_%d" % size]) < BAR
-    assert rel(out["gender"].cpu().numpy(), z["gender_%d" % size]) < BAR
-    # per-element relative error where the feature is not tiny
-    f, g = out["features"].cpu().numpy().astype(np.float64), z["feat_%d" % size].astype(np.float64)
-    big = np.abs(g) > 1e-3 * np.abs(g).max()
-    assert (np.abs(f - g)[big] / np.abs(g)[big]).max() < 1e-3
+    fp32_grade(out["features"].cpu().numpy(), z["feat_%d" % size], "features %d" % size)
+    fp32_grade(out["age_probs"].cpu().numpy(), z["age_%d" % size], "age_probs %d" % size)
+    fp32_grade(out["gender"].cpu().numpy(), z["gender_%d" % size], "gender %d" % size)
     eng.close()
     with pytest.raises(RuntimeError):
         eng.forward(torch_.from_numpy(x).cuda())
@@ -189,7 +201,8 @@ def test_every_layer_matches_the_oracle(torch_):
             y = ops.softmax(src.reshape(src.shape[0], -1))
         acts[i] = y
         w = np.asarray(want[i]).reshape(y.shape)
-        assert rel(y.cpu().numpy(), w) < BAR, "layer %d (%s)" % (i, L.name)
+        # (max-norm only: a layer's small outputs are differences of large sums, the embedding's are means of 36 pixels)
+        assert rel(y.cpu().numpy(), w) < BAR_MAXNORM, "layer %d (%s)" % (i, L.name)
 
 
 def test_tensorflow_inference_dropin_on_the_reference_image(torch_):
@@ -201,14 +214,15 @@ def test_tensorflow_inference_dropin_on_the_reference_image(torch_):
     assert (tfi.w, tfi.h) == (224, 224)
     f = tfi.extract_features(TEST_IMAGE)
     assert f.shape == (1024,) and f.dtype == np.float32
-    assert rel(f, z["feat_224"]) < BAR
+    fp32_grade(f, z["feat_224"], "z['feat_224']")
     x = tfi.preprocess_image(TEST_IMAGE, False)
     assert x.shape == (224, 224, 3) and x.dtype == np.float64
     tfi.close_session()
     t192 = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(192, 192))
-    assert rel(t192.extract_features(TEST_IMAGE), z["feat_192"]) < BAR
+    fp32_grade(t192.extract_features(TEST_IMAGE), z["feat_192"], "z['feat_192']")
     fb = t192.extract_files([TEST_IMAGE, TEST_IMAGE, TEST_IMAGE], batch=2)
-    assert fb.shape == (3, 1024) and rel(fb[2], z["feat_192"]) < BAR
+    assert fb.shape == (3, 1024)
+    fp32_grade(fb[2], z["feat_192"], "extract_files")
     assert np.array_equal(fb[0], fb[1]) and np.array_equal(fb[0], fb[2])
     with pytest.raises(ValueError):            # wrong spatial size fed, like sess.run's shape check
         t192.extract_batch(torch_.zeros((1, 224, 224, 3), device="cuda"))
@@ -225,13 +239,14 @@ def test_facial_image_processing_dropin(torch_):
     img = opl.imread_rgb(TEST_IMAGE)
     age, gender, feats = fip.age_gender_fun(img)
     assert abs(age - float(z["ag_res_age"])) < 1e-2
-    assert rel(gender, z["ag_gender"]) < BAR and rel(feats, z["ag_feat"]) < BAR
+    fp32_grade(gender, z["ag_gender"], "gender")
+    fp32_grade(feats, z["ag_feat"], "features")
     assert gender.shape == (1,) and feats.shape == (1024,)
     bgr = np.ascontiguousarray(img[..., ::-1])
     bboxes, points, ages, genders, ffs = fip.process_image(bgr, bounding_boxes=z["boxes"])
     assert len(bboxes) == 4 and bboxes[3][0] == 0
-    assert rel(np.asarray(ffs), z["crop_feats"]) < BAR
-    assert rel(np.asarray(genders), z["crop_genders"]) < BAR
+    fp32_grade(np.asarray(ffs), z["crop_feats"], "z['crop_feats']")
+    fp32_grade(np.asarray(genders), z["crop_genders"], "z['crop_genders']")
     assert np.abs(np.asarray(ages) - z["crop_ages"]).max() < 1e-2
     with pytest.raises(NotImplementedError):
         fip.process_image(bgr)                 # mtcnn_detector=False and no detector injected
@@ -257,7 +272,7 @@ def test_batch_256_properties_at_full_size(torch_):
     assert torch_.equal(again, full)                                                    # deterministic
     rows = [0, 131, 255]
     ref = tfo.GraphOracle(MODEL_PB, np.float64).run(FETCH[0], {"input_1:0": x[rows].cpu().numpy()})
-    assert rel(full[rows].cpu().numpy(), ref) < BAR
+    fp32_grade(full[rows].cpu().numpy(), ref, "ref")
     tfi.close_session()
 
 
@@ -288,7 +303,7 @@ def test_batch_512_properties_at_full_size(torch_):
     rows = [0, 257, 511]
     ref = tfo.GraphOracle(MODEL_PB, np.float64).run(list(FETCH), {"input_1:0": x[rows].cpu().numpy()})
     for k, r in zip(("features", "age_probs", "gender"), ref):
-        assert rel(full[k][rows].cpu().numpy(), r.reshape(3, -1)) < BAR, k
+        fp32_grade(full[k][rows].cpu().numpy(), r.reshape(3, -1), k)
     eng.close()
 
 
@@ -308,7 +323,7 @@ def test_vgg2_mobilenet_shaped_graph_through_the_reference_registry(torch_, tmp_
     got = tfi.extract_batch(x)
     want = tfo.GraphOracle(tfo.parse_graphdef(data), np.float64).run(
         "reshape_1/Reshape:0", {"input_1:0": x[:2], "conv1_bn/keras_learning_phase:0": 0}).reshape(2, -1)
-    assert rel(got[:2], want) < 1e-4
+    fp32_grade(got[:2], want, "vgg2_mobilenet-shaped graph")
     folded = TensorFlowInference(MODEL_PB, 'input_1:0', 'global_pooling/Mean:0', input_size=(192, 192), max_batch=8)
     assert rel(got, folded.extract_batch(x)) < 1e-5
     # the file-path API of the reference on its demo image (preprocess_image + one run, facerec_test.py:114-122)

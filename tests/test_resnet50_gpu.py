@@ -42,7 +42,13 @@ def close_bf16(got, want):
     (2, 12, 12, 64, 128, 3, 2, False, 1),
     # the window 3x3 kernel (csrc/conv3x3_win_bf16.hip; maps at least 40 wide): its four tile shapes, ragged image groups, residual
     (2, 6, 40, 64, 128, 3, 1, True, 1), (1, 4, 48, 128, 256, 3, 1, False, 1), (3, 2, 44, 64, 64, 3, 1, False, 0),
-    (1, 28, 56, 64, 64, 3, 1, True, 1), (2, 5, 41, 192, 192, 3, 1, False, 1)])
+    (1, 28, 56, 64, 64, 3, 1, True, 1), (2, 5, 41, 192, 192, 3, 1, False, 1),
+    # the four-wave window 3x3 kernel (csrc/conv3x3_w2_bf16.hip, round 5): its three geometries (rows of <= 16 / 32 / 64 pixels),
+    # several channel slabs, residual, heights that are not a multiple of the tile's rows, columns dropped at the right edge,
+    # more tiles than workgroups (a persistent workgroup walks two tiles)
+    (2, 14, 14, 256, 256, 3, 1, False, 1), (3, 13, 12, 64, 128, 3, 1, True, 1), (1, 15, 16, 128, 128, 3, 1, False, 0),
+    (2, 28, 28, 128, 128, 3, 1, False, 1), (1, 9, 25, 64, 128, 3, 1, True, 1), (1, 30, 32, 64, 256, 3, 1, False, 1),
+    (2, 6, 50, 128, 64, 3, 1, True, 1), (1, 7, 64, 64, 192, 3, 1, False, 1), (260, 14, 14, 64, 128, 3, 1, False, 1)])
 def test_conv_bf16_vs_oracle(env, n, h, w, c, cout, k, s, res, act):
     torch, ops, resnet50 = env
     rs = np.random.RandomState(h * 7 + c + cout + k)
@@ -95,7 +101,8 @@ def test_conv_bf16_exact_integers(env):
     """Small integers are exact in bf16 and fp32: any im2col / fragment-map / swizzle mix-up shows as an exact mismatch."""
     torch, ops, resnet50 = env
     rs = np.random.RandomState(1)
-    for (n, h, w, c, cout, k, s) in [(1, 6, 5, 64, 64, 3, 1), (2, 8, 8, 128, 128, 1, 2), (1, 4, 4, 64, 128, 3, 1)]:
+    for (n, h, w, c, cout, k, s) in [(1, 6, 5, 64, 64, 3, 1), (2, 8, 8, 128, 128, 1, 2), (1, 4, 4, 64, 128, 3, 1),
+                                     (1, 14, 14, 128, 128, 3, 1), (1, 28, 28, 64, 128, 3, 1), (1, 8, 56, 64, 64, 3, 1)]:    # (conv3x3_w2)
         x = rs.randint(-2, 3, (n, h, w, c)).astype(np.float64)
         kern = rs.randint(-1, 2, (k, k, c, cout)).astype(np.float32)
         pad = (k - 1) // 2

@@ -19,8 +19,10 @@ from kbench_conv import LAYERS, B
 
 g = torch.Generator(device="cuda").manual_seed(0)
 WIN = os.environ.get("CD_WIN", "0") == "1"       # CD_WIN=1: the window 3x3 kernel (csrc/conv3x3_win_bf16.hip) instead
+W2 = os.environ.get("CD_W2", "0") == "1"         # CD_W2=1: the four-wave window kernel (csrc/conv3x3_w2_bf16.hip)
 _lib.check(_lib.lib().hsefr_debug_set(b"cd_off", 2))
 _lib.check(_lib.lib().hsefr_debug_set(b"w3_off", 2 if WIN else 1))
+_lib.check(_lib.lib().hsefr_debug_set(b"w2_off", 2 if W2 else 1))
 RB = int(os.environ.get("CD_RB", "0"))
 _lib.check(_lib.lib().hsefr_debug_set(b"cd_rb", RB))
 for name in sys.argv[1:] or ["c4_3x3", "c4_red", "c4_inc"]:
@@ -33,11 +35,19 @@ for name in sys.argv[1:] or ["c4_3x3", "c4_red", "c4_inc"]:
     for _ in range(5):
         ops.conv_bf16(x, w, sc, sh, k, k, stride=s, pad=k // 2, res=r)
     torch.cuda.synchronize()
-    buf = np.zeros(256 * 12 * 8 - (2 if WIN else 1), np.uint64)
-    _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
-    b = np.concatenate([buf, [0] * (2 if WIN else 1)]).astype(np.float64).reshape(256, 12, 8)
-    for role, sl, names in (("MFMA waves", slice(0, 8), ["ds_read + mfma issue", "step barrier", "epilogue", "tile barrier"]),
-                            ("loader waves", slice(8, 12), ["DMA issue", "vmcnt wait", "step barrier", "tile barrier"])):
+    if W2:
+        buf = np.zeros(256 * 8 * 8, np.uint64)
+        _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        b = buf.astype(np.float64).reshape(256, 8, 8)
+        roles = (("MFMA waves", slice(0, 4), ["ds_read + mfma issue", "step barrier", "epilogue"]),
+                 ("loader waves", slice(4, 8), ["DMA issue", "vmcnt wait", "step barrier"]))
+    else:
+        buf = np.zeros(256 * 12 * 8 - (2 if WIN else 1), np.uint64)
+        _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        b = np.concatenate([buf, [0] * (2 if WIN else 1)]).astype(np.float64).reshape(256, 12, 8)
+        roles = (("MFMA waves", slice(0, 8), ["ds_read + mfma issue", "step barrier", "epilogue", "tile barrier"]),
+                 ("loader waves", slice(8, 12), ["DMA issue", "vmcnt wait", "step barrier", "tile barrier"]))
+    for role, sl, names in roles:
         rr = b[:, sl, :].reshape(-1, 8)
         rr = rr[rr[:, 7] > 0]
         print("%s %s: %d waves, lifetime %.0f cycles (min %.0f max %.0f), %.1f steps -> %.0f cycles per step" %

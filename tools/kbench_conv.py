@@ -58,6 +58,7 @@ def main():
         flops = 2.0 * B * oh * oh * cout * k * k * c
         knob("cd_off", 1)
         knob("w3_off", 1)
+        knob("w2_off", 1)
         t_old = timeit(fn)
         knob("cd_off", 2)
         out = "%-8s old %6.1f us (%4.0f TF) | dma" % (name, t_old, flops / t_old / 1e6)
@@ -71,8 +72,16 @@ def main():
         if k == 3 and s == 1:
             knob("w3_off", 2)
             out += "  | window %6.1f" % timeit(fn)
+        if k == 3 and s == 1:
+            knob("w3_off", 1)
+            knob("w2_off", 2)
+            try:
+                out += "  | w2 %6.1f" % timeit(fn)
+            except Exception as e:          # (shapes the four-wave window kernel does not cover: cout % 128 on the narrow maps)
+                out += "  | w2   n/a"
         knob("cd_off", 0)
         knob("w3_off", 0)
+        knob("w2_off", 0)
         t_prod = timeit(fn)
         out += "  | auto %6.1f us (%4.0f TF) | product dispatch %6.1f us" % (t, flops / t / 1e6, t_prod)
         print(out, flush=True)
