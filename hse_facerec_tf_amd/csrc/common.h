@@ -99,6 +99,18 @@ __device__ __forceinline__ void bstore16(hsefr_f32x4 v, __amdgpu_buffer_rsrc_t r
     hsefr_store_guard();
 }
 
+// fp32 -> bf16, round to nearest even, on gfx950's own instruction (v_cvt_pk_bf16_f32: two values per instruction).  Until round 5
+// every bf16 epilogue rounded with integer arithmetic on the bits -- (u + 0x7FFF + ((u >> 16) & 1)) >> 16: four vector
+// instructions per value, and the bf16 convolutions turned out to be EPILOGUE-bound where their K loop is short (the 1x1
+// "increase" layers: ~600 vector instructions per thread and 128 x 128 tile).  Same result for every finite input (NaNs stay NaNs
+// here; the integer form could turn one into an infinity: MI355X guide, correctness boundaries).
+typedef __bf16 hsefr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hsefr_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned hsefr_bf16_bits(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned hsefr_pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(hsefr_f32x2{lo, hi}, hsefr_bf16x2));
+}
+
 // Sweep direction.  Every kernel walks its output (and so its input) in one address order; consecutive layers sweep in
 // OPPOSITE orders, so that a layer starts on the bytes its producer wrote last -- the ones still in the 256 MiB
 // Infinity Cache -- instead of chasing an LRU that evicts every line just before it is needed (a 302 MB activation
@@ -157,6 +169,9 @@ int launch_conv_bf16(const void* x, const void* wt, const float* scale, const fl
 int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
                         long long P, int K, int cout, int act, hipStream_t s);
 bool conv1x1_bf16_enabled(bool has_res, int k, int cout);
+int launch_conv1x1_proj_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* x2, const void* wt2,
+                             const float* scale2, const float* shift2, void* y, int n, int oh, int ow, int K, int cout, int k2, int stride,
+                             int h2, int w2, int act, hipStream_t s);
 int launch_stem7x7_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h,
                         int w, int oh, int ow, int act, hipStream_t s);
 int mtcnn_post_capacity();

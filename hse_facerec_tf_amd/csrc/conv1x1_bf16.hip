@@ -14,6 +14,13 @@
 //   * the tile's RESIDUAL chunks are requested at the tile's first step (registers) and are long there when the epilogue
 //     needs them; the epilogue transposes through a wave-private LDS scratch (the stage just consumed) and leaves as
 //     16-byte stores of whole 128-B row segments.
+//
+// PROJ (round 5): the first block of a ResNet stage adds a PROJECTED shortcut -- a second 1x1 convolution (stride 1 or 2, its own
+// BatchNorm) of the block's input.  As two launches the projection's [P, Cout] tensor is written and read back (205 MB of the
+// 719 MB the pair moves in stage 2); here the tile's K loop simply starts with the projection's K-tiles (activation rows GATHERED
+// from the strided input pixels, the projection's weight rows), its result is rounded to bf16 where the tensor used to be
+// stored -- the same rounding points: oracle/resnet50.py -- and parked in 32 registers per lane, and the main product's epilogue
+// adds it:   Y = act( bf16( s W x + b ) + bf16( s2 W2 x2[stride] + b2 ) ).
 #include <type_traits>
 
 #include "common.h"
@@ -27,11 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 
-__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even (inputs are finite)
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (u16)(u >> 16);
-}
+__device__ __forceinline__ u16 f2bf(float f) { return (u16)hsefr_bf16_bits(f); }      // round-to-nearest-even (common.h)
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ int swzb(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7)); }
 
@@ -43,18 +46,28 @@ __device__ __forceinline__ void bstore8(bf16x8 v, __amdgpu_buffer_rsrc_t r, unsi
     hsefr_store_guard();
 }
 
-template <int BM, int BN, int OCC, bool RES, int ACT>
+struct ProjParams {        // the projected shortcut of PROJ kernels
+    const u16* x2;         // [N, H2, W2, K2] bf16: the block's input
+    const u16* wt2;        // [Cout][K2]
+    const float* scale2;   // [Cout]
+    const float* shift2;   // [Cout]
+    int K2, stride, H2, W2, OH, OW;
+    long long x2_bytes;
+};
+
+template <int BM, int BN, int OCC, bool RES, int ACT, bool PROJ = false>
 __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __restrict__ x, const u16* __restrict__ wt,
                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const u16* __restrict__ res, u16* __restrict__ y, long long P,
                                                                 int K, int Cout, unsigned tiles_n, unsigned total_tiles,
-                                                                int reverse) {
+                                                                int reverse, ProjParams pj) {
+    static_assert(!(PROJ && RES), "the projected shortcut takes the residual's place");
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int AP = BM / 32, BP = BN / 32;
     static_assert(WN == 64 || WN == 32, "wave tile width");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + BN) * 128];
-    __shared__ __attribute__((aligned(16))) float Et[2][2][BN];   // [tile parity][scale | shift][n]
+    __shared__ __attribute__((aligned(16))) float Et[2][PROJ ? 4 : 2][BN];   // [tile parity][scale | shift (| scale2 | shift2)][n]
     auto As = [&](int st) { return &smem[st][0]; };
     auto Bs = [&](int st) { return &smem[st][BM * 128]; };
 
@@ -62,19 +75,24 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int srow = tid >> 3, sch = tid & 7;
-    const int KT = K / 64;
+    const int KT2 = PROJ ? pj.K2 / 64 : 0;              // a tile's K loop: the projection's K-tiles first, then the main product's
+    const int KT = K / 64 + KT2;
     if (blockIdx.x >= total_tiles) return;
     const unsigned ntile = (total_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const unsigned nsteps = ntile * KT;
     const unsigned rowbytes = (unsigned)K * 2u;
     const unsigned voff = (unsigned)srow * rowbytes + 16u * sch;
+    const unsigned rowbytes2 = PROJ ? (unsigned)pj.K2 * 2u : 0u;
+    const unsigned voff2b = (unsigned)srow * rowbytes2 + 16u * sch;          // projection weight rows
+    unsigned avoff2[PROJ ? AP : 1];                                          // gathered projection input rows of the prefetch cursor's tile
 
     auto tile_origin = [&](unsigned i, long long& mm0, int& nn0) {
         const unsigned lt = xcd_remap_dir(blockIdx.x + (i < ntile ? i : ntile - 1) * gridDim.x, total_tiles, reverse);
         mm0 = (long long)(lt / tiles_n) * BM;
         nn0 = (lt % tiles_n) * BN;
     };
-    __amdgpu_buffer_rsrc_t ra_rsrc, rb_rsrc;
+    __amdgpu_buffer_rsrc_t ra_rsrc, rb_rsrc, rb2_rsrc;
+    const __amdgpu_buffer_rsrc_t ra2_rsrc = make_rsrc(PROJ ? pj.x2 : nullptr, PROJ ? pj.x2_bytes : 0);
     unsigned pf_i = 0;
     int pf_kt = 0;
     auto setup_rsrc = [&](unsigned i) {
@@ -83,11 +101,32 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
         tile_origin(i, mm0, nn0);
         ra_rsrc = make_rsrc(x + mm0 * K, (P - mm0) * (long long)rowbytes);
         rb_rsrc = make_rsrc(wt + (long long)nn0 * K, (long long)(Cout - nn0) * rowbytes);
+        if (PROJ) {
+            rb2_rsrc = make_rsrc(pj.wt2 + (long long)nn0 * pj.K2, (long long)(Cout - nn0) * rowbytes2);
+            const unsigned ohow = (unsigned)(pj.OH * pj.OW);
+#pragma unroll
+            for (int p = 0; p < AP; ++p) {
+                const long long m = mm0 + srow + 32 * p;                 // output pixel -> the input pixel it is projected from
+                const unsigned mu = (unsigned)(m < P ? m : 0);
+                const unsigned n = mu / ohow, rem = mu - n * ohow;
+                const unsigned oh = rem / (unsigned)pj.OW, ow = rem - oh * (unsigned)pj.OW;
+                const unsigned pix = (n * (unsigned)pj.H2 + oh * (unsigned)pj.stride) * (unsigned)pj.W2 + ow * (unsigned)pj.stride;
+                avoff2[PROJ ? p : 0] = m < P ? pix * rowbytes2 + 16u * sch : 0x80000000u;
+            }
+        }
     };
     bf16x8 ra[2][AP], rb[2][BP];
     auto gload = [&](auto SET) {
         constexpr int S = decltype(SET)::value;
-        const unsigned so = (unsigned)pf_kt * 128u;
+        if (PROJ && pf_kt < KT2) {                                       // (wave-uniform)
+            const unsigned so = (unsigned)pf_kt * 128u;
+#pragma unroll
+            for (int p = 0; p < AP; ++p) ra[S][p] = bload8(ra2_rsrc, avoff2[PROJ ? p : 0], so);
+#pragma unroll
+            for (int p = 0; p < BP; ++p) rb[S][p] = bload8(rb2_rsrc, voff2b, so + (unsigned)(32 * p) * rowbytes2);
+            return;
+        }
+        const unsigned so = (unsigned)(pf_kt - KT2) * 128u;
 #pragma unroll
         for (int p = 0; p < AP; ++p) ra[S][p] = bload8(ra_rsrc, voff, so + (unsigned)(32 * p) * rowbytes);
 #pragma unroll
@@ -139,15 +178,17 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
     const int erow = lane / CPR, ech = lane % CPR;
     const unsigned yvoff = ((unsigned)(wm * WM + erow) * (unsigned)Cout + (unsigned)(wn * WN + 8 * ech)) * 2u;
     bf16x8 rres[RES ? MI * (32 / RPI) : 1];
+    unsigned pk[PROJ ? NI : 1][PROJ ? MI : 1][PROJ ? 8 : 1];      // the projected shortcut of the tile, bf16 pairs in the accumulators' layout
 
     auto step = [&](auto PAR) {
         constexpr int PB = decltype(PAR)::value;
         const bool first = ckt == 0;
         f32x4 ec;
-        const bool fill = first && tid < BN / 2;
+        const bool fill = first && tid < (PROJ ? BN : BN / 2);
+        const int etab = tid / (BN / 4), ej = tid % (BN / 4);      // table 0..3 = scale | shift | scale2 | shift2, float4 index
         if (fill) {
-            const int j = tid < BN / 4 ? tid : tid - BN / 4;
-            ec = *(const f32x4*)((tid < BN / 4 ? scale : shift) + n0 + 4 * j);
+            const float* src = etab == 0 ? scale : etab == 1 ? shift : etab == 2 ? pj.scale2 : pj.shift2;
+            ec = *(const f32x4*)(src + n0 + 4 * ej);
         }
         if (RES && first) {      // this tile's residual chunks, in the layout the epilogue stores in (uniform branch)
             const __amdgpu_buffer_rsrc_t rr = make_rsrc(res + m0 * Cout + n0, ((P - m0) * Cout - n0) * 2ll);
@@ -172,10 +213,30 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
         }
         swrite(std::integral_constant<int, 1 - PB>(), 1 - PB);
-        if (fill) *(f32x4*)(&Et[ci & 1][tid < BN / 4 ? 0 : 1][4 * (tid < BN / 4 ? tid : tid - BN / 4)]) = ec;
+        if (fill) *(f32x4*)(&Et[ci & 1][etab][4 * ej]) = ec;
         __syncthreads();
         advance_prefetch();
-        if (++ckt == KT) {
+        ++ckt;
+        if (PROJ && ckt == KT2) {
+            // the projection is complete: scale2 / shift2, rounded to bf16 (where its tensor used to be stored), parked; the
+            // accumulators start again for the main product
+            const float* et = &Et[ci & 1][0][0];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = ni * 32 + 8 * g + 4 * lh;
+                        const f32x4 sc = *(const f32x4*)(et + 2 * BN + wn * WN + ch), sh = *(const f32x4*)(et + 3 * BN + wn * WN + ch);
+                        pk[PROJ ? ni : 0][PROJ ? mi : 0][PROJ ? 2 * g : 0] =
+                            hsefr_pack_bf16x2(fmaf(acc[ni][mi][4 * g + 0], sc[0], sh[0]), fmaf(acc[ni][mi][4 * g + 1], sc[1], sh[1]));
+                        pk[PROJ ? ni : 0][PROJ ? mi : 0][PROJ ? 2 * g + 1 : 0] =
+                            hsefr_pack_bf16x2(fmaf(acc[ni][mi][4 * g + 2], sc[2], sh[2]), fmaf(acc[ni][mi][4 * g + 3], sc[3], sh[3]));
+                    }
+            zero_acc();
+        }
+        if (ckt == KT) {
             const float* et = &Et[ci & 1][0][0];
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + m0 * Cout + n0, ((P - m0) * Cout - n0) * 2ll);
             unsigned char* scr = &smem[PB][wave * 4096];       // stage PB: every wave is past its last read (barrier above)
@@ -193,6 +254,13 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
                         o.y = f2bf(fmaf(acc[ni][mi][4 * g + 1], sc[1], sh[1]));
                         o.z = f2bf(fmaf(acc[ni][mi][4 * g + 2], sc[2], sh[2]));
                         o.w = f2bf(fmaf(acc[ni][mi][4 * g + 3], sc[3], sh[3]));
+                        if (PROJ) {      // + the parked shortcut, activation, second rounding (the residual path of the plain kernel)
+                            const unsigned q0 = pk[PROJ ? ni : 0][PROJ ? mi : 0][PROJ ? 2 * g : 0], q1 = pk[PROJ ? ni : 0][PROJ ? mi : 0][PROJ ? 2 * g + 1 : 0];
+                            o.x = f2bf(apply_act<ACT>(bf2f(o.x) + __uint_as_float(q0 << 16)));
+                            o.y = f2bf(apply_act<ACT>(bf2f(o.y) + __uint_as_float(q0 & 0xFFFF0000u)));
+                            o.z = f2bf(apply_act<ACT>(bf2f(o.z) + __uint_as_float(q1 << 16)));
+                            o.w = f2bf(apply_act<ACT>(bf2f(o.w) + __uint_as_float(q1 & 0xFFFF0000u)));
+                        }
                         // scratch row li (WN*2 bytes), 16-B chunk (ch >> 3) swizzled by the row, 8-B half (ch >> 2) & 1
                         *(ushort4*)(scr + li * (WN * 2) + 16 * ((ch >> 3) ^ (li % CPR)) + 8 * ((ch >> 2) & 1)) = o;
                     }
@@ -200,7 +268,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
                 for (int i = 0; i < 32 / RPI; ++i) {
                     const int r = erow + RPI * i;
                     bf16x8 v = *(const bf16x8*)(scr + r * (WN * 2) + 16 * (ech ^ (r % CPR)));
-                    if (RES || ACT != HSEFR_ACT_NONE) {
+                    if (!PROJ && (RES || ACT != HSEFR_ACT_NONE)) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             float f = bf2f((u16)v[e]);
@@ -238,7 +306,8 @@ int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shi
     const long long g = total < slots ? total : slots;
     dim3 grid((unsigned)g), block(256);
     const int rev = sweep_reverse();
-#define HSEFR_C11(R, A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, R, A>), grid, block, 0, s, x, wt, scale, shift, res, y, P, K, cout, tiles_n, (unsigned)total, rev)
+    const ProjParams nopj{};
+#define HSEFR_C11(R, A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, R, A>), grid, block, 0, s, x, wt, scale, shift, res, y, P, K, cout, tiles_n, (unsigned)total, rev, nopj)
     if (res) {
         if (act == HSEFR_ACT_RELU) HSEFR_C11(true, HSEFR_ACT_RELU);
         else if (act == HSEFR_ACT_RELU6) HSEFR_C11(true, HSEFR_ACT_RELU6);
@@ -250,6 +319,25 @@ int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shi
     }
 #undef HSEFR_C11
     return launch_status("conv1x1_bf16");
+}
+
+template <int BM, int BN, int OCC>
+int launch_proj_cfg(const u16* x, const u16* wt, const float* scale, const float* shift, u16* y, long long P, int K, int cout, int act,
+                    const ProjParams& pj, hipStream_t s) {
+    const long long tiles_m = (P + BM - 1) / BM;
+    const unsigned tiles_n = cout / BN;
+    const long long total = tiles_m * tiles_n;
+    HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv1x1_proj_bf16: too many tiles");
+    const long long slots = 256ll * OCC;
+    const long long g = total < slots ? total : slots;
+    dim3 grid((unsigned)g), block(256);
+    const int rev = sweep_reverse();
+#define HSEFR_C11P(A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, false, A, true>), grid, block, 0, s, x, wt, scale, shift, nullptr, y, P, K, cout, tiles_n, (unsigned)total, rev, pj)
+    if (act == HSEFR_ACT_RELU) HSEFR_C11P(HSEFR_ACT_RELU);
+    else if (act == HSEFR_ACT_RELU6) HSEFR_C11P(HSEFR_ACT_RELU6);
+    else HSEFR_C11P(HSEFR_ACT_NONE);
+#undef HSEFR_C11P
+    return launch_status("conv1x1_proj_bf16");
 }
 
 HSEFR_KNOB(g_c11, 1);   // dev builds: 0 = route 1x1 stride-1 layers through the general conv_bf16 kernel (A/B timing)
@@ -282,6 +370,31 @@ int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const
     const long long t128 = ((P + 127) / 128) * (cout / 128);
     if (cout % 128 == 0 && t128 >= 768) return launch_cfg<128, 128, 2>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
     return launch_cfg<128, 64, 3>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
+}
+
+// The increase layer of a stage's first block with its projected shortcut in the same launch (PROJ, see the header):
+//   y[p, :] = act( bf16( scale * (x[p, :] . wt) + shift ) + bf16( scale2 * (x2[pixel(p) * stride, :] . wt2) + shift2 ) )
+// x [P][K], wt [cout][K], x2 [n][h2][w2][k2], wt2 [cout][k2], y [P][cout]; P = n * oh * ow, output pixel (oh, ow) is projected from
+// input pixel (oh * stride, ow * stride).
+int launch_conv1x1_proj_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* x2, const void* wt2,
+                             const float* scale2, const float* shift2, void* y, int n, int oh, int ow, int K, int cout, int k2, int stride,
+                             int h2, int w2, int act, hipStream_t s) {
+    HSEFR_REQUIRE(K > 0 && K % 64 == 0 && k2 > 0 && k2 % 64 == 0 && cout > 0 && cout % 64 == 0, HSEFR_ERR_UNSUPPORTED,
+                  "conv1x1_proj_bf16: channels %d / %d -> %d must be multiples of 64", K, k2, cout);
+    HSEFR_REQUIRE(n >= 0 && oh > 0 && ow > 0 && stride >= 1 && (oh - 1) * stride < h2 && (ow - 1) * stride < w2, HSEFR_ERR_INVALID,
+                  "conv1x1_proj_bf16: a %dx%d output is not a stride-%d view of a %dx%d input", oh, ow, stride, h2, w2);
+    HSEFR_REQUIRE(act == HSEFR_ACT_NONE || act == HSEFR_ACT_RELU || act == HSEFR_ACT_RELU6, HSEFR_ERR_UNSUPPORTED, "conv1x1_proj_bf16: act %d", act);
+    if (n == 0) return HSEFR_OK;
+    const long long P = (long long)n * oh * ow;
+    ProjParams pj;
+    pj.x2 = (const u16*)x2; pj.wt2 = (const u16*)wt2; pj.scale2 = scale2; pj.shift2 = shift2;
+    pj.K2 = k2; pj.stride = stride; pj.H2 = h2; pj.W2 = w2; pj.OH = oh; pj.OW = ow;
+    pj.x2_bytes = (long long)n * h2 * w2 * k2 * 2;
+    HSEFR_REQUIRE(P < (1ll << 31) && pj.x2_bytes < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv1x1_proj_bf16: tensors beyond 2 GB");
+    const long long t128 = ((P + 127) / 128) * (cout / 128);
+    if (cout % 128 == 0 && t128 >= 768)
+        return launch_proj_cfg<128, 128, 2>((const u16*)x, (const u16*)wt, scale, shift, (u16*)y, P, K, cout, act, pj, s);
+    return launch_proj_cfg<128, 64, 3>((const u16*)x, (const u16*)wt, scale, shift, (u16*)y, P, K, cout, act, pj, s);
 }
 
 }  // namespace hsefr

@@ -49,11 +49,7 @@ __device__ unsigned long long g_w2_stamps[256 * 8 * 8];
 #define W2_STAMP_FLUSH do { } while (0)
 #endif
 
-__device__ __forceinline__ unsigned f2bf_bits(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
+__device__ __forceinline__ unsigned f2bf_bits(float f) { return hsefr_bf16_bits(f); }      // round-to-nearest-even (common.h)
 __device__ __forceinline__ float bfround(float f) { return __uint_as_float(f2bf_bits(f) << 16); }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_sgpr(const void* ptr, long long bytes) {
     const unsigned long long a = (unsigned long long)ptr;
@@ -412,7 +408,7 @@ __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const float f0 = fminf(fmaxf(v[2 * d], p.act_lo), p.act_hi), f1 = fminf(fmaxf(v[2 * d + 1], p.act_lo), p.act_hi);
-                        o[d] = __uint_as_float(f2bf_bits(f0) | (f2bf_bits(f1) << 16));
+                        o[d] = __uint_as_float(hsefr_pack_bf16x2(f0, f1));
                     }
                     bstore16_welded(o, ry, voff, soff);
                 }

@@ -45,11 +45,7 @@ constexpr int WIN_BYTES = 384 * ROWB;     // one window buffer: up to 384 rows (
 constexpr int WSLOTS = 12;                // window pieces per loader wave (4 x 12 x 8 rows = 384)
 
 __device__ __forceinline__ int swz_key(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
-__device__ __forceinline__ unsigned f2bf_bits(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
+__device__ __forceinline__ unsigned f2bf_bits(float f) { return hsefr_bf16_bits(f); }      // round-to-nearest-even (common.h)
 __device__ __forceinline__ float bfround(float f) { return __uint_as_float(f2bf_bits(f) << 16); }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_sgpr(const void* ptr, long long bytes) {
     const unsigned long long a = (unsigned long long)ptr;
@@ -377,7 +373,7 @@ __global__ __launch_bounds__(768, 1) void conv3x3_win_bf16_kernel(Win3Params p) 
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const float f0 = fminf(fmaxf(v[2 * d], p.act_lo), p.act_hi), f1 = fminf(fmaxf(v[2 * d + 1], p.act_lo), p.act_hi);
-                    o[d] = __uint_as_float(f2bf_bits(f0) | (f2bf_bits(f1) << 16));
+                    o[d] = __uint_as_float(hsefr_pack_bf16x2(f0, f1));
                 }
                 // rows past the tile's pixels belong to the NEXT tile: an out-of-range offset drops them
                 bstore16_welded(o, ry, (row0 + 16 * rb) < NPIX ? yvoff : 0x80000000u,

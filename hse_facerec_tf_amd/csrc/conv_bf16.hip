@@ -28,11 +28,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 
-__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even (inputs are finite)
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (u16)(u >> 16);
-}
+__device__ __forceinline__ u16 f2bf(float f) { return (u16)hsefr_bf16_bits(f); }      // round-to-nearest-even (common.h)
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float((unsigned)h << 16); }
 
 constexpr int BKB = 64;  // bf16 elements per K-tile = one 128-B LDS row

@@ -50,11 +50,7 @@ __device__ unsigned long long g_cd_stamps[256 * 12 * 8];
 #endif
 
 __device__ __forceinline__ int swz_key(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 2); }
-__device__ __forceinline__ unsigned f2bf_bits(float f) {  // round-to-nearest-even (inputs are finite)
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
+__device__ __forceinline__ unsigned f2bf_bits(float f) { return hsefr_bf16_bits(f); }      // round-to-nearest-even (common.h)
 __device__ __forceinline__ float bfround(float f) { return __uint_as_float(f2bf_bits(f) << 16); }
 
 // A buffer resource whose words are pinned to SGPRs: the inline-asm DMA / store take it under an "s" constraint, and with the
@@ -339,7 +335,7 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const float f0 = fminf(fmaxf(v[2 * d], p.act_lo), p.act_hi), f1 = fminf(fmaxf(v[2 * d + 1], p.act_lo), p.act_hi);
-                    o[d] = __uint_as_float(f2bf_bits(f0) | (f2bf_bits(f1) << 16));
+                    o[d] = __uint_as_float(hsefr_pack_bf16x2(f0, f1));
                 }
                 bstore16_welded(o, ry, yvoff, __builtin_amdgcn_readfirstlane((unsigned)(16 * rb) * (unsigned)p.Cout * 2u));
             }

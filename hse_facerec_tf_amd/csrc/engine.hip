@@ -143,6 +143,18 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
             case HSEFR_OP_CONV_BF16:
                 if (!need(o.w_off, kk * ci * co * 2, "kernel") || !need(o.scale_off, co * 4, "scale") || !need(o.shift_off, co * 4, "shift"))
                     return HSEFR_ERR_INVALID;
+                if (o.w2_off != HSEFR_NO_OFFSET) {
+                    // projected shortcut (round 5): res_buf is the BLOCK INPUT [h2, w2, k2], w2 its 1x1 kernel [cout][k2], shift2 =
+                    // [scale2 | shift2]; reserved = k2 | stride << 12 | h2 << 14 | w2 << 23
+                    const int k2 = o.reserved & 0xFFF, st2 = (o.reserved >> 12) & 3, h2 = (o.reserved >> 14) & 0x1FF, w2 = (o.reserved >> 23) & 0x1FF;
+                    HSEFR_REQUIRE(o.kh == 1 && o.kw == 1 && o.stride == 1 && o.res_buf >= 0 && k2 > 0 && k2 % 64 == 0 && st2 >= 1 &&
+                                      (o.oh - 1) * st2 < h2 && (o.ow - 1) * st2 < w2,
+                                  HSEFR_ERR_INVALID, "plan op %u: bad projected shortcut (k2 %d, stride %d, %dx%d)", i, k2, st2, h2, w2);
+                    if (!need(o.w2_off, (uint64_t)k2 * co * 2, "projection kernel") || !need(o.shift2_off, 2 * co * 4, "projection scale / shift"))
+                        return HSEFR_ERR_INVALID;
+                    HSEFR_REQUIRE((uint64_t)h2 * w2 * k2 * 2 <= bufs[o.res_buf].elems_per_image * bufs[o.res_buf].elem_bytes, HSEFR_ERR_INVALID,
+                                  "plan op %u: projected shortcut input exceeds buffer %d", i, o.res_buf);
+                }
                 break;
             case HSEFR_OP_STEM7X7_POOL_BF16:
                 HSEFR_REQUIRE(o.act == HSEFR_ACT_RELU && (o.reserved & ~0x11) == 0 && o.cin == 3 && o.cout == 64, HSEFR_ERR_INVALID,
@@ -496,6 +508,14 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                 rc = launch_softmax((const float*)in, (float*)out, n, o.cout, s);
                 break;
             case HSEFR_OP_CONV_BF16:
+                if (o.w2_off != HSEFR_NO_OFFSET) {      // increase layer + projected shortcut in one launch (csrc/conv1x1_bf16.hip, PROJ)
+                    const float* ss2 = (const float*)blob_ptr(e, o.shift2_off);
+                    rc = launch_conv1x1_proj_bf16(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
+                                                  (const float*)blob_ptr(e, o.shift_off), tab[o.res_buf], blob_ptr(e, o.w2_off), ss2, ss2 + o.cout,
+                                                  out, n, o.oh, o.ow, o.cin, o.cout, o.reserved & 0xFFF, (o.reserved >> 12) & 3,
+                                                  (o.reserved >> 14) & 0x1FF, (o.reserved >> 23) & 0x1FF, o.act, s);
+                    break;
+                }
                 rc = launch_conv_bf16(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
                                       (const float*)blob_ptr(e, o.shift_off),
                                       o.res_buf >= 0 ? tab[o.res_buf] : nullptr, out, n, o.h, o.w, o.cin, o.oh,
@@ -899,6 +919,14 @@ int hsefr_conv_bf16(const void* x, const void* wgt_t, const float* scale, const 
     HSEFR_REQUIRE(n == 0 || (x && wgt_t && scale && shift && y), HSEFR_ERR_INVALID, "conv_bf16: null pointer");
     return launch_conv_bf16(x, wgt_t, scale, shift, res, y, n, h, w, c, oh, ow, cout, kh, kw, stride, pad_t, pad_l, act,
                             (hipStream_t)stream);
+}
+
+int hsefr_conv1x1_proj_bf16(const void* x, const void* wgt_t, const float* scale, const float* shift, const void* x2, const void* wgt2_t,
+                            const float* scale2, const float* shift2, void* y, int n, int oh, int ow, int c, int cout, int c2, int stride2,
+                            int h2, int w2, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wgt_t && scale && shift && x2 && wgt2_t && scale2 && shift2 && y), HSEFR_ERR_INVALID, "conv1x1_proj_bf16: null pointer");
+    return launch_conv1x1_proj_bf16(x, wgt_t, scale, shift, x2, wgt2_t, scale2, shift2, y, n, oh, ow, c, cout, c2, stride2, h2, w2, act,
+                                    (hipStream_t)stream);
 }
 
 int hsefr_stem7x7_bf16(const float* x, const void* wgt_t, const float* scale, const float* shift, void* y, int n, int h,

@@ -187,6 +187,8 @@ class Layer:
     pad3: Tuple[int, int] = (0, 0)
     in_log2: int = 0                                   # STEM3_F16S: the input is pre-scaled by 2^in_log2 for its f16 split (|x| < 2^(15 - in_log2))
     u8_mean_bgr: Optional[Tuple[float, float, float]] = None   # STEM3_F16S: BGR mean folded into the uint8-input constants (None: no uint8 entry)
+    proj: Optional[Tuple[int, int, int, int]] = None   # CONV_BF16 + projected shortcut (fuse_proj): (cin2, stride2, h2, w2) of the 1x1 projection
+                                                       # of layer `res`'s output; w2 = its packed kernel [cout][cin2], shift2 = [scale2 | shift2]
     out_split: int = 0                                 # DWCONV3X3: > 0 = output stored as split rows scaled by 2^out_split
     in_split: bool = False                             # PWCONV: the input buffer holds split rows (wire kind OP_PWCONV_PS)
     out_buf: int = BUF_NONE
@@ -232,9 +234,15 @@ class Plan:
                 w = w.reshape(3, 3, -1)
                 if L.kind == OP_DWCONV3X3:
                     aux = L.out_split
-            w2 = None if L.w2 is None else np.ascontiguousarray(L.w2.reshape(L.w2.shape[-2], L.w2.shape[-1]).T)
+            w2 = None if (L.w2 is None or L.proj is not None) else np.ascontiguousarray(L.w2.reshape(L.w2.shape[-2], L.w2.shape[-1]).T)
             shift2 = L.shift2
             kw_field = L.kw
+            if L.proj is not None:              # the packed bf16 projection kernel as it is; geometry in the aux word (hsefr.h)
+                assert L.kind == OP_CONV_BF16 and L.res >= 0 and L.w2.dtype == np.uint16
+                c2, s2, h2, wd2 = L.proj
+                assert 0 < c2 < 4096 and 1 <= s2 <= 3 and 0 < h2 < 512 and 0 < wd2 < 512 and tuple(L.w2.shape) == (L.out_shape[2], c2)
+                w2 = L.w2
+                aux = c2 | (s2 << 12) | (h2 << 14) | (wd2 << 23)
             if L.kind in (OP_STEM2_F16S, OP_STEM3_F16S):
                 w = np.concatenate([L.w0.reshape(-1), L.shift0.reshape(-1), L.w.reshape(-1), L.scale.reshape(-1), L.shift.reshape(-1),
                                     L.w3.reshape(-1), L.scale3.reshape(-1), L.shift3.reshape(-1)]).astype(np.float32)
@@ -332,7 +340,7 @@ class Plan:
         """Algorithmic multiply-add flops of ONE layer per image (fused layers: the sum of what they replace)."""
         oh, ow, cout = L.out_shape
         if L.kind in (OP_CONV_C3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32):
-            return 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
+            return 2 * oh * ow * cout * (L.kh * L.kw * L.in_shape[2] + (L.proj[0] if L.proj is not None else 0))
         if L.kind == OP_DWCONV3X3:
             return 2 * oh * ow * cout * 9
         if L.kind in (OP_DWPW_F32, OP_DWPW_F16S):
@@ -852,6 +860,53 @@ def fuse_stem_pool(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer
     return layers, remap
 
 
+def fuse_proj(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
+    """ResNet, first block of a stage: the 1x1 PROJECTION of the block input (stride 1 or 2, no activation) whose ONLY consumer
+    is the residual operand of the block's 1x1 'increase' convolution folds into that layer (csrc/conv1x1_bf16.hip, PROJ): the
+    increase layer then reads the block input itself (`res` = the projection's source, `proj` = its geometry, `w2` / `shift2` =
+    its packed kernel and [scale | shift]), the projection's tensor is never written -- 411 of the 719 MB the pair moves at
+    56 x 56, batch 128 -- and both roundings stay where they were.  Call AFTER the bf16 post-conditions (packed kernels, scale
+    and shift present).  Returns (layers, old -> new index; a folded projection maps to -1)."""
+    consumers: Dict[int, List[Tuple[int, str]]] = {}
+    for i, L in enumerate(layers):
+        if L.src >= 0:
+            consumers.setdefault(L.src, []).append((i, "src"))
+        if L.res >= 0:
+            consumers.setdefault(L.res, []).append((i, "res"))
+    drop = set()
+    for i, P in enumerate(layers):
+        cons = consumers.get(i, [])
+        if not (P.kind == OP_CONV_BF16 and P.kh == 1 and P.kw == 1 and P.pad_t == 0 and P.pad_l == 0 and P.act == ACT_NONE and P.res < 0 and
+                P.proj is None and P.src >= 0 and i not in keep and len(cons) == 1 and cons[0][1] == "res" and 1 <= P.stride <= 3):
+            continue
+        I = layers[cons[0][0]]
+        h2, w2, c2 = P.in_shape
+        oh, ow, cout = I.out_shape
+        if not (I.kind == OP_CONV_BF16 and I.kh == 1 and I.kw == 1 and I.stride == 1 and I.pad_t == 0 and I.pad_l == 0 and I.proj is None and
+                I.src != i and tuple(P.out_shape) == tuple(I.out_shape) and c2 % 64 == 0 and I.in_shape[2] % 64 == 0 and cout % 64 == 0 and
+                c2 < 4096 and h2 < 512 and w2 < 512 and (oh - 1) * P.stride < h2 and (ow - 1) * P.stride < w2):
+            continue
+        I.res, I.proj, I.w2 = P.src, (c2, P.stride, h2, w2), P.w
+        I.shift2 = np.concatenate([P.scale.astype(np.float32).reshape(-1), P.shift.astype(np.float32).reshape(-1)])
+        I.tensors = list(I.tensors)
+        drop.add(i)
+    if not drop:
+        return layers, {i: i for i in range(len(layers))}
+    remap, new_layers = {}, []
+    for j, x in enumerate(layers):
+        if j in drop:
+            remap[j] = -1
+        else:
+            remap[j] = len(new_layers)
+            new_layers.append(x)
+    for x in new_layers:
+        if x.src >= 0:
+            x.src = remap[x.src]
+        if x.res >= 0:
+            x.res = remap[x.res]
+    return new_layers, remap
+
+
 def fuse_stem(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
     """conv 3x3/2 (3 -> 32, ReLU6) whose only consumer is a fused depthwise(stride 1) -> pointwise(32 -> 64) block becomes
     ONE layer (csrc/stem_fused.hip): the 96x96x32 map in between never reaches HBM.  Returns (layers, old -> new index)."""
@@ -1222,10 +1277,11 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
                             if float(input_bound) < 256.0:
                                 raise ValueError("uint8 input needs input_bound >= 256 (pixels minus a mean), not %r" % (input_bound,))
                             L.u8_mean_bgr = tuple(float(m) for m in u8_mean_bgr)
-    if fuse and dtype == "bf16":      # ResNet stem: conv1 + pool1 in one kernel
-        layers, remap = fuse_stem_pool(layers, [li for li, _ in out_layers.values()])
-        out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
-        tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
+    if fuse and dtype == "bf16":      # ResNet stem: conv1 + pool1 in one kernel; projected shortcuts inside their increase layer
+        for fuse_pass in (fuse_stem_pool, fuse_proj):
+            layers, remap = fuse_pass(layers, [li for li, _ in out_layers.values()])
+            out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
+            tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
     if fuse:   # early MobileNet blocks: depthwise result stays on the CU (csrc/dwpw_fused.hip)
         layers, remap = fuse_dwpw(layers, [li for li, _ in out_layers.values()])
         out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}

@@ -539,6 +539,26 @@ def conv_bf16(x, w_packed, scale, shift, kh: int, kw: int, stride: int = 1, pad:
 
 
 @_device_guarded
+def conv1x1_proj_bf16(x, w_packed, scale, shift, x2, w2_packed, scale2, shift2, stride2: int = 1, act: int = ACT_RELU):
+    """The increase layer of a ResNet stage's first block with its projected shortcut in one launch (hsefr_conv1x1_proj_bf16):
+    act(bf16(scale * x.w + shift) + bf16(scale2 * x2[::stride2, ::stride2].w2 + shift2)).  x [n,oh,ow,c] bf16, w_packed [cout,c],
+    x2 [n,h2,w2,c2] bf16 (the block input), w2_packed [cout,c2] -> [n,oh,ow,cout] bf16."""
+    torch = _lib.require_gpu()
+    _bf16c(x, "x"), _bf16c(w_packed, "w"), _f32c(scale, "scale"), _f32c(shift, "shift")
+    _bf16c(x2, "x2"), _bf16c(w2_packed, "w2"), _f32c(scale2, "scale2"), _f32c(shift2, "shift2")
+    n, oh, ow, c = x.shape
+    n2, h2, w2, c2 = x2.shape
+    cout = w_packed.shape[0]
+    if n2 != n or tuple(w2_packed.shape) != (cout, c2) or w_packed.shape[1] != c:
+        raise ValueError("conv1x1_proj_bf16: inconsistent shapes")
+    y = torch.empty((n, oh, ow, cout), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().hsefr_conv1x1_proj_bf16(x.data_ptr(), w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), x2.data_ptr(),
+                                                  w2_packed.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), y.data_ptr(), n, oh, ow, c, cout,
+                                                  c2, stride2, h2, w2, act, _lib.current_stream_ptr()), "hsefr_conv1x1_proj_bf16")
+    return y
+
+
+@_device_guarded
 def stem7x7_bf16(x, w_packed, scale, shift, act: int = ACT_RELU):
     torch = _lib.require_gpu()
     _f32c(x, "x"), _bf16c(w_packed, "w")

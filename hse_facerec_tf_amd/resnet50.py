@@ -88,7 +88,8 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
     """pool='caffe': pad-0 ceil-mode max-pool (112 -> 56); pool='valid': keras_vggface's valid pool (112 -> 55).
     dtype='bf16': the bf16-MFMA kernels (BASELINE config 3's throughput mode); dtype='f32': the same layers on the exact-fp32
     general kernels (OP_CONV_F32 / OP_MAXPOOL_F32 / OP_GAP) -- the fp32-grade mode, 1e-4 against the fp64 oracle.
-    fuse (bf16 only): conv1 + pool1 run as one kernel (lowering.fuse_stem_pool); False keeps every layer's tensor."""
+    fuse (bf16 only): conv1 + pool1 run as one kernel (lowering.fuse_stem_pool) and the four projected shortcuts run inside their
+    block's increase layer (lowering.fuse_proj); False keeps every layer's tensor."""
     if dtype not in ("bf16", "f32"):
         raise ValueError("dtype must be 'bf16' or 'f32', not %r" % (dtype,))
     f32 = dtype == "f32"
@@ -141,6 +142,8 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
     if fuse and not f32:
         layers, remap = lowering.fuse_stem_pool(layers, [gap])
         gap = remap[gap]
+        layers, remap = lowering.fuse_proj(layers, [gap])
+        gap = remap[gap]
     buffers = assign_buffers(layers, {gap})
     names = {L.name: i for i, L in enumerate(layers)}
     return Plan(layers, (H, W, 3), buffers, {OUT_FEATURES: (gap, cin)}, names)
@@ -152,8 +155,7 @@ def flops_per_image(plan: Plan) -> int:
         if L.kind == lowering.OP_STEM7X7_POOL_BF16:
             tot += Plan.layer_flops(L)
         if L.kind in (OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32):
-            oh, ow, cout = L.out_shape
-            tot += 2 * oh * ow * cout * L.kh * L.kw * L.in_shape[2]
+            tot += Plan.layer_flops(L)          # (a projected shortcut folded into its increase layer counts there)
     return tot
 
 
@@ -162,8 +164,14 @@ def activation_bytes_per_image(plan: Plan) -> int:
     for L in plan.layers:
         in_b = 4 if L.kind in (OP_STEM7X7_BF16, lowering.OP_STEM7X7_POOL_BF16) else 2
         tot += int(np.prod(L.in_shape)) * in_b + L.out_bytes
-        if L.res >= 0:
+        if L.res >= 0 and L.proj is None:
             tot += plan.layers[L.res].out_bytes
+        elif L.res >= 0:
+            # the UNFUSED pair's traffic (the layer-wise figure SURVEY 8d prices the network with, unchanged by the fusion): the
+            # projection reads the block input and writes its tensor, the increase layer reads it back
+            c2, s2, h2, w2 = L.proj
+            oh, ow, cout = L.out_shape
+            tot += h2 * w2 * c2 * 2 + 2 * oh * ow * cout * 2
     return tot
 
 

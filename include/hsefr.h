@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define HSEFR_VERSION 120 /* 0.1.2: round-4 ABI (added: hsefr_stem5_stream, hsefr_engine_input_overflow_async; 110 = round 3, 100 = round 1-2) */
+#define HSEFR_VERSION 130 /* 0.1.3: round-5 ABI (added: hsefr_conv1x1_proj_bf16, the projected-shortcut form of HSEFR_OP_CONV_BF16; 120 = round 4, 110 = round 3, 100 = round 1-2) */
 
 typedef enum hsefr_status {
     HSEFR_OK = 0,
@@ -385,6 +385,16 @@ int hsefr_softmax(const float* x, float* y, int n, int c, hsefr_stream_t stream)
 int hsefr_conv_bf16(const void* x, const void* wgt_t, const float* scale, const float* shift, const void* res, void* y,
                     int n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t,
                     int pad_l, int act, hsefr_stream_t stream);
+
+/* The "increase" 1x1 convolution of a ResNet stage's first bottleneck with its PROJECTED shortcut in the same launch (round 5):
+ *   y[p, :] = act( bf16( scale * (x[p, :] . wgt_t) + shift ) + bf16( scale2 * (x2[n, oh * stride2, ow * stride2, :] . wgt2_t) + shift2 ) )
+ * -- the rounding points of the two-launch form (hsefr_conv_bf16 for the projection, then hsefr_conv_bf16 with res): the projection's
+ * [n, oh, ow, cout] tensor is never written.  x [n,oh,ow,c], wgt_t [cout][c], x2 [n,h2,w2,c2] (the block's input), wgt2_t [cout][c2],
+ * y [n,oh,ow,cout], all bf16; c, c2, cout multiples of 64.  What the engine runs for an HSEFR_OP_CONV_BF16 whose w2_off is set
+ * (res_buf = the block input, shift2 = [scale2 | shift2], reserved = c2 | stride2 << 12 | h2 << 14 | w2 << 23). */
+int hsefr_conv1x1_proj_bf16(const void* x, const void* wgt_t, const float* scale, const float* shift, const void* x2, const void* wgt2_t,
+                            const float* scale2, const float* shift2, void* y, int n, int oh, int ow, int c, int cout, int c2, int stride2,
+                            int h2, int w2, int act, hsefr_stream_t stream);
 
 /* ResNet stem: 7x7 / stride 2 / pad 3 conv over the fp32 image [n,h,w,3] -> [n,oh,ow,64] bf16, + scale + shift + act.
  * wgt_t [64][256] bf16 with k = dy*32 + dx*3 + ci, zero padded. */

@@ -198,7 +198,16 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
             pr = max((ow - 1) * stride + kw - w - pad_l, 0)
             y = tfo.conv2d(src, k, (stride, stride), "", explicit_pads=(pad_t, pb, pad_l, pr))
             y = bf16_round(y * arr(sc_off, cout) + arr(sh_off, cout))
-            if res is not None:
+            if res is not None and w2_off != NO_OFFSET:
+                # projected shortcut (lowering.fuse_proj): res_buf is the BLOCK INPUT, w2 its 1x1 kernel [cout][c2], shift2 = [scale2 | shift2],
+                # the aux word c2 | stride2 << 12 | h2 << 14 | w2 << 23; the projection is rounded to bf16 where its tensor used to be stored
+                c2, s2, h2, wd2 = _r & 0xFFF, (_r >> 12) & 3, (_r >> 14) & 0x1FF, (_r >> 23) & 0x1FF
+                assert kh == 1 and kw == 1 and stride == 1
+                k2 = arr_bf16(w2_off, c2 * cout).reshape(cout, 1, 1, c2).transpose(1, 2, 3, 0)
+                ss2 = arr(sh2_off, 2 * cout)
+                pr_ = tfo.conv2d(res.reshape(n, h2, wd2, c2), k2, (s2, s2), "", explicit_pads=(0, 0, 0, 0))
+                y = y + bf16_round(pr_ * ss2[:cout] + ss2[cout:]).reshape(y.shape)
+            elif res is not None:
                 y = y + res.reshape(y.shape)
             y = bf16_round(_act(y, act))
         elif kind == 10:     # 7x7/2 pad-3 stem on the fp32 image: weights [64][8][32] bf16 (k = dy*32 + dx*3 + ci)

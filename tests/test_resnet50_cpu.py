@@ -21,7 +21,16 @@ def test_topology_counts_and_sizes():
     from hse_facerec_tf_amd import lowering
     fused = resnet50.build_plan(resnet50.synthetic_weights(1), (224, 224), "caffe")
     assert fused.layers[0].kind == lowering.OP_STEM7X7_POOL_BF16 and fused.layers[0].out_shape == (56, 56, 64) and fused.layers[0].pad3 == (0, 0)
-    assert len(fused.layers) == 54 and fused.layers[1].src == 0
+    assert len(fused.layers) == 50 and fused.layers[1].src == 0      # 55 layers - conv1 (inside the pool) - the four projections
+    # round 5: every stage's projected shortcut runs inside its block's increase layer (lowering.fuse_proj), which then reads the block input
+    pj = {L.name: L for L in fused.layers if L.proj is not None}
+    assert sorted(pj) == ["conv%d_1_1x1_increase" % k for k in (2, 3, 4, 5)] and not any("proj" in L.name for L in fused.layers)
+    assert pj["conv2_1_1x1_increase"].proj == (64, 1, 56, 56) and pj["conv3_1_1x1_increase"].proj == (256, 2, 56, 56)
+    assert pj["conv5_1_1x1_increase"].proj == (1024, 2, 14, 14) and fused.layers[pj["conv3_1_1x1_increase"].res].name == "conv2_3_1x1_increase"
+    for L in fused.layers:
+        for s_ in (L.src, L.res):
+            if s_ >= 0:
+                assert fused.layers[s_].out_buf != L.out_buf
     plan = resnet50.build_plan(resnet50.synthetic_weights(1), (224, 224), "caffe", fuse=False)
     assert resnet50.flops_per_image(fused) == resnet50.flops_per_image(plan)
     assert resnet50.activation_bytes_per_image(plan) - resnet50.activation_bytes_per_image(fused) == 2 * 112 * 112 * 64 * 2   # conv1's map: one write, one read
@@ -55,7 +64,7 @@ def test_plan_equals_oracle(size, pool, fuse):
     w = resnet50.synthetic_weights(7)
     x = np.random.RandomState(3).uniform(-120, 130, (1, size, size, 3)).astype(np.float32)
     plan = resnet50.build_plan(w, (size, size), pool, fuse=fuse)
-    assert len(plan.layers) == (54 if fuse else 55)
+    assert len(plan.layers) == (50 if fuse else 55)          # fuse: conv1 inside the pool, the four projections inside their increase layers
     got = plan_ref.run(plan.serialize(), x)["features"]
     want = ores.forward(w, x, pool)
     assert got.shape == want.shape == (1, 2048)
@@ -75,7 +84,9 @@ def test_generic_lowering_of_a_resnet_style_graph(pool, bn, head, hw):
     fused = lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"}, dtype="bf16")
     x = np.random.RandomState(1).uniform(-100, 120, (2, hw, hw, 3)).astype(np.float32)
     plan = lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"}, dtype="bf16", fuse=False)
-    assert fused.layers[0].kind == lowering.OP_STEM7X7_POOL_BF16 and len(fused.layers) == len(plan.layers) - 1
+    assert fused.layers[0].kind == lowering.OP_STEM7X7_POOL_BF16 and len(fused.layers) == len(plan.layers) - 1 - 2      # conv1, two projections
+    assert sorted(L.name for L in fused.layers if L.proj is not None) == ["conv2_1_1x1_increase", "conv3_1_1x1_increase"]
+    assert {L.name: L for L in fused.layers}["conv3_1_1x1_increase"].proj[1] == 2            # the stride-2 projection of the second stage
     assert fused.layers[0].pad3 == (plan.layers[1].pad_t, plan.layers[1].pad_l) == ((1, 1) if (pool, hw) == ("SAME", 38) else (0, 0))
     assert np.array_equal(plan_ref.run(fused.serialize(), x)["features"], plan_ref.run(plan.serialize(), x)["features"])
     # conv1's tensor requested as an output keeps the stem unfused

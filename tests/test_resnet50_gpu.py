@@ -97,6 +97,42 @@ def test_conv1x1_persistent_kernel_bit_for_bit_and_run_to_run(env, n, hw, c, cou
         assert torch.equal(ops.conv_bf16(x, w, sc, sh, 1, 1, 1, 0, r, act), ref)
 
 
+@pytest.mark.parametrize("n,oh,ow,c,cout,c2,s2,h2,w2,act", [
+    (2, 14, 14, 64, 256, 64, 1, 14, 14, 1), (1, 14, 14, 128, 512, 256, 2, 28, 28, 1), (3, 7, 7, 256, 1024, 512, 2, 14, 14, 1),
+    (2, 4, 4, 512, 2048, 1024, 2, 7, 7, 1), (5, 9, 11, 64, 192, 128, 2, 17, 22, 0), (37, 13, 13, 64, 128, 64, 1, 13, 13, 1)])
+def test_increase_layer_with_projected_shortcut_vs_oracle_and_vs_the_two_launch_form(env, n, oh, ow, c, cout, c2, s2, h2, w2, act):
+    """csrc/conv1x1_bf16.hip PROJ (round 5): act(bf16(s W x + b) + bf16(s2 W2 x2[::s2] + b2)) in one launch -- against the oracle's
+    two convolutions with the projection's tensor rounded to bf16 in between, and BIT FOR BIT against the two launches it replaces
+    (same kernel family, same K order per product, same rounding points).  Shapes: the four stage-entry blocks of ResNet-50 in small,
+    an odd-sized stride-2 view (h2 = 2 oh - 1), a ragged last tile, several tiles per workgroup."""
+    torch, ops, resnet50 = env
+    rs = np.random.RandomState(oh * 7 + c + cout + c2)
+    x = ores.bf16_round(rs.uniform(0, 2, (n, oh, ow, c)))
+    x2 = ores.bf16_round(rs.uniform(0, 2, (n, h2, w2, c2)))
+    k1 = (rs.randn(1, 1, c, cout) * np.sqrt(2.0 / c)).astype(np.float32)
+    k2 = (rs.randn(1, 1, c2, cout) * np.sqrt(2.0 / c2)).astype(np.float32)
+    sc, sh = rs.uniform(0.5, 1.5, cout).astype(np.float32), (rs.randn(cout) * 0.1).astype(np.float32)
+    sc2, sh2 = rs.uniform(0.5, 1.5, cout).astype(np.float32), (rs.randn(cout) * 0.1).astype(np.float32)
+    proj = ores.bf16_round(tfo.conv2d(x2, ores.bf16_round(k2), (s2, s2), "", explicit_pads=(0,) * 4) * sc2 + sh2)
+    assert proj.shape == (n, oh, ow, cout)
+    ya = ores.bf16_round(tfo.conv2d(x, ores.bf16_round(k1), (1, 1), "", explicit_pads=(0,) * 4) * sc + sh)
+    y = ya + proj
+    want = ores.bf16_round(np.maximum(y, 0) if act == 1 else y)
+    d = lambda a: to_dev_bf16(torch, ops, resnet50, a.astype(np.float32))
+    f = lambda a: torch.from_numpy(a).cuda()
+    pk = lambda k: ops.bf16_from_bits(resnet50.pack_conv_weight(k))
+    got = ops.conv1x1_proj_bf16(d(x), pk(k1), f(sc), f(sh), d(x2), pk(k2), f(sc2), f(sh2), s2, act)
+    # each ADDEND is a stored bf16 value and may sit one ulp from the oracle's where its fp32 sum is next to a rounding boundary;
+    # where the two nearly cancel that ulp is large against the result: close_bf16's bound + one ulp of each addend
+    g64 = got.float().cpu().numpy().astype(np.float64)
+    tol = 2.0 ** -7 * np.abs(want) + 2.0 ** -9 * np.abs(want).max() + 2.0 ** -8 * (np.abs(ya) + np.abs(proj))
+    assert (np.abs(g64 - want) <= tol).all(), "max rel err %.3e" % (np.abs(g64 - want) / np.abs(want).max()).max()
+    p_dev = ops.conv_bf16(d(x2), pk(k2), f(sc2), f(sh2), 1, 1, s2, 0, None, 0)
+    two = ops.conv_bf16(d(x), pk(k1), f(sc), f(sh), 1, 1, 1, 0, p_dev, act)
+    assert torch.equal(got, two)
+    assert torch.equal(ops.conv1x1_proj_bf16(d(x), pk(k1), f(sc), f(sh), d(x2), pk(k2), f(sc2), f(sh2), s2, act), got)     # run to run
+
+
 def test_conv_bf16_exact_integers(env):
     """Small integers are exact in bf16 and fp32: any im2col / fragment-map / swizzle mix-up shows as an exact mismatch."""
     torch, ops, resnet50 = env
