@@ -20,6 +20,10 @@
 //   * a FOUR-stage weight ring published ONE STEP EARLY (the loaders run three steps ahead): during step g the MFMA wave already
 //     reads step g + 1's first fragments -- a single wave per SIMD has no partner to hide the LDS latency behind the step barrier;
 //     weight fragments are re-loaded into the registers of the ones they replace right after their last use;
+//   * FLAT geometry for maps of at most 7 x 7 pixels (the last stage): a tile is IMG whole images as a flat list of 8-pixel rows --
+//     [zero row][7 image rows][zero row][7 image rows] ... with a zero cell in front of every row -- so that the zero row under one
+//     image is the zero row over the next, the zero cell in front of a row is the right neighbour of the row before it, and output
+//     slot s = 64 img + 8 y + x reads window cell s + 8 kh + kw for EVERY tap: the same affine addressing (49 of 64 slots are pixels);
 //   * everything else as before: LDS-DMA with out-of-range offsets for the padding, weights first (a lane owns 8 consecutive
 //     channels: 16-byte stores straight from the accumulators), one barrier per step, persistent workgroups.
 // Every output element is accumulated in one fixed order by one wave: bit-identical run to run, independent of the grid.
@@ -78,8 +82,8 @@ struct W2Params {
 };
 
 // RB: 16-row blocks per MFMA wave; WAVES_M x (4 / WAVES_M) MFMA waves; the WAVES_M waves are WX across x and WAVES_M / WX down y;
-// a wave's RB blocks are RBX across x and RB / RBX down y.
-template <int RB, int WAVES_M, int WX, int RBX>
+// a wave's RB blocks are RBX across x and RB / RBX down y.  FLAT: the geometry for maps of at most 7 x 7 (WX = RBX = 1 unused).
+template <int RB, int WAVES_M, int WX, int RBX, bool FLAT = false>
 __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int BN = WAVES_N * 64;
@@ -89,8 +93,10 @@ __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
     static_assert(WY * WX == WAVES_M && RBY * RBX == RB, "wave / row-block grids");
     constexpr int TR = WY * RBY;                    // image rows per tile
     constexpr int CBX = WX * RBX;                   // 16-column blocks per image row
-    constexpr int PX = 16 * CBX + 2;                // window pitch in pixels: columns -1 .. 16 CBX
-    constexpr int NWR = (TR + 2) * PX;              // window pixels
+    constexpr int PX = FLAT ? 8 : 16 * CBX + 2;     // window pitch in pixels: columns -1 .. 16 CBX (FLAT: the zero cell + 7 pixels)
+    constexpr int IMG = WAVES_M * RB / 4;           // FLAT: images per tile (64 slots = 4 row blocks each)
+    static_assert(!FLAT || (WAVES_M * RB) % 4 == 0, "FLAT tiles hold whole images");
+    constexpr int NWR = FLAT ? IMG * 64 + 24 : (TR + 2) * PX;      // window pixels (FLAT: + the cells the last slots' taps reach)
     constexpr int WPIECES = (NWR + 7) / 8;
     constexpr int WIN_BYTES = WPIECES * 1024;
     constexpr int WSLOTS = (WPIECES + 3) / 4;       // window pieces per loader wave
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
     constexpr int E_OFF = RING_OFF + NSTG * BSTAGE;
     constexpr int DUMMY_OFF = E_OFF + 4096;         // 1 KiB that absorbs the pieces issued only to keep the counts fixed
     static_assert(DUMMY_OFF + 1024 <= 160 * 1024, "LDS budget");
-    static_assert(((TR + 1) * PX + 16 * (RBX - 1)) * ROWB + 64 < 65536, "tap / row-block displacements are 16-bit immediates");
+    static_assert((FLAT ? 16 * (RB - 1) + 16 : (TR + 1) * PX + 16 * (RBX - 1)) * ROWB + 64 < 65536, "tap / row-block displacements are 16-bit immediates");
     static_assert((9 * RB) % 3 == 0, "the fragment ring keeps its phase from slab to slab");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[DUMMY_OFF + 1024];
 
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
         const unsigned lt = xcd_remap_dir(blockIdx.x + (i < ntile ? i : ntile - 1) * gridDim.x, p.total_tiles, p.reverse);
         const unsigned tm = lt / p.tiles_n;
         cc0 = (int)(lt - tm * p.tiles_n) * BN;
+        if (FLAT) { tn = (int)tm * IMG; ty0 = 0; return; }
         tn = (int)(tm / (unsigned)p.tiles_y);
         ty0 = (int)(tm - (unsigned)tn * (unsigned)p.tiles_y) * TR;
     };
@@ -151,10 +158,12 @@ __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
             for (int s = 0; s < WSLOTS; ++s) {
                 const int pw = lw + 4 * s;
                 const int w = pw * 8 + (lane >> 3);
-                const int wy = w / PX, wx = w - wy * PX;
+                int wy, wx, img = 0;
+                if (FLAT) { img = w >> 6; wy = (w >> 3) & 7; wx = w & 7; }      // row 0 of an image's eight = the shared zero row
+                else { wy = w / PX; wx = w - wy * PX; }
                 const int iy = ty0 - 1 + wy, ix = wx - 1;
-                const bool ok = w < NWR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                wbase[s] = ok ? (unsigned)((tn * p.H + iy) * p.W + ix) * (unsigned)(p.C * 2) + 16u * (unsigned)((lane & 7) ^ (wx & 6)) : 0x80000000u;
+                const bool ok = w < NWR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && tn + img < p.N && (!FLAT || img < IMG);
+                wbase[s] = ok ? (unsigned)(((tn + img) * p.H + iy) * p.W + ix) * (unsigned)(p.C * 2) + 16u * (unsigned)((lane & 7) ^ (wx & 6)) : 0x80000000u;
             }
         };
         // issue window slots [s0, s0 + cnt) of the window with sequence number wq (buffer wq & 1), slab offset wsl; slots that do not
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
     // =================================== MFMA waves 0..3 ===================================
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l16 = lane & 15, lq = lane >> 4;
-    const int y0w = (wm / WX) * RBY, x0w = 16 * RBX * (wm % WX);        // the wave's first row block: tile row, column
+    const int y0w = FLAT ? 0 : (wm / WX) * RBY, x0w = FLAT ? 16 * RB * wm : 16 * RBX * (wm % WX);      // the wave's first row block: tile row, column (FLAT: slot)
     // fragment addresses: window pixel (y0w + dy + kh, x0w + dx + l16 + kw) [window coordinates: image column + 1], 16-byte chunk
     // (4 half + lq) ^ ((l16 + kw) & 6): one register per kw (half 1 = the same ^ 64), (dy + kh, dx) is an immediate
     unsigned acur[2][3], anext[2][3];                                   // [half][kw]
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
         return *(const bf16x8*)(smem + bb[half] + nb * 16 * ROWB);
     };
     // displacement of row block rb for tap row kh, bytes
-    auto aimm = [](int rb, int kh) constexpr { return ((rb / RBX + kh) * PX + 16 * (rb % RBX)) * ROWB; };
+    auto aimm = [](int rb, int kh) constexpr { return FLAT ? (16 * rb + 8 * kh) * ROWB : ((rb / RBX + kh) * PX + 16 * (rb % RBX)) * ROWB; };
 
     step_barrier();                                         // P
     {
@@ -370,7 +379,8 @@ __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
         if (++slab_in_tile == (unsigned)CS) {
             slab_in_tile = 0;
             // ---- epilogue: lane (l16, lq) holds, per row block, pixel l16 x channels 64 wn + 32 j + 8 lq .. + 7 (j = 0, 1) ----
-            const long long yorg = (((long long)tn * p.H + ty0 + y0w) * p.W + x0w) * p.Cout * 2ll + (long long)(c0 + wn * 64) * 2ll;
+            const long long yorg = FLAT ? (long long)tn * p.H * p.W * p.Cout * 2ll + (long long)(c0 + wn * 64) * 2ll
+                                        : (((long long)tn * p.H + ty0 + y0w) * p.W + x0w) * p.Cout * 2ll + (long long)(c0 + wn * 64) * 2ll;
             const long long ybytes = (long long)p.M * p.Cout * 2ll - yorg;
             const __amdgpu_buffer_rsrc_t ry = make_rsrc_sgpr((char*)p.y + yorg, ybytes);
             const __amdgpu_buffer_rsrc_t rr = make_rsrc_sgpr((const char*)p.res + yorg, p.res ? ybytes : 0);
@@ -381,12 +391,16 @@ __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
                 e_sc[v] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * 2048 + cch * 4);
                 e_sh[v] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * 2048 + 1024 + 512 + cch * 4);
             }
-            const unsigned ylane = (unsigned)l16 * (unsigned)p.Cout * 2u + 16u * (unsigned)lq;
+            // FLAT: a block is two 8-slot rows of one image: lane -> (row l16 >> 3, column l16 & 7)
+            const unsigned ylane = (FLAT ? (unsigned)((l16 >> 3) * p.W + (l16 & 7)) : (unsigned)l16) * (unsigned)p.Cout * 2u + 16u * (unsigned)lq;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int dy = rb / RBX, dx = 16 * (rb % RBX);
-                const bool ok = (x0w + dx + l16) < p.W && (ty0 + y0w + dy) < p.H;
-                const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(dy * p.W + dx) * (unsigned)p.Cout * 2u);
+                const int fb = wm * RB + rb;                 // FLAT: block of the tile -> image fb / 4, rows 2 (fb % 4) and + 1
+                const bool ok = FLAT ? ((l16 & 7) < p.W && 2 * (fb & 3) + (l16 >> 3) < p.H && tn + (fb >> 2) < p.N)
+                                     : ((x0w + dx + l16) < p.W && (ty0 + y0w + dy) < p.H);
+                const unsigned soff = __builtin_amdgcn_readfirstlane(FLAT ? (unsigned)((fb >> 2) * p.H * p.W + 2 * (fb & 3) * p.W) * (unsigned)p.Cout * 2u
+                                                                          : (unsigned)(dy * p.W + dx) * (unsigned)p.Cout * 2u);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const unsigned voff = ok ? ylane + 64u * (unsigned)j : 0x80000000u;
@@ -424,23 +438,25 @@ __global__ __launch_bounds__(512) void conv3x3_w2_bf16_kernel(W2Params p) {
 
 HSEFR_KNOB(g_w2_off, 0);    // dev builds: 1 = never use this kernel, 2 = for every shape it covers
 
-template <int RB, int WAVES_M, int WX, int RBX>
+template <int RB, int WAVES_M, int WX, int RBX, bool FLAT = false>
 int launch_w2(W2Params& p, hipStream_t s) {
     constexpr int BN = (4 / WAVES_M) * 64;
     constexpr int TR = (WAVES_M / WX) * (RB / RBX);
+    constexpr int IMG = WAVES_M * RB / 4;
     p.tiles_n = (unsigned)(p.Cout / BN);
-    p.tiles_y = (p.H + TR - 1) / TR;
-    const long long total = (long long)p.N * p.tiles_y * p.tiles_n;
+    p.tiles_y = FLAT ? 1 : (p.H + TR - 1) / TR;
+    const long long total = (FLAT ? (long long)((p.N + IMG - 1) / IMG) : (long long)p.N * p.tiles_y) * p.tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv3x3_w2: too many tiles");
     p.total_tiles = (unsigned)total;
     const unsigned g = (unsigned)(total < 256 ? total : 256);
-    hipLaunchKernelGGL((conv3x3_w2_bf16_kernel<RB, WAVES_M, WX, RBX>), dim3(g), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((conv3x3_w2_bf16_kernel<RB, WAVES_M, WX, RBX, FLAT>), dim3(g), dim3(512), 0, s, p);
     return launch_status("conv3x3_w2_bf16");
 }
 
-// 0: not covered; 1: rows of <= 16 pixels, 14 per tile (14 x 14 maps); 2: <= 32 pixels, 7 rows (28 x 28); 3: <= 64 pixels, 4 rows x 64 channels (56 x 56)
+// 0: not covered; 1: rows of <= 16 pixels, 14 per tile (14 x 14 maps); 2: <= 32 pixels, 7 rows (28 x 28); 3: <= 64 pixels, 4 rows x 64 channels (56 x 56);
+// 4: maps of at most 7 x 7, four images x 64 channels per tile (FLAT)
 int w2_config(int h, int w, int cout) {
-    (void)h;
+    if (w <= 7 && h <= 7) return 4;
     if (w <= 16 && cout % 128 == 0) return 1;
     if (w <= 32 && cout % 128 == 0) return 2;
     if (w <= 64 && cout % 64 == 0) return 3;
@@ -480,6 +496,7 @@ bool conv3x3_w2_bf16_preferred(int h, int w, int cout) {
     if (cfg == 1) return w >= 12 && h >= 12;
     if (cfg == 2) return w >= 24;
     if (cfg == 3) return w >= 48;
+    if (cfg == 4) return w >= 6 && h >= 6;
     return false;
 }
 
@@ -498,6 +515,7 @@ int launch_conv3x3_w2_bf16(const void* x, const void* wt, const float* scale, co
     switch (w2_config(h, w, cout)) {
         case 1: return launch_w2<7, 2, 1, 1>(p, s);
         case 2: return launch_w2<7, 2, 2, 1>(p, s);
+        case 4: return launch_w2<4, 4, 1, 1, true>(p, s);
         default: return launch_w2<4, 4, 1, 4>(p, s);
     }
 }

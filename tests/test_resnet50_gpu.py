@@ -48,7 +48,9 @@ def close_bf16(got, want):
     # more tiles than workgroups (a persistent workgroup walks two tiles)
     (2, 14, 14, 256, 256, 3, 1, False, 1), (3, 13, 12, 64, 128, 3, 1, True, 1), (1, 15, 16, 128, 128, 3, 1, False, 0),
     (2, 28, 28, 128, 128, 3, 1, False, 1), (1, 9, 25, 64, 128, 3, 1, True, 1), (1, 30, 32, 64, 256, 3, 1, False, 1),
-    (2, 6, 50, 128, 64, 3, 1, True, 1), (1, 7, 64, 64, 192, 3, 1, False, 1), (260, 14, 14, 64, 128, 3, 1, False, 1)])
+    (2, 6, 50, 128, 64, 3, 1, True, 1), (1, 7, 64, 64, 192, 3, 1, False, 1), (260, 14, 14, 64, 128, 3, 1, False, 1),
+    # ... and its FLAT geometry for maps of at most 7 x 7: whole images per tile, ragged image groups, 6-pixel edges, residual
+    (6, 7, 7, 128, 128, 3, 1, False, 1), (5, 6, 7, 64, 64, 3, 1, True, 1), (2, 7, 6, 128, 192, 3, 1, False, 0), (131, 7, 7, 64, 128, 3, 1, True, 1)])
 def test_conv_bf16_vs_oracle(env, n, h, w, c, cout, k, s, res, act):
     torch, ops, resnet50 = env
     rs = np.random.RandomState(h * 7 + c + cout + k)
@@ -138,7 +140,7 @@ def test_conv_bf16_exact_integers(env):
     torch, ops, resnet50 = env
     rs = np.random.RandomState(1)
     for (n, h, w, c, cout, k, s) in [(1, 6, 5, 64, 64, 3, 1), (2, 8, 8, 128, 128, 1, 2), (1, 4, 4, 64, 128, 3, 1),
-                                     (1, 14, 14, 128, 128, 3, 1), (1, 28, 28, 64, 128, 3, 1), (1, 8, 56, 64, 64, 3, 1)]:    # (conv3x3_w2)
+                                     (1, 14, 14, 128, 128, 3, 1), (1, 28, 28, 64, 128, 3, 1), (1, 8, 56, 64, 64, 3, 1), (3, 7, 7, 64, 64, 3, 1)]:    # (conv3x3_w2)
         x = rs.randint(-2, 3, (n, h, w, c)).astype(np.float64)
         kern = rs.randint(-1, 2, (k, k, c, cout)).astype(np.float32)
         pad = (k - 1) // 2

@@ -23,6 +23,7 @@ def main():
     shapes = [(2, 14, 14, 64, 128, False), (3, 14, 14, 256, 256, True), (1, 15, 16, 128, 128, False), (2, 13, 12, 64, 128, True),
               (2, 28, 28, 128, 128, False), (1, 9, 25, 64, 128, True), (1, 30, 32, 64, 256, False),
               (1, 56, 56, 64, 64, False), (2, 6, 50, 128, 64, True), (1, 7, 64, 64, 192, False),
+              (3, 7, 7, 512, 512, False), (5, 6, 7, 64, 64, True), (2, 7, 6, 128, 192, False), (130, 7, 7, 128, 512, True), (128, 7, 7, 512, 512, False),
               (260, 14, 14, 64, 128, False), (70, 28, 28, 64, 128, True), (20, 56, 56, 64, 64, False),
               (128, 14, 14, 256, 256, False), (128, 28, 28, 128, 128, False), (128, 56, 56, 64, 64, False)]
     for (n, h, w, c, cout, res) in shapes:
