@@ -75,13 +75,22 @@ static_assert(WPIECES % 2 == 0 && WROWS * WDQ <= 64, "one lane per pair of piece
 constexpr int WRP = WPIECES * 8 + 16;     // bytes per window row and plane: the pieces as f16 + 16 that stay zero
 constexpr int WPLANE = WROWS * WRP;
 constexpr int WSHIFT = 2;                 // a window row starts this many values into its first piece
-constexpr int COP = 36;                   // floats per conv1 pixel in LDS (32 + 4)
-constexpr int P1P = 68;                   // floats per pointwise pixel in LDS (64 + 4)
+// Round 5: the conv1 and pointwise rows in LDS are DENSE (128 / 256 bytes per pixel) with their 16-byte chunks XOR-swizzled by
+// pkey(pixel) = ((pixel & 1) << 2) | ((pixel >> 1) & 3).  The padded pitches of round 4 (36 / 68 floats) kept the MFMA epilogues'
+// 16-byte stores conflict-free but made every depthwise tap read -- 4 pixels x 4 channel quads per ds_read_b128 lane group -- a
+// 7-pass access where 4 is the floor (PMC: 18.6 % of the kernel's LDS cycles were bank conflicts, and the LDS is this kernel's
+// binding unit; no additive pitch serves both sides: tools' bank model, DESIGN.md lesson 48).  With the swizzle both sides are
+// conflict-free for EVERY tap: two pixels that share a lane group's half of the bank window are 2 apart, and pkey keeps their
+// bit 2 equal.  The key of pixel p + tap depends on (p + tap) & 7 only, so a lane keeps FOUR (depthwise 1) / SIX (depthwise 2)
+// pre-swizzled chunk offsets for good and every tap / round / row displacement is an instruction immediate.
+constexpr int COP = 32;                   // floats per conv1 pixel in LDS
+constexpr int P1P = 64;                   // floats per pointwise pixel in LDS
+__device__ __forceinline__ int pkey(int px) { return ((px & 1) << 2) | ((px >> 1) & 3); }
 constexpr int CMB = (2 * CXW + 15) / 16;  // MFMA row blocks of the conv1 GEMM (2 x 15 pixels -> 2)
 constexpr int PMB = (2 * PXW + 15) / 16;  // ... of the pointwise GEMM (2 x 13 -> 2)
 constexpr int NR1 = (PXW + 7) / 8;        // depthwise-1 rounds: 8 columns x 8 channel quads per round
 constexpr int NR2 = (KS + 3) / 4;         // depthwise-2 rounds: 4 output columns x 16 channel quads per round
-constexpr int OFF_CO = 2 * WPLANE;
+constexpr int OFF_CO = (2 * WPLANE + 127) / 128 * 128;      // (128-byte aligned regions: a channel block / key bit is then an XOR of the address)
 constexpr int OFF_AS = OFF_CO + 2 * CXW * COP * 4;
 constexpr int OFF_P1 = OFF_AS + 2 * PXW * 128;         // the A tile's last rows (read, never used) alias the first of these
 constexpr int WAVE_LDS = OFF_P1 + 2 * PXW * P1P * 4;
@@ -103,7 +112,8 @@ __device__ __forceinline__ void wave_order() { asm volatile("" ::: "memory"); }
 
 template <int ACT, bool U8>
 __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5Params p) {
-    __shared__ __attribute__((aligned(16))) unsigned char Lw[WAVES * WAVE_LDS];
+    __shared__ __attribute__((aligned(128))) unsigned char Lw[WAVES * WAVE_LDS];
+    static_assert(OFF_CO % 128 == 0 && OFF_AS % 128 == 0 && OFF_P1 % 128 == 0 && WAVE_LDS % 128 == 0, "swizzled regions are 128-byte aligned");
     __shared__ __attribute__((aligned(16))) unsigned char Wp[64 * 128];   // the pointwise split rows (8 KB): read per step, see below
     __shared__ __attribute__((aligned(16))) float4 W2[9 * 16];
     __shared__ __attribute__((aligned(16))) float4 W1[9 * 8];
@@ -159,7 +169,8 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
         c_ry[mb] = m >= CXW ? 1 : 0;
         c_rx[mb] = m - CXW * c_ry[mb];
         caddr[mb] = (unsigned)((2 * c_ry[mb] + min(q4, 2)) * WRP + 2 * WSHIFT + 12 * c_rx[mb]);
-        coaddr[mb] = (unsigned)(OFF_CO + (c_ry[mb] * CXW + c_rx[mb]) * COP * 4 + 16 * q4);        // + 64 nb
+        // chunk (4 nb + q4) ^ pkey(pixel): channel block nb lands at this ^ (64 nb)
+        coaddr[mb] = (unsigned)(OFF_CO + m * COP * 4 + 16 * (q4 ^ (pkey(m) & 3)) + 64 * (pkey(m) >> 2));
     }
     // pointwise GEMM, row block mb: pixel m = 16 mb + l16 of the 2 x PXW new block-1 pixels
     int p_pr[PMB], p_x[PMB];
@@ -170,13 +181,32 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
         p_x[mb] = m - PXW * p_pr[mb];
     }
     const bool p_store_last = 16 * (PMB - 1) + l16 < 2 * PXW;      // the last row block is partly empty
+    unsigned paddr[PMB];                                           // pointwise pixel's row, chunk (4 cb + q4) ^ pkey(pixel): + 64 cb, ^ 64 (pkey >> 2)
+#pragma unroll
+    for (int mb = 0; mb < PMB; ++mb) {
+        const int m = p_pr[mb] * PXW + p_x[mb];
+        paddr[mb] = (unsigned)(OFF_P1 + m * P1P * 4 + 16 * (q4 ^ (pkey(m) & 3)) + 64 * (pkey(m) >> 2));
+    }
     // window pieces: lane = WDQ row + dq loads pieces 2 dq and 2 dq + 1 of input row `row`
     const int wl_row = lane / WDQ, wl_dq = lane - WDQ * wl_row;
     const bool wl_on = lane < WDQ * WROWS;
     // depthwise 1: (column x, channel quad): round rd covers x = 8 rd .. 8 rd + 7
     const int d1_q = lane & 7, d1_x0 = lane >> 3;
+    // tap reads: conv pixel cr * CXW + 8 rd + d1_x0 + tap, chunk d1_q ^ pkey(pixel); (pixel & 7) = (d1_x0 + tap - cr) & 7, four cases
+    unsigned d1f[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) d1f[v] = (unsigned)(OFF_CO + d1_x0 * COP * 4 + 16 * (d1_q ^ pkey((d1_x0 + v - 1) & 7)));
     // depthwise 2: (output column j, channel quad of 16): round rd covers j = 4 rd .. 4 rd + 3
     const int d2_q = lane & 15, d2_j = lane >> 4;
+    // tap reads: pointwise pixel row * PXW + 8 rd + 2 d2_j + tap, chunk d2_q ^ pkey(pixel); (pixel & 7) = (5 row + 2 d2_j + tap) & 7, six cases
+    // (2 d2_j is even: pixel 2 d2_j + 1 has the key of 2 d2_j with bit 2 set, its address is the same ^ 64; likewise row 1's taps 1
+    // and 2 -- pixels 2 d2_j + 6 and + 7 -- so four of the six live in registers and two are one XOR away)
+    static_assert(PXW % 8 == 5, "the key pairs of depthwise 2's taps");
+    unsigned d2f[2][2];
+    d2f[0][0] = (unsigned)(OFF_P1 + 2 * d2_j * P1P * 4 + 16 * (d2_q ^ pkey((2 * d2_j) & 7)));
+    d2f[0][1] = (unsigned)(OFF_P1 + 2 * d2_j * P1P * 4 + 16 * (d2_q ^ pkey((2 * d2_j + 2) & 7)));
+    d2f[1][0] = (unsigned)(OFF_P1 + 2 * d2_j * P1P * 4 + 16 * (d2_q ^ pkey((2 * d2_j + 5) & 7)));
+    d2f[1][1] = (unsigned)(OFF_P1 + 2 * d2_j * P1P * 4 + 16 * (d2_q ^ pkey((2 * d2_j + 6) & 7)));
 
     typedef typename std::conditional<U8, unsigned, f32x4>::type raw_t;
     constexpr int VB = U8 ? 1 : 4;
@@ -320,7 +350,7 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = __builtin_amdgcn_fmed3f(o[e], 0.f, 6.f);
                         o = o * vmul;          // (a uniform `if` around it came back as 4 selects per vector: the multiply is cheaper)
-                        *(f32x4*)(L + coaddr[mb] + 64 * nb) = o;
+                        *(f32x4*)(L + (coaddr[mb] ^ (64u * nb))) = o;
                     }
                     wave_order();
                 }
@@ -337,9 +367,12 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
                 for (int cr = 0; cr < 2; ++cr) {
 #pragma unroll
                     for (int rd = 0; rd < NR1; ++rd) {
-                        const int x = min(8 * rd + d1_x0, PXW - 1);          // (lanes past the last column repeat it and do not store)
-                        const float* t = (const float*)(L + OFF_CO) + (cr * CXW + x) * COP + 4 * d1_q;
-                        const f32x4 t0 = *(const f32x4*)(t), t1 = *(const f32x4*)(t + COP), t2 = *(const f32x4*)(t + 2 * COP);
+                        // (lanes past the last column read on -- into cells of the A tile behind the conv rows, finite or not: their
+                        // sums are never stored -- instead of repeating the last column: the address stays lane constant + immediate)
+                        const int x = 8 * rd + d1_x0;
+                        const f32x4 t0 = *(const f32x4*)(L + d1f[1 - cr] + (cr * CXW + 8 * rd) * COP * 4);
+                        const f32x4 t1 = *(const f32x4*)(L + d1f[2 - cr] + (cr * CXW + 8 * rd + 1) * COP * 4);
+                        const f32x4 t2 = *(const f32x4*)(L + d1f[3 - cr] + (cr * CXW + 8 * rd + 2) * COP * 4);
                         f32x4 sP = aQ[rd];                 // the row that had kernel rows 0 and 1: this is its third -> complete
                         sP = vfma(t0, w1[6], sP); sP = vfma(t1, w1[7], sP); sP = vfma(t2, w1[8], sP);
                         f32x4 sQ = aR[rd];                 // the row that had kernel row 0
@@ -355,7 +388,7 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
                         const f16x4 hi = __builtin_convertvector(v, f16x4);
                         const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
                         const int q = cr * PXW + x;
-                        if (8 * rd + 8 <= PXW || 8 * rd + d1_x0 < PXW) {
+                        if (8 * rd + 8 <= PXW || x < PXW) {
                             *(f16x4*)(L + OFF_AS + swzb(q, d1_q >> 1) + 8 * (d1_q & 1)) = hi;
                             *(f16x4*)(L + OFF_AS + swzb(q, 4 + (d1_q >> 1)) + 8 * (d1_q & 1)) = lo;
                         }
@@ -402,7 +435,7 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = __builtin_amdgcn_fmed3f(o[e], 0.f, 6.f);
                             o = o * vmul;
-                            *(f32x4*)((float*)(L + OFF_P1) + (p_pr[mb] * PXW + p_x[mb]) * P1P + cb * 16 + 4 * q4) = o;
+                            *(f32x4*)(L + ((paddr[mb] + 64u * (cb & 2)) ^ (64u * (cb & 1)))) = o;
                         }
                     }
                     wave_order();
@@ -419,10 +452,12 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
                 for (int k = 0; k < 9; ++k) w2[k] = as_v(W2z[k * 16 + d2_q]);
 #pragma unroll
                 for (int rd = 0; rd < NR2; ++rd) {
-                    const int j = min(4 * rd + d2_j, KS - 1);          // (lanes past the last column repeat it and do not store)
-                    const float* t = (const float*)(L + OFF_P1) + (2 * j) * P1P + 4 * d2_q;
-                    const f32x4 a0 = *(const f32x4*)(t), a1 = *(const f32x4*)(t + P1P), a2 = *(const f32x4*)(t + 2 * P1P);
-                    const f32x4 b0 = *(const f32x4*)(t + PXW * P1P), b1 = *(const f32x4*)(t + (PXW + 1) * P1P), b2 = *(const f32x4*)(t + (PXW + 2) * P1P);
+                    // (lanes past the last column read on, past the wave's own rows -- other waves' cells or the constants behind them, in
+                    // bounds of the workgroup's LDS: never stored)
+                    const f32x4 a0 = *(const f32x4*)(L + d2f[0][0] + (8 * rd) * P1P * 4), a1 = *(const f32x4*)(L + (d2f[0][0] ^ 64u) + (8 * rd + 1) * P1P * 4);
+                    const f32x4 a2 = *(const f32x4*)(L + d2f[0][1] + (8 * rd + 2) * P1P * 4);
+                    const f32x4 b0 = *(const f32x4*)(L + d2f[1][0] + (PXW + 8 * rd) * P1P * 4), b1 = *(const f32x4*)(L + d2f[1][1] + (PXW + 8 * rd + 1) * P1P * 4);
+                    const f32x4 b2 = *(const f32x4*)(L + (d2f[1][1] ^ 64u) + (PXW + 8 * rd + 2) * P1P * 4);
                     f32x4 sO = aO[rd];
                     sO = vfma(a0, w2[3], sO); sO = vfma(a1, w2[4], sO); sO = vfma(a2, w2[5], sO);
                     sO = vfma(b0, w2[6], sO); sO = vfma(b1, w2[7], sO); sO = vfma(b2, w2[8], sO);
