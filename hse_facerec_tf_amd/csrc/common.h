@@ -190,6 +190,11 @@ bool conv3x3_w2_bf16_supported(long long n, int h, int w, int c, int cout);
 bool conv3x3_w2_bf16_preferred(int h, int w, int cout);
 int launch_conv3x3_w2_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
                            int w, int c, int cout, int act, hipStream_t s);
+bool conv1x1_w4_forced();
+bool conv1x1_w4_bf16_supported(long long n, int h, int w, int c, int oh, int ow, int cout, int stride);
+bool conv1x1_w4_bf16_preferred(long long pixels, int c, int cout, bool has_res);
+int launch_conv1x1_w4_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
+                           int w, int c, int oh, int ow, int cout, int stride, int act, hipStream_t s);
 bool conv_dma_forced();
 bool conv_dma_bf16_supported(long long n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw);
 int launch_conv_dma_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
@@ -286,6 +291,8 @@ void set_psdw_mode(int v);
 void set_cd_rb(int v);
 void set_w3_off(int v);
 void set_w2_off(int v);
+void set_w4_off(int v);
+int read_w4_stamps(void* host_out, size_t bytes);
 int read_w2_stamps(void* host_out, size_t bytes);
 int read_w3_stamps(void* host_out, size_t bytes);
 int read_cd_stamps(void* host_out, size_t bytes);

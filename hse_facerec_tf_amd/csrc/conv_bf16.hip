@@ -450,6 +450,10 @@ int launch_conv_bf16(const void* x, const void* wt, const float* scale, const fl
     if (n == 0) return HSEFR_OK;
     const long long P = (long long)n * oh * ow;
     HSEFR_REQUIRE(P < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv_bf16: too many output pixels");
+    // 1x1 (stride 1 | 2) on the four-wave LDS-DMA GEMM (conv1x1_w4_bf16.hip, round 5)
+    if (kh == 1 && kw == 1 && pad_t == 0 && pad_l == 0 && (conv1x1_w4_forced() || conv1x1_w4_bf16_preferred(P, c, cout, res != nullptr)) &&
+        conv1x1_w4_bf16_supported(n, h, w, c, oh, ow, cout, stride))
+        return launch_conv1x1_w4_bf16(x, wt, scale, shift, res, y, n, h, w, c, oh, ow, cout, stride, act, s);
     // 3x3 / stride 1 / pad 1, window resident in LDS, four wide MFMA waves (conv3x3_w2_bf16.hip, round 5): the 56 / 28 / 14-pixel maps
     if (kh == 3 && kw == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && oh == h && ow == w && conv3x3_w2_bf16_supported(n, h, w, c, cout) &&
         (conv3x3_w2_bf16_preferred(h, w, cout) || conv3x3_w2_forced()))

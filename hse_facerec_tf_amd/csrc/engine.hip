@@ -300,6 +300,7 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "cd_off")) { set_cd_off(value); return HSEFR_OK; }
     if (!strcmp(key, "w3_off")) { set_w3_off(value); return HSEFR_OK; }
     if (!strcmp(key, "w2_off")) { set_w2_off(value); return HSEFR_OK; }
+    if (!strcmp(key, "w4_off")) { set_w4_off(value); return HSEFR_OK; }
     if (!strcmp(key, "c11")) { set_c11(value); return HSEFR_OK; }
     if (!strcmp(key, "stem4_grid")) { set_stem4_grid(value); return HSEFR_OK; }
     if (!strcmp(key, "stem4")) { g_stem4 = value; return HSEFR_OK; }
@@ -331,6 +332,7 @@ int hsefr_debug_read_stamps(void* host_out, size_t bytes) {
     // the split-f16 GEMM's stamps, (bytes == 512*4*10*8) the fused stem's, or (bytes == 256*12*8*8) the pre-split GEMM's
     if (bytes == 256 * 12 * 8 * 8) return read_ps_stamps(host_out, bytes);
     if (bytes == 256 * 12 * 8 * 8 - 8) return read_cd_stamps(host_out, bytes);
+    if (bytes == 256 * 8 * 8 * 8 - 8) return read_w4_stamps(host_out, bytes);         // (one word short: the four-wave 1x1 GEMM's)
     if (bytes == 256 * 8 * 8 * 8) return read_w2_stamps(host_out, bytes);             // (eight waves per workgroup: the second window 3x3 convolution's)
     if (bytes == 256 * 12 * 8 * 8 - 16) return read_w3_stamps(host_out, bytes);     // (two words short: the window 3x3 convolution's)      // (one word short: the bf16 DMA convolution's)
     return bytes == 512 * 4 * 10 * 8 ? read_stem_stamps(host_out, bytes) : read_pws_stamps(host_out, bytes);

@@ -49,6 +49,9 @@ def close_bf16(got, want):
     (2, 14, 14, 256, 256, 3, 1, False, 1), (3, 13, 12, 64, 128, 3, 1, True, 1), (1, 15, 16, 128, 128, 3, 1, False, 0),
     (2, 28, 28, 128, 128, 3, 1, False, 1), (1, 9, 25, 64, 128, 3, 1, True, 1), (1, 30, 32, 64, 256, 3, 1, False, 1),
     (2, 6, 50, 128, 64, 3, 1, True, 1), (1, 7, 64, 64, 192, 3, 1, False, 1), (260, 14, 14, 64, 128, 3, 1, False, 1),
+    # the four-wave 1x1 GEMM (csrc/conv1x1_w4_bf16.hip, round 5: K-deep reductions with >= 20 000 output pixels): stride 1 and 2 (gathered
+    # rows), a ragged last tile, several tiles per workgroup
+    (103, 14, 14, 256, 128, 1, 1, False, 1), (30, 53, 54, 256, 128, 1, 2, False, 1), (27, 28, 28, 512, 256, 1, 1, False, 0),
     # ... and its FLAT geometry for maps of at most 7 x 7: whole images per tile, ragged image groups, 6-pixel edges, residual
     (6, 7, 7, 128, 128, 3, 1, False, 1), (5, 6, 7, 64, 64, 3, 1, True, 1), (2, 7, 6, 128, 192, 3, 1, False, 0), (131, 7, 7, 64, 128, 3, 1, True, 1)])
 def test_conv_bf16_vs_oracle(env, n, h, w, c, cout, k, s, res, act):

@@ -20,9 +20,11 @@ from kbench_conv import LAYERS, B
 g = torch.Generator(device="cuda").manual_seed(0)
 WIN = os.environ.get("CD_WIN", "0") == "1"       # CD_WIN=1: the window 3x3 kernel (csrc/conv3x3_win_bf16.hip) instead
 W2 = os.environ.get("CD_W2", "0") == "1"         # CD_W2=1: the four-wave window kernel (csrc/conv3x3_w2_bf16.hip)
+W4 = os.environ.get("CD_W4", "0") == "1"         # CD_W4=1: the four-wave 1x1 GEMM (csrc/conv1x1_w4_bf16.hip)
 _lib.check(_lib.lib().hsefr_debug_set(b"cd_off", 2))
 _lib.check(_lib.lib().hsefr_debug_set(b"w3_off", 2 if WIN else 1))
 _lib.check(_lib.lib().hsefr_debug_set(b"w2_off", 2 if W2 else 1))
+_lib.check(_lib.lib().hsefr_debug_set(b"w4_off", 2 if W4 else 1))
 RB = int(os.environ.get("CD_RB", "0"))
 _lib.check(_lib.lib().hsefr_debug_set(b"cd_rb", RB))
 for name in sys.argv[1:] or ["c4_3x3", "c4_red", "c4_inc"]:
@@ -35,10 +37,10 @@ for name in sys.argv[1:] or ["c4_3x3", "c4_red", "c4_inc"]:
     for _ in range(5):
         ops.conv_bf16(x, w, sc, sh, k, k, stride=s, pad=k // 2, res=r)
     torch.cuda.synchronize()
-    if W2:
-        buf = np.zeros(256 * 8 * 8, np.uint64)
+    if W2 or W4:
+        buf = np.zeros(256 * 8 * 8 - (1 if W4 else 0), np.uint64)
         _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
-        b = buf.astype(np.float64).reshape(256, 8, 8)
+        b = np.concatenate([buf, [0] * (1 if W4 else 0)]).astype(np.float64).reshape(256, 8, 8)
         roles = (("MFMA waves", slice(0, 4), ["ds_read + mfma issue", "step barrier", "epilogue"]),
                  ("loader waves", slice(4, 8), ["DMA issue", "vmcnt wait", "step barrier"]))
     else:

@@ -79,6 +79,10 @@ def main():
                 out += "  | w2 %6.1f" % timeit(fn)
             except Exception as e:          # (shapes the four-wave window kernel does not cover: cout % 128 on the narrow maps)
                 out += "  | w2   n/a"
+        if k == 1:
+            knob("w4_off", 2)
+            out += "  | w4 %6.1f" % timeit(fn)
+            knob("w4_off", 0)
         knob("cd_off", 0)
         knob("w3_off", 0)
         knob("w2_off", 0)
