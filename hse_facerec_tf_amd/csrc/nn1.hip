@@ -277,40 +277,57 @@ int launch_l2_normalize(const float* x, float* y, int n, int d, hipStream_t s) {
     return launch_status("l2_normalize");
 }
 
+HSEFR_KNOB(g_nn1_y_mb, 256);      // dev builds: bound of the distance-matrix slice in MiB (tests force several query blocks with a small one)
+#define NN1_Y_BYTES ((long long)g_nn1_y_mb << 20)
+#ifdef HSEFR_DEV
+void set_nn1_y_mb(int v) { g_nn1_y_mb = v > 0 ? v : 1; }
+#endif
+
 int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2, hipStream_t s) {
     HSEFR_REQUIRE(d > 0 && d % 8 == 0, HSEFR_ERR_UNSUPPORTED, "nn1: d=%d must be a multiple of 8", d);
     HSEFR_REQUIRE(nq >= 0 && ng > 0, HSEFR_ERR_INVALID, "nn1: nq=%d ng=%d", nq, ng);
     if (nq == 0) return HSEFR_OK;
     if (d % 32 == 0 && (long long)nq * ng * d >= (1ll << 28)) {
-        // the split-f16 GEMM path; its workspace (scaled probes, split gallery, the [nq, ng_pad] matrix) is stream-ordered
+        // the split-f16 GEMM path; its workspace (scaled probes, split gallery, a [block, ng_pad] slice of the distance matrix) is
+        // stream-ordered.  The matrix is walked in QUERY BLOCKS so that it stays bounded (NN1_Y_BYTES: 100 000 x 100 000 would be
+        // 40 GB in one piece -- ADVICE r4); rows are independent, so the blocking changes no bit.  If the allocation fails (the
+        // caller's allocator may hold the memory) the search runs on nn1_kernel, which needs no workspace.
         const int ng_pad = (ng + 63) / 64 * 64;
-        const size_t b_qs = (size_t)nq * d * 4, b_w = (size_t)ng_pad * d * 4, b_y = (size_t)nq * ng_pad * 4;
+        const long long y_rows_max = NN1_Y_BYTES / ((long long)ng_pad * 4);
+        const int qb = (int)(y_rows_max >= nq ? nq : (y_rows_max < 256 ? 256 : y_rows_max / 256 * 256));     // query rows per block
+        const size_t b_qs = (size_t)nq * d * 4, b_w = (size_t)ng_pad * d * 4, b_y = (size_t)qb * ng_pad * 4;
         const size_t b_small = ((size_t)nq + 2 * (size_t)ng_pad + 64) * 4;
         char* ws = nullptr;
-        HSEFR_HIP_CHECK(hipMallocAsync((void**)&ws, b_qs + b_w + b_y + b_small, s));
-        float* qs = (float*)ws;
-        unsigned short* w = (unsigned short*)(ws + b_qs);
-        float* y = (float*)(ws + b_qs + b_w);
-        float* qq = (float*)(ws + b_qs + b_w + b_y);
-        float* descale = qq + nq;
-        float* shift = descale + ng_pad;
-        unsigned* qmax = (unsigned*)(shift + ng_pad);
-        int rc = HSEFR_OK;
-        if (hipMemsetAsync(qmax, 0, 4, s) != hipSuccess) rc = HSEFR_ERR_HIP;
-        if (rc == HSEFR_OK) {
-            hipLaunchKernelGGL(nn1_prep_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, q, nq, d, qq, qmax);
-            hipLaunchKernelGGL(nn1_split_gallery_kernel, dim3((ng_pad + 3) / 4), dim3(256), 0, s, g, ng, ng_pad, d, w, descale, shift, qmax);
-            const long long n4 = (long long)nq * d / 4;
-            hipLaunchKernelGGL(nn1_scale_queries_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, q, qs, n4, qmax);
-            rc = launch_status("nn1 (split-f16 preparation)");
+        if (hipMallocAsync((void**)&ws, b_qs + b_w + b_y + b_small, s) == hipSuccess && ws) {
+            float* qs = (float*)ws;
+            unsigned short* w = (unsigned short*)(ws + b_qs);
+            float* y = (float*)(ws + b_qs + b_w);
+            float* qq = (float*)(ws + b_qs + b_w + b_y);
+            float* descale = qq + nq;
+            float* shift = descale + ng_pad;
+            unsigned* qmax = (unsigned*)(shift + ng_pad);
+            int rc = HSEFR_OK;
+            if (hipMemsetAsync(qmax, 0, 4, s) != hipSuccess) rc = HSEFR_ERR_HIP;
+            if (rc == HSEFR_OK) {
+                hipLaunchKernelGGL(nn1_prep_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, q, nq, d, qq, qmax);
+                hipLaunchKernelGGL(nn1_split_gallery_kernel, dim3((ng_pad + 3) / 4), dim3(256), 0, s, g, ng, ng_pad, d, w, descale, shift, qmax);
+                const long long n4 = (long long)nq * d / 4;
+                hipLaunchKernelGGL(nn1_scale_queries_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, q, qs, n4, qmax);
+                rc = launch_status("nn1 (split-f16 preparation)");
+            }
+            for (int q0 = 0; q0 < nq && rc == HSEFR_OK; q0 += qb) {
+                const int m = nq - q0 < qb ? nq - q0 : qb;
+                rc = launch_pwconv_f16s(qs + (size_t)q0 * d, w, descale, shift, y, m, d, ng_pad, 12, HSEFR_ACT_NONE, s);
+                if (rc == HSEFR_OK) {
+                    hipLaunchKernelGGL(nn1_row_argmin_kernel, dim3((m + 3) / 4), dim3(256), 0, s, y, m, ng, ng_pad, qq + q0, nn_index + q0,
+                                       nn_dist2 ? nn_dist2 + q0 : nullptr);
+                    rc = launch_status("nn1 (row arg-min)");
+                }
+            }
+            (void)hipFreeAsync(ws, s);
+            return rc;
         }
-        if (rc == HSEFR_OK) rc = launch_pwconv_f16s(qs, w, descale, shift, y, nq, d, ng_pad, 12, HSEFR_ACT_NONE, s);
-        if (rc == HSEFR_OK) {
-            hipLaunchKernelGGL(nn1_row_argmin_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, y, nq, ng, ng_pad, qq, nn_index, nn_dist2);
-            rc = launch_status("nn1 (row arg-min)");
-        }
-        (void)hipFreeAsync(ws, s);
-        return rc;
+        (void)hipGetLastError();          // the failed allocation: not this call's result -- fall through to the workspace-free kernel
     }
     dim3 grid((nq + 31) / 32), block(256);
     hipLaunchKernelGGL(nn1_kernel, grid, block, 0, s, q, g, nq, ng, d, nn_index, nn_dist2);

@@ -88,6 +88,29 @@ def test_nn1_split_f16_gemm_path_vs_fp64(torch_, nq, ng, d, scale):
     assert 0 <= idx.min() and idx.max() < ng
 
 
+def test_nn1_gemm_path_walks_large_searches_in_query_blocks(torch_):
+    """the [nq, ng] distance matrix of the split-f16 GEMM path is bounded (256 MiB slices, walked in query blocks; a failed
+    workspace allocation falls back to the workspace-free kernel) instead of growing with the search.  20 000 x 4096 (a 327 MB matrix)
+    takes two blocks: the same neighbours as the same search done in halves that fit one block each -- rows are independent -- and
+    a sample of rows on both sides of the block boundary against fp64."""
+    from hse_facerec_tf_amd import ops
+    nq, ng, d = 20000, 4096, 32
+    assert nq * ng * d >= 1 << 28 and nq * ng * 4 > 256 << 20
+    g_ = torch_.Generator(device="cuda").manual_seed(5)
+    gal = torch_.randn((ng, d), device="cuda", generator=g_)
+    q = gal[torch_.randint(0, ng, (nq,), device="cuda", generator=g_)] + 0.3 * torch_.randn((nq, d), device="cuda", generator=g_)
+    idx, dist = ops.nn1(q, gal)
+    halves = [ops.nn1(q[a:b].contiguous(), gal) for a, b in ((0, 10000), (10000, 20000))]
+    # (each search scales its probes by ONE power of two taken from its own largest value: the halves may use another exponent than
+    # the whole, which changes no product but can move the split's last bit -- indices must agree, distances to rounding)
+    assert torch_.equal(idx, torch_.cat([h[0] for h in halves]))
+    assert float((dist - torch_.cat([h[1] for h in halves])).abs().max()) < 1e-4
+    rows = np.array([0, 1, 9999, 10000, 16383, 16384, 16385, 19999])           # both sides of the block boundary
+    d2 = ((q[rows].double()[:, None, :] - gal.double()[None]) ** 2).sum(-1)
+    assert torch_.equal(idx[rows].long(), d2.argmin(dim=1))
+    assert float((dist[rows].double() - d2.min(dim=1).values).abs().max()) < 1e-3
+
+
 def test_nn1_ties_resolve_to_lowest_index(torch_):
     from hse_facerec_tf_amd import ops
     g = np.zeros((40, 8), np.float32)
