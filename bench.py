@@ -474,6 +474,27 @@ def time_engine(eng, x, want, steps, warm):
     return dt
 
 
+def profile_traffic_per_forward(tag, once_kernel=None):
+    """HBM bytes per forward of a side config from its newest committed PMC profile (profiles/rNN_<tag>_traffic.json, written by
+    tools/make_profile_summary.py from tools/gpu_pmc.sh over tools/bench_configs.py <config>: separate FETCH_SIZE / WRITE_SIZE passes,
+    FETCH_SIZE doubled): sum over the kernels of launches x bytes per launch, divided by the number of forwards the profiled command
+    ran (the profile's `forwards`, or the launch count of a once-per-forward kernel).  -> (bytes | None, source | None, stale | None)"""
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_traffic.json" % tag)))
+        if not cands:
+            return None, None, None
+        pj = json.load(open(cands[-1]))
+        ks = pj["kernels"]
+        fwd = pj.get("forwards") or (max([v["launches"] for k, v in ks.items() if once_kernel and once_kernel in k] or [0]))
+        if not fwd:
+            return None, None, None
+        return (int(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks.values()) / fwd), os.path.relpath(cands[-1], ROOT),
+                pj.get("csrc_hash") != csrc_hash())
+    except Exception:
+        return None, None, None
+
+
 def run_other_configs(args, dev):
     import torch
     from hse_facerec_tf_amd import lowering, resnet50
@@ -501,19 +522,7 @@ def run_other_configs(args, dev):
         # measured HBM bytes per forward from the committed PMC profile of this config (tools/gpu_pmc.sh over
         # tools/bench_configs.py resnet50: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled): sum over its kernels
         # of launches x bytes per launch, divided by the number of forwards (= launches of the once-per-forward stem kernel)
-        rn_traffic, rn_src, rn_stale = None, None, None
-        try:
-            import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_resnet50_traffic.json")))
-            if cands:
-                pj = json.load(open(cands[-1]))
-                ks = pj["kernels"]
-                fwd = max([v["launches"] for k, v in ks.items() if "stem7x7_pool" in k] or [0])
-                if fwd:
-                    rn_traffic = int(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks.values()) / fwd)
-                    rn_src, rn_stale = os.path.relpath(cands[-1], ROOT), pj.get("csrc_hash") != csrc_hash()
-        except Exception:
-            rn_traffic = None
+        rn_traffic, rn_src, rn_stale = profile_traffic_per_forward("resnet50", "stem7x7_pool")
         out.append({"config": "BASELINE configs[2]: ResNet-50 embeddings (2048-D), batch 128, 224x224x3, bf16 storage + bf16 MFMA, fp32 accumulate",
                     "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "dtype": "bf16",
                     "weights": "synthetic (seed 123)", "tflops": round(fl * B / dt / 1e12, 1),
@@ -537,12 +546,17 @@ def run_other_configs(args, dev):
         eng = Engine(plan, max_batch=B, device=dev.index)
         dt = time_engine(eng, gen(B, 224), (0, 1, 2), steps, warm)
         by = 40.948e6 * B + 12.74e6          # unfused layer-wise bytes per face @224 + weights per batch
+        ag_traffic, ag_src, ag_stale = profile_traffic_per_forward("agegender", "stem5_stream")
         out.append({"config": "BASELINE configs[3]: age_gender_tf2 MobileNet-224 multi-head (features + age softmax + gender sigmoid), batch 512, fp32",
                     "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "dtype": "f32",
                     "weights": "age_gender_tf2_new-01-0.14-0.92_quantized.pb",
                     "roofline": {"bound": "hbm", "achieved": round(by / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(by / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                                 "note": "unfused layer-wise algorithmic bytes (40.948 MB/face, SURVEY 8d) / time"}})
+                                 "frac": round(by / dt / 1e9 / HBM_PEAK_GBS, 4), "traffic": ag_traffic,
+                                 "traffic_unit": "HBM bytes per forward (batch %d), PMC counters" % B, "traffic_source": ag_src, "traffic_stale": ag_stale,
+                                 "measured_hbm_gbs": None if not ag_traffic else round(ag_traffic / dt / 1e9, 1),
+                                 "algorithmic_bytes_per_forward": int(by),
+                                 "note": "achieved / frac: unfused layer-wise algorithmic bytes (40.948 MB/face, SURVEY 8d) / time; measured_hbm_gbs: "
+                                         "counter bytes (the fused plan moves fewer) / time"}})
         eng.close()
     except Exception as e:
         out.append({"config": "BASELINE configs[3]: age/gender MobileNet-224", "error": repr(e)})
@@ -554,11 +568,13 @@ def run_other_configs(args, dev):
         eng = Engine(plan, max_batch=B, device=dev.index)
         dt = time_engine(eng, gen(B, S), (0,), steps, warm)
         fl = plan.flops_per_image([lowering.OP_PWCONV_F32])
+        f32_traffic, f32_src, f32_stale = profile_traffic_per_forward("mobilenet_f32")
         out.append({"config": "BASELINE configs[1] with pw_math='f32': MobileNet-192 batch %d, every product on the fp32 pipes "
                               "(v_mfma_f32_32x32x2_f32 / fp32 FMA), no f16 split" % B,
                     "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "dtype": "f32",
                     "roofline": {"bound": "mfma", "achieved": round(plan.flops_per_image() * B / dt / 1e12, 1), "peak": MFMA_F32_PEAK_TF,
-                                 "unit": "TFLOP/s", "frac": round(plan.flops_per_image() * B / dt / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                                 "unit": "TFLOP/s", "frac": round(plan.flops_per_image() * B / dt / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": f32_traffic,
+                                 "traffic_unit": "HBM bytes per forward (batch %d), PMC counters" % B, "traffic_source": f32_src, "traffic_stale": f32_stale,
                                  "note": "whole-net flops (%.0f %% pointwise) over the fp32-MFMA peak" % (100.0 * fl / plan.flops_per_image())}})
         eng.close()
     except Exception as e:

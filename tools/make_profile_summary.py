@@ -13,6 +13,7 @@ import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+forwards = int(sys.argv[3]) if len(sys.argv) > 3 else None      # forwards of the profiled command (tools/bench_configs.py prints it): bench.py divides by it
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -62,10 +63,22 @@ for k, v in traffic.items():
                                        "this kernel" % ("%.2f" % clock if clock else "?", dur_us, "counter pass" if v.get("pmc_pass_us") else "trace pass"))
     if v.get("SQ_LDS_IDX_ACTIVE"):
         v["lds_conflict_share"] = round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"], 4)
+# Round 5: a kernel whose own GRBM_GUI_ACTIVE window was rejected (dispatches under ~40 us: the window is longer
+# than the kernel) still gets a utilisation -- its matrix-pipe busy cycles over its duration IN THE COUNTER PASS at the REFERENCE CLOCK
+# of that pass, the median clock of the kernels whose windows were accepted (they ran interleaved with it, in the same process, on
+# the same box) -- and says so.  busy / (1024 SIMDs x duration x clock): the same quotient with the denominator taken from neighbours.
+clocks = sorted(v["gfx_clock_ghz"] for v in traffic.values() if "gfx_clock_ghz" in v)
+if clocks:
+    ref = clocks[len(clocks) // 2]
+    for v in traffic.values():
+        if "mfma_util_rejected" in v and v.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and (v.get("pmc_pass_us") or v.get("avg_us")):
+            dur_us = v.get("pmc_pass_us") or v.get("avg_us")
+            v["mfma_util"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * dur_us * 1e3 * ref), 4)
+            v["mfma_util_basis"] = "reference clock %.3f GHz (median of the accepted kernels of this pass); own window: %s" % (ref, v.pop("mfma_util_rejected"))
 traffic = {k: v for k, v in traffic.items() if "hbm_bytes_per_launch" in v and not k.startswith("void at::") and not k.startswith("__amd")}
 sys.path.insert(0, root)
 import bench  # noqa: E402  (csrc_hash: bench.py marks the traffic figures stale when the kernels changed since this profile)
-json.dump({"csrc_hash": bench.csrc_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); "
+json.dump({"csrc_hash": bench.csrc_hash(), "forwards": forwards, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); "
                      "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
            "kernels": traffic}, open(os.path.join(out, "%s_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(traffic, indent=1))

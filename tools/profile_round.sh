@@ -1,0 +1,31 @@
+#!/bin/bash
+# One round's judged profile set, on the GPU box (through gpurun):   bash tools/profile_round.sh r05
+# -> gpurun_out/prof_<tag>{,_resnet,_agegender,_f32}/ (tools/gpu_pmc.sh: kernel-trace stats + one PMC group per pass), the per-LAYER
+# tables of the four configs and the default bench line of the same box.  Then, here:  bash tools/profile_round.sh r05 collect
+set -u
+TAG=${1:-r05}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+if [ "${2:-}" = "collect" ]; then
+  fw() { grep -m1 '^forwards' "gpurun_out/prof_${TAG}$1/layers.txt" | awk '{print $2}'; }
+  python3 tools/make_profile_summary.py gpurun_out/prof_${TAG} ${TAG}
+  python3 tools/make_profile_summary.py gpurun_out/prof_${TAG}_resnet ${TAG}_resnet50 "$(fw _resnet)"
+  python3 tools/make_profile_summary.py gpurun_out/prof_${TAG}_agegender ${TAG}_agegender "$(fw _agegender)"
+  python3 tools/make_profile_summary.py gpurun_out/prof_${TAG}_f32 ${TAG}_mobilenet_f32 "$(fw _f32)"
+  cp gpurun_out/prof_${TAG}/layers.txt profiles/${TAG}_layers.txt
+  cp gpurun_out/prof_${TAG}_resnet/layers.txt profiles/${TAG}_resnet50_layers.txt
+  cp gpurun_out/prof_${TAG}_agegender/layers.txt profiles/${TAG}_agegender_layers.txt
+  cp gpurun_out/prof_${TAG}_f32/layers.txt profiles/${TAG}_mobilenet_f32_layers.txt
+  [ -s gpurun_out/prof_${TAG}/bench_line.json ] && cp gpurun_out/prof_${TAG}/bench_line.json profiles/${TAG}_bench_line.json
+  exit 0
+fi
+cd "$R"
+HEAD="--steps 20 --warmup 5 --no-config5 --no-other-configs --no-pipeline --no-latency --no-cpu-baseline --no-sustained"
+bash tools/gpu_pmc.sh gpurun_out/prof_${TAG} python3 $R/bench.py $HEAD
+bash tools/gpu_pmc.sh gpurun_out/prof_${TAG}_resnet python3 $R/tools/bench_configs.py resnet50
+bash tools/gpu_pmc.sh gpurun_out/prof_${TAG}_agegender python3 $R/tools/bench_configs.py agegender
+bash tools/gpu_pmc.sh gpurun_out/prof_${TAG}_f32 python3 $R/tools/bench_configs.py mobilenet_f32
+cd "$R"
+python3 tools/bench_configs.py mobilenet192 > gpurun_out/prof_${TAG}/layers.txt 2>&1
+python3 tools/bench_configs.py resnet50 > gpurun_out/prof_${TAG}_resnet/layers.txt 2>&1
+python3 tools/bench_configs.py agegender > gpurun_out/prof_${TAG}_agegender/layers.txt 2>&1
+python3 tools/bench_configs.py mobilenet_f32 > gpurun_out/prof_${TAG}_f32/layers.txt 2>&1
