@@ -40,13 +40,43 @@ def default_workers() -> int:
     return max(1, min(n // local_world, 32))
 
 
-def _worker_main(shm_name: str, tasks, results) -> None:
+def cpu_order() -> List[int]:
+    """The CPUs this process may use, ordered so that DISTINCT PHYSICAL CORES come first (one hardware thread of every core, then the
+    second threads): worker k of a pool is pinned to entry k of this list, so up to one worker per core never shares a core with another
+    decoder, and a worker never migrates (its decoder's tables stay in its core's caches).  Falls back to the affinity mask in numeric
+    order where the topology files are not readable."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return list(range(os.cpu_count() or 1))
+    firsts, rest, seen = [], [], set()
+    for c in allowed:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as fh:
+                sib = fh.read().strip()
+        except OSError:
+            sib = str(c)
+        if sib in seen:
+            rest.append(c)
+        else:
+            seen.add(sib)
+            firsts.append(c)
+    return firsts + rest
+
+
+def _worker_main(shm_name: str, tasks, results, cpu: Optional[int] = None) -> None:
     """Runs in the worker process.  task = (task_id, [paths], byte offset, byte capacity) or None to stop.
     result = (task_id, [(offset, H, W) | None per image], spill, error): images that did not fit the region are returned
-    pickled in ``spill`` {position: ndarray}; ``error`` = (exception type name, message) of the first failing file."""
+    pickled in ``spill`` {position: ndarray}; ``error`` = (exception type name, message) of the first failing file.
+    cpu: the CPU this worker pins itself to (None: wherever the scheduler puts it)."""
     import signal
     from multiprocessing import shared_memory
     signal.signal(signal.SIGINT, signal.SIG_IGN)          # the parent decides when the pool stops
+    if cpu is not None:
+        try:
+            os.sched_setaffinity(0, {cpu})
+        except (AttributeError, OSError):
+            pass
     from PIL import Image
     shm = shared_memory.SharedMemory(name=shm_name)
     buf = np.frombuffer(shm.buf, dtype=np.uint8)
@@ -113,10 +143,18 @@ class DecodePool:
     """``slots`` staging slots of ``slot_bytes`` each in one shared block; a chunk of files is decoded into one slot by
     tasks of ``task_files`` files, each task owning a fixed sub-region (so workers never contend for space)."""
 
-    def __init__(self, workers: Optional[int] = None, slot_bytes: int = 64 << 20, slots: int = 3, task_files: int = 8):
+    def __init__(self, workers: Optional[int] = None, slot_bytes: int = 64 << 20, slots: int = 3, task_files: int = 8, pin: bool = True):
+        """pin: every worker pins itself to one CPU of cpu_order() -- distinct physical cores first; under torchrun the ranks of a node
+        take consecutive runs of that list (LOCAL_RANK), so eight ranks' decoders do not sit on the same cores."""
         import multiprocessing as mp
         from multiprocessing import shared_memory
         self.workers = int(workers or default_workers())
+        cpus = cpu_order() if pin else []
+        try:
+            first = max(0, int(os.environ.get("LOCAL_RANK", "0"))) * self.workers
+        except ValueError:
+            first = 0
+        self.cpus = [cpus[(first + k) % len(cpus)] for k in range(self.workers)] if cpus else [None] * self.workers
         self.slot_bytes, self.slots, self.task_files = int(slot_bytes), int(slots), int(task_files)
         self._ctx = mp.get_context("spawn")
         self._shm = shared_memory.SharedMemory(create=True, size=self.slot_bytes * self.slots)
@@ -134,8 +172,8 @@ class DecodePool:
                     if saved[0] is not None:
                         del main.__file__
                     main.__spec__ = None
-                for _ in range(self.workers):
-                    p = self._ctx.Process(target=_worker_main, args=(self._shm.name, self._tasks, self._results), daemon=True)
+                for k in range(self.workers):
+                    p = self._ctx.Process(target=_worker_main, args=(self._shm.name, self._tasks, self._results, self.cpus[k]), daemon=True)
                     p.start()
                     self._procs.append(p)
             finally:
