@@ -307,7 +307,7 @@ def run_pipeline(args, tfi, dev):
         for i in range(distinct):
             Image.fromarray(rs.randint(0, 256, (250, 250, 3), dtype=np.uint8)).save(os.path.join(d, "%04d.jpg" % i), quality=90)
         paths = [os.path.join(d, "%04d.jpg" % (i % distinct)) for i in range(args.pipeline_files)]
-        from hse_facerec_tf_amd.decode_pool import DecodePool, default_workers
+        from hse_facerec_tf_amd.decode_pool import DecodePool, cpu_quota, default_workers
         workers = default_workers()
 
         def decode_rates(nw, files, passes=2):     # decode only: the pool's workers writing into their staging slots, no GPU
@@ -333,7 +333,15 @@ def run_pipeline(args, tfi, dev):
             finally:
                 pool.close()
         dec_all = decode_rates(workers, paths)
-        dec_one = decode_rates(1, paths[:max(B, len(paths) // 16)], passes=1)[0]
+        # worker-count sweep: where the decoders stop scaling on THIS host -- on the round-5 boxes at the container's
+        # CPU quota (16 CPUs of the 256 listed: 32 workers decode what 16 do), not in the pool
+        sweep = {}
+        for nw in (1, 4, 8, 16, 32):
+            if nw == workers:
+                sweep[nw] = max(dec_all)
+            elif nw < 2 * workers or nw <= 4:
+                sweep[nw] = decode_rates(nw, paths[:min(len(paths), max(2 * B, B * nw))], passes=1)[0]
+        dec_one = sweep.get(1) or decode_rates(1, paths[:max(B, len(paths) // 16)], passes=1)[0]
         tfi.extract_files(paths[:2 * B], batch=B)          # warm-up: starts the extractor's own decoder processes
         runs = []
         for _ in range(2):                                 # the host side is noisy (32 decoder processes beside this one): best of two, both reported
@@ -348,6 +356,9 @@ def run_pipeline(args, tfi, dev):
                                  "host_decode_runs_faces_per_s": [round(v, 1) for v in dec_all],
                                  "host_decode_faces_per_s_per_worker": round(max(dec_all) / workers, 1),
                                  "host_decode_faces_per_s_one_worker_alone": round(dec_one, 1),
+                                 "host_decode_worker_sweep": {str(k): {"faces_per_s": round(v, 1), "per_worker": round(v / k, 1)} for k, v in sorted(sweep.items())},
+                                 "host_cpus": {"affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
+                                               "cgroup_quota_cpus": cpu_quota()},
                                  "fraction_of_host_decode": round(len(paths) / st["seconds"] / max(dec_all), 3),
                                  "what": "%d JPEG files (250x250, quality 90; %d distinct) -> TensorFlowInference.extract_files: %d decoder "
                                          "PROCESSES (PIL) writing into shared page-locked staging, upload on a copy stream, device "
@@ -954,14 +965,16 @@ def main():
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
-        cores = max(1, min(avail, 32))
+        from hse_facerec_tf_amd.decode_pool import cpu_quota
+        quota = cpu_quota()                  # the container's cgroup CPU quota (round-5 boxes: 16 of the 256 CPUs listed): threads beyond it are throttled
+        cores = max(1, min(avail, 32, int(quota) if quota else 32))
         bud = args.cpu_baseline_seconds
         out_t = "global_pooling/Mean:0"
         fps, n_img = time_reference_loop(AGE_GENDER_PB, out_t, x_host[:32], cores, budget_s=bud, batch=1)
         fps256, n256 = time_reference_loop(AGE_GENDER_PB, out_t, x_host, cores, budget_s=bud, batch=B)
         ffps, fn_img = time_fused_loop(AGE_GENDER_PB, out_t, x_host[:32], cores, budget_s=bud, batch=1)
         ffps256, fn256 = time_fused_loop(AGE_GENDER_PB, out_t, x_host, cores, budget_s=bud, batch=B)
-        cpu_baseline = {"value": round(ffps, 2), "unit": "faces/s", "cores": cores, "kind": "port",
+        cpu_baseline = {"value": round(ffps, 2), "unit": "faces/s", "cores": cores, "kind": "port", "host_cpus_listed": avail, "cgroup_quota_cpus": quota,
                         "sample": "%d images of the same synthetic %dx%dx3 batch through the reference's batch-1 loop (facerec_test.py:394) "
                                   "on the FUSED CPU port of the same frozen graph (oracle/torch_cpu.py FusedChainCPU: per-channel scales "
                                   "folded into the kernels, bias in the convolution, Relu/Minimum/Maximum as one in-place clamp, "

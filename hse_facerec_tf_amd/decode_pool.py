@@ -25,14 +25,37 @@ import numpy as np
 _MAIN_PATCH_LOCK = threading.Lock()       # DecodePool.__init__ edits sys.modules['__main__'] for a moment: one thread at a time
 
 
+def cpu_quota() -> Optional[float]:
+    """CPUs' worth of time the container may use per period (cgroup v2 ``cpu.max``, v1 ``cpu.cfs_quota_us``), or None if unlimited.
+    The affinity mask does not show it: the GPU boxes of round 5 list 256 CPUs and run under ``1600000 100000`` = 16 CPUs -- a pool of
+    32 decoders there decodes exactly what 16 do (34-36 k photos/s) and is throttled in half of the scheduler's periods."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+            q = float(fh.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+            per = float(fh.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def default_workers() -> int:
-    """Decoder processes for ONE extractor: the cores this process may use, SHARED between the ranks of the node
-    (``LOCAL_WORLD_SIZE``, set by torchrun: eight ranks of a file-driven gallery job on one host get an eighth of the cores
-    each, not 32 decoders apiece), at most 32."""
+    """Decoder processes for ONE extractor: the cores this process may use -- the affinity mask capped by the container's CPU
+    QUOTA (cpu_quota) -- SHARED between the ranks of the node (``LOCAL_WORLD_SIZE``, set by torchrun: eight ranks of a file-driven
+    gallery job on one host get an eighth of the cores each, not 32 decoders apiece), at most 32."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    q = cpu_quota()
+    if q is not None:
+        n = max(1, min(n, int(q)))
     try:
         local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     except ValueError:
@@ -151,7 +174,7 @@ class DecodePool:
         self.workers = int(workers or default_workers())
         cpus = cpu_order() if pin else []
         try:
-            first = max(0, int(os.environ.get("LOCAL_RANK", "0"))) * self.workers
+            first = max(0, int(os.environ.get("LOCAL_RANK", "0"))) * self.workers + int(os.environ.get("HSEFR_DECODE_CPU_OFFSET", "0"))
         except ValueError:
             first = 0
         self.cpus = [cpus[(first + k) % len(cpus)] for k in range(self.workers)] if cpus else [None] * self.workers

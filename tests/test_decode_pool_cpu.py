@@ -96,9 +96,21 @@ def test_worker_errors_rebuild_in_the_parent_and_workers_share_the_node(monkeypa
     assert type(e) is FileNotFoundError and e.filename == "/x/y.jpg"
     assert type(decode_pool._rebuild_error("ValueError", "bad", "p", b"not a pickle")) is ValueError
     monkeypatch.setattr(decode_pool.os, "sched_getaffinity", lambda _pid: set(range(64)), raising=False)
+    monkeypatch.setattr(decode_pool, "cpu_quota", lambda: None)
     monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     assert decode_pool.default_workers() == 32
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
     assert decode_pool.default_workers() == 8                               # 64 cores / 8 ranks: 64 decoders on the host, not 256
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "128")
     assert decode_pool.default_workers() == 1
+    # round 5: the container's CPU quota caps the pool (the GPU boxes list 256 CPUs under a 16-CPU cgroup quota: 32 decoders decoded
+    # what 16 do), and the workers pin themselves to distinct physical cores first
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.setattr(decode_pool, "cpu_quota", lambda: 16.0)
+    assert decode_pool.default_workers() == 16
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert decode_pool.default_workers() == 2
+    q = decode_pool.cpu_quota.__wrapped__() if hasattr(decode_pool.cpu_quota, "__wrapped__") else None
+    assert q is None or q > 0
+    order = decode_pool.cpu_order()
+    assert sorted(order) == sorted(set(order)) and len(order) >= 1

@@ -65,6 +65,17 @@ def main():
             rp = rates(nw, paths[:n], True)
             ru = rates(nw, paths[:n], False)
             print("%2d workers: pinned %7.0f img/s (%5.0f per worker) | unpinned %7.0f (%5.0f per worker)" % (nw, rp, rp / nw, ru, ru / nw), flush=True)
+        # where does it stop scaling?  other runs of CPUs (the first ones of a shared host are everybody's favourite), more workers
+        for off in (32, 64, 96):
+            if off + 32 <= len(order):
+                os.environ["HSEFR_DECODE_CPU_OFFSET"] = str(off)
+                r = rates(32, paths[:min(nfiles, 8192)], True)
+                print("32 workers on cpus %d..%d: %7.0f img/s (%5.0f per worker)" % (off, off + 31, r, r / 32), flush=True)
+        os.environ["HSEFR_DECODE_CPU_OFFSET"] = "0"
+        for nw in (48, 64, 96):
+            if nw <= len(order):
+                r = rates(nw, paths[:min(nfiles, 8192)], True)
+                print("%2d workers: pinned %7.0f img/s (%5.0f per worker)" % (nw, r, r / nw), flush=True)
         nw = min(32, len(order))
         for tf in (4, 16):
             r = rates(nw, paths[:min(nfiles, 256 * nw)], True, task_files=tf)
