@@ -281,6 +281,7 @@ void set_stem4_grid(int v);
 void set_stem5_grid(int v);
 void set_stem5_segs(int v);
 void set_c11(int v);
+void set_c11_tile(int v);
 void set_dwpws_tw(int v);
 void set_dwpws_bn(int v);
 void set_pw_tile(int v);

@@ -340,12 +340,14 @@ int launch_proj_cfg(const u16* x, const u16* wt, const float* scale, const float
     return launch_status("conv1x1_proj_bf16");
 }
 
+HSEFR_KNOB(g_c11_tile, 0);   // dev builds: 1 = 128 x 64 tiles (three workgroups per CU) everywhere, 2 = 128 x 128 everywhere
 HSEFR_KNOB(g_c11, 1);   // dev builds: 0 = route 1x1 stride-1 layers through the general conv_bf16 kernel (A/B timing)
 
 }  // namespace
 
 #ifdef HSEFR_DEV
 void set_c11(int v) { g_c11 = v; }
+void set_c11_tile(int v) { g_c11_tile = v; }
 #endif
 bool conv1x1_bf16_enabled(bool has_res, int k, int cout) {
     switch (g_c11) {      // values > 1: bisection aids
@@ -368,7 +370,7 @@ int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const
     u16* yy = (u16*)y;
     // 128 x 128 tiles when there are enough of them to fill the machine twice over, 128 x 64 otherwise
     const long long t128 = ((P + 127) / 128) * (cout / 128);
-    if (cout % 128 == 0 && t128 >= 768) return launch_cfg<128, 128, 2>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
+    if (cout % 128 == 0 && (g_c11_tile == 2 || (t128 >= 768 && g_c11_tile != 1))) return launch_cfg<128, 128, 2>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
     return launch_cfg<128, 64, 3>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
 }
 

@@ -79,6 +79,14 @@ def main():
                 out += "  | w2 %6.1f" % timeit(fn)
             except Exception as e:          # (shapes the four-wave window kernel does not cover: cout % 128 on the narrow maps)
                 out += "  | w2   n/a"
+        if k == 1 and s == 1:
+            knob("w4_off", 1)
+            knob("cd_off", 1)
+            for tile in (1, 2):
+                knob("c11_tile", tile)
+                out += "  | c11 %s %6.1f" % ("128x64" if tile == 1 else "128x128", timeit(fn))
+            knob("c11_tile", 0)
+            knob("cd_off", 2)
         if k == 1:
             knob("w4_off", 2)
             out += "  | w4 %6.1f" % timeit(fn)
