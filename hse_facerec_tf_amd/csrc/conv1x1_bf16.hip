@@ -46,6 +46,20 @@ __device__ __forceinline__ void bstore8(bf16x8 v, __amdgpu_buffer_rsrc_t r, unsi
     hsefr_store_guard();
 }
 
+#ifdef HSEFR_CD_STAMPS
+// Diagnostic build only: per-wave s_memtime sums -- [0] loads issued + fragment reads + MFMAs, [1] LDS stage writes (the wait for the
+// global loads of two steps ago sits here), [2] step barrier, [3] epilogue, [4] the barrier behind it; [6] lifetime, [7] steps
+__device__ unsigned long long g_c11_stamps[512 * 4 * 8];
+#define C11_STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); st[i] += _t - tprev; tprev = _t; } while (0)
+#define C11_STAMP_DECL unsigned long long st[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tprev = __builtin_amdgcn_s_memtime(); const unsigned long long tstart = tprev
+#define C11_STAMP_FLUSH do { if (lane == 0 && blockIdx.x < 512) { unsigned long long* o = g_c11_stamps + (blockIdx.x * 4 + wave) * 8; \
+    for (int i_ = 0; i_ < 6; ++i_) o[i_] = st[i_]; o[6] = __builtin_amdgcn_s_memtime() - tstart; o[7] = nsteps; } } while (0)
+#else
+#define C11_STAMP(i) do { } while (0)
+#define C11_STAMP_DECL do { } while (0)
+#define C11_STAMP_FLUSH do { } while (0)
+#endif
+
 struct ProjParams {        // the projected shortcut of PROJ kernels
     const u16* x2;         // [N, H2, W2, K2] bf16: the block's input
     const u16* wt2;        // [Cout][K2]
@@ -180,6 +194,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
     bf16x8 rres[RES ? MI * (32 / RPI) : 1];
     unsigned pk[PROJ ? NI : 1][PROJ ? MI : 1][PROJ ? 8 : 1];      // the projected shortcut of the tile, bf16 pairs in the accumulators' layout
 
+    C11_STAMP_DECL;
     auto step = [&](auto PAR) {
         constexpr int PB = decltype(PAR)::value;
         const bool first = ckt == 0;
@@ -212,9 +227,12 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
         }
+        C11_STAMP(0);
         swrite(std::integral_constant<int, 1 - PB>(), 1 - PB);
         if (fill) *(f32x4*)(&Et[ci & 1][etab][4 * ej]) = ec;
+        C11_STAMP(1);
         __syncthreads();
+        C11_STAMP(2);
         advance_prefetch();
         ++ckt;
         if (PROJ && ckt == KT2) {
@@ -281,7 +299,9 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
                     bstore8(v, ry, yvoff, (unsigned)(mi * 32 + RPI * i) * (unsigned)Cout * 2u);
                 }
             }
+            C11_STAMP(3);
             __syncthreads();   // the scratch is the stage the next step refills
+            C11_STAMP(4);
             zero_acc();
             ckt = 0;
             ++ci;
@@ -293,6 +313,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
         if (g + 1 >= nsteps) break;
         step(S1());
     }
+    C11_STAMP_FLUSH;
 }
 
 template <int BM, int BN, int OCC>
@@ -346,6 +367,17 @@ HSEFR_KNOB(g_c11, 1);   // dev builds: 0 = route 1x1 stride-1 layers through the
 }  // namespace
 
 #ifdef HSEFR_DEV
+int read_c11_stamps(void* host_out, size_t bytes) {
+#ifdef HSEFR_CD_STAMPS
+    HSEFR_REQUIRE(bytes <= sizeof(unsigned long long) * 512 * 4 * 8, HSEFR_ERR_INVALID, "read_c11_stamps: too many bytes");
+    HSEFR_HIP_CHECK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_c11_stamps), bytes));
+    return HSEFR_OK;
+#else
+    (void)host_out; (void)bytes;
+    set_error("read_c11_stamps: library built without -DHSEFR_CD_STAMPS");
+    return HSEFR_ERR_UNSUPPORTED;
+#endif
+}
 void set_c11(int v) { g_c11 = v; }
 void set_c11_tile(int v) { g_c11_tile = v; }
 #endif

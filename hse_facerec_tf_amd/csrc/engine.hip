@@ -334,6 +334,7 @@ int hsefr_debug_read_stamps(void* host_out, size_t bytes) {
     // the split-f16 GEMM's stamps, (bytes == 512*4*10*8) the fused stem's, or (bytes == 256*12*8*8) the pre-split GEMM's
     if (bytes == 256 * 12 * 8 * 8) return read_ps_stamps(host_out, bytes);
     if (bytes == 256 * 12 * 8 * 8 - 8) return read_cd_stamps(host_out, bytes);
+    if (bytes == 512 * 4 * 8 * 8 - 16) return read_c11_stamps(host_out, bytes);       // (two words short: the register-staged 1x1 GEMM's)
     if (bytes == 256 * 8 * 8 * 8 - 8) return read_w4_stamps(host_out, bytes);         // (one word short: the four-wave 1x1 GEMM's)
     if (bytes == 256 * 8 * 8 * 8) return read_w2_stamps(host_out, bytes);             // (eight waves per workgroup: the second window 3x3 convolution's)
     if (bytes == 256 * 12 * 8 * 8 - 16) return read_w3_stamps(host_out, bytes);     // (two words short: the window 3x3 convolution's)      // (one word short: the bf16 DMA convolution's)

@@ -21,7 +21,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 WIN = os.environ.get("CD_WIN", "0") == "1"       # CD_WIN=1: the window 3x3 kernel (csrc/conv3x3_win_bf16.hip) instead
 W2 = os.environ.get("CD_W2", "0") == "1"         # CD_W2=1: the four-wave window kernel (csrc/conv3x3_w2_bf16.hip)
 W4 = os.environ.get("CD_W4", "0") == "1"         # CD_W4=1: the four-wave 1x1 GEMM (csrc/conv1x1_w4_bf16.hip)
-_lib.check(_lib.lib().hsefr_debug_set(b"cd_off", 2))
+C11 = os.environ.get("CD_C11", "0") == "1"       # CD_C11=1: the register-staged persistent 1x1 GEMM (csrc/conv1x1_bf16.hip)
+_lib.check(_lib.lib().hsefr_debug_set(b"cd_off", 1 if C11 else 2))
 _lib.check(_lib.lib().hsefr_debug_set(b"w3_off", 2 if WIN else 1))
 _lib.check(_lib.lib().hsefr_debug_set(b"w2_off", 2 if W2 else 1))
 _lib.check(_lib.lib().hsefr_debug_set(b"w4_off", 2 if W4 else 1))
@@ -37,7 +38,12 @@ for name in sys.argv[1:] or ["c4_3x3", "c4_red", "c4_inc"]:
     for _ in range(5):
         ops.conv_bf16(x, w, sc, sh, k, k, stride=s, pad=k // 2, res=r)
     torch.cuda.synchronize()
-    if W2 or W4:
+    if C11:
+        buf = np.zeros(512 * 4 * 8 - 2, np.uint64)
+        _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        b = np.concatenate([buf, [0, 0]]).astype(np.float64).reshape(512, 4, 8)
+        roles = (("all four waves", slice(0, 4), ["loads issued + reads + MFMA", "wait for loads + LDS stage writes", "step barrier", "epilogue", "barrier behind it"]),)
+    elif W2 or W4:
         buf = np.zeros(256 * 8 * 8 - (1 if W4 else 0), np.uint64)
         _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
         b = np.concatenate([buf, [0] * (1 if W4 else 0)]).astype(np.float64).reshape(256, 8, 8)
