@@ -132,7 +132,13 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     // The four pixels of a lane lie in one image row when 4 divides the map width (bordered 12 x 12 maps; always in the
     // unbordered layouts, whose rows are the pixel indices).  14- and 7-pixel maps keep the old orientation: with a cell
     // computed per pixel (36 divisions per lane and tile) the 224 x 224 plan lost 3.5 % in a same-box A/B.
-    constexpr bool SWAP = DW && (!BORDERED || MW % 4 == 0);
+    // PADROW (round 5): 14 x 14 maps ride in the 224-row tile as 14 image rows of SIXTEEN tile rows each (two rows per image row
+    // are zero operands, computed and never parked) instead of 196 consecutive pixels + 28 rows of the next map that were computed
+    // and dropped anyway: the same MFMA count, but a lane's four pixels now always share an image row, so the 14 x 14 layers take the
+    // SWAP orientation too (conflict-free dword parking instead of 16-byte columns: their LDS conflict share was 0.26-0.31) with no
+    // per-pixel cell arithmetic at all -- tile row block = image row.  The loaders gather the rows (per-lane source offsets).
+    constexpr bool PADROW = BORDERED && MW == 14 && MB == 7;
+    constexpr bool SWAP = DW && (!BORDERED || MW % 4 == 0 || PADROW);
 
     // ---- DW epilogue, shared by both roles: the depthwise of one 32-channel chunk of the tile from the chunk buffer cb ----
     // cb layout: rows 0 .. BM-1 = the chunk's activated pointwise results [pixel][32 ch] fp32, two zero rows (taps outside the
@@ -327,6 +333,8 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             const int p = lw * PPW + j;
             const int r = (p < BM / 8 ? p * 8 : (p - BM / 8) * 8) + (lane >> 3);     // row inside its own tile (A or B)
             pv[j] = (unsigned)r * rowbytes + 16u * (unsigned)((lane & 7) ^ swz_key(r));
+            if (PADROW && p < BM / 8)          // tile row r = image row r >> 4, column r & 15: pixel 14 (r >> 4) + (r & 15) of the map, columns 14, 15 zero
+                pv[j] = (r & 15) < MW ? (unsigned)((r >> 4) * MW + (r & 15)) * rowbytes + 16u * (unsigned)((lane & 7) ^ swz_key(r)) : 0x80000000u;
         }
         auto piece = [&](const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
             // issued from asm: hipcc serialises builtin LDS-DMA against every later ds_read (DESIGN.md lesson 15b)
@@ -567,7 +575,14 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb) {
                             const int p0 = wm * 16 * MB + 16 * mb + 4 * lq;
-                            {
+                            if constexpr (PADROW) {      // image row wm MB + mb, columns 4 lq .. 4 lq + 3 (columns 14, 15 do not exist)
+                                const int row = 1 + PITCH + PITCH * (wm * MB + mb) + 4 * lq;
+#pragma unroll
+                                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (4 * lq + e < MW) *(float*)(cb + (row + e) * ROWB + (16 * nb + l16) * 4) = acc[mb][nb][e];
+                            } else {
                                 int row = p0;
                                 if constexpr (BORDERED) {
                                     const int pt = row < MAPS * MHW ? row : MAPS * MHW - 4;
