@@ -20,6 +20,10 @@
 //   * activation rows are GATHERED by the DMA's per-lane source address: a stride-2 layer costs the same as a dense one;
 //   * swizzle chunk ^ (row & 6): conflict-free ds_read_b128 for any 16 consecutive rows (conv3x3_w2_bf16.hip).
 // Every output element is accumulated over K in one fixed order by one wave: bit-identical run to run, independent of the grid.
+//
+// Where it runs (conv1x1_w4_bf16_preferred, measured: tools/kbench_conv.py): the K-deep REDUCTIONS of the 28- and 14-pixel stages, stride 1
+// and 2 (26 -> 23 us per layer).  It covers the increase layers too (residual path, tests) but is 10 % slower there than the register-
+// staged kernel's two workgroups per CU: those layers are bound by what the CU's vector-memory path moves (DESIGN.md lesson 54).
 #include <type_traits>
 
 #include "common.h"

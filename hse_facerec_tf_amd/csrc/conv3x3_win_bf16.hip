@@ -1,3 +1,6 @@
+// (Round 5: superseded on every ResNet-50 shape by conv3x3_w2_bf16.hip -- four wide MFMA waves, padded-row pixel mapping, a swizzle that is
+// conflict-free under every tap; this kernel's stamps are what showed why: profiles/r05_conv_stamps.txt.  It still serves 3x3 layers the
+// new one's geometries do not prefer -- maps 40-47 pixels wide -- and stays the A/B reference of tools/kbench_conv.py.)
 // 3x3 / stride 1 / pad 1 bf16 convolution + scale + shift (+ residual) + act with the INPUT WINDOW resident in LDS: the sixteen
 // 3x3 layers of ResNet-50's bottlenecks (resnet50_ft, the graph behind vgg2_resnet.pb at facerec_test.py:213).  NHWC bf16 in / out,
 // fp32 accumulation, gfx950.  Same results contract as conv_bf16.hip / conv_dma_bf16.hip (rounding points of oracle/resnet50.py).

@@ -165,7 +165,9 @@ typedef struct hsefr_plan_op {
     int32_t oh, ow, cout; /* output                                                    */
     int32_t kh, kw, stride;
     int32_t pad_t, pad_l; /* TF SAME: pad_total//2 on top/left (0 for even input, k=3, s=2) */
-    int32_t reserved;   /* PWCONV_F16S / PWCONV_PS / fused kinds: a_log2 (activation pre-scale exponent);
+    int32_t reserved;   /* CONV_BF16 with w2_off set (round 5, projected shortcut): c2 | stride2 << 12 | h2 << 14 | w2 << 23 -- res_buf is then
+                           the BLOCK INPUT [h2, w2, c2], w2_off its 1x1 projection kernel [cout][c2] bf16, shift2_off [scale2 | shift2];
+                           PWCONV_F16S / PWCONV_PS / fused kinds: a_log2 (activation pre-scale exponent);
                            DWCONV3X3: 0 = fp32 output, a_log2 > 0 = output stored as split rows scaled by 2^a_log2
                            (act must be ReLU6, c % 32 == 0); 0 otherwise */
     uint64_t w_off;     /* weights; layout depends on kind (see the per-kernel entry points) */
