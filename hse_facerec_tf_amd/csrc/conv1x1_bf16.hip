@@ -67,6 +67,10 @@ struct ProjParams {        // the projected shortcut of PROJ kernels
     const float* shift2;   // [Cout]
     int K2, stride, H2, W2, OH, OW;
     long long x2_bytes;
+    int b_resident;        // (both kernel forms) 1: a tile's K loop is at most two steps AND every tile of a workgroup has the same channel
+                           // origin -- each LDS stage then always holds the SAME weight tile: it is loaded with the first two steps and
+                           // never again (a quarter to a half of the kernel's load instructions on the K <= 128 layers, which are bound
+                           // by what they issue: DESIGN.md lesson 54)
 };
 
 template <int BM, int BN, int OCC, bool RES, int ACT, bool PROJ = false>
@@ -130,21 +134,26 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
         }
     };
     bf16x8 ra[2][AP], rb[2][BP];
-    auto gload = [&](auto SET) {
+    const bool b_res = pj.b_resident != 0;
+    auto gload = [&](auto SET, bool with_b) {
         constexpr int S = decltype(SET)::value;
         if (PROJ && pf_kt < KT2) {                                       // (wave-uniform)
             const unsigned so = (unsigned)pf_kt * 128u;
 #pragma unroll
             for (int p = 0; p < AP; ++p) ra[S][p] = bload8(ra2_rsrc, avoff2[PROJ ? p : 0], so);
+            if (with_b) {
 #pragma unroll
-            for (int p = 0; p < BP; ++p) rb[S][p] = bload8(rb2_rsrc, voff2b, so + (unsigned)(32 * p) * rowbytes2);
+                for (int p = 0; p < BP; ++p) rb[S][p] = bload8(rb2_rsrc, voff2b, so + (unsigned)(32 * p) * rowbytes2);
+            }
             return;
         }
         const unsigned so = (unsigned)(pf_kt - KT2) * 128u;
 #pragma unroll
         for (int p = 0; p < AP; ++p) ra[S][p] = bload8(ra_rsrc, voff, so + (unsigned)(32 * p) * rowbytes);
+        if (with_b) {
 #pragma unroll
-        for (int p = 0; p < BP; ++p) rb[S][p] = bload8(rb_rsrc, voff, so + (unsigned)(32 * p) * rowbytes);
+            for (int p = 0; p < BP; ++p) rb[S][p] = bload8(rb_rsrc, voff, so + (unsigned)(32 * p) * rowbytes);
+        }
     };
     auto advance_prefetch = [&]() {
         if (++pf_kt == KT) {
@@ -152,12 +161,14 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
             setup_rsrc(++pf_i);
         }
     };
-    auto swrite = [&](auto SET, int buf) {
+    auto swrite = [&](auto SET, int buf, bool with_b) {
         constexpr int S = decltype(SET)::value;
 #pragma unroll
         for (int p = 0; p < AP; ++p) *(bf16x8*)(As(buf) + swzb(srow + 32 * p, sch)) = ra[S][p];
+        if (with_b) {
 #pragma unroll
-        for (int p = 0; p < BP; ++p) *(bf16x8*)(Bs(buf) + swzb(srow + 32 * p, sch)) = rb[S][p];
+            for (int p = 0; p < BP; ++p) *(bf16x8*)(Bs(buf) + swzb(srow + 32 * p, sch)) = rb[S][p];
+        }
     };
 
     f32x16 acc[NI][MI];
@@ -178,12 +189,13 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
     int ckt = 0;
     tile_origin(0, m0, n0);
     setup_rsrc(0);
-    gload(S0());
+    gload(S0(), true);
     advance_prefetch();
-    gload(S1());
+    gload(S1(), true);
     advance_prefetch();
-    swrite(S0(), 0);
+    swrite(S0(), 0, true);
     __syncthreads();
+    unsigned gstep = 0;            // steps done: step g loads step g + 2 and parks step g + 1 -- with resident weights only steps 0, 1 carry a weight tile
     const int xrow = wm * WM + li, wrow = wn * WN + li;
     // epilogue geometry (after the transpose): a wave's tile row is WN bf16 = WN*2 bytes = CPR chunks of 16 B;
     // lane -> (row erow of a 32-row block, chunk ech); 64 / CPR rows per store instruction
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
                 for (int i = 0; i < 32 / RPI; ++i)
                     rres[RES ? mi * (32 / RPI) + i : 0] = bload8(rr, yvoff, (unsigned)(mi * 32 + RPI * i) * (unsigned)Cout * 2u);
         }
-        gload(PAR);
+        gload(PAR, !b_res);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             bf16x8 xa[MI], wb[NI];
@@ -228,7 +240,8 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
         }
         C11_STAMP(0);
-        swrite(std::integral_constant<int, 1 - PB>(), 1 - PB);
+        swrite(std::integral_constant<int, 1 - PB>(), 1 - PB, !b_res || gstep == 0);
+        ++gstep;
         if (fill) *(f32x4*)(&Et[ci & 1][etab][4 * ej]) = ec;
         C11_STAMP(1);
         __syncthreads();
@@ -316,6 +329,8 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
     C11_STAMP_FLUSH;
 }
 
+HSEFR_KNOB(g_c11_bres, 1);   // dev builds: 0 = reload the weight tile every step also where it could stay resident (A/B timing)
+
 template <int BM, int BN, int OCC>
 int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shift, const u16* res, u16* y, long long P, int K,
                int cout, int act, hipStream_t s) {
@@ -327,7 +342,9 @@ int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shi
     const long long g = total < slots ? total : slots;
     dim3 grid((unsigned)g), block(256);
     const int rev = sweep_reverse();
-    const ProjParams nopj{};
+    ProjParams nopj{};
+    // resident weight tiles: K <= 128 (at most two steps per tile) and a grid whose stride keeps a workgroup on one channel origin
+    nopj.b_resident = (total > g && K <= 128 && g % 8 == 0 && (g / 8) % tiles_n == 0 && g_c11_bres) ? 1 : 0;
 #define HSEFR_C11(R, A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, R, A>), grid, block, 0, s, x, wt, scale, shift, res, y, P, K, cout, tiles_n, (unsigned)total, rev, nopj)
     if (res) {
         if (act == HSEFR_ACT_RELU) HSEFR_C11(true, HSEFR_ACT_RELU);
@@ -353,7 +370,9 @@ int launch_proj_cfg(const u16* x, const u16* wt, const float* scale, const float
     const long long g = total < slots ? total : slots;
     dim3 grid((unsigned)g), block(256);
     const int rev = sweep_reverse();
-#define HSEFR_C11P(A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, false, A, true>), grid, block, 0, s, x, wt, scale, shift, nullptr, y, P, K, cout, tiles_n, (unsigned)total, rev, pj)
+    ProjParams pjr = pj;
+    pjr.b_resident = (total > g && K + pj.K2 <= 128 && g % 8 == 0 && (g / 8) % tiles_n == 0 && g_c11_bres) ? 1 : 0;
+#define HSEFR_C11P(A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, false, A, true>), grid, block, 0, s, x, wt, scale, shift, nullptr, y, P, K, cout, tiles_n, (unsigned)total, rev, pjr)
     if (act == HSEFR_ACT_RELU) HSEFR_C11P(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_RELU6) HSEFR_C11P(HSEFR_ACT_RELU6);
     else HSEFR_C11P(HSEFR_ACT_NONE);
@@ -380,6 +399,7 @@ int read_c11_stamps(void* host_out, size_t bytes) {
 }
 void set_c11(int v) { g_c11 = v; }
 void set_c11_tile(int v) { g_c11_tile = v; }
+void set_c11_bres(int v) { g_c11_bres = v; }
 #endif
 bool conv1x1_bf16_enabled(bool has_res, int k, int cout) {
     switch (g_c11) {      // values > 1: bisection aids

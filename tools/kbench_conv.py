@@ -86,6 +86,9 @@ def main():
                 knob("c11_tile", tile)
                 out += "  | c11 %s %6.1f" % ("128x64" if tile == 1 else "128x128", timeit(fn))
             knob("c11_tile", 0)
+            knob("c11_bres", 0)
+            out += "  | c11 weights reloaded %6.1f" % timeit(fn)
+            knob("c11_bres", 1)
             knob("cd_off", 2)
         if k == 1:
             knob("w4_off", 2)
