@@ -422,9 +422,13 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                     dw_masks();
 #pragma unroll 1
                     for (int c = 0; c < 4; ++c) {
+                        PS_STAMP(3);                        // (diagnostic builds: 3 = the tile's other work, 4 = barrier waits, 5 = the depthwise)
                         __syncthreads();
+                        PS_STAMP(4);
                         dw_chunk(c, cb, mm0, tn0);
+                        PS_STAMP(5);
                         __syncthreads();
+                        PS_STAMP(4);
                     }
                     tile_origin(++ci, mm0, e_n0);
                 } else {
@@ -440,7 +444,10 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
     }
 
     // =================================== MFMA waves 0..7: wave tile rows [wm * 16 MB, +16 MB) x columns [wn * 32, +32) ===================================
-    const int wm = wave >> 2, wn = wave & 3;
+    // (wm from the wave's low bit: the two waves that park a 32-channel chunk in the depthwise epilogue -- (0, wn) and (1, wn) -- are then
+    // NEIGHBOURS in the workgroup, so they sit on different SIMDs and on both halves of the LDS store path; as waves wn and wn + 4 they
+    // shared one SIMD's issue and one half's store rate while ten waves waited at the barrier)
+    const int wm = wave & 1, wn = wave >> 1;
     const int l16 = lane & 15, lq = lane >> 4;
     // fragment byte offsets inside a stage: row (base + l16), logical chunk lq (hi) / 4 + lq (lo); + 16-row block strides
     const int arow = wm * 16 * MB + l16, brow = BM + wn * 32 + l16;
@@ -582,6 +589,15 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
 #pragma unroll
                                     for (int e = 0; e < 4; ++e)
                                         if (4 * lq + e < MW) *(float*)(cb + (row + e) * ROWB + (16 * nb + l16) * 4) = acc[mb][nb][e];
+                            } else if constexpr (BORDERED && MW == 12 && MB == 9) {
+                                // wave half = map (288 rows = two 144-pixel maps), t = 4 mb + lq = the pixel quad inside the map: image row t / 3,
+                                // column 4 (t % 3) -> chunk-buffer row 1 + PITCH + IMG wm + 13 (t / 3) + 4 (t % 3) = ... + 4 t + t / 3, and
+                                // t / 3 = (4 mb) / 3 + ((4 mb) % 3 + lq) / 3: a compile-time part and one of three per-lane constants
+                                const int row = 1 + PITCH + IMG * wm + 16 * mb + 4 * lq + (4 * mb) / 3 + ((4 * mb) % 3 + lq) / 3;
+#pragma unroll
+                                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) *(float*)(cb + (row + e) * ROWB + (16 * nb + l16) * 4) = acc[mb][nb][e];
                             } else {
                                 int row = p0;
                                 if constexpr (BORDERED) {

@@ -43,7 +43,7 @@ for hw, k, n in ((12, 512, 512), (6, 1024, 1024), (24, 128, 256)):
     _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
     b = buf.astype(np.float64)
     for role, sl, names in (("MFMA waves", slice(0, 8), ["ds_read + mfma issue", "step barrier", "epilogue (DW: the depthwise)", "tile barrier", "DW: parking", "DW: barrier waits"]),
-                            ("loader waves", slice(8, 12), ["DMA issue", "vmcnt wait", "step barrier", "tile barrier"])):
+                            ("loader waves", slice(8, 12), ["DMA issue", "vmcnt wait", "step barrier", "tile barrier / epilogue set-up", "DW: barrier waits", "DW: the depthwise"])):
         r = b[:, sl, :].reshape(-1, 8)
         r = r[r[:, 7] > 0]
         print("%dx%dx%d %s: %d waves, lifetime %.0f cycles (min %.0f max %.0f), %.1f steps -> %.0f cycles per step" %
