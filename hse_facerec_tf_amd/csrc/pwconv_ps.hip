@@ -53,9 +53,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef HSEFR_PS_STAMPS
-// Diagnostic build only (HSEFR_DEV=1 HSEFR_EXTRA_FLAGS=-DHSEFR_PS_STAMPS build.sh): per-wave s_memtime sums of the step phases.
+// Diagnostic build only (HSEFR_DEV=1 HSEFR_EXTRA_FLAGS=-DHSEFR_PS_STAMPS=1 build.sh): per-wave s_memtime sums of the step phases.
 __device__ unsigned long long g_ps_stamps[256 * 12 * 8];
+#if HSEFR_PS_STAMPS == 2      // -DHSEFR_PS_STAMPS=2: only the waves' lifetimes (no stamp inside the loops: DESIGN.md lesson 56)
+#define PS_STAMP(i) do { } while (0)
+#else
 #define PS_STAMP(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); st[i] += _t - tprev; tprev = _t; } while (0)
+#endif
 #define PS_STAMP_DECL unsigned long long st[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tprev = __builtin_amdgcn_s_memtime(); const unsigned long long tstart = tprev
 #define PS_STAMP_FLUSH do { if (lane == 0 && blockIdx.x < 256) { unsigned long long* o = g_ps_stamps + (blockIdx.x * 12 + wave) * 8; \
     for (int i_ = 0; i_ < 6; ++i_) o[i_] = st[i_]; o[6] = __builtin_amdgcn_s_memtime() - tstart; o[7] = nsteps; } } while (0)
