@@ -193,6 +193,10 @@ int launch_conv3x3_w2_bf16(const void* x, const void* wt, const float* scale, co
 bool conv1x1_w4_forced();
 bool conv1x1_w4_bf16_supported(long long n, int h, int w, int c, int oh, int ow, int cout, int stride);
 bool conv1x1_w4_bf16_preferred(long long pixels, int c, int cout, bool has_res);
+bool conv1x1_w4_proj_preferred(long long pixels, int c, int c2, int cout);
+int launch_conv1x1_w4_proj_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* x2, const void* wt2,
+                                const float* scale2, const float* shift2, void* y, int n, int oh, int ow, int c, int cout, int c2, int stride2,
+                                int h2, int w2, int act, hipStream_t s);
 int launch_conv1x1_w4_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
                            int w, int c, int oh, int ow, int cout, int stride, int act, hipStream_t s);
 bool conv_dma_forced();

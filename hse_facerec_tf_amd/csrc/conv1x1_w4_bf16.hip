@@ -21,9 +21,12 @@
 //   * swizzle chunk ^ (row & 6): conflict-free ds_read_b128 for any 16 consecutive rows (conv3x3_w2_bf16.hip).
 // Every output element is accumulated over K in one fixed order by one wave: bit-identical run to run, independent of the grid.
 //
-// Where it runs (conv1x1_w4_bf16_preferred, measured: tools/kbench_conv.py): the K-deep REDUCTIONS of the 28- and 14-pixel stages, stride 1
-// and 2 (26 -> 23 us per layer).  It covers the increase layers too (residual path, tests) but is 10 % slower there than the register-
-// staged kernel's two workgroups per CU: those layers are bound by what the CU's vector-memory path moves (DESIGN.md lesson 54).
+// Where it runs (conv1x1_w4_bf16_preferred / conv1x1_w4_proj_preferred, measured in the network at batch 128): the K-deep REDUCTIONS of the
+// 28- and 14-pixel stages, stride 1 and 2 (26 -> 23 us per layer); PROJ -- the increase layer of a stage's first block with its
+// projected shortcut as extra K-steps in front (conv1x1_bf16.hip's header: same rounding points) -- on the 28-, 14- and 7-pixel stages,
+// where the pair is 39.5 GFLOP of matrix work (78 -> 64, 74 -> 54, 72 -> 48 us); the K = 512 increase layers of the 7-pixel stage.  The
+// other increase layers (K <= 256) are 10 % slower here than on the register-staged kernel's two workgroups per CU: they are bound
+// by what the CU's vector-memory path moves (DESIGN.md lesson 54).
 #include <type_traits>
 
 #include "common.h"
@@ -73,9 +76,17 @@ struct W4Params {
     unsigned M;                     // N * OH * OW
     unsigned tiles_n, total_tiles;
     int reverse;
+    // PROJ kernels (the projected shortcut of a stage's first block, conv1x1_bf16.hip's header): a tile's K loop starts with the K2 / 64
+    // steps of x2[pixel * stride2, :] . wt2, whose result -- scale2, shift2, rounded to bf16 -- takes the residual's place
+    const void* x2;      // [N,H2,W2,K2] bf16: the block's input
+    const void* wt2;     // [Cout][K2] bf16
+    const float* scale2;
+    const float* shift2;
+    long long x2_bytes;
+    int K2, stride2, H2, W2;
 };
 
-template <int RB, int WAVES_M>
+template <int RB, int WAVES_M, bool PROJ = false>
 __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int BM = WAVES_M * RB * 16, BN = WAVES_N * 64;
@@ -84,17 +95,20 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
     constexpr int ASTAGE = BM * ROWB, BSTAGE = BN * ROWB;
     constexpr int B_OFF = NA * ASTAGE;
     constexpr int E_OFF = B_OFF + NB * BSTAGE;
-    static_assert(E_OFF + 4096 <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[E_OFF + 4096];
+    constexpr int E_PAR = PROJ ? 4096 : 2048;      // epilogue constants per tile parity: [scale 1 KiB | shift 1 KiB] (| scale2 | shift2)
+    static_assert(E_OFF + 2 * E_PAR <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[E_OFF + 2 * E_PAR];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int KT = p.K / 64;
+    const int KT2 = PROJ ? p.K2 / 64 : 0;          // a tile's K loop: the projection's steps first, then the main product's
+    const int KT = p.K / 64 + KT2;
     if (blockIdx.x >= p.total_tiles) return;
     const unsigned ntile = (p.total_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const unsigned nsteps = ntile * (unsigned)KT;
     const unsigned wrowbytes = (unsigned)p.K * 2u;
+    const unsigned wrowbytes2 = PROJ ? (unsigned)p.K2 * 2u : 0u;
 
     auto tile_origin = [&](unsigned i, unsigned& mm0, int& nn0) __attribute__((always_inline)) {
         const unsigned lt = xcd_remap_dir(blockIdx.x + (i < ntile ? i : ntile - 1) * gridDim.x, p.total_tiles, p.reverse);
@@ -113,16 +127,19 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
         };
         const __amdgpu_buffer_rsrc_t rx = make_rsrc_sgpr(p.x, p.x_bytes);
         // weight pieces: LDS row R = 64 wn + 16 nb + i holds output channel 64 wn + 32 (nb >> 1) + 8 (i >> 2) + 4 (nb & 1) + (i & 3)
-        unsigned pvb[BPW];
+        unsigned pvb[BPW], pvb2[PROJ ? BPW : 1];
+        const __amdgpu_buffer_rsrc_t rx2 = make_rsrc_sgpr(PROJ ? p.x2 : nullptr, PROJ ? p.x2_bytes : 0);
 #pragma unroll
         for (int j = 0; j < BPW; ++j) {
             const int R = (lw * BPW + j) * 8 + (lane >> 3);
             const int nb = (R >> 4) & 3, i = R & 15;
             const int ch = (R & ~63) + 32 * (nb >> 1) + 8 * (i >> 2) + 4 * (nb & 1) + (i & 3);
             pvb[j] = (unsigned)ch * wrowbytes + 16u * (unsigned)((lane & 7) ^ (R & 6));
+            if (PROJ) pvb2[PROJ ? j : 0] = (unsigned)ch * wrowbytes2 + 16u * (unsigned)((lane & 7) ^ (R & 6));
         }
         // the two cursors: activations two steps ahead of the MFMA waves, weights three
         unsigned pa[APW];                 // activation cursor's tile: byte offset of the lane's 16 bytes, K-tile 0 (out-of-range marker for rows >= M)
+        unsigned pa2[PROJ ? APW : 1];     // ... of the projection's gathered input rows
         unsigned a_tile = 0, a_kt = 0, a_step = 0;
         const unsigned ohow = (unsigned)(p.OH * p.OW);
         auto setup_a = [&](unsigned i) __attribute__((always_inline)) {
@@ -141,23 +158,41 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
                     pix = (n * (unsigned)p.H + oh * (unsigned)p.stride) * (unsigned)p.W + ow * (unsigned)p.stride;
                 }
                 pa[j] = m < p.M ? pix * wrowbytes + 16u * chunk : 0x80000000u;
+                if (PROJ) {      // output pixel (n, oh, ow) is projected from input pixel (n, oh stride2, ow stride2) of the block's input
+                    const unsigned n = m / ohow, rem = m - n * ohow;
+                    const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;
+                    const unsigned pix2 = (n * (unsigned)p.H2 + oh * (unsigned)p.stride2) * (unsigned)p.W2 + ow * (unsigned)p.stride2;
+                    pa2[PROJ ? j : 0] = m < p.M ? pix2 * wrowbytes2 + 16u * chunk : 0x80000000u;
+                }
             }
         };
         auto issue_a = [&]() __attribute__((always_inline)) {
             const unsigned base = lds0 + (a_step % NA) * ASTAGE;
             const bool live = a_step < nsteps;
             unsigned voff[APW];
+            const bool proj_step = PROJ && a_kt < (unsigned)KT2;       // (wave-uniform)
+            if (proj_step) {
 #pragma unroll
-            for (int j = 0; j < APW; ++j) voff[j] = (live && pa[j] != 0x80000000u) ? pa[j] + a_kt * 128u : 0x80000000u;
+                for (int j = 0; j < APW; ++j) voff[j] = (live && pa2[PROJ ? j : 0] != 0x80000000u) ? pa2[PROJ ? j : 0] + a_kt * 128u : 0x80000000u;
+            } else {
+#pragma unroll
+                for (int j = 0; j < APW; ++j) voff[j] = (live && pa[j] != 0x80000000u) ? pa[j] + (a_kt - (unsigned)KT2) * 128u : 0x80000000u;
+            }
 #pragma unroll
             for (int j = 0; j < APW; ++j) asm volatile("" : "+v"(voff[j]));
+            if (proj_step) {
 #pragma unroll
-            for (int j = 0; j < APW; ++j) piece(rx, base + (lw * APW + j) * 1024, voff[j]);
+                for (int j = 0; j < APW; ++j) piece(rx2, base + (lw * APW + j) * 1024, voff[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < APW; ++j) piece(rx, base + (lw * APW + j) * 1024, voff[j]);
+            }
             ++a_step;
             if (++a_kt == (unsigned)KT) { a_kt = 0; setup_a(++a_tile); }
         };
         const char* w_ptr = nullptr;
-        long long w_bytes = 0;
+        const char* w2_ptr = nullptr;
+        long long w_bytes = 0, w2_bytes = 0;
         unsigned b_tile = 0, b_kt = 0, b_step = 0;
         auto setup_b = [&](unsigned i) __attribute__((always_inline)) {
             unsigned mm0;
@@ -165,14 +200,20 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
             tile_origin(i, mm0, nn0);
             w_ptr = (const char*)p.wt + (long long)nn0 * wrowbytes;
             w_bytes = (long long)(p.Cout - nn0) * wrowbytes;
+            if (PROJ) {
+                w2_ptr = (const char*)p.wt2 + (long long)nn0 * wrowbytes2;
+                w2_bytes = (long long)(p.Cout - nn0) * wrowbytes2;
+            }
         };
         auto issue_b = [&]() __attribute__((always_inline)) {
-            const __amdgpu_buffer_rsrc_t rw = make_rsrc_sgpr(w_ptr, w_bytes);
+            const bool proj_step = PROJ && b_kt < (unsigned)KT2;       // (wave-uniform)
+            const __amdgpu_buffer_rsrc_t rw = make_rsrc_sgpr(proj_step ? w2_ptr : w_ptr, proj_step ? w2_bytes : w_bytes);
             const unsigned base = lds0 + B_OFF + (b_step & (NB - 1)) * BSTAGE;
             const bool live = b_step < nsteps;
             unsigned voff[BPW];
 #pragma unroll
-            for (int j = 0; j < BPW; ++j) voff[j] = live ? pvb[j] + b_kt * 128u : 0x80000000u;
+            for (int j = 0; j < BPW; ++j)
+                voff[j] = !live ? 0x80000000u : proj_step ? pvb2[PROJ ? j : 0] + b_kt * 128u : pvb[j] + (b_kt - (unsigned)KT2) * 128u;
 #pragma unroll
             for (int j = 0; j < BPW; ++j) asm volatile("" : "+v"(voff[j]));
 #pragma unroll
@@ -202,9 +243,15 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
                 tile_origin(ci, mm0, e_n0);
                 const __amdgpu_buffer_rsrc_t rd = make_rsrc_sgpr(p.scale + e_n0, (long long)(p.Cout - e_n0) * 4),
                                              rs = make_rsrc_sgpr(p.shift + e_n0, (long long)(p.Cout - e_n0) * 4);
-                const unsigned eb = lds0 + E_OFF + (ci & 1u) * 2048u;
+                const unsigned eb = lds0 + E_OFF + (ci & 1u) * E_PAR;
                 piece(rd, eb, lane < 32 ? 16u * lane : 0x80000000u);
                 piece(rs, eb + 1024, lane >= 32 ? 16u * (unsigned)(lane - 32) : 0x80000000u);
+                if (PROJ) {
+                    const __amdgpu_buffer_rsrc_t rd2 = make_rsrc_sgpr(p.scale2 + e_n0, (long long)(p.Cout - e_n0) * 4),
+                                                 rs2 = make_rsrc_sgpr(p.shift2 + e_n0, (long long)(p.Cout - e_n0) * 4);
+                    piece(rd2, eb + 2048, lane < 32 ? 16u * lane : 0x80000000u);
+                    piece(rs2, eb + 3072, lane >= 32 ? 16u * (unsigned)(lane - 32) : 0x80000000u);
+                }
             }
             issue_a();                                          // step g + 2: its slot held step g - 1, released at the last barrier
             issue_b();                                          // step g + 3: likewise
@@ -268,7 +315,7 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
         const unsigned bn0 = b0 + ((g + 1u) & (NB - 1)) * BSTAGE;
         const unsigned bnext[2] = {bn0, bn0 ^ 64u};
         const bool last = ckt == KT - 1;
-        if (last && p.res) {
+        if (!PROJ && last && p.res) {
             // the tile's residual fragments, requested now: there when the epilogue starts (rows past M: out-of-range offset, zeros)
             const long long yorg = ((long long)m0 * p.Cout + n0) * 2ll, ybytes = ((long long)(p.M - m0) * p.Cout - n0) * 2ll;
             const __amdgpu_buffer_rsrc_t rr = make_rsrc_sgpr((const char*)p.res + yorg, ybytes);
@@ -312,7 +359,32 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
         step_barrier();                                     // B_g
         W4_STAMP(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (++ckt == KT) {
+        ++ckt;
+        if (PROJ && ckt == KT2) {
+            // the projection is complete: scale2 / shift2, rounded to bf16 where its tensor used to be stored, parked as bf16 pairs in
+            // the registers (and the layout) of the plain kernel's residual fragments; the accumulators start again
+            f32x4 e_sc[4], e_sh[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int cch = wn * 64 + 32 * (v >> 1) + 8 * lq + 4 * (v & 1);
+                e_sc[v] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * E_PAR + 2048 + cch * 4);
+                e_sh[v] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * E_PAR + 3072 + 512 + cch * 4);
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * h + e] = fmaf(acc[rb][2 * j + h][e], e_sc[2 * j + h][e], e_sh[2 * j + h][e]);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) rres[rb][j][d] = __uint_as_float(hsefr_pack_bf16x2(v[2 * d], v[2 * d + 1]));
+                }
+            zero_acc();
+        }
+        if (ckt == KT) {
             ckt = 0;
             const long long yorg = ((long long)m0 * p.Cout + n0) * 2ll, ybytes = ((long long)(p.M - m0) * p.Cout - n0) * 2ll;
             const __amdgpu_buffer_rsrc_t ry = make_rsrc_sgpr((char*)p.y + yorg, ybytes);
@@ -320,8 +392,8 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int cch = wn * 64 + 32 * (v >> 1) + 8 * lq + 4 * (v & 1);
-                e_sc[v] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * 2048 + cch * 4);
-                e_sh[v] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * 2048 + 1024 + 512 + cch * 4);
+                e_sc[v] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * E_PAR + cch * 4);
+                e_sh[v] = *(const f32x4*)(smem + E_OFF + (ci & 1u) * E_PAR + 1024 + 512 + cch * 4);
             }
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -333,7 +405,7 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[4 * h + e] = fmaf(acc[rb][2 * j + h][e], e_sc[2 * j + h][e], e_sh[2 * j + h][e]);
-                    if (p.res) {
+                    if (PROJ || p.res) {
 #pragma unroll
                         for (int d = 0; d < 4; ++d) {
                             const unsigned rw2 = __float_as_uint(rres[rb][j][d]);
@@ -362,7 +434,7 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
 
 HSEFR_KNOB(g_w4_off, 0);    // dev builds: 1 = never use this kernel, 2 = for every shape it covers
 
-template <int RB, int WAVES_M>
+template <int RB, int WAVES_M, bool PROJ = false>
 int launch_w4(W4Params& p, hipStream_t s) {
     constexpr int BM = WAVES_M * RB * 16, BN = (4 / WAVES_M) * 64;
     const long long tiles_m = ((long long)p.M + BM - 1) / BM;
@@ -371,7 +443,7 @@ int launch_w4(W4Params& p, hipStream_t s) {
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv1x1_w4: too many tiles");
     p.total_tiles = (unsigned)total;
     const unsigned g = (unsigned)(total < 256 ? total : 256);
-    hipLaunchKernelGGL((conv1x1_w4_bf16_kernel<RB, WAVES_M>), dim3(g), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((conv1x1_w4_bf16_kernel<RB, WAVES_M, PROJ>), dim3(g), dim3(512), 0, s, p);
     return launch_status("conv1x1_w4_bf16");
 }
 
@@ -406,7 +478,9 @@ bool conv1x1_w4_bf16_supported(long long n, int h, int w, int c, int oh, int ow,
 // by what the CU's vector-memory path moves (operand fill + residual + stores: ~30 B/clk) on every kernel tried -- they stay on
 // conv1x1_bf16.hip, whose two workgroups per CU overlap a tile's stores with the other's loads.
 bool conv1x1_w4_bf16_preferred(long long pixels, int c, int cout, bool has_res) {
-    return !has_res && c >= 256 && c <= 1024 && cout % 128 == 0 && pixels >= 20000;
+    // (+ the K = 512 increase layers of the 7-pixel stage, residual and all: 31.1 -> 27.9 us in the network at batch 128)
+    if (has_res) return c >= 512 && cout % 128 == 0 && ((pixels + 223) / 224) * (cout / 128) >= 192;
+    return c >= 256 && c <= 1024 && cout % 128 == 0 && pixels >= 20000;
 }
 
 int launch_conv1x1_w4_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
@@ -421,8 +495,38 @@ int launch_conv1x1_w4_bf16(const void* x, const void* wt, const float* scale, co
     p.act_hi = act == HSEFR_ACT_RELU6 ? 6.f : INFINITY;
     p.M = (unsigned)((long long)n * oh * ow);
     p.reverse = sweep_reverse();
+    p.x2 = nullptr; p.wt2 = nullptr; p.scale2 = nullptr; p.shift2 = nullptr; p.x2_bytes = 0; p.K2 = 0; p.stride2 = 1; p.H2 = 0; p.W2 = 0;
     if (cout % 128 == 0) return launch_w4<7, 2>(p, s);
     return launch_w4<4, 4>(p, s);
+}
+
+// the increase layer of a stage's first block with its projected shortcut (PROJ): where the pair is matrix work -- the 28-, 14- and
+// 7-pixel stages of ResNet-50 at batch 128, 39.5 GFLOP each -- this kernel's wide waves run it at the 3x3 layers' rate; the 56-pixel
+// stage (K = K2 = 64: 308 MB for 26 GFLOP) stays on the register-staged kernel (measured: tools/kbench_conv.py)
+bool conv1x1_w4_proj_preferred(long long pixels, int c, int c2, int cout) {
+    if (g_w4_off == 1) return false;
+    if (g_w4_off == 2) return cout % 128 == 0;
+    // (at least three quarters of the CUs get a 224 x 128 tile: below that the register-staged kernel's 128 x 64 tiles fill the chip better)
+    return cout % 128 == 0 && c + c2 >= 256 && ((pixels + 223) / 224) * (cout / 128) >= 192;
+}
+
+int launch_conv1x1_w4_proj_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* x2, const void* wt2,
+                                const float* scale2, const float* shift2, void* y, int n, int oh, int ow, int c, int cout, int c2, int stride2,
+                                int h2, int w2, int act, hipStream_t s) {
+    HSEFR_REQUIRE(cout % 128 == 0 && conv1x1_w4_bf16_supported(n, oh, ow, c, oh, ow, cout, 1) && conv1x1_w4_bf16_supported(n, h2, w2, c2, oh, ow, cout, stride2),
+                  HSEFR_ERR_UNSUPPORTED, "conv1x1_w4_proj_bf16: shape not covered");
+    W4Params p;
+    p.x = x; p.wt = wt; p.scale = scale; p.shift = shift; p.res = nullptr; p.y = y;
+    p.x_bytes = (long long)n * oh * ow * c * 2;
+    p.K = c; p.Cout = cout; p.stride = 1; p.H = oh; p.W = ow; p.OH = oh; p.OW = ow;
+    p.act_lo = act == HSEFR_ACT_NONE ? -INFINITY : 0.f;
+    p.act_hi = act == HSEFR_ACT_RELU6 ? 6.f : INFINITY;
+    p.M = (unsigned)((long long)n * oh * ow);
+    p.reverse = sweep_reverse();
+    p.x2 = x2; p.wt2 = wt2; p.scale2 = scale2; p.shift2 = shift2;
+    p.x2_bytes = (long long)n * h2 * w2 * c2 * 2;
+    p.K2 = c2; p.stride2 = stride2; p.H2 = h2; p.W2 = w2;
+    return launch_w4<7, 2, true>(p, s);
 }
 
 }  // namespace hsefr
