@@ -343,6 +343,36 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
             setup_halo(++pf_i);
         }
     };
+    // weight DMA duty.  A consumer wave refills ITS slice of the weight stage (BPW KB; the slice's first 4 KB are also its epilogue
+    // scratch, so no other wave may write there).  BN = 256 (BSPLIT): the slice is 8 KB and the consumers were the patch's critical
+    // path -- 16.4 k cycles of MFMA + 8.4 k of DMA issue + 7.2 k of epilogue against the producers' 19.8 k of depthwise + 6 k of
+    // halo issue (profiles/r05_blk_stamps.txt) -- so producer wave i issues the UPPER half of consumer i's slice (the half that is
+    // never scratch), ahead of its halo pieces: its counted wait at the end of the step then covers them.
+    constexpr bool BSPLIT = BN == 256;
+    constexpr int BPI = BSPLIT ? BPW / 2 : BPW;                // pieces a wave issues per step
+    const int bslice = wave & 3, bfirst = (BSPLIT && wave < 4) ? BPW / 2 : 0;
+    unsigned bv[BPI];
+    unsigned pb_i = 0;
+    int pb_kc = 0, pb_step = 0;
+    auto setup_b = [&](unsigned i) {
+        const Item it = decode(i);
+#pragma unroll
+        for (int j = 0; j < BPI; ++j) {
+            const int r = (bslice * BPW + bfirst + j) * 8 + (lane >> 3);
+            bv[j] = ((unsigned)(it.n0 + r) * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7) ^ ((r & 1) << 2))) * 4u;
+        }
+    };
+    auto b_dma = [&]() {
+        const unsigned base = lds0 + B_OFF + (pb_step & 1) * B_ST;
+        const unsigned so = (unsigned)pb_kc * 128u;
+#pragma unroll
+        for (int j = 0; j < BPI; ++j) piece(rw, base + (bslice * BPW + bfirst + j) * 1024, bv[j], so);
+        ++pb_step;
+        if (++pb_kc == KT) {
+            pb_kc = 0;
+            setup_b(++pb_i);
+        }
+    };
     STEM_STAMP_DECL;
 
     if (wave < 4) {
@@ -356,10 +386,12 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
                 if (i < nsteps) halo_dma();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (BSPLIT) setup_b(0);
         __syncthreads();
         int dkc = 0;                      // chunk of the step the depthwise works on (step g + 1)
         for (int g = -1; g < nsteps; ++g) {
             const bool issued = !HALO_BY_CONSUMER && pf_step < nsteps;
+            if (BSPLIT && pb_step < nsteps) b_dma();   // this wave's half of the weights of step g + 1 (see BSPLIT above), BEFORE the halo pieces
             if (issued) halo_dma();
             STEM_STAMP(1);
             if (g + 1 < nsteps) {
@@ -416,28 +448,6 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
         const int li = lane & 31, lh = lane >> 5;
         const int arow = wm * 64 + li, brow = wn * WN + li;
         const int erow = lane >> 3, ech = lane & 7;
-        unsigned bv[BPW];
-        unsigned pb_i = 0;
-        int pb_kc = 0, pb_step = 0;
-        auto setup_b = [&](unsigned i) {
-            const Item it = decode(i);
-#pragma unroll
-            for (int j = 0; j < BPW; ++j) {
-                const int r = (cw * BPW + j) * 8 + (lane >> 3);
-                bv[j] = ((unsigned)(it.n0 + r) * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7) ^ ((r & 1) << 2))) * 4u;
-            }
-        };
-        auto b_dma = [&]() {
-            const unsigned base = lds0 + B_OFF + (pb_step & 1) * B_ST;
-            const unsigned so = (unsigned)pb_kc * 128u;
-#pragma unroll
-            for (int j = 0; j < BPW; ++j) piece(rw, base + (cw * BPW + j) * 1024, bv[j], so);
-            ++pb_step;
-            if (++pb_kc == KT) {
-                pb_kc = 0;
-                setup_b(++pb_i);
-            }
-        };
         f32x16 acc[2][NI];
         auto zero_acc = [&]() {
 #pragma unroll
