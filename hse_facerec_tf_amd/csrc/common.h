@@ -299,6 +299,7 @@ void set_cd_rb(int v);
 void set_w3_off(int v);
 void set_w2_off(int v);
 void set_w4_off(int v);
+void set_w4_bres(int v);
 void set_nn1_y_mb(int v);
 int read_w4_stamps(void* host_out, size_t bytes);
 int read_w2_stamps(void* host_out, size_t bytes);

@@ -84,6 +84,9 @@ struct W4Params {
     const float* shift2;
     long long x2_bytes;
     int K2, stride2, H2, W2;
+    int b_resident;      // 1: the K loop's steps divide the four weight stages (K = 64, 128 or 256, no projection) AND every tile of a workgroup has
+                         // the same channel origin -- stage s then always holds the SAME weight rows: they are loaded with the first four
+                         // steps and never again (16 of a step's 44 KB on layers that are bound by what the CU's loaders can issue)
 };
 
 template <int RB, int WAVES_M, bool PROJ = false>
@@ -210,14 +213,16 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
             const __amdgpu_buffer_rsrc_t rw = make_rsrc_sgpr(proj_step ? w2_ptr : w_ptr, proj_step ? w2_bytes : w_bytes);
             const unsigned base = lds0 + B_OFF + (b_step & (NB - 1)) * BSTAGE;
             const bool live = b_step < nsteps;
-            unsigned voff[BPW];
+            if (!(p.b_resident && b_step >= (unsigned)NB)) {      // (wave-uniform; resident weights: the stage already holds these rows)
+                unsigned voff[BPW];
 #pragma unroll
-            for (int j = 0; j < BPW; ++j)
-                voff[j] = !live ? 0x80000000u : proj_step ? pvb2[PROJ ? j : 0] + b_kt * 128u : pvb[j] + (b_kt - (unsigned)KT2) * 128u;
+                for (int j = 0; j < BPW; ++j)
+                    voff[j] = !live ? 0x80000000u : proj_step ? pvb2[PROJ ? j : 0] + b_kt * 128u : pvb[j] + (b_kt - (unsigned)KT2) * 128u;
 #pragma unroll
-            for (int j = 0; j < BPW; ++j) asm volatile("" : "+v"(voff[j]));
+                for (int j = 0; j < BPW; ++j) asm volatile("" : "+v"(voff[j]));
 #pragma unroll
-            for (int j = 0; j < BPW; ++j) piece(rw, base + (lw * BPW + j) * 1024, voff[j]);
+                for (int j = 0; j < BPW; ++j) piece(rw, base + (lw * BPW + j) * 1024, voff[j]);
+            }
             ++b_step;
             if (++b_kt == (unsigned)KT) { b_kt = 0; setup_b(++b_tile); }
         };
@@ -256,7 +261,9 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
             issue_a();                                          // step g + 2: its slot held step g - 1, released at the last barrier
             issue_b();                                          // step g + 3: likewise
             W4_STAMP(0);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + BPW) : "memory");      // everything older than this iteration's pieces has landed
+            // everything older than this iteration's pieces has landed (resident weights: from its second iteration on a loader issues none)
+            if (p.b_resident && g + 3u >= (unsigned)NB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APW + BPW) : "memory");
             W4_STAMP(1);
             step_barrier();                                     // B_g: activations of step g + 1 and weights of step g + 2 are there
             W4_STAMP(2);
@@ -432,7 +439,9 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
     W4_STAMP_FLUSH;
 }
 
+
 HSEFR_KNOB(g_w4_off, 0);    // dev builds: 1 = never use this kernel, 2 = for every shape it covers
+HSEFR_KNOB(g_w4_bres, 1);   // dev builds: 0 = reload the weight stages every step also where they could stay resident (A/B timing)
 
 template <int RB, int WAVES_M, bool PROJ = false>
 int launch_w4(W4Params& p, hipStream_t s) {
@@ -443,6 +452,9 @@ int launch_w4(W4Params& p, hipStream_t s) {
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv1x1_w4: too many tiles");
     p.total_tiles = (unsigned)total;
     const unsigned g = (unsigned)(total < 256 ? total : 256);
+    // resident weights: the steps of a tile divide the ring (K = 64 / 128 / 256) and the grid's stride keeps a workgroup on one channel origin
+    // (xcd_remap_dir permutes inside blocks of eight: conv1x1_bf16.hip's rule)
+    p.b_resident = (!PROJ && g_w4_bres && total > g && (p.K == 64 || p.K == 128 || p.K == 256) && g % 8 == 0 && (g / 8) % p.tiles_n == 0) ? 1 : 0;
     hipLaunchKernelGGL((conv1x1_w4_bf16_kernel<RB, WAVES_M, PROJ>), dim3(g), dim3(512), 0, s, p);
     return launch_status("conv1x1_w4_bf16");
 }
@@ -462,6 +474,7 @@ int read_w4_stamps(void* host_out, size_t bytes) {
 #endif
 }
 void set_w4_off(int v) { g_w4_off = v; }
+void set_w4_bres(int v) { g_w4_bres = v; }
 #endif
 
 bool conv1x1_w4_forced() { return g_w4_off == 2; }

@@ -301,6 +301,7 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "w3_off")) { set_w3_off(value); return HSEFR_OK; }
     if (!strcmp(key, "w2_off")) { set_w2_off(value); return HSEFR_OK; }
     if (!strcmp(key, "w4_off")) { set_w4_off(value); return HSEFR_OK; }
+    if (!strcmp(key, "w4_bres")) { set_w4_bres(value); return HSEFR_OK; }
     if (!strcmp(key, "nn1_y_mb")) { set_nn1_y_mb(value); return HSEFR_OK; }
     if (!strcmp(key, "c11")) { set_c11(value); return HSEFR_OK; }
     if (!strcmp(key, "c11_tile")) { set_c11_tile(value); return HSEFR_OK; }
