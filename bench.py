@@ -35,6 +35,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -753,7 +754,25 @@ def main():
         per = max((time.perf_counter() - tw) / nw, 1e-5)
         n_win = max(2, int(args.sustained_s * 1.05 / (100 * per)) + 1)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
+        # socket power and shader clock while the windows run (rocm-smi from a thread, rank 0 only): the MFMA-dense kernels of this
+        # forward run under the chip's power management (DESIGN.md lesson 56), so a roofline fraction is read against these
+        smi = {}
+
+        def smi_sample():
+            try:
+                time.sleep(min(0.5, args.sustained_s / 2))
+                o = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+                for ln in o.splitlines():
+                    if "Socket Graphics Package Power" in ln or "Average Graphics Package Power" in ln:
+                        smi["socket_power_w"] = float(ln.rsplit(":", 1)[1])
+                    elif "sclk clock level" in ln and "Mhz" in ln:
+                        smi["sclk_mhz"] = float(ln.rsplit("(", 1)[1].split("Mhz")[0])
+            except Exception as e:      # (a box without rocm-smi: the fields stay out of the line)
+                smi["error"] = repr(e)[:80]
+        smi_thread = threading.Thread(target=smi_sample) if rank == 0 else None
         barrier()
+        if smi_thread:
+            smi_thread.start()
         t1 = time.perf_counter()
         evs[0].record()
         for wi in range(n_win):
@@ -768,6 +787,9 @@ def main():
                      "window_steps": 100, "window_faces_per_s_min": round(B * 100 / (max(win_ms) * 1e-3), 1),
                      "window_faces_per_s_max": round(B * 100 / (min(win_ms) * 1e-3), 1),
                      "window_faces_per_s_first_last": [round(B * 100 / (win_ms[0] * 1e-3), 1), round(B * 100 / (win_ms[-1] * 1e-3), 1)]}
+        if smi_thread:
+            smi_thread.join()
+            sustained.update({"rocm_smi_" + k: v for k, v in smi.items()})
 
     # ---- the same `steps` forwards again with HIP events around every launch, recorded on the
     # forward's own stream into a ring (no sync inside the region).  Kept out of the region above

@@ -262,18 +262,26 @@ constexpr int CMAX2 = 512;          // channel bound of the resident depthwise c
 // in-kernel stamps put 45 % of a wave's life in barriers.  Here waves 0-3 (one per SIMD) are PRODUCERS -- halo DMA and the
 // depthwise of step g+1 into A[(g+1) & 1] -- while waves 4-7 are CONSUMERS -- weight DMA, the MFMAs of step g from
 // A[g & 1], and the epilogue.  One barrier per step; on every SIMD a producer's VALU/LDS work runs beside a consumer's
-// matrix work.  The halo ring is HS deep (3 where LDS allows: two steps of lookahead for the HBM stream; vmcnt retires
+// matrix work.  BN = 256: EIGHT consumer waves (4-11, two per SIMD) of 64 x 64 each instead of four of 64 x 128 -- the consumers were
+// the patch's critical path (16.4 k cycles of MFMA + 8.4 k of weight-piece issue + 7.2 k of epilogue stores against the producers'
+// 19.8 k of depthwise, profiles/r05_blk_stamps.txt): the matrix work per SIMD is the same, but the epilogue and the weight DMA of a
+// patch are now split eight ways, and a wave holds 64 accumulators instead of 128 (twelve waves per CU: 168 registers each).  The halo ring is HS deep (3 where LDS allows: two steps of lookahead for the HBM stream; vmcnt retires
 // in order, so a producer waits with one step's pieces still in flight).  A consumer's epilogue scratch is the part of
 // the weight stage its own next DMA pieces will overwrite, so it needs no synchronisation beyond program order.
 template <int TW, int BN, int HS, int ACT>
-__global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
+__global__ __launch_bounds__(256 + 64 * (BN == 256 ? 8 : 4), BN == 256 ? 1 : 2) void dwpw3_f16s_kernel(DwPwSParams p) {
+    constexpr int NCW = BN == 256 ? 8 : 4;                      // consumer waves: 2 (M) x NCW / 2 (N)
+    constexpr int CWN = NCW / 2;
+    constexpr int NTHR = 256 + 64 * NCW;
     constexpr int TH = 128 / TW, HC = TW + 2;
     constexpr int WCAP = 256;                                   // channel capacity of the resident depthwise constants
     constexpr int B_ST = BN * ROWB;
     constexpr int B_OFF = HS * HALO_B, A_OFF = B_OFF + 2 * B_ST, W_OFF = A_OFF + 2 * 128 * ROWB, E_OFF = W_OFF + 11 * WCAP * 4;
-    constexpr int WN = BN / 2, NI = WN / 32;                    // consumer wave tile 64 x WN (2 x 2 waves)
-    constexpr int BPW = BN / 32;                                // weight DMA pieces per consumer wave (its scratch: BPW KB >= 4)
-    constexpr int HPW = 6;                                      // halo DMA pieces per producer wave
+    constexpr int WN = BN / CWN, NI = WN / 32;                  // consumer wave tile 64 x 64
+    constexpr int BPW = BN / 8 / NCW;                           // weight DMA pieces per consumer wave (its scratch: BPW KB = 4)
+    static_assert(BPW == 4 && NI == 2, "a consumer's slice of the weight stage is its 4 KB epilogue scratch");
+    constexpr bool HALO_BY_CONSUMER = false;                    // (see the halo DMA duty note below)
+    constexpr int HPW = 24 / (HALO_BY_CONSUMER ? NCW : 4);       // halo DMA pieces per issuing wave
     static_assert(E_OFF + 2 * CMAX2 * 4 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[E_OFF + 2 * CMAX2 * 4];
 
@@ -283,10 +291,10 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
     const int C = p.C4 * 4, KT = p.KT;
     {
         float4* wl = (float4*)(smem + W_OFF);
-        for (int i = tid; i < 9 * p.C4; i += 512) wl[i] = p.wd[i];
-        for (int i = tid; i < p.C4; i += 512) { wl[9 * p.C4 + i] = p.dscale[i]; wl[10 * p.C4 + i] = p.dshift[i]; }
+        for (int i = tid; i < 9 * p.C4; i += NTHR) wl[i] = p.wd[i];
+        for (int i = tid; i < p.C4; i += NTHR) { wl[9 * p.C4 + i] = p.dscale[i]; wl[10 * p.C4 + i] = p.dshift[i]; }
         float* el = (float*)(smem + E_OFF);
-        for (int i = tid; i < p.Cout; i += 512) { el[i] = p.descale[i]; el[CMAX2 + i] = p.pshift[i]; }
+        for (int i = tid; i < p.Cout; i += NTHR) { el[i] = p.descale[i]; el[CMAX2 + i] = p.pshift[i]; }
     }
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long long)p.nimg * p.H * p.W * C * 4);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.wsplit, (long long)p.Cout * C * 4);
@@ -316,8 +324,10 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
     // whichever waves issue the vector-memory instructions.  Neither did keeping all the weight rows of the 128-channel block
     // resident in LDS (-29 % instructions) nor slicing the epilogue's stores over the next patch's steps: at 611 MB per
     // launch in ~145 us the block runs at 4.2 TB/s of HBM traffic, 85 % of what a streaming copy reaches on the same box.)
-    constexpr bool HALO_BY_CONSUMER = false;
-    const int hw = wave & 3;              // index of this wave among the four that issue the halo pieces
+    // (Round 5, BN = 256 with eight consumer waves: the producers are then the patch's critical path by the stamps -- 18.9 k cycles of
+    // depthwise + 5.2 k of halo issue against 6.7 k of MFMA + 7.4 k of epilogue per consumer -- and the halo duty on the consumers, three
+    // pieces each, was still SLOWER: 99 -> 108 us.  With a two-deep halo ring the issuing wave waits for its pieces inside the step.)
+    const int hw = HALO_BY_CONSUMER ? wave - 4 : wave & 3;      // index of this wave among those that issue the halo pieces
     unsigned hv[HPW];
     unsigned pf_i = 0;
     int pf_kc = 0, pf_step = 0;
@@ -343,36 +353,6 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
             setup_halo(++pf_i);
         }
     };
-    // weight DMA duty.  A consumer wave refills ITS slice of the weight stage (BPW KB; the slice's first 4 KB are also its epilogue
-    // scratch, so no other wave may write there).  BN = 256 (BSPLIT): the slice is 8 KB and the consumers were the patch's critical
-    // path -- 16.4 k cycles of MFMA + 8.4 k of DMA issue + 7.2 k of epilogue against the producers' 19.8 k of depthwise + 6 k of
-    // halo issue (profiles/r05_blk_stamps.txt) -- so producer wave i issues the UPPER half of consumer i's slice (the half that is
-    // never scratch), ahead of its halo pieces: its counted wait at the end of the step then covers them.
-    constexpr bool BSPLIT = BN == 256;
-    constexpr int BPI = BSPLIT ? BPW / 2 : BPW;                // pieces a wave issues per step
-    const int bslice = wave & 3, bfirst = (BSPLIT && wave < 4) ? BPW / 2 : 0;
-    unsigned bv[BPI];
-    unsigned pb_i = 0;
-    int pb_kc = 0, pb_step = 0;
-    auto setup_b = [&](unsigned i) {
-        const Item it = decode(i);
-#pragma unroll
-        for (int j = 0; j < BPI; ++j) {
-            const int r = (bslice * BPW + bfirst + j) * 8 + (lane >> 3);
-            bv[j] = ((unsigned)(it.n0 + r) * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7) ^ ((r & 1) << 2))) * 4u;
-        }
-    };
-    auto b_dma = [&]() {
-        const unsigned base = lds0 + B_OFF + (pb_step & 1) * B_ST;
-        const unsigned so = (unsigned)pb_kc * 128u;
-#pragma unroll
-        for (int j = 0; j < BPI; ++j) piece(rw, base + (bslice * BPW + bfirst + j) * 1024, bv[j], so);
-        ++pb_step;
-        if (++pb_kc == KT) {
-            pb_kc = 0;
-            setup_b(++pb_i);
-        }
-    };
     STEM_STAMP_DECL;
 
     if (wave < 4) {
@@ -386,12 +366,10 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
                 if (i < nsteps) halo_dma();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (BSPLIT) setup_b(0);
         __syncthreads();
         int dkc = 0;                      // chunk of the step the depthwise works on (step g + 1)
         for (int g = -1; g < nsteps; ++g) {
             const bool issued = !HALO_BY_CONSUMER && pf_step < nsteps;
-            if (BSPLIT && pb_step < nsteps) b_dma();   // this wave's half of the weights of step g + 1 (see BSPLIT above), BEFORE the halo pieces
             if (issued) halo_dma();
             STEM_STAMP(1);
             if (g + 1 < nsteps) {
@@ -444,10 +422,32 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
         STEM_STAMP_FLUSH(p.stamps, lane, wave);
     } else {
         // =============================== consumer: weight DMA + MFMA + epilogue ===============================
-        const int cw = wave - 4, wm = cw >> 1, wn = cw & 1;
+        const int cw = wave - 4, wm = cw / CWN, wn = cw % CWN;
         const int li = lane & 31, lh = lane >> 5;
         const int arow = wm * 64 + li, brow = wn * WN + li;
         const int erow = lane >> 3, ech = lane & 7;
+        unsigned bv[BPW];
+        unsigned pb_i = 0;
+        int pb_kc = 0, pb_step = 0;
+        auto setup_b = [&](unsigned i) {
+            const Item it = decode(i);
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) {
+                const int r = (cw * BPW + j) * 8 + (lane >> 3);
+                bv[j] = ((unsigned)(it.n0 + r) * (unsigned)C + 4u * ((lane & 7) ^ ((r >> 1) & 7) ^ ((r & 1) << 2))) * 4u;
+            }
+        };
+        auto b_dma = [&]() {
+            const unsigned base = lds0 + B_OFF + (pb_step & 1) * B_ST;
+            const unsigned so = (unsigned)pb_kc * 128u;
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) piece(rw, base + (cw * BPW + j) * 1024, bv[j], so);
+            ++pb_step;
+            if (++pb_kc == KT) {
+                pb_kc = 0;
+                setup_b(++pb_i);
+            }
+        };
         f32x16 acc[2][NI];
         auto zero_acc = [&]() {
 #pragma unroll
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(512, 2) void dwpw3_f16s_kernel(DwPwSParams p) {
         }
         if (pending) { epilogue(cur, (nsteps - 1) & 1); STEM_STAMP_COUNT; }
 #ifdef HSEFR_STEM_STAMPS
-        if (lane == 0 && p.stamps && blockIdx.x < 256) {      // consumer waves report in the upper half of the stamp table
+        if (lane == 0 && p.stamps && blockIdx.x < 256 && cw < 4) {      // consumer waves (the first four) report in the upper half of the stamp table
             unsigned long long* o = p.stamps + ((blockIdx.x + 256) * 4 + cw) * 10;
             for (int i_ = 0; i_ < 8; ++i_) o[i_] = st[i_];
             o[8] = __builtin_amdgcn_s_memtime() - tstart;
@@ -625,7 +625,7 @@ int launch_v3(DwPwSParams& p, int n, int act, hipStream_t s) {
     HSEFR_REQUIRE(total * (long long)(p.tiles_n > p.tiles_w ? (p.tiles_n > p.tiles_h ? p.tiles_n : p.tiles_h) : (p.tiles_w > p.tiles_h ? p.tiles_w : p.tiles_h)) < (1ll << 32),
                   HSEFR_ERR_UNSUPPORTED, "dwpw_f16split: grid too large for the quotient multipliers");
     const unsigned g = p.total < 256u ? p.total : 256u;
-#define HSEFR_DWPW3(A) hipLaunchKernelGGL((dwpw3_f16s_kernel<TW, BN, HS, A>), dim3(g), dim3(512), 0, s, p)
+#define HSEFR_DWPW3(A) hipLaunchKernelGGL((dwpw3_f16s_kernel<TW, BN, HS, A>), dim3(g), dim3(256 + 64 * (BN == 256 ? 8 : 4)), 0, s, p)
     if (act == HSEFR_ACT_RELU6) HSEFR_DWPW3(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_DWPW3(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_DWPW3(HSEFR_ACT_NONE);
