@@ -344,7 +344,8 @@ int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shi
     const int rev = sweep_reverse();
     ProjParams nopj{};
     // resident weight tiles: K <= 128 (at most two steps per tile) and a grid whose stride keeps a workgroup on one channel origin
-    nopj.b_resident = (total > g && K <= 128 && g % 8 == 0 && (g / 8) % tiles_n == 0 && g_c11_bres) ? 1 : 0;
+    // (and BM >= 128: the epilogue's 16 KB of wave-private scratch must fit the stage's ACTIVATION rows, or it lands on the weights)
+    nopj.b_resident = (BM >= 128 && total > g && K <= 128 && g % 8 == 0 && (g / 8) % tiles_n == 0 && g_c11_bres) ? 1 : 0;
 #define HSEFR_C11(R, A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, R, A>), grid, block, 0, s, x, wt, scale, shift, res, y, P, K, cout, tiles_n, (unsigned)total, rev, nopj)
     if (res) {
         if (act == HSEFR_ACT_RELU) HSEFR_C11(true, HSEFR_ACT_RELU);
@@ -371,7 +372,7 @@ int launch_proj_cfg(const u16* x, const u16* wt, const float* scale, const float
     dim3 grid((unsigned)g), block(256);
     const int rev = sweep_reverse();
     ProjParams pjr = pj;
-    pjr.b_resident = (total > g && K + pj.K2 <= 128 && g % 8 == 0 && (g / 8) % tiles_n == 0 && g_c11_bres) ? 1 : 0;
+    pjr.b_resident = (BM >= 128 && total > g && K + pj.K2 <= 128 && g % 8 == 0 && (g / 8) % tiles_n == 0 && g_c11_bres) ? 1 : 0;
 #define HSEFR_C11P(A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, false, A, true>), grid, block, 0, s, x, wt, scale, shift, nullptr, y, P, K, cout, tiles_n, (unsigned)total, rev, pjr)
     if (act == HSEFR_ACT_RELU) HSEFR_C11P(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_RELU6) HSEFR_C11P(HSEFR_ACT_RELU6);
@@ -422,6 +423,9 @@ int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const
     u16* yy = (u16*)y;
     // 128 x 128 tiles when there are enough of them to fill the machine twice over, 128 x 64 otherwise
     const long long t128 = ((P + 127) / 128) * (cout / 128);
+    // (dev builds: 64 x 128 tiles, three workgroups per CU.  Measured on the short-K increase layers: 3-7 % SLOWER than 128 x 128 -- its 16 KB
+    // of epilogue scratch does not fit beside resident weights in a 64-row stage, and with the weights re-loaded every step it loses)
+    if (cout % 128 == 0 && g_c11_tile == 3) return launch_cfg<64, 128, 3>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
     if (cout % 128 == 0 && (g_c11_tile == 2 || (t128 >= 768 && g_c11_tile != 1))) return launch_cfg<128, 128, 2>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
     return launch_cfg<128, 64, 3>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
 }
