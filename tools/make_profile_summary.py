@@ -17,8 +17,10 @@ forwards = int(sys.argv[3]) if len(sys.argv) > 3 else None      # forwards of th
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, os.path.join(out, "%s_kernel_stats.csv" % tag))
+# (gpurun merges every call's files into the same local directory under their process ids: the NEWEST trace is this profile's)
+stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+if stats:
+    shutil.copy(stats[-1], os.path.join(out, "%s_kernel_stats.csv" % tag))
 shutil.copy(os.path.join(src, "summary.txt"), os.path.join(out, "%s_pmc_summary.txt" % tag))
 traffic = {}
 cur = None
