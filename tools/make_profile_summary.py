@@ -80,7 +80,11 @@ if clocks:
 traffic = {k: v for k, v in traffic.items() if "hbm_bytes_per_launch" in v and not k.startswith("void at::") and not k.startswith("__amd")}
 sys.path.insert(0, root)
 import bench  # noqa: E402  (csrc_hash: bench.py marks the traffic figures stale when the kernels changed since this profile)
-json.dump({"csrc_hash": bench.csrc_hash(), "forwards": forwards, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); "
+# the hash of the kernel sources AS PROFILED (tools/profile_round.sh writes it on the box, next to the counters); a directory without the
+# file predates that and gets the hash of the sources at collect time, as before
+hf = os.path.join(src, "csrc_hash.txt")
+profiled_hash = open(hf).read().strip() if os.path.exists(hf) else bench.csrc_hash()
+json.dump({"csrc_hash": profiled_hash, "forwards": forwards, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); "
                      "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
            "kernels": traffic}, open(os.path.join(out, "%s_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(traffic, indent=1))

@@ -29,3 +29,4 @@ python3 tools/bench_configs.py mobilenet192 > gpurun_out/prof_${TAG}/layers.txt 
 python3 tools/bench_configs.py resnet50 > gpurun_out/prof_${TAG}_resnet/layers.txt 2>&1
 python3 tools/bench_configs.py agegender > gpurun_out/prof_${TAG}_agegender/layers.txt 2>&1
 python3 tools/bench_configs.py mobilenet_f32 > gpurun_out/prof_${TAG}_f32/layers.txt 2>&1
+for d in "" _resnet _agegender _f32; do python3 -c "import bench; print(bench.csrc_hash())" > gpurun_out/prof_${TAG}$d/csrc_hash.txt; done      # the sources these counters belong to
