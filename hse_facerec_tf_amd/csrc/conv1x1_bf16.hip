@@ -444,7 +444,8 @@ int launch_conv1x1_proj_bf16(const void* x, const void* wt, const float* scale, 
     HSEFR_REQUIRE(act == HSEFR_ACT_NONE || act == HSEFR_ACT_RELU || act == HSEFR_ACT_RELU6, HSEFR_ERR_UNSUPPORTED, "conv1x1_proj_bf16: act %d", act);
     if (n == 0) return HSEFR_OK;
     const long long P = (long long)n * oh * ow;
-    if (conv1x1_w4_proj_preferred(P, K, k2, cout))      // the matrix-bound pairs: four wide MFMA waves + loaders (csrc/conv1x1_w4_bf16.hip)
+    if (conv1x1_w4_proj_preferred(P, K, k2, cout) && conv1x1_w4_bf16_supported(n, oh, ow, K, oh, ow, cout, 1) &&
+        conv1x1_w4_bf16_supported(n, h2, w2, k2, oh, ow, cout, stride))      // the matrix-bound pairs: four wide MFMA waves + loaders (csrc/conv1x1_w4_bf16.hip)
         return launch_conv1x1_w4_proj_bf16(x, wt, scale, shift, x2, wt2, scale2, shift2, y, n, oh, ow, K, cout, k2, stride, h2, w2, act, s);
     ProjParams pj;
     pj.x2 = (const u16*)x2; pj.wt2 = (const u16*)wt2; pj.scale2 = scale2; pj.shift2 = shift2;
