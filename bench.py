@@ -691,7 +691,19 @@ def main():
             os.environ["MASTER_PORT"] = str(s.getsockname()[1])
             s.close()
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL prints a version banner on STDOUT when its communicator is created; this program's stdout is ONE JSON line, so the
+            # file descriptor points at stderr while the group comes up (the first collective creates the communicator)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
