@@ -81,7 +81,9 @@ def test_conv_bf16_vs_oracle(env, n, h, w, c, cout, k, s, res, act):
 
 @pytest.mark.parametrize("n,hw,c,cout,res,act", [(128, 56, 64, 256, False, 0), (128, 56, 64, 64, False, 1), (128, 56, 64, 256, True, 1),
                                                  (128, 56, 256, 64, False, 1), (128, 28, 128, 512, True, 1), (128, 14, 1024, 256, False, 1),
-                                                 (128, 7, 512, 2048, True, 1), (3, 9, 64, 192, True, 1), (1, 5, 128, 64, False, 0)])
+                                                 (128, 7, 512, 2048, True, 1), (3, 9, 64, 192, True, 1), (1, 5, 128, 64, False, 0),
+                                                 # (the four-wave GEMM with RESIDENT weight stages: K = 256 / 128, one and two channel tiles)
+                                                 (128, 28, 256, 128, False, 1), (128, 28, 256, 256, False, 0), (96, 28, 256, 128, False, 1)])
 def test_conv1x1_persistent_kernel_bit_for_bit_and_run_to_run(env, n, hw, c, cout, res, act):
     """The persistent 1x1 kernel (conv1x1_bf16.hip) must reproduce the general implicit-GEMM kernel BIT FOR BIT on every
     1x1 stride-1 layer shape of ResNet-50 at batch 128, three launches in a row (an unguarded store-data hazard -- DESIGN.md
