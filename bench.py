@@ -962,7 +962,10 @@ def main():
         return {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
                 "unit": k["unit"], "frac": k["frac"], "traffic": k["traffic"], "traffic_stale": k["traffic_stale"],
                 "avg_launch_us": k["avg_launch_us"],
-                "launches_per_step": k["launches_per_step"], "mfma_util_pmc": k.get("mfma_util_pmc")}
+                "launches_per_step": k["launches_per_step"], "mfma_util_pmc": k.get("mfma_util_pmc"),
+                **({"peak_note": "the dense f16 peak at 2.4 GHz / 3 split products; inside back-to-back forwards this kernel's waves count 1.67 GHz "
+                                 "(tools/ps_clock_net.py, DESIGN.md lesson 56): the chip's power management, not the kernel, sets that clock"}
+                   if k["bound"] == "mfma" else {})}
 
     # the depthwise class, honestly split: the layers that run as their own kernel vs the ones inside fused kernels
     roofline_dw = roof(dw)
