@@ -787,12 +787,23 @@ def main():
             smi_thread.start()
         t1 = time.perf_counter()
         evs[0].record()
-        for wi in range(n_win):
-            for _ in range(100):
-                out = step()
-            evs[wi + 1].record()
-        barrier()
-        wall = time.perf_counter() - t1
+        done, plan_n = 0, n_win
+        while True:
+            for _w in range(plan_n):
+                for _ in range(100):
+                    out = step()
+                done += 1
+                if done >= len(evs):
+                    evs.append(torch.cuda.Event(enable_timing=True))
+                evs[done].record()
+            barrier()
+            wall = time.perf_counter() - t1
+            # (the window count came from the warm-up's estimate; a host that other jobs load makes that estimate too slow and the run too
+            # short: more windows until the requested duration is there -- one extra barrier, a few microseconds in two seconds)
+            if wall >= args.sustained_s or done >= 2000:
+                break
+            plan_n = max(1, int((args.sustained_s - wall) / (wall / done)) + 1)
+        n_win = done
         win_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_win)]
         sustained = {"value": round(B * 100 * n_win / wall, 1), "unit": "faces/s (this rank)", "seconds": round(wall, 3), "steps": 100 * n_win,
                      "warmup_seconds": args.sustained_warmup_s, "ms_per_step": round(wall / (100 * n_win) * 1e3, 4),
