@@ -2,6 +2,9 @@
 # One round's judged profile set, on the GPU box (through gpurun):   bash tools/profile_round.sh r05
 # -> gpurun_out/prof_<tag>{,_resnet,_agegender,_f32}/ (tools/gpu_pmc.sh: kernel-trace stats + one PMC group per pass), the per-LAYER
 # tables of the four configs and the default bench line of the same box.  Then, here:  bash tools/profile_round.sh r05 collect
+# (bench.py marks its traffic figures stale unless profiles/<tag>_traffic.json carries the hash of the sources it runs on: for a bench line
+# with fresh traffic run  `profile_round.sh <tag>; profile_round.sh <tag> collect; python bench.py > gpurun_out/prof_<tag>/bench_line.json`
+# in ONE gpurun call -- gpurun_out/ does not travel to the box -- and collect again here.)
 set -u
 TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
