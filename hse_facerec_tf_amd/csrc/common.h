@@ -94,6 +94,12 @@ __device__ __forceinline__ hsefr_f32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigne
 __device__ __forceinline__ void bstore16_welded(hsefr_f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
+// The same with the non-temporal hint: for a layer's output that nothing re-reads before the next launch streams it in.  Measured per
+// kernel in the network (round 5): the epilogue GEMMs' split rows -2.5 us per layer; the fused blocks' and the pointwise GEMMs' outputs
+// must NOT have it (the depthwise layers behind them read more slowly: +7 / +3 us), nor the bf16 ResNet kernels' (-5 % on the forward).
+__device__ __forceinline__ void bstore16_welded_nt(hsefr_f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
 __device__ __forceinline__ void bstore16(hsefr_f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hsefr_u32x4, v), r, voff, soff, 0);
     hsefr_store_guard();

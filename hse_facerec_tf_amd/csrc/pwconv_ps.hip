@@ -277,7 +277,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
                 recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
                 const u32x4 out = odd ? u32x4{recv.x, recv.y, lb.x, lb.y} : u32x4{hb.x, hb.y, recv.x, recv.y};
                 const unsigned ovoff = (nb_mask[0] >> 31) ? 0x80000000u : (unsigned)(P0 + j) * (unsigned)Cout * 4u + (unsigned)c * 128u + 16u * unit;
-                bstore16_welded(__builtin_bit_cast(f32x4, out), ro, ovoff, 0u);
+                bstore16_welded_nt(__builtin_bit_cast(f32x4, out), ro, ovoff, 0u);
             }
             return;
         }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
             // (stride 2: lanes past the tile's 72 output pixels computed a duplicate of pixel 71; an out-of-range offset drops their store)
             const bool drop = (DWM == 3 && P >= MAPS * (MW / 2) * (MW / 2)) || (DWM == 1 && !(nb_mask[k3] >> 16)) || (DWM == 2 && (nb_mask[k3] >> 31));
             const unsigned ovoff = drop ? 0x80000000u : (unsigned)P * (unsigned)Cout * 4u + (unsigned)c * 128u + 16u * unit;
-            bstore16_welded(__builtin_bit_cast(f32x4, out), ro, ovoff, 0u);
+            bstore16_welded_nt(__builtin_bit_cast(f32x4, out), ro, ovoff, 0u);
         }
     };
 
