@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256, LOOK == 2 ? 4 : (LOOK <= 4 ? 3 : 2)) void dwco
             recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
             const u32x4 out = odd ? u32x4{recv.x, recv.y, lb.x, lb.y} : u32x4{hb.x, hb.y, recv.x, recv.y};
             const f4 ov = __builtin_bit_cast(f4, out);
-            yout[(size_t)oh * p.OW * p.C4] = make_float4(ov.x, ov.y, ov.z, ov.w);
+            if (NT & 2) ntstore(make_float4(ov.x, ov.y, ov.z, ov.w), yout + (size_t)oh * p.OW * p.C4);
+            else yout[(size_t)oh * p.OW * p.C4] = make_float4(ov.x, ov.y, ov.z, ov.w);
             return;
         }
         if (NT & 2) ntstore(o, yout + (size_t)oh * p.OW * p.C4);
@@ -241,6 +242,7 @@ static int launch_dwconv3x3_impl(const float* x, const float* wgt, const float* 
         if (a_log2) {   /* split rows for the GEMM behind (ReLU6 only: checked above) */           \
             if (A == HSEFR_ACT_RELU6) {                                                             \
                 if (S == 1) hipLaunchKernelGGL((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 0, 4, 1>), grid, block, 0, s, p); \
+                else if (g_dw_variant & 4) hipLaunchKernelGGL((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 2, 2, 1>), grid, block, 0, s, p); \
                 else hipLaunchKernelGGL((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 0, 2, 1>), grid, block, 0, s, p);      \
             }                                                                                       \
             break;                                                                                  \
@@ -249,7 +251,12 @@ static int launch_dwconv3x3_impl(const float* x, const float* wgt, const float* 
         if (look == 4) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 4>), grid, block, 0, s, p); break; } \
         if (look == 5 && S == 1) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 5>), grid, block, 0, s, p); break; } \
         switch (g_dw_variant & 3) {                                                                 \
-            case 0: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 2>), grid, block, 0, s, p); break;   \
+            /* stride 2 (the layer in front of a pointwise GEMM): the output leaves with the non-temporal hint -- in the network the   \
+               GEMM behind it runs 5 us faster (57.5 -> 52.3 at 24 x 24 x 128 -> 256) and the layer itself 1-3 us; non-temporal LOADS \
+               (variants 1, 3) cost the layer 13 us, the hint on the split-row form (variant bit 2) nothing either way */        \
+            case 0: if (S == 2) hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 2, 2>), grid, block, 0, s, p);                          \
+                    else hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 2>), grid, block, 0, s, p);                                  \
+                    break;                                                                                                            \
             case 1: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 1, 2>), grid, block, 0, s, p); break;   \
             case 2: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 2, 2>), grid, block, 0, s, p); break;   \
             default: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 3, 2>), grid, block, 0, s, p); break;  \
