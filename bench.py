@@ -316,7 +316,7 @@ def run_pipeline(args, tfi, dev):
             never having opened a JPEG, and came out 2.7x BELOW the pipeline it was meant to bound): one untimed pass over the
             whole list -- every worker has imported its decoder, every staging page has been touched, every file is in the page
             cache -- then `passes` timed passes of the same chunks the pipeline uses."""
-            pool = DecodePool(nw, slot_bytes=max(8 << 20, B * (256 << 10)), slots=3)
+            pool = DecodePool(nw, slot_bytes=max(8 << 20, B * (256 << 10)), slots=3, pin=True)   # this job owns the host's quota
             try:
                 chunks = [files[i:i + B] for i in range(0, len(files), B)]
 
@@ -649,6 +649,9 @@ def main():
     # both launch paths (self-launched above, pre-launched by torchrun, or a plain single rank): this pool's host driver only
     # supports dmabuf IPC, RCCL fails with `hipIpcGetMemHandle: invalid argument` without it -- set before HIP initialises
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # this job owns the host: its decoder pools pin their workers (decode_pool.pin_offset: ranks take consecutive runs of cores through
+    # LOCAL_RANK; a plain single rank starts at core 0) -- a DecodePool pins by default only when a launcher says where it is
+    os.environ.setdefault("HSEFR_DECODE_CPU_OFFSET", "0")
 
     import torch
     import torch.distributed as dist
@@ -765,6 +768,10 @@ def main():
             nw += 50
         per = max((time.perf_counter() - tw) / nw, 1e-5)
         n_win = max(2, int(args.sustained_s * 1.05 / (100 * per)) + 1)
+        if grouped and world > 1:      # every rank runs the same number of windows (their count decides how often barrier() is called)
+            nt = torch.tensor([n_win], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(nt, op=dist.ReduceOp.MAX)
+            n_win = int(nt.item())
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
         # socket power and shader clock while the windows run (rocm-smi from a thread, rank 0 only): the MFMA-dense kernels of this
         # forward run under the chip's power management (DESIGN.md lesson 56), so a roofline fraction is read against these
@@ -800,9 +807,16 @@ def main():
             wall = time.perf_counter() - t1
             # (the window count came from the warm-up's estimate; a host that other jobs load makes that estimate too slow and the run too
             # short: more windows until the requested duration is there -- one extra barrier, a few microseconds in two seconds)
-            if wall >= args.sustained_s or done >= 2000:
+            # The decision is COLLECTIVE: every rank branches on the SLOWEST rank's clock -- with each rank reading its own,
+            # a wall time near the threshold lets one rank leave while another calls barrier() again: mismatched collectives.
+            wall_all = wall
+            if grouped and world > 1:
+                wt = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+                dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+                wall_all = float(wt.item())
+            if wall_all >= args.sustained_s or done >= 2000:
                 break
-            plan_n = max(1, int((args.sustained_s - wall) / (wall / done)) + 1)
+            plan_n = max(1, int((args.sustained_s - wall_all) / (wall_all / done)) + 1)
         n_win = done
         win_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_win)]
         sustained = {"value": round(B * 100 * n_win / wall, 1), "unit": "faces/s (this rank)", "seconds": round(wall, 3), "steps": 100 * n_win,

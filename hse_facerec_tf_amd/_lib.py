@@ -24,6 +24,7 @@ SIGNATURES = {
     "hsefr_engine_set_graph_batch": (c_int, [c_void_p, c_int]),
     "hsefr_engine_graph_launches": (c_longlong, [c_void_p]),
     "hsefr_engine_create": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
+    "hsefr_plan_validate": (c_int, [c_void_p, c_size_t]),
     "hsefr_engine_workspace_bytes": (c_size_t, [c_void_p]),
     "hsefr_engine_max_batch": (c_int, [c_void_p]),
     "hsefr_engine_forward": (c_int, [c_void_p, _fp, c_int, _fp, _fp, _fp, c_void_p]),
@@ -48,15 +49,16 @@ SIGNATURES = {
     "hsefr_engine_forward_u8": (c_int, [c_void_p, _fp, c_int, _fp, _fp, _fp, c_void_p]),
     "hsefr_engine_input_overflow": (c_int, [c_void_p, POINTER(c_int), c_void_p]),
     "hsefr_engine_input_overflow_async": (c_int, [c_void_p, POINTER(c_int), c_void_p]),
-    "hsefr_stem_fused": (c_int, [_fp] * 6 + [c_void_p, _fp, _fp, _fp] + [c_int] * 9 + [c_void_p]),
     "hsefr_dwpw_f16split": (c_int, [_fp, _fp, _fp, _fp, c_void_p, _fp, _fp, _fp] + [c_int] * 12 + [c_void_p]),
     "hsefr_pwconv1x1_f16split": (c_int, [_fp, c_void_p, _fp, _fp, _fp, c_longlong, c_int, c_int, c_int, c_int, c_void_p]),
     "hsefr_dwpw_fused": (c_int, [_fp] * 7 + [c_int] * 10 + [c_void_p]),
     "hsefr_gap": (c_int, [_fp, _fp, c_int, c_int, c_int, c_void_p]),
     "hsefr_dense": (c_int, [_fp, _fp, _fp, _fp, c_int, c_int, c_int, c_int, c_void_p]),
     "hsefr_softmax": (c_int, [_fp, _fp, c_int, c_int, c_void_p]),
+    "hsefr_heads_fused": (c_int, [_fp] * 11 + [c_int] * 3 + [c_void_p]),
     "hsefr_conv_bf16": (c_int, [_fp, _fp, _fp, _fp, _fp, _fp] + [c_int] * 13 + [c_void_p]),
     "hsefr_conv1x1_proj_bf16": (c_int, [_fp] * 9 + [c_int] * 10 + [c_void_p]),
+    "hsefr_conv1x1_pair_bf16": (c_int, [_fp] * 14 + [c_longlong] + [c_int] * 6 + [c_void_p]),
     "hsefr_stem7x7_bf16": (c_int, [_fp, _fp, _fp, _fp, _fp] + [c_int] * 6 + [c_void_p]),
     "hsefr_stem7x7_pool_bf16": (c_int, [_fp, c_void_p, _fp, _fp, c_void_p] + [c_int] * 7 + [c_void_p]),
     "hsefr_maxpool3x3s2_bf16": (c_int, [_fp, _fp] + [c_int] * 8 + [c_void_p]),
@@ -78,14 +80,16 @@ SIGNATURES = {
     "hsefr_mtcnn_crops": (c_int, [_fp, _fp, _fp, c_int, c_int, c_int, c_int, c_void_p]),
     "hsefr_pairwise_dist": (c_int, [_fp, _fp, c_int, c_int, c_int, _fp, c_void_p]),
     "hsefr_nn1": (c_int, [_fp, _fp, c_int, c_int, c_int, _fp, _fp, c_void_p]),
+    "hsefr_nn1_fallbacks": (c_longlong, []),
 }
 
 # development builds only (csrc/hsefr_dev.h; build.sh with HSEFR_DEV=1): bound when the loaded library has them
 DEV_SIGNATURES = {
     "hsefr_debug_set": (c_int, [c_char_p, c_int]),
-    "hsefr_debug_read_stamps": (c_int, [c_void_p, ctypes.c_size_t]),
+    "hsefr_debug_read_stamps": (c_int, [c_int, c_void_p, ctypes.c_size_t]),
     "hsefr_debug_clock_probe": (c_int, [_fp, c_int, c_int, c_void_p]),
     "hsefr_debug_copy": (c_int, [_fp, _fp, c_size_t, c_void_p]),
+    "hsefr_stem_fused": (c_int, [_fp] * 6 + [c_void_p, _fp, _fp, _fp] + [c_int] * 9 + [c_void_p]),     # round 1's stem: dev builds only since round 6
 }
 
 

@@ -165,9 +165,12 @@ int launch_gap(const float* x, float* y, int n, int hw, int c, hipStream_t s);
 int launch_dense(const float* x, const float* wgt, const float* bias, float* y, int n, int k, int cout,
                  int act, hipStream_t s);
 int launch_softmax(const float* x, float* y, int n, int c, hipStream_t s);
+int launch_heads_fused(const float* x, const float* w1, const float* b1, const float* wa, const float* ba, const float* wg, const float* bg,
+                       float* hidden, float* logits, float* age_probs, float* gender, int n, int k, int a, hipStream_t s);
 int launch_l2_normalize(const float* x, float* y, int n, int d, hipStream_t s);
 int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2,
                hipStream_t s);
+long long nn1_fallbacks();
 
 int launch_conv_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
                      int n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t,
@@ -205,6 +208,12 @@ int launch_conv1x1_w4_proj_bf16(const void* x, const void* wt, const float* scal
                                 int h2, int w2, int act, hipStream_t s);
 int launch_conv1x1_w4_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
                            int w, int c, int oh, int ow, int cout, int stride, int act, hipStream_t s);
+bool conv1x1_pair_bf16_shape_supported(int c, int cout1, int cout2, int c2);
+bool conv1x1_pair_bf16_supported(long long pixels, int c, int cout1, int cout2, int c2);
+int launch_conv1x1_pair_bf16(const void* x, const void* w1, const float* scale1, const float* shift1, const void* res, const void* x2,
+                             const void* wp, const float* scale_p, const float* shift_p, void* y1, const void* w2, const float* scale2,
+                             const float* shift2, void* y2, long long pixels, int c, int cout1, int cout2, int c2, int act1, int act2,
+                             hipStream_t s);
 bool conv_dma_forced();
 bool conv_dma_bf16_supported(long long n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw);
 int launch_conv_dma_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
@@ -306,6 +315,7 @@ void set_w3_off(int v);
 void set_w2_off(int v);
 void set_w4_off(int v);
 void set_w4_bres(int v);
+void set_pair_off(int v);
 void set_nn1_y_mb(int v);
 int read_w4_stamps(void* host_out, size_t bytes);
 int read_w2_stamps(void* host_out, size_t bytes);

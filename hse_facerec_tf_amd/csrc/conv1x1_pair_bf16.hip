@@ -1,0 +1,325 @@
+// Two chained 1x1 bf16 convolutions in ONE launch (round 6): a bottleneck's "increase" layer (+ residual | + projected shortcut,
+// + ReLU) and the NEXT bottleneck's "reduce" layer (+ ReLU) of ResNet-50 (resnet50_ft, the graph behind vgg2_resnet.pb at
+// facerec_test.py:213).  NHWC bf16 in / out, fp32 accumulation, gfx950; rounding points of oracle/resnet50.py, the same as the two
+// launches this replaces:
+//
+//   Y1[p, n] = act1( bf16( s1[n] * sum_k X[p, k] * W1[n, k] + b1[n] ) + R[p, n] )                  (stored: the next block's shortcut)
+//   Y2[p, m] = act2( bf16( s2[m] * sum_n Y1[p, n] * W2[m, n] + b2[m] ) )                           (stored: the next 3x3's input)
+//   PROJ:  R[p, n] = bf16( sp[n] * sum_k X2[p, k] * WP[n, k] + bp[n] )      (the block input's projection, never stored)
+//
+// Why: in the 56-pixel stage both layers run at HBM speed (profiles/r05_resnet50_layers.txt: 5.3-5.5 TB/s), and the reduce layer's only
+// HBM read is the tensor the increase layer has just written -- 205 MB per pair at batch 128, 40 % of what the pair moves.  Here a
+// wave keeps its pixels' Y1 in registers:
+//   * weights first in v_mfma_f32_16x16x32_bf16 with permuted weight rows (conv1x1_w4_bf16.hip): a lane leaves a pair of 16-channel
+//     blocks with EIGHT CONSECUTIVE channels of one pixel -- which is (a) a 16-byte store of Y1 and (b), rounded to bf16, exactly the
+//     B operand of the second product's 32-channel K chunk (lane (pixel l16, k group lq) holds k = 8 lq .. 8 lq + 7): the chain needs no
+//     LDS transpose, no shuffle, and W2 keeps its natural K order;
+//   * the walk is CHUNKED over Y1's channels: 32 channels at a time -- first product (K1 / 32 x 2 MFMAs per pixel block), epilogue,
+//     store, then that chunk's contribution to every channel of Y2 -- so only 2 x PB accumulator blocks of Y1 exist at any time;
+//   * all three weight matrices are RESIDENT in LDS (32 KB each at 64 -> 256 -> 64), loaded once per workgroup; the waves share nothing
+//     else: no barrier after the prologue, every wave streams its own 16 PB pixels (residual chunks requested two chunks ahead);
+//   * every vector-memory operation is a compiler-visible builtin (loads AND stores), so hipcc's own in-order vmcnt arithmetic is exact.
+// Every output element is accumulated over K in one fixed order by one wave: bit-identical run to run, independent of the grid; and K
+// is walked in the order the separate kernels walk it.
+#include "common.h"
+
+namespace hsefr {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bfround(float f) { return __uint_as_float(hsefr_bf16_bits(f) << 16); }
+
+struct PairParams {
+    const void* x;        // [M][K1] bf16
+    const void* w1;       // [N1][K1] bf16
+    const float* scale1;
+    const float* shift1;
+    const void* res;      // [M][N1] bf16 (null with PROJ)
+    const void* x2;       // PROJ: [M][K2] bf16, the block input at the same pixels
+    const void* wp;       // PROJ: [N1][K2] bf16
+    const float* scale_p;
+    const float* shift_p;
+    void* y1;             // [M][N1] bf16
+    const void* w2;       // [N2][N1] bf16
+    const float* scale2;
+    const float* shift2;
+    void* y2;             // [M][N2] bf16
+    unsigned M;
+    unsigned ntiles;      // ceil(M / (16 PB))
+    int reverse;
+    float act1_lo, act1_hi, act2_lo, act2_hi;
+};
+
+// LDS row R of a weight image <-> output channel (conv1x1_w4_bf16.hip's permutation, per 32 channels): rows 16 b + i of a pair of
+// 16-row blocks hold channel 8 (i >> 2) + 4 b + (i & 3), so that accumulator element e of block b in lane (l16, lq) is channel
+// 8 lq + 4 b + e
+__device__ __forceinline__ int perm_channel(int R) {
+    const int i = R & 15, b = (R >> 4) & 1;
+    return (R & ~31) + 8 * (i >> 2) + 4 * b + (i & 3);
+}
+
+template <int K1, int K2, int N1, int N2, int PB, int WAVES, bool PROJ>
+__global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParams p) {
+    static_assert(K1 % 64 == 0 && K2 % 64 == 0 && N1 % 64 == 0 && N2 % 32 == 0, "whole 64-channel K steps");
+    constexpr int NT = WAVES * 64;
+    constexpr int W1_OFF = 0, W1_BYTES = N1 * K1 * 2;
+    constexpr int WP_OFF = W1_OFF + W1_BYTES, WP_BYTES = PROJ ? N1 * K2 * 2 : 0;
+    constexpr int W2_OFF = WP_OFF + WP_BYTES, W2_BYTES = N2 * N1 * 2;
+    constexpr int C_OFF = W2_OFF + W2_BYTES;            // constants: scale1 | shift1 | (scale_p | shift_p) | scale2 | shift2
+    constexpr int C_BYTES = (2 * N1 + (PROJ ? 2 * N1 : 0) + 2 * N2) * 4;
+    static_assert(C_OFF + C_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[C_OFF + C_BYTES];
+    constexpr int H1 = K1 / 32, HP = K2 / 32, CH = N1 / 32, MB2 = N2 / 16;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lq = lane >> 4;
+
+    // ---- prologue: the weight images and the constants, once per workgroup ----
+    auto fill = [&](int off, const void* w, int rows, int k) __attribute__((always_inline)) {
+        const int cpr = k / 8;                                     // 16-byte chunks per weight row
+        for (int idx = tid; idx < rows * cpr; idx += NT) {
+            const int R = idx / cpr, cc = idx - R * cpr;
+            const int s = cc >> 3, c = cc & 7;
+            const uint4 v = *(const uint4*)((const char*)w + ((size_t)perm_channel(R) * k + cc * 8) * 2);
+            *(uint4*)(smem + off + s * rows * 128 + R * 128 + 16 * (c ^ (R & 6))) = v;
+        }
+    };
+    fill(W1_OFF, p.w1, N1, K1);
+    if (PROJ) fill(WP_OFF, p.wp, N1, K2);
+    fill(W2_OFF, p.w2, N2, N1);
+    {
+        float* cst = (float*)(smem + C_OFF);
+        for (int i = tid; i < N1; i += NT) {
+            cst[i] = p.scale1[i];
+            cst[N1 + i] = p.shift1[i];
+            if (PROJ) {
+                cst[2 * N1 + i] = p.scale_p[i];
+                cst[3 * N1 + i] = p.shift_p[i];
+            }
+        }
+        for (int i = tid; i < N2; i += NT) {
+            cst[(PROJ ? 4 : 2) * N1 + i] = p.scale2[i];
+            cst[(PROJ ? 4 : 2) * N1 + N2 + i] = p.shift2[i];
+        }
+    }
+    __syncthreads();
+    const float* cst = (const float*)(smem + C_OFF);
+    constexpr int C_SP = 2 * N1, C_S2 = (PROJ ? 4 : 2) * N1;
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long long)p.M * K1 * 2);
+    const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(PROJ ? p.x2 : nullptr, PROJ ? (long long)p.M * K2 * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(PROJ ? nullptr : p.res, PROJ ? 0 : (long long)p.M * N1 * 2);
+    const __amdgpu_buffer_rsrc_t ry1 = make_rsrc(p.y1, (long long)p.M * N1 * 2);
+    const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(p.y2, (long long)p.M * N2 * 2);
+
+    // fragment address of a weight image: row (16 blk + l16), K half hh (32 channels), swizzled like the four-wave GEMM's stages
+    const unsigned fr0 = (unsigned)(l16 * 128 + 16 * (lq ^ (l16 & 6)));
+    auto wfrag = [&](int off, int rows, int blk, int hh) __attribute__((always_inline)) -> bf16x8 {
+        return *(const bf16x8*)(smem + off + (hh >> 1) * rows * 128 + blk * 16 * 128 + (fr0 ^ ((hh & 1) ? 64u : 0u)));
+    };
+
+    const unsigned gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
+    for (unsigned t = gw; t < p.ntiles; t += nw) {
+        const unsigned tt = p.reverse ? p.ntiles - 1u - t : t;
+        const unsigned pix0 = tt * (16u * PB) + (unsigned)l16;             // the lane's pixel in pixel block 0
+        // ---- the tile's activations, in B-operand layout straight from memory (rows past M: zeros) ----
+        bf16x8 xf[PB][H1];
+        bf16x8 x2f[PROJ ? PB : 1][PROJ ? HP : 1];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+#pragma unroll
+            for (int hh = 0; hh < H1; ++hh)
+                xf[pb][hh] = __builtin_bit_cast(bf16x8, bload16(rx, (pix0 + 16u * pb) * (K1 * 2u) + (unsigned)(64 * hh + 16 * lq), 0));
+            if (PROJ) {
+#pragma unroll
+                for (int hh = 0; hh < HP; ++hh)
+                    x2f[PROJ ? pb : 0][PROJ ? hh : 0] =
+                        __builtin_bit_cast(bf16x8, bload16(rx2, (pix0 + 16u * pb) * (K2 * 2u) + (unsigned)(64 * hh + 16 * lq), 0));
+            }
+        }
+        const unsigned y1lane = pix0 * (N1 * 2u) + (unsigned)(16 * lq);      // + 16 pb rows, + 64 j bytes
+        f32x4 rr[3][PB];                                                    // residual chunks: a ring, two chunks ahead
+        auto load_res = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) rr[j % 3][pb] = bload16(rres, y1lane + (unsigned)(16 * pb * N1 * 2 + 64 * j), 0);
+        };
+        if (!PROJ) {
+            load_res(0);
+            if (CH > 1) load_res(1);
+        }
+        f32x4 acc2[MB2][PB];
+#pragma unroll
+        for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) acc2[mb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (!PROJ && j + 2 < CH) load_res(j + 2);
+            f32x4 acc[2][PB];
+            if (PROJ) {
+                // the projected shortcut of these 32 channels: scaled, shifted, rounded to bf16 where its tensor used to be stored
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) acc[b][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int hh = 0; hh < HP; ++hh)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const bf16x8 a = wfrag(WP_OFF, N1, 2 * j + b, hh);
+#pragma unroll
+                        for (int pb = 0; pb < PB; ++pb)
+                            acc[b][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, x2f[PROJ ? pb : 0][PROJ ? hh : 0], acc[b][pb], 0, 0, 0);
+                    }
+                f32x4 sc[2], sh[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    sc[b] = *(const f32x4*)(cst + C_SP + 32 * j + 8 * lq + 4 * b);
+                    sh[b] = *(const f32x4*)(cst + C_SP + N1 + 32 * j + 8 * lq + 4 * b);
+                }
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) {
+                    float v[8];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * b + e] = fmaf(acc[b][pb][e], sc[b][e], sh[b][e]);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) rr[0][pb][d] = __uint_as_float(hsefr_pack_bf16x2(v[2 * d], v[2 * d + 1]));
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc[b][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hh = 0; hh < H1; ++hh)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const bf16x8 a = wfrag(W1_OFF, N1, 2 * j + b, hh);
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) acc[b][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xf[pb][hh], acc[b][pb], 0, 0, 0);
+                }
+            // ---- epilogue of the chunk: Y1's 32 channels, stored AND kept (rounded) as the second product's B operand ----
+            f32x4 sc[2], sh[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                sc[b] = *(const f32x4*)(cst + 32 * j + 8 * lq + 4 * b);
+                sh[b] = *(const f32x4*)(cst + N1 + 32 * j + 8 * lq + 4 * b);
+            }
+            bf16x8 yf[PB];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                float v[8];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * b + e] = fmaf(acc[b][pb][e], sc[b][e], sh[b][e]);
+                const f32x4 r = rr[PROJ ? 0 : j % 3][pb];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned rw = __float_as_uint(r[d]);
+                    v[2 * d] = bfround(v[2 * d]) + __uint_as_float(rw << 16);
+                    v[2 * d + 1] = bfround(v[2 * d + 1]) + __uint_as_float(rw & 0xFFFF0000u);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float f0 = fminf(fmaxf(v[2 * d], p.act1_lo), p.act1_hi), f1 = fminf(fmaxf(v[2 * d + 1], p.act1_lo), p.act1_hi);
+                    o[d] = __uint_as_float(hsefr_pack_bf16x2(f0, f1));
+                }
+                bstore16(o, ry1, y1lane + (unsigned)(16 * pb * N1 * 2 + 64 * j), 0);
+                yf[pb] = __builtin_bit_cast(bf16x8, o);
+            }
+            // ---- the chunk's contribution to every channel of Y2 ----
+#pragma unroll
+            for (int mb = 0; mb < MB2; ++mb) {
+                const bf16x8 a = wfrag(W2_OFF, N2, mb, j);
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc2[mb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, yf[pb], acc2[mb][pb], 0, 0, 0);
+            }
+        }
+        // ---- Y2's epilogue ----
+        const unsigned y2lane = pix0 * (N2 * 2u) + (unsigned)(16 * lq);
+#pragma unroll
+        for (int m2 = 0; m2 < MB2 / 2; ++m2) {
+            f32x4 sc[2], sh[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                sc[b] = *(const f32x4*)(cst + C_S2 + 32 * m2 + 8 * lq + 4 * b);
+                sh[b] = *(const f32x4*)(cst + C_S2 + N2 + 32 * m2 + 8 * lq + 4 * b);
+            }
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                float v[8];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * b + e] = fmaf(acc2[2 * m2 + b][pb][e], sc[b][e], sh[b][e]);
+                f32x4 o;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float f0 = fminf(fmaxf(v[2 * d], p.act2_lo), p.act2_hi), f1 = fminf(fmaxf(v[2 * d + 1], p.act2_lo), p.act2_hi);
+                    o[d] = __uint_as_float(hsefr_pack_bf16x2(f0, f1));
+                }
+                bstore16(o, ry2, y2lane + (unsigned)(16 * pb * N2 * 2 + 64 * m2), 0);
+            }
+        }
+    }
+}
+
+HSEFR_KNOB(g_pair_off, 0);     // dev builds: 1 = the engine never pairs (A/B timing against the two launches)
+
+template <int K1, int K2, int N1, int N2, int PB, int WAVES, bool PROJ>
+int launch_pair(PairParams& p, hipStream_t s) {
+    p.ntiles = (p.M + 16u * PB - 1u) / (16u * PB);
+    const unsigned need = (p.ntiles + WAVES - 1) / WAVES;
+    const unsigned g = need < 256u ? need : 256u;
+    hipLaunchKernelGGL((conv1x1_pair_bf16_kernel<K1, K2, N1, N2, PB, WAVES, PROJ>), dim3(g), dim3(WAVES * 64), 0, s, p);
+    return launch_status("conv1x1_pair_bf16");
+}
+
+}  // namespace
+
+#ifdef HSEFR_DEV
+void set_pair_off(int v) { g_pair_off = v; }
+#endif
+
+// c -> cout1 (+ residual, or + the projection of x2 [.., c2]) -> cout2, all at the same pixels
+bool conv1x1_pair_bf16_shape_supported(int c, int cout1, int cout2, int c2) {
+    return c == 64 && cout1 == 256 && cout2 == 64 && (c2 == 0 || c2 == 64);
+}
+bool conv1x1_pair_bf16_supported(long long pixels, int c, int cout1, int cout2, int c2) {
+    if (g_pair_off == 1) return false;
+    return pixels > 0 && pixels * (long long)cout1 * 2 < (1ll << 31) && conv1x1_pair_bf16_shape_supported(c, cout1, cout2, c2);
+}
+
+int launch_conv1x1_pair_bf16(const void* x, const void* w1, const float* scale1, const float* shift1, const void* res, const void* x2,
+                             const void* wp, const float* scale_p, const float* shift_p, void* y1, const void* w2, const float* scale2,
+                             const float* shift2, void* y2, long long pixels, int c, int cout1, int cout2, int c2, int act1, int act2,
+                             hipStream_t s) {
+    HSEFR_REQUIRE(conv1x1_pair_bf16_supported(pixels, c, cout1, cout2, c2), HSEFR_ERR_UNSUPPORTED,
+                  "conv1x1_pair_bf16: %d -> %d -> %d (projection from %d) over %lld pixels not covered", c, cout1, cout2, c2, pixels);
+    HSEFR_REQUIRE((c2 > 0) != (res != nullptr), HSEFR_ERR_INVALID, "conv1x1_pair_bf16: exactly one of residual / projected shortcut");
+    for (int a : {act1, act2})
+        HSEFR_REQUIRE(a == HSEFR_ACT_NONE || a == HSEFR_ACT_RELU || a == HSEFR_ACT_RELU6, HSEFR_ERR_UNSUPPORTED, "conv1x1_pair_bf16: act %d", a);
+    PairParams p;
+    p.x = x; p.w1 = w1; p.scale1 = scale1; p.shift1 = shift1; p.res = res; p.x2 = x2; p.wp = wp; p.scale_p = scale_p; p.shift_p = shift_p;
+    p.y1 = y1; p.w2 = w2; p.scale2 = scale2; p.shift2 = shift2; p.y2 = y2;
+    p.M = (unsigned)pixels;
+    p.reverse = sweep_reverse();
+    p.act1_lo = act1 == HSEFR_ACT_NONE ? -INFINITY : 0.f;
+    p.act1_hi = act1 == HSEFR_ACT_RELU6 ? 6.f : INFINITY;
+    p.act2_lo = act2 == HSEFR_ACT_NONE ? -INFINITY : 0.f;
+    p.act2_hi = act2 == HSEFR_ACT_RELU6 ? 6.f : INFINITY;
+    if (c2 > 0) return launch_pair<64, 64, 256, 64, 4, 8, true>(p, s);
+    return launch_pair<64, 64, 256, 64, 4, 8, false>(p, s);
+}
+
+}  // namespace hsefr

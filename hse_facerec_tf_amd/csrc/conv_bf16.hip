@@ -458,11 +458,13 @@ int launch_conv_bf16(const void* x, const void* wt, const float* scale, const fl
     if (kh == 3 && kw == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && oh == h && ow == w && conv3x3_w2_bf16_supported(n, h, w, c, cout) &&
         (conv3x3_w2_bf16_preferred(h, w, cout) || conv3x3_w2_forced()))
         return launch_conv3x3_w2_bf16(x, wt, scale, shift, res, y, n, h, w, c, cout, act, s);
-    // 3x3 / stride 1 / pad 1 with the input window resident in LDS (conv3x3_win_bf16.hip): wide maps, W >= 40 (56x56x64 at batch 128:
-    // 54 us against 80 register-staged and 84 im2col-by-DMA); on the smaller maps it ties with conv_dma_bf16.hip, which stays there
-    if (kh == 3 && kw == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && oh == h && ow == w && (w >= 40 || conv3x3_win_forced()) &&
+#ifdef HSEFR_DEV
+    // development builds, only when forced ("w3_off" = 2): the first window 3x3 kernel (conv3x3_win_bf16.hip, round 2) -- conv3x3_w2_bf16.hip
+    // took every 3x3 layer of ResNet-50 in round 5; maps wider than 64 pixels run on the kernels below in the product
+    if (kh == 3 && kw == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && oh == h && ow == w && conv3x3_win_forced() &&
         conv3x3_win_bf16_supported(n, h, w, c, cout))
         return launch_conv3x3_win_bf16(x, wt, scale, shift, res, y, n, h, w, c, cout, act, s);
+#endif
     // the LDS-DMA implicit GEMM (conv_dma_bf16.hip) where it measured faster at ResNet-50's shapes (tools/kbench_conv.py, batch 128):
     // the K-deep layers -- 3x3 convolutions up to ~150k output pixels (45 vs 63 us on the 14x14x256 layers), the stride-2
     // 1x1 layers from 256+ channels (a strided gather costs the DMA nothing: 57 vs 84 us on 56x56x256 -> 28x28x512), the 1x1 reductions from 1024+ channels.  The other 1x1 layers and the 64-channel stage stay

@@ -207,11 +207,16 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                               HSEFR_ERR_UNSUPPORTED, "plan op %u: fused stem+dw2 cin=%d cout=%d stride=%d not covered", i, o.cin, o.cout, o.stride);
                 break;
             case HSEFR_OP_STEM_F16S:
+#ifndef HSEFR_DEV
+                set_error("plan op %u: HSEFR_OP_STEM_F16S (round 1's fused stem) runs on development builds of the library only", i);
+                return HSEFR_ERR_UNSUPPORTED;
+#else
                 HSEFR_REQUIRE(stem_fused_supported(o.cin, 32, o.cout, o.stride, 1, o.kh, o.kw) && o.reserved > 0 && o.reserved <= 12 &&
                                   o.w_off != HSEFR_NO_OFFSET && o.w2_off != HSEFR_NO_OFFSET && o.shift2_off != HSEFR_NO_OFFSET &&
                                   o.w_off + 1248 * 4 <= h.blob_bytes && o.in_buf == HSEFR_BUF_INPUT,
                               HSEFR_ERR_UNSUPPORTED, "plan op %u: fused stem cin=%d cout=%d stride=%d not covered", i, o.cin, o.cout, o.stride);
                 break;
+#endif
             case HSEFR_OP_DWPW_F16S:
                 if (!need(o.w_off, 9 * ci * 4, "depthwise kernel") || !need(o.scale_off, ci * 4, "scale") || !need(o.shift_off, ci * 4, "shift") ||
                     !need(o.w2_off, ci * co * 4, "split rows") || !need(o.shift2_off, 2 * co * 4, "descale | shift"))
@@ -232,6 +237,44 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
             default:
                 set_error("plan op %u: unknown kind %u", i, o.kind);
                 return HSEFR_ERR_UNSUPPORTED;
+        }
+    }
+    // launch-level fusions (hsefr_op_flags): the pattern behind a flagged op must be exactly the one its fused launch computes
+    for (uint32_t i = 0; i < h.n_ops; ++i) {
+        const hsefr_plan_op& o = ops[i];
+        HSEFR_REQUIRE((o.flags & ~(HSEFR_OPF_PAIR_NEXT | HSEFR_OPF_HEADS)) == 0, HSEFR_ERR_INVALID, "plan op %u: unknown flags 0x%x", i, o.flags);
+        if (o.flags & HSEFR_OPF_PAIR_NEXT) {
+            HSEFR_REQUIRE(i + 1 < h.n_ops, HSEFR_ERR_INVALID, "plan op %u: PAIR_NEXT on the last op", i);
+            const hsefr_plan_op& b = ops[i + 1];
+            const bool proj = o.w2_off != HSEFR_NO_OFFSET;
+            const int c2 = proj ? (o.reserved & 0xFFF) : 0, st2 = (o.reserved >> 12) & 3, h2 = (o.reserved >> 14) & 0x1FF, w2 = (o.reserved >> 23) & 0x1FF;
+            HSEFR_REQUIRE(o.kind == HSEFR_OP_CONV_BF16 && b.kind == HSEFR_OP_CONV_BF16 && o.kh == 1 && o.kw == 1 && o.stride == 1 && o.pad_t == 0 &&
+                              o.pad_l == 0 && o.oh == o.h && o.ow == o.w && b.kh == 1 && b.kw == 1 && b.stride == 1 && b.pad_t == 0 && b.pad_l == 0 &&
+                              b.h == o.oh && b.w == o.ow && b.oh == b.h && b.ow == b.w && b.cin == o.cout && b.in_buf == o.out_buf &&
+                              b.res_buf == HSEFR_BUF_NONE && b.w2_off == HSEFR_NO_OFFSET && b.flags == 0 && o.res_buf >= 0 &&
+                              (!proj || (st2 == 1 && h2 == o.oh && w2 == o.ow)),
+                          HSEFR_ERR_INVALID, "plan op %u: PAIR_NEXT needs two 1x1 stride-1 bf16 convolutions at the same pixels, the first with a residual "
+                          "or a same-pixel projected shortcut, the second reading the first", i);
+            HSEFR_REQUIRE(b.out_buf != o.in_buf && b.out_buf != o.res_buf && b.out_buf != o.out_buf, HSEFR_ERR_INVALID,
+                          "plan op %u: PAIR_NEXT: the second output (buffer %d) aliases an operand of the first", i, b.out_buf);
+            HSEFR_REQUIRE(conv1x1_pair_bf16_shape_supported(o.cin, o.cout, b.cout, c2), HSEFR_ERR_UNSUPPORTED,
+                          "plan op %u: PAIR_NEXT %d -> %d -> %d (projection from %d) not covered", i, o.cin, o.cout, b.cout, c2);
+        }
+        if (o.flags & HSEFR_OPF_HEADS) {
+            HSEFR_REQUIRE(i + 3 < h.n_ops, HSEFR_ERR_INVALID, "plan op %u: HEADS needs three ops behind it", i);
+            const hsefr_plan_op &a = ops[i + 1], &sm = ops[i + 2], &g = ops[i + 3];
+            HSEFR_REQUIRE(o.kind == HSEFR_OP_DENSE && o.act == HSEFR_ACT_RELU && o.cout == 256 && o.cin % 64 == 0 && o.cin <= 2048 &&
+                              o.shift_off != HSEFR_NO_OFFSET && a.kind == HSEFR_OP_DENSE && a.act == HSEFR_ACT_NONE && a.cin == 256 && a.cout >= 1 &&
+                              a.cout <= 128 && a.in_buf == o.out_buf && a.shift_off != HSEFR_NO_OFFSET && sm.kind == HSEFR_OP_SOFTMAX &&
+                              sm.in_buf == a.out_buf && sm.cout == a.cout && g.kind == HSEFR_OP_DENSE && g.act == HSEFR_ACT_SIGMOID && g.cin == 256 &&
+                              g.cout == 1 && g.in_buf == o.out_buf && g.shift_off != HSEFR_NO_OFFSET && a.flags == 0 && sm.flags == 0 && g.flags == 0,
+                          HSEFR_ERR_INVALID, "plan op %u: HEADS needs DENSE k -> 256 + ReLU, DENSE 256 -> a (<= 128) + bias, SOFTMAX, DENSE 256 -> 1 + sigmoid", i);
+            const int outs[4] = {o.out_buf, a.out_buf, sm.out_buf, g.out_buf};
+            for (int x = 0; x < 4; ++x) {
+                HSEFR_REQUIRE(outs[x] != o.in_buf, HSEFR_ERR_INVALID, "plan op %u: HEADS: an output aliases the pooled features", i);
+                for (int y = x + 1; y < 4; ++y)
+                    HSEFR_REQUIRE(outs[x] != outs[y], HSEFR_ERR_INVALID, "plan op %u: HEADS: two of the four tensors share buffer %d", i, outs[x]);
+            }
         }
     }
     for (int s = 0; s < HSEFR_N_OUTPUT_SLOTS; ++s) {
@@ -279,6 +322,7 @@ void set_sweep_reverse(int v) { g_sweep_reverse = v; }
 }  // namespace hsefr
 HSEFR_KNOB(g_sweep_alternate, 1);   // dev builds: 0 turns the alternation off (A/B timing)
 HSEFR_KNOB(g_stem5, 1);             // dev builds: 0 = stem4_fused.hip (round 3's patch kernel) where stem5_stream.hip covers the shape (A/B timing)
+HSEFR_KNOB(g_heads_off, 0);         // dev builds: 1 = the four head launches also where a DENSE op carries HSEFR_OPF_HEADS (A/B timing)
 HSEFR_KNOB(g_stem4, 1);             // dev builds: 0 = stem3_fused.hip also where stem4_fused.hip covers the shape (A/B timing)
 
 #pragma GCC visibility push(default)   // the library is built with -fvisibility=hidden: the C ABI below is ALL it exports
@@ -311,6 +355,8 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "stem5")) { g_stem5 = value; return HSEFR_OK; }
     if (!strcmp(key, "stem5_grid")) { set_stem5_grid(value); return HSEFR_OK; }
     if (!strcmp(key, "stem5_segs")) { set_stem5_segs(value); return HSEFR_OK; }
+    if (!strcmp(key, "pair_off")) { set_pair_off(value); return HSEFR_OK; }
+    if (!strcmp(key, "heads_off")) { g_heads_off = value; return HSEFR_OK; }
     if (!strcmp(key, "dw_look")) { set_dw_look(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_look2")) { set_dw_look2(value); return HSEFR_OK; }
     if (!strcmp(key, "sweep_alternate")) { g_sweep_alternate = value; return HSEFR_OK; }
@@ -332,15 +378,18 @@ int hsefr_debug_copy(const void* d_src, void* d_dst, size_t bytes, hsefr_stream_
     return launch_copy(d_src, d_dst, bytes, (hipStream_t)stream);
 }
 
-int hsefr_debug_read_stamps(void* host_out, size_t bytes) {
-    // the split-f16 GEMM's stamps, (bytes == 512*4*10*8) the fused stem's, or (bytes == 256*12*8*8) the pre-split GEMM's
-    if (bytes == 256 * 12 * 8 * 8) return read_ps_stamps(host_out, bytes);
-    if (bytes == 256 * 12 * 8 * 8 - 8) return read_cd_stamps(host_out, bytes);
-    if (bytes == 512 * 4 * 8 * 8 - 16) return read_c11_stamps(host_out, bytes);       // (two words short: the register-staged 1x1 GEMM's)
-    if (bytes == 256 * 8 * 8 * 8 - 8) return read_w4_stamps(host_out, bytes);         // (one word short: the four-wave 1x1 GEMM's)
-    if (bytes == 256 * 8 * 8 * 8) return read_w2_stamps(host_out, bytes);             // (eight waves per workgroup: the second window 3x3 convolution's)
-    if (bytes == 256 * 12 * 8 * 8 - 16) return read_w3_stamps(host_out, bytes);     // (two words short: the window 3x3 convolution's)      // (one word short: the bf16 DMA convolution's)
-    return bytes == 512 * 4 * 10 * 8 ? read_stem_stamps(host_out, bytes) : read_pws_stamps(host_out, bytes);
+int hsefr_debug_read_stamps(int kernel, void* host_out, size_t bytes) {
+    switch (kernel) {
+        case HSEFR_STAMPS_PWS: return read_pws_stamps(host_out, bytes);
+        case HSEFR_STAMPS_STEM: return read_stem_stamps(host_out, bytes);
+        case HSEFR_STAMPS_PS: return read_ps_stamps(host_out, bytes);
+        case HSEFR_STAMPS_CD: return read_cd_stamps(host_out, bytes);
+        case HSEFR_STAMPS_C11: return read_c11_stamps(host_out, bytes);
+        case HSEFR_STAMPS_W4: return read_w4_stamps(host_out, bytes);
+        case HSEFR_STAMPS_W2: return read_w2_stamps(host_out, bytes);
+        case HSEFR_STAMPS_W3: return read_w3_stamps(host_out, bytes);
+        default: set_error("debug_read_stamps: unknown kernel id %d", kernel); return HSEFR_ERR_INVALID;
+    }
 }
 
 int hsefr_debug_clock_probe(unsigned long long* d_out, int blocks, int iters, hsefr_stream_t stream) {
@@ -348,31 +397,52 @@ int hsefr_debug_clock_probe(unsigned long long* d_out, int blocks, int iters, hs
 }
 #endif  // HSEFR_DEV
 
+// size and structure of a plan blob, then validate_plan: everything hsefr_engine_create checks before it touches the device
+static int check_plan_blob(const void* plan, size_t plan_bytes, hsefr_plan_header& h, std::vector<hsefr_plan_buffer>& bufs,
+                           std::vector<hsefr_plan_op>& ops, const char*& blob) {
+    HSEFR_REQUIRE(plan, HSEFR_ERR_INVALID, "plan: null pointer");
+    HSEFR_REQUIRE(plan_bytes >= sizeof(hsefr_plan_header), HSEFR_ERR_INVALID, "engine_create: plan too short");
+    memcpy(&h, plan, sizeof(h));
+    HSEFR_REQUIRE(h.magic == HSEFR_PLAN_MAGIC && h.version == 2, HSEFR_ERR_INVALID, "engine_create: bad plan magic/version");
+    // (64-bit sums of 32-bit counts: no overflow; a blob_bytes field near 2^64 cannot equal plan_bytes minus the tables)
+    const unsigned long long tables = sizeof(h) + (unsigned long long)h.n_buffers * sizeof(hsefr_plan_buffer) +
+                                      (unsigned long long)h.n_ops * sizeof(hsefr_plan_op);
+    HSEFR_REQUIRE(tables <= plan_bytes && h.blob_bytes == plan_bytes - tables, HSEFR_ERR_INVALID,
+                  "engine_create: plan is %zu bytes, header implies %llu + %llu", plan_bytes, tables, (unsigned long long)h.blob_bytes);
+    HSEFR_REQUIRE(h.n_buffers > 0 && h.n_ops > 0, HSEFR_ERR_INVALID, "engine_create: plan without %s", h.n_ops ? "buffers" : "ops");
+    const char* p = (const char*)plan + sizeof(h);
+    try {
+        bufs.resize(h.n_buffers);
+        ops.resize(h.n_ops);
+    } catch (const std::bad_alloc&) {
+        set_error("engine_create: out of host memory for %u buffers / %u ops", h.n_buffers, h.n_ops);
+        return HSEFR_ERR_NOMEM;
+    }
+    memcpy(bufs.data(), p, h.n_buffers * sizeof(hsefr_plan_buffer));
+    p += h.n_buffers * sizeof(hsefr_plan_buffer);
+    memcpy(ops.data(), p, h.n_ops * sizeof(hsefr_plan_op));
+    blob = p + h.n_ops * sizeof(hsefr_plan_op);
+    return validate_plan(h, bufs.data(), ops.data());
+}
+
+int hsefr_plan_validate(const void* plan, size_t plan_bytes) {
+    hsefr_plan_header h;
+    std::vector<hsefr_plan_buffer> bufs;
+    std::vector<hsefr_plan_op> ops;
+    const char* blob = nullptr;
+    return check_plan_blob(plan, plan_bytes, h, bufs, ops, blob);
+}
+
 int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsefr_engine** out) {
     HSEFR_REQUIRE(plan && out, HSEFR_ERR_INVALID, "engine_create: null argument");
     *out = nullptr;
     HSEFR_REQUIRE(max_batch > 0, HSEFR_ERR_INVALID, "engine_create: max_batch=%d", max_batch);
-    HSEFR_REQUIRE(plan_bytes >= sizeof(hsefr_plan_header), HSEFR_ERR_INVALID, "engine_create: plan too short");
-    hsefr_plan_header h;
-    memcpy(&h, plan, sizeof(h));
-    HSEFR_REQUIRE(h.magic == HSEFR_PLAN_MAGIC && h.version == 2, HSEFR_ERR_INVALID,
-                  "engine_create: bad plan magic/version");
-    const size_t need = sizeof(h) + (size_t)h.n_buffers * sizeof(hsefr_plan_buffer) +
-                        (size_t)h.n_ops * sizeof(hsefr_plan_op) + h.blob_bytes;
-    HSEFR_REQUIRE(plan_bytes == need, HSEFR_ERR_INVALID, "engine_create: plan is %zu bytes, header implies %zu",
-                  plan_bytes, need);
-    const char* p = (const char*)plan + sizeof(h);
     hsefr_engine* e = new (std::nothrow) hsefr_engine();
     HSEFR_REQUIRE(e, HSEFR_ERR_NOMEM, "engine_create: out of host memory");
-    e->hdr = h;
-    e->bufs.resize(h.n_buffers);
-    memcpy(e->bufs.data(), p, h.n_buffers * sizeof(hsefr_plan_buffer));
-    p += h.n_buffers * sizeof(hsefr_plan_buffer);
-    e->ops.resize(h.n_ops);
-    memcpy(e->ops.data(), p, h.n_ops * sizeof(hsefr_plan_op));
-    p += h.n_ops * sizeof(hsefr_plan_op);
-    int rc = validate_plan(h, e->bufs.data(), e->ops.data());
+    const char* p = nullptr;
+    int rc = check_plan_blob(plan, plan_bytes, e->hdr, e->bufs, e->ops, p);
     if (rc != HSEFR_OK) { delete e; return rc; }
+    const hsefr_plan_header& h = e->hdr;
     e->max_batch = max_batch;
 
     auto fail = [&](int code) { hsefr_engine_destroy(e); return code; };
@@ -463,7 +533,30 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
         const void* in = buf_ptr(tab, o.in_buf, d_input);
         void* out = buf_ptr(tab, o.out_buf, d_input);
         int rc = HSEFR_OK;
+        size_t covered = 0;       // ops behind this one that its launch computes as well (hsefr_op_flags)
         set_sweep_reverse(g_sweep_alternate ? (int)(i & 1) : 0);   // consecutive layers sweep in opposite directions (common.h)
+        if ((o.flags & HSEFR_OPF_PAIR_NEXT) && needed[i + 1] && conv1x1_pair_bf16_supported((long long)n * o.oh * o.ow, o.cin, o.cout, e->ops[i + 1].cout,
+                                                                                           o.w2_off != HSEFR_NO_OFFSET ? (o.reserved & 0xFFF) : 0)) {
+            // increase (+ residual | + projected shortcut) -> the next block's reduce in one launch (csrc/conv1x1_pair_bf16.hip; the pattern
+            // was checked by validate_plan): both tensors are written, the second product reads the first from registers
+            const hsefr_plan_op& b = e->ops[i + 1];
+            const bool proj = o.w2_off != HSEFR_NO_OFFSET;
+            const float* ssp = (const float*)blob_ptr(e, o.shift2_off);
+            rc = launch_conv1x1_pair_bf16(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
+                                          proj ? nullptr : tab[o.res_buf], proj ? tab[o.res_buf] : nullptr, proj ? blob_ptr(e, o.w2_off) : nullptr,
+                                          proj ? ssp : nullptr, proj ? ssp + o.cout : nullptr, out, blob_ptr(e, b.w_off),
+                                          (const float*)blob_ptr(e, b.scale_off), (const float*)blob_ptr(e, b.shift_off), tab[b.out_buf],
+                                          (long long)n * o.oh * o.ow, o.cin, o.cout, b.cout, proj ? (o.reserved & 0xFFF) : 0, o.act, b.act, s);
+            covered = 1;
+        } else if ((o.flags & HSEFR_OPF_HEADS) && !g_heads_off && needed[i + 1] && needed[i + 2] && needed[i + 3]) {
+            // the age / gender heads in one launch (csrc/pool_dense.hip): hidden, logits, probabilities and the gender sigmoid are all written
+            const hsefr_plan_op &a = e->ops[i + 1], &sm = e->ops[i + 2], &g = e->ops[i + 3];
+            rc = launch_heads_fused((const float*)in, (const float*)blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.shift_off),
+                                    (const float*)blob_ptr(e, a.w_off), (const float*)blob_ptr(e, a.shift_off), (const float*)blob_ptr(e, g.w_off),
+                                    (const float*)blob_ptr(e, g.shift_off), (float*)out, (float*)tab[a.out_buf], (float*)tab[sm.out_buf],
+                                    (float*)tab[g.out_buf], n, o.cin, a.cout, s);
+            covered = 3;
+        } else
         switch (o.kind) {
             case HSEFR_OP_CONV_C3:
                 rc = launch_conv_c3((const float*)in, (const float*)blob_ptr(e, o.w_off),
@@ -598,6 +691,7 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                         (o.kw >> 4) & 1, (o.kw >> 5) & 1, o.oh, o.ow, o.reserved, o.act, s);
                 break;
             }
+#ifdef HSEFR_DEV
             case HSEFR_OP_STEM_F16S: {
                 const float* pk = (const float*)blob_ptr(e, o.w_off);
                 const float* ds2 = (const float*)blob_ptr(e, o.shift2_off);
@@ -605,6 +699,7 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                        ds2 + o.cout, (float*)out, n, o.h, o.w, o.pad_t, o.pad_l, o.oh, o.ow, o.reserved, o.act, s);
                 break;
             }
+#endif
             case HSEFR_OP_DWPW_F16S: {
                 const float* ds2 = (const float*)blob_ptr(e, o.shift2_off);
                 rc = launch_dwpw_f16s((const float*)in, (const float*)blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
@@ -618,7 +713,9 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                 rc = HSEFR_ERR_UNSUPPORTED;
         }
         if (rc != HSEFR_OK) return rc;
-        if (prof) HSEFR_HIP_CHECK(hipEventRecord(pev[i + 1], s));
+        for (size_t k = 0; k <= covered; ++k)         // (the covered ops' own intervals are empty: their time is the flagged op's)
+            if (prof) HSEFR_HIP_CHECK(hipEventRecord(pev[i + 1 + k], s));
+        i += covered;
     }
     set_sweep_reverse(0);
     return HSEFR_OK;
@@ -878,6 +975,7 @@ int hsefr_stem5_stream(const void* x, int x_is_u8, const void* cw4, const float*
                                d_overflow, n, h, w, in_log2, a_log2, act, (hipStream_t)stream);
 }
 
+#ifdef HSEFR_DEV
 int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd, const float* dscale,
                      const float* dshift, const void* w_split, const float* descale, const float* pshift, float* y, int n,
                      int h, int w, int cpad_t, int cpad_l, int oh, int ow, int a_log2, int act, hsefr_stream_t stream) {
@@ -886,6 +984,7 @@ int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shif
     return launch_stem_fused(x, conv_w, conv_shift, wd, dscale, dshift, w_split, descale, pshift, y, n, h, w, cpad_t, cpad_l,
                              oh, ow, a_log2, act, (hipStream_t)stream);
 }
+#endif
 
 int hsefr_dwpw_f16split(const float* x, const float* wd, const float* dscale, const float* dshift, const void* w_split,
                         const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride,
@@ -915,6 +1014,13 @@ int hsefr_dense(const float* x, const float* wgt, const float* bias, float* y, i
     return launch_dense(x, wgt, bias, y, n, k, cout, act, (hipStream_t)stream);
 }
 
+int hsefr_heads_fused(const float* x, const float* w1, const float* b1, const float* wa, const float* ba, const float* wg, const float* bg,
+                      float* hidden, float* logits, float* age_probs, float* gender, int n, int k, int a, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && w1 && b1 && wa && ba && wg && bg && hidden && logits && age_probs && gender), HSEFR_ERR_INVALID,
+                  "heads_fused: null pointer");
+    return launch_heads_fused(x, w1, b1, wa, ba, wg, bg, hidden, logits, age_probs, gender, n, k, a, (hipStream_t)stream);
+}
+
 int hsefr_softmax(const float* x, float* y, int n, int c, hsefr_stream_t stream) {
     HSEFR_REQUIRE(n == 0 || (x && y), HSEFR_ERR_INVALID, "softmax: null pointer");
     return launch_softmax(x, y, n, c, (hipStream_t)stream);
@@ -934,6 +1040,18 @@ int hsefr_conv1x1_proj_bf16(const void* x, const void* wgt_t, const float* scale
     HSEFR_REQUIRE(n == 0 || (x && wgt_t && scale && shift && x2 && wgt2_t && scale2 && shift2 && y), HSEFR_ERR_INVALID, "conv1x1_proj_bf16: null pointer");
     return launch_conv1x1_proj_bf16(x, wgt_t, scale, shift, x2, wgt2_t, scale2, shift2, y, n, oh, ow, c, cout, c2, stride2, h2, w2, act,
                                     (hipStream_t)stream);
+}
+
+int hsefr_conv1x1_pair_bf16(const void* x, const void* w1_t, const float* scale1, const float* shift1, const void* res, const void* x2,
+                            const void* wp_t, const float* scale_p, const float* shift_p, void* y1, const void* w2_t, const float* scale2,
+                            const float* shift2, void* y2, long long pixels, int c, int cout1, int cout2, int c2, int act1, int act2,
+                            hsefr_stream_t stream) {
+    HSEFR_REQUIRE(pixels >= 0, HSEFR_ERR_INVALID, "conv1x1_pair_bf16: pixels=%lld", pixels);
+    if (pixels == 0) return HSEFR_OK;
+    HSEFR_REQUIRE(x && w1_t && scale1 && shift1 && y1 && w2_t && scale2 && shift2 && y2 && (c2 == 0 ? res != nullptr : (x2 && wp_t && scale_p && shift_p)),
+                  HSEFR_ERR_INVALID, "conv1x1_pair_bf16: null pointer");
+    return launch_conv1x1_pair_bf16(x, w1_t, scale1, shift1, c2 == 0 ? res : nullptr, x2, wp_t, scale_p, shift_p, y1, w2_t, scale2, shift2, y2, pixels,
+                                    c, cout1, cout2, c2, act1, act2, (hipStream_t)stream);
 }
 
 int hsefr_stem7x7_bf16(const float* x, const void* wgt_t, const float* scale, const float* shift, void* y, int n, int h,
@@ -989,6 +1107,8 @@ int hsefr_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_ind
     HSEFR_REQUIRE(nq == 0 || (q && g && nn_index), HSEFR_ERR_INVALID, "nn1: null pointer");
     return launch_nn1(q, g, nq, ng, d, nn_index, nn_dist2, (hipStream_t)stream);
 }
+
+long long hsefr_nn1_fallbacks(void) { return nn1_fallbacks(); }
 
 int hsefr_conv2d_direct(const float* x, const float* wgt, const float* bias, const float* alpha, float* y, int n, int h, int w, int c,
                         int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, hsefr_stream_t stream) {

@@ -10,6 +10,8 @@
 // round-robin, each keeps a per-lane running (min, index) for its 16 accumulator rows, and the
 // candidates meet once at the end (wavefront shuffles, then LDS across the 4 waves).  Row norms
 // are accumulated from the very fragments that feed the MFMAs.
+#include <atomic>
+
 #include "common.h"
 
 namespace hsefr {
@@ -283,6 +285,9 @@ HSEFR_KNOB(g_nn1_y_mb, 256);      // dev builds: bound of the distance-matrix sl
 void set_nn1_y_mb(int v) { g_nn1_y_mb = v > 0 ? v : 1; }
 #endif
 
+static std::atomic<long long> g_nn1_fallbacks{0};
+long long nn1_fallbacks() { return g_nn1_fallbacks.load(); }
+
 int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2, hipStream_t s) {
     HSEFR_REQUIRE(d > 0 && d % 8 == 0, HSEFR_ERR_UNSUPPORTED, "nn1: d=%d must be a multiple of 8", d);
     HSEFR_REQUIRE(nq >= 0 && ng > 0, HSEFR_ERR_INVALID, "nn1: nq=%d ng=%d", nq, ng);
@@ -294,11 +299,21 @@ int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_in
         // caller's allocator may hold the memory) the search runs on nn1_kernel, which needs no workspace.
         const int ng_pad = (ng + 63) / 64 * 64;
         const long long y_rows_max = NN1_Y_BYTES / ((long long)ng_pad * 4);
-        const int qb = (int)(y_rows_max >= nq ? nq : (y_rows_max < 256 ? 256 : y_rows_max / 256 * 256));     // query rows per block
-        const size_t b_qs = (size_t)nq * d * 4, b_w = (size_t)ng_pad * d * 4, b_y = (size_t)qb * ng_pad * 4;
+        int qb = (int)(y_rows_max >= nq ? nq : (y_rows_max < 256 ? 256 : y_rows_max / 256 * 256));     // query rows per block
+        const size_t b_qs = (size_t)nq * d * 4, b_w = (size_t)ng_pad * d * 4;
+        size_t b_y = (size_t)qb * ng_pad * 4;
         const size_t b_small = ((size_t)nq + 2 * (size_t)ng_pad + 64) * 4;
         char* ws = nullptr;
-        if (hipMallocAsync((void**)&ws, b_qs + b_w + b_y + b_small, s) == hipSuccess && ws) {
+        // a failed allocation is retried with HALF the query block, down to 256 rows (the slice of the distance matrix is
+        // the only part of the workspace that can shrink), before the search gives up on this path
+        while (hipMallocAsync((void**)&ws, b_qs + b_w + b_y + b_small, s) != hipSuccess || !ws) {
+            (void)hipGetLastError();
+            ws = nullptr;
+            if (qb <= 256) break;
+            qb = qb / 2 < 256 ? 256 : qb / 2 / 256 * 256;
+            b_y = (size_t)qb * ng_pad * 4;
+        }
+        if (ws) {
             float* qs = (float*)ws;
             unsigned short* w = (unsigned short*)(ws + b_qs);
             float* y = (float*)(ws + b_qs + b_w);
@@ -327,7 +342,12 @@ int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_in
             (void)hipFreeAsync(ws, s);
             return rc;
         }
-        (void)hipGetLastError();          // the failed allocation: not this call's result -- fall through to the workspace-free kernel
+        // no workspace even for a 256-row block: the search runs on nn1_kernel (no workspace; another summation order, far slower at
+        // these sizes).  Not an error -- but COUNTED and described, so a perf cliff or a last-bit difference can be traced to it
+        // (hsefr_nn1_fallbacks, hsefr_last_error_string)
+        g_nn1_fallbacks.fetch_add(1);
+        set_error("nn1: no stream-ordered workspace (%zu bytes) for the split-f16 search of %d x %d x %d; ran the workspace-free kernel",
+                  b_qs + b_w + b_y + b_small, nq, ng, d);
     }
     dim3 grid((nq + 31) / 32), block(256);
     hipLaunchKernelGGL(nn1_kernel, grid, block, 0, s, q, g, nq, ng, d, nn_index, nn_dist2);

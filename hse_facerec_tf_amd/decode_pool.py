@@ -87,6 +87,27 @@ def cpu_order() -> List[int]:
     return firsts + rest
 
 
+_RUNS_LOCK = threading.Lock()
+_LIVE_RUNS = set()                        # runs of cpu_order() held by the pinned pools alive in this process
+
+
+def pin_offset(workers: int) -> Optional[int]:
+    """First entry of cpu_order() for this process's pinned decoders, from what a launcher says about our place on the node:
+    HSEFR_DECODE_CPU_OFFSET (explicit) plus LOCAL_RANK (torchrun) or SLURM_LOCALID (srun) times the pool size.  None when the
+    environment says nothing -- the caller then does not pin by default."""
+    off, known = 0, False
+    for key, scale in (("HSEFR_DECODE_CPU_OFFSET", 1), ("LOCAL_RANK", workers), ("SLURM_LOCALID", workers)):
+        v = os.environ.get(key)
+        if v is None or (key == "SLURM_LOCALID" and "LOCAL_RANK" in os.environ):
+            continue
+        try:
+            off += max(0, int(v)) * scale
+            known = True
+        except ValueError:
+            pass
+    return off if known else None
+
+
 def _worker_main(shm_name: str, tasks, results, cpu: Optional[int] = None) -> None:
     """Runs in the worker process.  task = (task_id, [paths], byte offset, byte capacity) or None to stop.
     result = (task_id, [(offset, H, W) | None per image], spill, error): images that did not fit the region are returned
@@ -166,17 +187,28 @@ class DecodePool:
     """``slots`` staging slots of ``slot_bytes`` each in one shared block; a chunk of files is decoded into one slot by
     tasks of ``task_files`` files, each task owning a fixed sub-region (so workers never contend for space)."""
 
-    def __init__(self, workers: Optional[int] = None, slot_bytes: int = 64 << 20, slots: int = 3, task_files: int = 8, pin: bool = True):
-        """pin: every worker pins itself to one CPU of cpu_order() -- distinct physical cores first; under torchrun the ranks of a node
-        take consecutive runs of that list (LOCAL_RANK), so eight ranks' decoders do not sit on the same cores."""
+    def __init__(self, workers: Optional[int] = None, slot_bytes: int = 64 << 20, slots: int = 3, task_files: int = 8,
+                 pin: Optional[bool] = None):
+        """pin: every worker pins itself to one CPU of cpu_order() -- distinct physical cores first -- starting at the offset
+        pin_offset() derives from the launcher's environment: under torchrun / srun the ranks of a node take consecutive runs of that
+        list, so eight ranks' decoders do not sit on the same cores.  None (default): pin only when such an offset is KNOWN
+        (LOCAL_RANK, SLURM_LOCALID or HSEFR_DECODE_CPU_OFFSET is set) -- processes started by hand (eight jobs with
+        HIP_VISIBLE_DEVICES, say) would otherwise all pin to the same first cores, and the scheduler spreads them better than that
+        (ADVICE r5).  True: pin regardless (a single job that owns the host: bench.py).  Pools alive in ONE process take consecutive
+        runs of the list either way."""
         import multiprocessing as mp
         from multiprocessing import shared_memory
         self.workers = int(workers or default_workers())
+        first = pin_offset(self.workers)
+        if pin is None:
+            pin = first is not None
         cpus = cpu_order() if pin else []
-        try:
-            first = max(0, int(os.environ.get("LOCAL_RANK", "0"))) * self.workers + int(os.environ.get("HSEFR_DECODE_CPU_OFFSET", "0"))
-        except ValueError:
-            first = 0
+        self._run = None
+        if cpus:
+            with _RUNS_LOCK:                                   # the lowest run of `workers` CPUs no live pool of this process holds
+                self._run = next(r for r in range(len(_LIVE_RUNS) + 1) if r not in _LIVE_RUNS)
+                _LIVE_RUNS.add(self._run)
+            first = (first or 0) + self._run * self.workers
         self.cpus = [cpus[(first + k) % len(cpus)] for k in range(self.workers)] if cpus else [None] * self.workers
         self.slot_bytes, self.slots, self.task_files = int(slot_bytes), int(slots), int(task_files)
         self._ctx = mp.get_context("spawn")
@@ -296,6 +328,10 @@ class DecodePool:
             if p.is_alive():
                 p.terminate()
         self._procs = []
+        if self._run is not None:
+            with _RUNS_LOCK:
+                _LIVE_RUNS.discard(self._run)
+            self._run = None
         if self._tensor is not None and self._pinned:
             try:
                 import torch

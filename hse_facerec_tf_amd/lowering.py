@@ -47,7 +47,8 @@ NO_OFFSET = 0xFFFFFFFFFFFFFFFF
 
 _HEADER = struct.Struct("<QIIIIII3i3IQ")          # hsefr_plan_header
 _BUFFER = struct.Struct("<QII")                   # hsefr_plan_buffer
-_OP = struct.Struct("<II3i3i3i3i2ii4x5Q")        # hsefr_plan_op (112 bytes, 8-aligned tail)
+_OP = struct.Struct("<II3i3i3i3i2iii5Q")         # hsefr_plan_op (112 bytes; `flags` sits where the struct's padding was until round 6)
+OPF_PAIR_NEXT, OPF_HEADS = 1, 2                   # hsefr_op_flags
 
 
 class LoweringError(NotImplementedError):
@@ -191,6 +192,7 @@ class Layer:
                                                        # of layer `res`'s output; w2 = its packed kernel [cout][cin2], shift2 = [scale2 | shift2]
     out_split: int = 0                                 # DWCONV3X3: > 0 = output stored as split rows scaled by 2^out_split
     in_split: bool = False                             # PWCONV: the input buffer holds split rows (wire kind OP_PWCONV_PS)
+    flags: int = 0                                     # hsefr_op_flags: launch-level fusion with the op(s) BEHIND this one (mark_pairs, mark_heads)
     out_buf: int = BUF_NONE
 
     @property
@@ -243,6 +245,8 @@ class Plan:
                 assert 0 < c2 < 4096 and 1 <= s2 <= 3 and 0 < h2 < 512 and 0 < wd2 < 512 and tuple(L.w2.shape) == (L.out_shape[2], c2)
                 w2 = L.w2
                 aux = c2 | (s2 << 12) | (h2 << 14) | (wd2 << 23)
+                if aux >= 1 << 31:              # w2 >= 256 reaches bit 31 of the signed wire field; the C side masks after >> 23
+                    aux -= 1 << 32
             if L.kind in (OP_STEM2_F16S, OP_STEM3_F16S):
                 w = np.concatenate([L.w0.reshape(-1), L.shift0.reshape(-1), L.w.reshape(-1), L.scale.reshape(-1), L.shift.reshape(-1),
                                     L.w3.reshape(-1), L.scale3.reshape(-1), L.shift3.reshape(-1)]).astype(np.float32)
@@ -304,7 +308,7 @@ class Plan:
             h, wd, cin = L.in_shape
             oh, ow, cout = L.out_shape
             ops.append(_OP.pack(kind, L.act, in_buf, L.out_buf, res_buf, h, wd, cin, oh, ow, cout,
-                                L.kh, kw_field, L.stride, L.pad_t, L.pad_l, aux, put(w), put(scale),
+                                L.kh, kw_field, L.stride, L.pad_t, L.pad_l, aux, L.flags, put(w), put(scale),
                                 put(None if L.kind in (OP_STEM_F16S, OP_STEM2_F16S, OP_STEM3_F16S) else L.shift), put(w2), put(shift2)))
         while len(blob) % 16:
             blob.append(0)
@@ -765,6 +769,14 @@ def assign_buffers(layers: List[Layer], pinned) -> List[int]:
         for s in (L.src, L.res):
             if s >= 0:
                 last_use[s] = i
+    # a flagged op's launch also computes the ops behind it (hsefr_op_flags): whatever any of them reads or writes stays live
+    # until the last of them, so no output of the group aliases an operand of the group
+    for i, L in enumerate(layers):
+        span = 1 if L.flags & OPF_PAIR_NEXT else 3 if L.flags & OPF_HEADS else 0
+        for j in range(i, min(i + span, len(layers) - 1) + 1 if span else i):
+            for s in (layers[j].src, layers[j].res, j):
+                if s >= 0:
+                    last_use[s] = max(last_use[s], i + span)
     buffers: List[int] = []
     free: List[int] = []
     for i, L in enumerate(layers):
@@ -905,6 +917,49 @@ def fuse_proj(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Di
         if x.res >= 0:
             x.res = remap[x.res]
     return new_layers, remap
+
+
+def pair_fusable(A: Layer, B: Layer, a_index: int) -> bool:
+    """csrc/conv1x1_pair_bf16.hip (conv1x1_pair_bf16_shape_supported): a 1x1 stride-1 bf16 convolution 64 -> 256 with a residual or a
+    same-pixel projected shortcut from 64 channels, read by the 1x1 stride-1 convolution 256 -> 64 right behind it."""
+    def plain_1x1(L):
+        return (L.kind == OP_CONV_BF16 and L.kh == 1 and L.kw == 1 and L.stride == 1 and L.pad_t == 0 and L.pad_l == 0 and
+                tuple(L.in_shape[:2]) == tuple(L.out_shape[:2]) and L.flags == 0)
+    if not (plain_1x1(A) and plain_1x1(B) and B.src == a_index and B.res < 0 and B.proj is None and A.res >= 0):
+        return False
+    if A.proj is not None and not (A.proj[0] == 64 and A.proj[1] == 1 and tuple(A.proj[2:]) == tuple(A.out_shape[:2])):
+        return False
+    return A.in_shape[2] == 64 and A.out_shape[2] == 256 and B.out_shape[2] == 64 and A.act in (ACT_NONE, ACT_RELU, ACT_RELU6) and \
+        B.act in (ACT_NONE, ACT_RELU, ACT_RELU6)
+
+
+def mark_pairs(layers: List[Layer]) -> int:
+    """ResNet-50, 56-pixel stage: an 'increase' layer and the NEXT bottleneck's 'reduce' layer run as one launch (round 6): the
+    256-channel tensor is written once and never read back by the reduce layer (205 of the 512 MB the pair moves at batch 128).  Both
+    layers stay in the plan; the first carries OPF_PAIR_NEXT and the engine skips the second.  Call after fuse_proj, before
+    assign_buffers.  Returns the number of pairs."""
+    n = 0
+    for i in range(len(layers) - 1):
+        if layers[i].flags == 0 and pair_fusable(layers[i], layers[i + 1], i):
+            layers[i].flags |= OPF_PAIR_NEXT
+            n += 1
+    return n
+
+
+def mark_heads(layers: List[Layer]) -> int:
+    """The age / gender heads (facial_analysis.py:109): DENSE k -> 256 + ReLU, DENSE 256 -> a + bias, SOFTMAX, DENSE 256 -> 1 + sigmoid, in
+    this order and adjacent, run as ONE launch (csrc/pool_dense.hip heads_kernel, same bits as the four): the first carries OPF_HEADS."""
+    n = 0
+    for i in range(len(layers) - 3):
+        F, A, S, G = layers[i:i + 4]
+        if (F.kind == OP_DENSE and F.act == ACT_RELU and F.out_shape[2] == 256 and F.in_shape[2] % 64 == 0 and F.in_shape[2] <= 2048 and F.flags == 0 and
+                A.kind == OP_DENSE and A.act == ACT_NONE and A.src == i and 1 <= A.out_shape[2] <= 128 and
+                S.kind == OP_SOFTMAX and S.src == i + 1 and
+                G.kind == OP_DENSE and G.act == ACT_SIGMOID and G.src == i and G.out_shape[2] == 1 and
+                all(L.shift is not None and L.scale is None for L in (F, A, G))):
+            F.flags |= OPF_HEADS
+            n += 1
+    return n
 
 
 def fuse_stem(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Dict[int, int]]:
@@ -1173,7 +1228,7 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
                 feeds: Optional[Dict[str, object]] = None, fuse: bool = True, dtype: str = "f32",
                 pw_math: Optional[str] = None, fuse_stem_block: Optional[bool] = None, stem_fusion: Optional[str] = None,
                 block_fusion: Optional[str] = None, presplit: Optional[str] = None, input_bound: Optional[float] = None,
-                pwdw_fusion: Optional[str] = None, u8_mean_bgr: Optional[Sequence[float]] = None) -> Plan:
+                pwdw_fusion: Optional[str] = None, u8_mean_bgr: Optional[Sequence[float]] = None, launch_fusion: bool = True) -> Plan:
     """outputs: {slot: 'tensor:0'}.  feeds: constant feeds such as the Keras learning phase.
     fuse: merge depthwise -> pointwise pairs into one kernel where a fused kernel covers the shape.  stem_fusion:
     'stem2' (default) = conv1 + block 1 + the depthwise of block 2 in one
@@ -1196,6 +1251,8 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
     depthwise layer on a map of at most 288 pixels (whole maps per GEMM tile) runs that depthwise in its epilogue (fuse_pwdw):
     the pointwise tensor never reaches HBM and the depthwise launch disappears (the last pointwise layer takes the global
     average pool the same way: fuse_pwgap); 'none'.
+    launch_fusion (default True): groups of adjacent ops the engine runs as one launch (hsefr_op_flags: mark_pairs on bf16 plans, mark_heads
+    for the age / gender heads); False keeps one launch per op.
     dtype 'f32': the MobileNet kernels (exact fp32); 'bf16': ResNet-style graphs on the bf16-MFMA kernels
     (general KxK Conv2D, Pad, FusedBatchNorm / Mul+Add, residual Add, MaxPool 3x3/2, global AvgPool / Mean); 'f32g': the
     same ResNet-style graph patterns on exact-fp32 kernels (OP_CONV_F32 / OP_MAXPOOL_F32 / OP_GAP) -- the fp32-grade mode
@@ -1315,5 +1372,10 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
                 layers, remap = fuse_pwgap(layers, [li for li, _ in out_layers.values()])
                 out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
                 tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
+    if fuse and launch_fusion:        # launch-level fusions: the ops stay, the engine runs flagged groups as one launch (hsefr_op_flags)
+        if dtype == "bf16":
+            mark_pairs(layers)
+        if dtype == "f32":
+            mark_heads(layers)
     buffers = assign_buffers(layers, {li for li, _ in out_layers.values()})
     return Plan(layers, (input_hw[0], input_hw[1], low.in_c), buffers, out_layers, tensor_layer)

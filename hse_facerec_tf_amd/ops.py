@@ -232,6 +232,8 @@ def stem_fused(x, conv_w, conv_shift, w_hwc, dscale, dshift, wp_t, pshift, act: 
     """The MobileNet stem in one kernel (csrc/stem_fused.hip): conv 3x3/2 SAME 3->32 + shift + ReLU6 -> depthwise 3x3/1 +
     scale + shift + ReLU6 -> pointwise 32->64 + shift + act.  conv_w TF HWIO [3,3,3,32], w_hwc [3,3,32], wp_t [64,32]."""
     torch = _lib.require_gpu()
+    if not hasattr(_lib.lib(), "hsefr_stem_fused"):
+        raise NotImplementedError("round 1's fused stem is part of DEVELOPMENT builds of the library only (HSEFR_LIB=libhsefr_dev.so)")
     for t, nm in ((x, "x"), (conv_w, "conv_w"), (conv_shift, "conv_shift"), (w_hwc, "w"), (dscale, "dscale"), (dshift, "dshift"),
                   (pshift, "pshift")):
         _f32c(t, nm)
@@ -398,6 +400,27 @@ def softmax(x):
 
 
 @_device_guarded
+def heads_fused(x, w1, b1, wa, ba, wg, bg):
+    """The age / gender heads in one launch (hsefr_heads_fused; facial_analysis.py:109): x [n,k] -> (hidden [n,256] = relu(x.w1 + b1),
+    logits [n,a] = hidden.wa + ba, age_probs = softmax(logits), gender [n,1] = sigmoid(hidden.wg + bg)); w1 [k,256], wa [256,a], wg [256,1]."""
+    torch = _lib.require_gpu()
+    for t, nm in ((x, "x"), (w1, "w1"), (b1, "b1"), (wa, "wa"), (ba, "ba"), (wg, "wg"), (bg, "bg")):
+        _f32c(t, nm)
+    n, k = x.shape
+    a = wa.shape[1]
+    if tuple(w1.shape) != (k, 256) or wa.shape[0] != 256 or tuple(wg.shape) != (256, 1):
+        raise ValueError("heads_fused: w1 [k,256], wa [256,a], wg [256,1]")
+    hidden = torch.empty((n, 256), dtype=torch.float32, device=x.device)
+    logits = torch.empty((n, a), dtype=torch.float32, device=x.device)
+    probs = torch.empty((n, a), dtype=torch.float32, device=x.device)
+    gender = torch.empty((n, 1), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hsefr_heads_fused(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), wa.data_ptr(), ba.data_ptr(), wg.data_ptr(), bg.data_ptr(),
+                                            hidden.data_ptr(), logits.data_ptr(), probs.data_ptr(), gender.data_ptr(), n, k, a,
+                                            _lib.current_stream_ptr()), "hsefr_heads_fused")
+    return hidden, logits, probs, gender
+
+
+@_device_guarded
 def l2_normalize(x):
     """preprocessing.normalize(X, norm='l2') (facerec_test.py:401)."""
     torch = _lib.require_gpu()
@@ -556,6 +579,40 @@ def conv1x1_proj_bf16(x, w_packed, scale, shift, x2, w2_packed, scale2, shift2, 
                                                   w2_packed.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), y.data_ptr(), n, oh, ow, c, cout,
                                                   c2, stride2, h2, w2, act, _lib.current_stream_ptr()), "hsefr_conv1x1_proj_bf16")
     return y
+
+
+@_device_guarded
+def conv1x1_pair_bf16(x, w1_packed, scale1, shift1, w2_packed, scale2, shift2, res=None, x2=None, wp_packed=None, scale_p=None, shift_p=None,
+                      act1: int = ACT_RELU, act2: int = ACT_RELU):
+    """A bottleneck's increase layer and the next bottleneck's reduce layer in one launch (hsefr_conv1x1_pair_bf16):
+    y1 = act1(bf16(scale1 * x.w1 + shift1) + R), R = res or bf16(scale_p * x2.wp + shift_p);  y2 = act2(bf16(scale2 * y1.w2 + shift2)).
+    x [n,h,w,c] bf16, w1_packed [cout1,c], res [n,h,w,cout1] | x2 [n,h,w,c2] with wp_packed [cout1,c2], w2_packed [cout2,cout1]
+    -> (y1 [n,h,w,cout1], y2 [n,h,w,cout2]) bf16."""
+    torch = _lib.require_gpu()
+    _bf16c(x, "x"), _bf16c(w1_packed, "w1"), _f32c(scale1, "scale1"), _f32c(shift1, "shift1")
+    _bf16c(w2_packed, "w2"), _f32c(scale2, "scale2"), _f32c(shift2, "shift2")
+    n, h, w, c = x.shape
+    cout1, cout2 = w1_packed.shape[0], w2_packed.shape[0]
+    if w1_packed.shape[1] != c or w2_packed.shape[1] != cout1:
+        raise ValueError("conv1x1_pair_bf16: inconsistent shapes")
+    c2 = 0
+    if res is not None:
+        _bf16c(res, "res")
+        if tuple(res.shape) != (n, h, w, cout1) or x2 is not None:
+            raise ValueError("conv1x1_pair_bf16: res must be [n,h,w,cout1], and exclusive with the projected shortcut")
+    else:
+        _bf16c(x2, "x2"), _bf16c(wp_packed, "wp"), _f32c(scale_p, "scale_p"), _f32c(shift_p, "shift_p")
+        c2 = x2.shape[3]
+        if tuple(x2.shape[:3]) != (n, h, w) or tuple(wp_packed.shape) != (cout1, c2):
+            raise ValueError("conv1x1_pair_bf16: the projected shortcut reads the same pixels")
+    y1 = torch.empty((n, h, w, cout1), dtype=torch.bfloat16, device=x.device)
+    y2 = torch.empty((n, h, w, cout2), dtype=torch.bfloat16, device=x.device)
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    _lib.check(_lib.lib().hsefr_conv1x1_pair_bf16(x.data_ptr(), w1_packed.data_ptr(), scale1.data_ptr(), shift1.data_ptr(), ptr(res), ptr(x2),
+                                                  ptr(wp_packed), ptr(scale_p), ptr(shift_p), y1.data_ptr(), w2_packed.data_ptr(),
+                                                  scale2.data_ptr(), shift2.data_ptr(), y2.data_ptr(), n * h * w, c, cout1, cout2, c2, act1, act2,
+                                                  _lib.current_stream_ptr()), "hsefr_conv1x1_pair_bf16")
+    return y1, y2
 
 
 @_device_guarded

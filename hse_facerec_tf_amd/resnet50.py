@@ -84,12 +84,13 @@ def pack_stem_weight(kernel_hwio: np.ndarray) -> np.ndarray:
 
 
 def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224, 224), pool: str = "caffe", dtype: str = "bf16",
-               fuse: bool = True) -> Plan:
+               fuse: bool = True, pair: bool = True) -> Plan:
     """pool='caffe': pad-0 ceil-mode max-pool (112 -> 56); pool='valid': keras_vggface's valid pool (112 -> 55).
     dtype='bf16': the bf16-MFMA kernels (BASELINE config 3's throughput mode); dtype='f32': the same layers on the exact-fp32
     general kernels (OP_CONV_F32 / OP_MAXPOOL_F32 / OP_GAP) -- the fp32-grade mode, 1e-4 against the fp64 oracle.
     fuse (bf16 only): conv1 + pool1 run as one kernel (lowering.fuse_stem_pool) and the four projected shortcuts run inside their
-    block's increase layer (lowering.fuse_proj); False keeps every layer's tensor."""
+    block's increase layer (lowering.fuse_proj); False keeps every layer's tensor.
+    pair (with fuse): the 56-pixel stage's increase layers run in one launch with the next block's reduce layer (lowering.mark_pairs)."""
     if dtype not in ("bf16", "f32"):
         raise ValueError("dtype must be 'bf16' or 'f32', not %r" % (dtype,))
     f32 = dtype == "f32"
@@ -144,6 +145,8 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
         gap = remap[gap]
         layers, remap = lowering.fuse_proj(layers, [gap])
         gap = remap[gap]
+        if pair:
+            lowering.mark_pairs(layers)
     buffers = assign_buffers(layers, {gap})
     names = {L.name: i for i, L in enumerate(layers)}
     return Plan(layers, (H, W, 3), buffers, {OUT_FEATURES: (gap, cin)}, names)

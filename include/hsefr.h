@@ -35,7 +35,9 @@
 extern "C" {
 #endif
 
-#define HSEFR_VERSION 130 /* 0.1.3: round-5 ABI (added: hsefr_conv1x1_proj_bf16, the projected-shortcut form of HSEFR_OP_CONV_BF16; 120 = round 4, 110 = round 3, 100 = round 1-2) */
+#define HSEFR_VERSION 140 /* 0.1.4: round-6 ABI (added: hsefr_plan_op.flags with HSEFR_OPF_PAIR_NEXT / HSEFR_OPF_HEADS, hsefr_conv1x1_pair_bf16, hsefr_heads_fused,
+                             hsefr_plan_validate, hsefr_nn1_fallbacks; removed from the product library: hsefr_stem_fused / HSEFR_OP_STEM_F16S (development builds only);
+                             130 = round 5, 120 = round 4, 110 = round 3, 100 = round 1-2) */
 
 typedef enum hsefr_status {
     HSEFR_OK = 0,
@@ -93,7 +95,8 @@ typedef enum hsefr_op_kind {
                                   cout % 64, pointwise products as in PWCONV_F16S (csrc/dwpw_f16s.hip).  w_off/scale_off/
                                   shift_off = depthwise; w2_off = split rows; shift2_off = [2][cout]: descale, then shift;
                                   `reserved` = a_log2 (the depthwise result is in [0,6]: 12)                         */
-    HSEFR_OP_STEM_F16S = 14,   /* the whole MobileNet stem (csrc/stem_fused.hip): conv 3x3/2 3->32 + shift + ReLU6 ->
+    HSEFR_OP_STEM_F16S = 14,   /* DEVELOPMENT BUILDS ONLY since round 6 (the product library answers HSEFR_ERR_UNSUPPORTED; no default lowering emits it).
+                                  The whole MobileNet stem (csrc/stem_fused.hip): conv 3x3/2 3->32 + shift + ReLU6 ->
                                   depthwise 3x3/1 + scale + shift + ReLU6 -> pointwise 32->64 + shift + act.  h,w,cin = the
                                   image, oh,ow,cout = the block output, pad_t/pad_l = the conv's; w_off = fp32 pack
                                   [conv HWIO 864 | conv shift 32 | dw 3x3x32 288 | dw scale 32 | dw shift 32];
@@ -157,6 +160,18 @@ typedef struct hsefr_plan_buffer {
     uint32_t reserved;
 } hsefr_plan_buffer;
 
+/* Launch-level fusions the engine applies between CONSECUTIVE ops (round 6).  The ops stay in the plan as they are -- buffers, liveness,
+ * per-layer tensors and the CPU plan checker do not change -- and the flagged op's launch also computes the ops behind it, which are then
+ * skipped.  hsefr_engine_create validates the pattern; a forward that does not need the covered ops (or an all-layers forward asked to
+ * keep their tensors: every tensor is still written) runs the flagged op alone. */
+typedef enum hsefr_op_flags {
+    HSEFR_OPF_PAIR_NEXT = 1, /* CONV_BF16 1x1 (+ residual | + projected shortcut) whose output the NEXT op, a CONV_BF16 1x1 at the same
+                                pixels, reads: both in one launch, the first output stored and chained through registers into the second
+                                product (csrc/conv1x1_pair_bf16.hip): ResNet-50's increase -> next reduce in the 56-pixel stage          */
+    HSEFR_OPF_HEADS = 2      /* DENSE k -> 256 + ReLU followed by DENSE 256 -> A (<= 128) + bias, SOFTMAX over it, and DENSE 256 -> 1 +
+                                sigmoid: the age / gender heads of facial_analysis.py:109 in one launch (csrc/pool_dense.hip)         */
+} hsefr_op_flags;
+
 typedef struct hsefr_plan_op {
     uint32_t kind; /* hsefr_op_kind */
     uint32_t act;  /* hsefr_act     */
@@ -170,6 +185,7 @@ typedef struct hsefr_plan_op {
                            PWCONV_F16S / PWCONV_PS / fused kinds: a_log2 (activation pre-scale exponent);
                            DWCONV3X3: 0 = fp32 output, a_log2 > 0 = output stored as split rows scaled by 2^a_log2
                            (act must be ReLU6, c % 32 == 0); 0 otherwise */
+    int32_t flags;      /* hsefr_op_flags (round 6; the four bytes were padding before: plans written by older lowerings read as 0) */
     uint64_t w_off;     /* weights; layout depends on kind (see the per-kernel entry points) */
     uint64_t scale_off; /* per-channel scale (DWCONV), descale (PWCONV_F16S)                 */
     uint64_t shift_off; /* per-channel shift / bias                                          */
@@ -186,6 +202,12 @@ typedef struct hsefr_engine hsefr_engine;
  * allocates the activation workspace for `max_batch` images.  `plan` is host memory and may
  * be freed after the call.  Replaces tf.import_graph_def + tf.Session (facerec_test.py:41-58). */
 int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsefr_engine** out);
+
+/* The checks hsefr_engine_create runs on a plan BEFORE it touches the device, alone (no GPU needed): size against the header, buffer ids,
+ * blob offsets and operand extents, per-kind shape support, the fusion flags' patterns, the output slots.  HSEFR_OK, or the status and
+ * message hsefr_engine_create would return for this blob.  The entry point the sanitizer / fuzz build drives
+ * (csrc/build.sh with HSEFR_ASAN=1, tests/test_plan_blob_fuzz_cpu.py). */
+int hsefr_plan_validate(const void* plan, size_t plan_bytes);
 
 /* Batches of at most `max_n` images (default 0 = never) run as ONE hipGraph launch: the op sequence of a (batch size,
  * requested outputs) pair is captured once, reading an engine-owned copy of the input, and replayed.  For callers whose
@@ -315,14 +337,6 @@ int hsefr_dwpw_f16split(const float* x, const float* wd, const float* dscale, co
                         const float* descale, const float* pshift, float* y, int n, int h, int w, int c, int stride,
                         int pad_t, int pad_l, int oh, int ow, int cout, int a_log2, int act, hsefr_stream_t stream);
 
-/* The MobileNet stem in one kernel (graph nodes #30-#49): conv 3x3 stride 2 SAME (3 -> 32) + shift + ReLU6 -> depthwise
- * 3x3 stride 1 SAME + scale + shift + ReLU6 -> pointwise 1x1 (32 -> 64) + shift + act (split-f16 products).
- * x [n,h,w,3]; conv_w TF HWIO [3,3,3,32]; wd [3,3,32]; w_split/descale as for hsefr_pwconv1x1_f16split;
- * y [n,oh,ow,64] with oh = ceil(h/2), ow = ceil(w/2); cpad_t/cpad_l = the conv's top/left padding. */
-int hsefr_stem_fused(const float* x, const float* conv_w, const float* conv_shift, const float* wd, const float* dscale,
-                     const float* dshift, const void* w_split, const float* descale, const float* pshift, float* y, int n,
-                     int h, int w, int cpad_t, int cpad_l, int oh, int ow, int a_log2, int act, hsefr_stream_t stream);
-
 /* The stem plus the depthwise half of block 2 (graph nodes #30-#55) in one kernel: ... -> pointwise 32->64 + shift + ReLU6
  * -> depthwise 3x3 stride 2 SAME + scale + shift + act.  wd2 [3,3,64]; y [n,oh2,ow2,64] with h1 = ceil(h/2),
  * oh2 = ceil(h1/2) (same for w); pad_t2/pad_l2 = the stride-2 depthwise's top/left padding (0 for even h1/w1). */
@@ -379,6 +393,15 @@ int hsefr_dense(const float* x, const float* wgt, const float* bias, float* y, i
 /* Softmax over the last axis (graph node #241): x,y [n,c], c <= 1024. */
 int hsefr_softmax(const float* x, float* y, int n, int c, hsefr_stream_t stream);
 
+/* The age / gender heads in ONE launch (graph nodes #232-241; sess.run([age, gender, feats]) at facial_analysis.py:109):
+ *   hidden = relu(x . w1 + b1)                      x [n,k], w1 [k,256], hidden [n,256]
+ *   age_probs = softmax(hidden . wa + ba)           wa [256,a], a <= 128; logits [n,a], age_probs [n,a]
+ *   gender = sigmoid(hidden . wg + bg)              wg [256,1]; gender [n,1]
+ * Same contraction splits and summation order as hsefr_dense / hsefr_softmax: the four outputs equal the four launches' bit for bit.
+ * k % 64 == 0, k <= 2048.  What the engine runs for a DENSE op flagged HSEFR_OPF_HEADS. */
+int hsefr_heads_fused(const float* x, const float* w1, const float* b1, const float* wa, const float* ba, const float* wg, const float* bg,
+                      float* hidden, float* logits, float* age_probs, float* gender, int n, int k, int a, hsefr_stream_t stream);
+
 /* ---- bf16 ResNet-50 path (vgg2_resnet.pb, facerec_test.py:213): activations bf16 NHWC, fp32 accumulate ---- */
 
 /* KxK convolution (1x1 / 3x3, stride 1|2, explicit zero padding) as a bf16-MFMA implicit GEMM with the folded
@@ -397,6 +420,20 @@ int hsefr_conv_bf16(const void* x, const void* wgt_t, const float* scale, const 
 int hsefr_conv1x1_proj_bf16(const void* x, const void* wgt_t, const float* scale, const float* shift, const void* x2, const void* wgt2_t,
                             const float* scale2, const float* shift2, void* y, int n, int oh, int ow, int c, int cout, int c2, int stride2,
                             int h2, int w2, int act, hsefr_stream_t stream);
+
+/* Two chained 1x1 convolutions at the same pixels in ONE launch (round 6; csrc/conv1x1_pair_bf16.hip): a bottleneck's increase layer
+ * and the next bottleneck's reduce layer,
+ *   y1[p, :] = act1( bf16( scale1 * (x[p, :] . w1_t) + shift1 ) + R[p, :] ),   R = res[p, :]  or  bf16( scale_p * (x2[p, :] . wp_t) + shift_p )
+ *   y2[p, :] = act2( bf16( scale2 * (y1[p, :] . w2_t) + shift2 ) )
+ * -- the rounding points of hsefr_conv_bf16 (+ res) / hsefr_conv1x1_proj_bf16 followed by hsefr_conv_bf16; y1 is stored and ALSO kept in
+ * registers as the second product's operand, so it is not read back.  x [pixels,c], w1_t [cout1][c], res / y1 [pixels,cout1], w2_t
+ * [cout2][cout1], y2 [pixels,cout2], all bf16; exactly one of res and (x2 [pixels,c2], wp_t [cout1][c2], scale_p, shift_p) is given
+ * (c2 = 0 without a projection).  Covered: c = 64, cout1 = 256, cout2 = 64, c2 in {0, 64} (ResNet-50's 56-pixel stage).  What the
+ * engine runs for a CONV_BF16 op flagged HSEFR_OPF_PAIR_NEXT. */
+int hsefr_conv1x1_pair_bf16(const void* x, const void* w1_t, const float* scale1, const float* shift1, const void* res, const void* x2,
+                            const void* wp_t, const float* scale_p, const float* shift_p, void* y1, const void* w2_t, const float* scale2,
+                            const float* shift2, void* y2, long long pixels, int c, int cout1, int cout2, int c2, int act1, int act2,
+                            hsefr_stream_t stream);
 
 /* ResNet stem: 7x7 / stride 2 / pad 3 conv over the fp32 image [n,h,w,3] -> [n,oh,ow,64] bf16, + scale + shift + act.
  * wgt_t [64][256] bf16 with k = dy*32 + dx*3 + ci, zero padded. */
@@ -444,6 +481,10 @@ int hsefr_l2_normalize(const float* x, float* y, int n, int d, hsefr_stream_t st
  * ties resolve to the lowest gallery index.  d multiple of 4. */
 int hsefr_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_index, float* nn_dist2,
               hsefr_stream_t stream);
+/* Large searches run on the split-f16 GEMM and need a stream-ordered workspace; when even its smallest form cannot be allocated the
+ * search runs on the workspace-free kernel instead (same nearest neighbours up to last-bit ties, far slower at 10^5 x 10^5).  This
+ * counts those searches since the library was loaded, so a perf cliff can be traced to the allocator (hsefr_last_error_string says which). */
+long long hsefr_nn1_fallbacks(void);
 
 /* ---- generic small-CNN kernels: the MTCNN detection cascade (facial_analysis.py:334-352,478-604; mtcnn.pb) ---------- */
 

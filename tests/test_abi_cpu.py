@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libhsefr.so does not export %s" % name
     # and the binding table covers the header one-to-one
     assert sorted(_lib.SIGNATURES) == declared_functions()
-    assert L.hsefr_version() == 130
+    assert L.hsefr_version() == 140
 
 
 def test_code_object_targets_gfx950_only():
@@ -158,7 +158,7 @@ def test_plan_validation_guards_the_in_place_outputs():
     from hse_facerec_tf_amd import _lib, graphdef, lowering
     L = _lib.lib()
     plan = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0", {0: "global_pooling/Mean:0", 1: "age_pred/Softmax:0",
-                                                                             2: "gender_pred/Sigmoid:0"}, (96, 96))
+                                                                             2: "gender_pred/Sigmoid:0"}, (96, 96), launch_fusion=False)
 
     def create(p):
         blob = p.serialize()
@@ -185,3 +185,76 @@ def test_plan_validation_guards_the_in_place_outputs():
     # the untouched plan passes validation (and then fails, or not, only for lack of a GPU)
     rc, msg = create(plan)
     assert rc == 0 or "producing ops" not in msg and "the slot declares" not in msg
+
+
+def test_plan_validate_alone_and_the_launch_fusion_flags():
+    """Round 6: hsefr_plan_validate runs engine_create's pre-device checks alone, and the fusion flags of hsefr_plan_op are validated
+    against the pattern their fused launch computes -- a flag on the wrong op, a second output that aliases an operand, a pair whose
+    shapes the kernel does not cover and an unknown flag bit are all refused before any device is touched."""
+    import copy
+    from conftest import MODEL_PB
+    from hse_facerec_tf_amd import _lib, graphdef, lowering, resnet50
+    L = _lib.lib()
+
+    def validate(p):
+        blob = p.serialize()
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        rc = L.hsefr_plan_validate(ctypes.cast(buf, ctypes.c_void_p), len(blob))
+        return rc, _lib.last_error()
+    rn = resnet50.build_plan(resnet50.synthetic_weights(1), (64, 64), "caffe")
+    pairs = [i for i, x in enumerate(rn.layers) if x.flags & lowering.OPF_PAIR_NEXT]
+    assert [rn.layers[i].name for i in pairs] == ["conv2_1_1x1_increase", "conv2_2_1x1_increase"]
+    assert validate(rn)[0] == 0
+    bad = copy.deepcopy(rn)                                           # the last increase layer of the stage: the op behind it has stride 2
+    bad.layers[pairs[1] + 3].flags = lowering.OPF_PAIR_NEXT
+    rc, msg = validate(bad)
+    assert rc == _lib.ERR_INVALID and "PAIR_NEXT" in msg, (rc, msg)
+    bad = copy.deepcopy(rn)                                           # the reduce layer's output in the increase layer's input buffer
+    bad.layers[pairs[0] + 1].out_buf = rn.layers[rn.layers[pairs[0]].src].out_buf
+    rc, msg = validate(bad)
+    assert rc == _lib.ERR_INVALID and ("aliases" in msg or "exceeds" in msg), (rc, msg)
+    bad = copy.deepcopy(rn)                                           # a stage-3 increase layer (128 -> 512): pattern fine up to the shapes
+    j = next(i for i, x in enumerate(bad.layers) if x.name == "conv3_2_1x1_increase")
+    bad.layers[j].flags = lowering.OPF_PAIR_NEXT
+    rc, msg = validate(bad)
+    assert rc == _lib.ERR_UNSUPPORTED and "not covered" in msg, (rc, msg)
+    bad = copy.deepcopy(rn)
+    bad.layers[3].flags = 64
+    rc, msg = validate(bad)
+    assert rc == _lib.ERR_INVALID and "unknown flags" in msg, (rc, msg)
+
+    ag = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0", {0: "global_pooling/Mean:0", 1: "age_pred/Softmax:0",
+                                                                           2: "gender_pred/Sigmoid:0"}, (96, 96))
+    hi = [i for i, x in enumerate(ag.layers) if x.flags & lowering.OPF_HEADS]
+    assert len(hi) == 1 and validate(ag)[0] == 0
+    bad = copy.deepcopy(ag)
+    bad.layers[hi[0]].flags = 0
+    bad.layers[hi[0] + 1].flags = lowering.OPF_HEADS                  # on age_pred: not the head of the group
+    rc, msg = validate(bad)
+    assert rc == _lib.ERR_INVALID and "HEADS" in msg, (rc, msg)
+    # truncated and over-long blobs, and the no-GPU contract of the new entry point
+    blob = ag.serialize()
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    assert L.hsefr_plan_validate(ctypes.cast(buf, ctypes.c_void_p), len(blob) - 16) == _lib.ERR_INVALID
+    assert L.hsefr_plan_validate(ctypes.cast(buf, ctypes.c_void_p), 40) == _lib.ERR_INVALID
+    assert L.hsefr_plan_validate(None, 0) == _lib.ERR_INVALID
+    assert L.hsefr_nn1_fallbacks() == 0
+
+
+def test_round_one_stem_left_the_product_library():
+    """csrc/stem_fused.hip (reachable only through lower_graph(stem_fusion="stem")) and csrc/conv3x3_win_bf16.hip are
+    development-build sources; a plan that asks for HSEFR_OP_STEM_F16S is refused by the product with a message that says so, and the
+    product stays below 4 MB."""
+    from conftest import MODEL_PB
+    from hse_facerec_tf_amd import _lib, graphdef, lowering
+    L = _lib.lib()
+    if hasattr(L, "hsefr_debug_set"):
+        pytest.skip("a development build is loaded")
+    assert not hasattr(L, "hsefr_stem_fused")
+    plan = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0", {0: "global_pooling/Mean:0"}, (96, 96), stem_fusion="stem")
+    assert plan.layers[0].kind == lowering.OP_STEM_F16S
+    blob = plan.serialize()
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    rc = L.hsefr_plan_validate(ctypes.cast(buf, ctypes.c_void_p), len(blob))
+    assert rc == _lib.ERR_UNSUPPORTED and "development builds" in _lib.last_error()
+    assert os.path.getsize(_lib.LIB_PATH) < 4_000_000

@@ -114,3 +114,47 @@ def test_worker_errors_rebuild_in_the_parent_and_workers_share_the_node(monkeypa
     assert q is None or q > 0
     order = decode_pool.cpu_order()
     assert sorted(order) == sorted(set(order)) and len(order) >= 1
+
+
+def test_pinning_is_opt_in_unless_a_launcher_says_where_the_process_is(monkeypatch):
+    from hse_facerec_tf_amd import decode_pool
+    """ADVICE r5: processes started by hand have no LOCAL_RANK -- pinning them all to cpu_order()[0:workers] would stack every
+    job's decoders on the same cores.  Default: pin only when LOCAL_RANK / SLURM_LOCALID / HSEFR_DECODE_CPU_OFFSET is set; pools
+    alive in one process take consecutive runs of the list; a closed pool gives its run back."""
+    for k in ("LOCAL_RANK", "SLURM_LOCALID", "HSEFR_DECODE_CPU_OFFSET"):
+        monkeypatch.delenv(k, raising=False)
+    assert decode_pool.pin_offset(4) is None
+    monkeypatch.setenv("SLURM_LOCALID", "3")
+    assert decode_pool.pin_offset(4) == 12
+    monkeypatch.setenv("LOCAL_RANK", "2")                      # torchrun wins over srun's variable when both are set
+    assert decode_pool.pin_offset(4) == 8
+    monkeypatch.setenv("HSEFR_DECODE_CPU_OFFSET", "5")
+    assert decode_pool.pin_offset(4) == 13
+    for k in ("LOCAL_RANK", "SLURM_LOCALID", "HSEFR_DECODE_CPU_OFFSET"):
+        monkeypatch.delenv(k, raising=False)
+    order = decode_pool.cpu_order()
+    a = DecodePool(1, slot_bytes=1 << 20, slots=1)
+    try:
+        assert a.cpus == [None]                                  # nothing known about the node: the scheduler places the worker
+    finally:
+        a.close()
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    a = DecodePool(1, slot_bytes=1 << 20, slots=1)
+    b = DecodePool(1, slot_bytes=1 << 20, slots=1)
+    try:
+        assert a.cpus == [order[1 % len(order)]] and b.cpus == [order[2 % len(order)]]
+        a.close()
+        c = DecodePool(1, slot_bytes=1 << 20, slots=1, pin=True)
+        try:
+            assert c.cpus == a.cpus                              # the released run is taken again
+        finally:
+            c.close()
+    finally:
+        a.close()
+        b.close()
+    monkeypatch.delenv("LOCAL_RANK")
+    d = DecodePool(1, slot_bytes=1 << 20, slots=1, pin=True)   # forced: offset 0
+    try:
+        assert d.cpus == [order[0]]
+    finally:
+        d.close()

@@ -63,7 +63,9 @@ def test_native_library_is_the_one_loaded(torch_):
 @pytest.mark.parametrize("stem_fusion", ["stem2", "stem", "none"])
 @pytest.mark.parametrize("size", [192, 100])
 def test_engine_matches_golden_for_every_stem_fusion(torch_, size, stem_fusion):
-    from hse_facerec_tf_amd import engine, graphdef, lowering
+    from hse_facerec_tf_amd import _lib, engine, graphdef, lowering
+    if stem_fusion == "stem" and not hasattr(_lib.lib(), "hsefr_stem_fused"):
+        pytest.skip("HSEFR_OP_STEM_F16S (round 1's fused stem) runs on development builds of the library only")
     z = np.load(os.path.join(GOLDEN, "e2e_synthetic.npz"))
     n = z["feat_%d" % size].shape[0]
     plan = lowering.lower_graph(graphdef.read_graph(MODEL_PB), "input_1:0", {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]}, (size, size),
@@ -389,3 +391,37 @@ def test_zz_report_the_worst_errors_the_bar_saw():
     """(runs last in this file) the largest errors fp32_grade met: visible with -s, and a guard that the bars are not vacuous."""
     print("fp32_grade over this session:", WORST)
     assert WORST["maxnorm"] < BAR_MAXNORM and WORST["rel_above_1e-2"] < BAR
+
+
+def test_fused_heads_plan_equals_the_four_launch_plan_bit_for_bit(torch_):
+    """lowering.mark_heads (round 6): the feats op carries HSEFR_OPF_HEADS and the engine runs feats + age_pred + softmax + gender_pred as
+    one launch -- features, age distribution and gender equal the plan lowered with launch_fusion=False bit for bit (batch 37: a ragged
+    last row group), every layer's tensor too, and the three covered ops' profiled intervals are empty.  A forward that asks for the
+    features alone runs none of the heads, as before."""
+    from hse_facerec_tf_amd import graphdef, lowering
+    from hse_facerec_tf_amd.engine import Engine
+    g = graphdef.read_graph(MODEL_PB)
+    outs = {0: FETCH[0], 1: FETCH[1], 2: FETCH[2]}
+    fused = lowering.lower_graph(g, "input_1:0", outs, (96, 96), input_bound=256.0)
+    plain = lowering.lower_graph(g, "input_1:0", outs, (96, 96), input_bound=256.0, launch_fusion=False)
+    hi = [i for i, L in enumerate(fused.layers) if L.flags & lowering.OPF_HEADS]
+    assert len(hi) == 1 and fused.layers[hi[0]].name.startswith("feats") and not any(L.flags for L in plain.layers)
+    assert [L.kind for L in fused.layers[hi[0]:hi[0] + 4]] == [lowering.OP_DENSE, lowering.OP_DENSE, lowering.OP_SOFTMAX, lowering.OP_DENSE]
+    ea, eb = Engine(fused, max_batch=37), Engine(plain, max_batch=37)
+    gen = torch_.Generator(device="cuda").manual_seed(9)
+    x = (torch_.rand((37, 96, 96, 3), device="cuda", generator=gen) * 256.0 - 128.0).contiguous()
+    ra, rb = ea.forward(x, (0, 1, 2)), eb.forward(x, (0, 1, 2))
+    for k in ("features", "age_probs", "gender"):
+        assert torch_.equal(ra[k], rb[k]), k
+    assert torch_.equal(ea.forward(x, (0,))["features"], rb["features"])
+    assert torch_.equal(ea.forward(x, (2,))["gender"], rb["gender"])          # gender alone: age_pred / softmax are not needed -> four-launch path
+    ea.forward_all_layers(x)
+    eb.forward_all_layers(x)
+    for i in range(hi[0], hi[0] + 4):
+        assert torch_.equal(ea.layer_output(i, 37), eb.layer_output(i, 37)), fused.layers[i].name
+    ea.set_profiling(1)
+    ea.forward(x, (0, 1, 2))
+    t = ea.op_times_ms(0)
+    assert t[hi[0]] > 0 and max(t[hi[0] + 1:hi[0] + 4]) < 0.002
+    ea.close()
+    eb.close()

@@ -148,3 +148,22 @@ def test_generic_lowering_of_a_resnet_style_graph_to_the_fp32_grade_plan(pool, b
     assert rel(got, want) < 1e-6          # fp32 constants of the folded BatchNorm vs the fp64 graph
     with pytest.raises(ValueError):
         lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"}, dtype="fp32")
+
+
+def test_projected_shortcut_geometry_of_a_256_pixel_block_input_serializes():
+    """aux = c2 | stride2 << 12 | h2 << 14 | w2 << 23 reaches bit 31 of the signed wire field from w2 = 256 on (a ResNet-50
+    about 1021 px wide): the plan must still serialize, and the reader's masks must give the geometry back."""
+    import struct
+    from hse_facerec_tf_amd import lowering
+    plan = resnet50.build_plan(resnet50.synthetic_weights(1), (1024, 1024), "caffe")
+    pj = [L for L in plan.layers if L.proj is not None]
+    assert pj[0].proj == (64, 1, 256, 256) and pj[1].proj == (256, 2, 256, 256)
+    data = plan.serialize()
+    n_buf, n_ops = struct.unpack_from("<II", data, 12)
+    seen = []
+    for i in range(n_ops):
+        f = lowering._OP.unpack_from(data, lowering._HEADER.size + n_buf * lowering._BUFFER.size + i * lowering._OP.size)
+        if f[0] == lowering.OP_CONV_BF16 and f[-2] != lowering.NO_OFFSET:
+            r = f[16]
+            seen.append((r & 0xFFF, (r >> 12) & 3, (r >> 14) & 0x1FF, (r >> 23) & 0x1FF))
+    assert seen == [tuple(L.proj) for L in pj]

@@ -394,3 +394,91 @@ def test_resnet50_fused_stem_equals_unfused_network(env):
     fa, fb = a.extract_batch(x), b.extract_batch(x)
     assert float((fa - fb).abs().max() / fb.abs().max()) < 5e-3
     a.close_session(), b.close_session()
+
+
+@pytest.mark.parametrize("n,h,w,proj,act1,act2", [
+    (2, 14, 14, False, 1, 1), (1, 9, 7, True, 1, 1), (3, 5, 5, False, 0, 1), (37, 13, 13, True, 1, 0),
+    # more wave tiles than the grid's waves (a wave walks several tiles), a ragged last tile, and the BASELINE shape itself
+    (300, 31, 29, False, 1, 1), (128, 56, 56, True, 1, 1), (128, 56, 56, False, 1, 1)])
+def test_increase_reduce_pair_vs_oracle_and_bit_for_bit_vs_the_two_launches(env, n, h, w, proj, act1, act2):
+    """csrc/conv1x1_pair_bf16.hip (round 6): a 64 -> 256 increase layer (+ residual | + projected shortcut) and the 256 -> 64 reduce layer
+    behind it in one launch, the 256-channel tensor chained through registers.  Against the oracle's convolutions with every stored
+    tensor rounded to bf16 (small shapes), and BIT FOR BIT, both outputs, against the launches it replaces (every shape)."""
+    torch, ops, resnet50 = env
+    c, c1, c2o = 64, 256, 64
+    rs = np.random.RandomState(h * 7 + w + n)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    pk = lambda k: ops.bf16_from_bits(resnet50.pack_conv_weight(k))
+    k1 = (rs.randn(1, 1, c, c1) * np.sqrt(2.0 / c)).astype(np.float32)
+    k2 = (rs.randn(1, 1, c1, c2o) * np.sqrt(2.0 / c1)).astype(np.float32)
+    kp = (rs.randn(1, 1, 64, c1) * np.sqrt(2.0 / 64)).astype(np.float32)
+    sc1, sh1 = rs.uniform(0.5, 1.5, c1).astype(np.float32), (rs.randn(c1) * 0.1).astype(np.float32)
+    sc2, sh2 = rs.uniform(0.5, 1.5, c2o).astype(np.float32), (rs.randn(c2o) * 0.1).astype(np.float32)
+    scp, shp = rs.uniform(0.5, 1.5, c1).astype(np.float32), (rs.randn(c1) * 0.1).astype(np.float32)
+    g = torch.Generator(device="cuda").manual_seed(h * 31 + w)
+    x = (torch.rand((n, h, w, c), device="cuda", generator=g) * 2).to(torch.bfloat16)
+    x2 = (torch.rand((n, h, w, 64), device="cuda", generator=g) * 2).to(torch.bfloat16)
+    r = (torch.rand((n, h, w, c1), device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
+    if proj:
+        y1, y2 = ops.conv1x1_pair_bf16(x, pk(k1), f(sc1), f(sh1), pk(k2), f(sc2), f(sh2), x2=x2, wp_packed=pk(kp), scale_p=f(scp), shift_p=f(shp),
+                                       act1=act1, act2=act2)
+        ref1 = ops.conv1x1_proj_bf16(x, pk(k1), f(sc1), f(sh1), x2, pk(kp), f(scp), f(shp), 1, act1)
+    else:
+        y1, y2 = ops.conv1x1_pair_bf16(x, pk(k1), f(sc1), f(sh1), pk(k2), f(sc2), f(sh2), res=r, act1=act1, act2=act2)
+        ref1 = ops.conv_bf16(x, pk(k1), f(sc1), f(sh1), 1, 1, 1, 0, r, act1)
+    ref2 = ops.conv_bf16(ref1, pk(k2), f(sc2), f(sh2), 1, 1, 1, 0, None, act2)
+    assert torch.equal(y1, ref1), "increase output differs from the single launch in %d elements" % int((y1 != ref1).sum())
+    assert torch.equal(y2, ref2), "reduce output differs from the single launch in %d elements" % int((y2 != ref2).sum())
+    for _ in range(2):      # run to run
+        if proj:
+            z1, z2 = ops.conv1x1_pair_bf16(x, pk(k1), f(sc1), f(sh1), pk(k2), f(sc2), f(sh2), x2=x2, wp_packed=pk(kp), scale_p=f(scp),
+                                           shift_p=f(shp), act1=act1, act2=act2)
+        else:
+            z1, z2 = ops.conv1x1_pair_bf16(x, pk(k1), f(sc1), f(sh1), pk(k2), f(sc2), f(sh2), res=r, act1=act1, act2=act2)
+        assert torch.equal(z1, y1) and torch.equal(z2, y2)
+    if n * h * w > 20000:
+        return
+    xo = x.float().cpu().numpy().astype(np.float64)
+    conv = lambda a, k: tfo.conv2d(a, ores.bf16_round(k), (1, 1), "", explicit_pads=(0,) * 4)
+    ya = ores.bf16_round(conv(xo, k1) * sc1 + sh1)
+    rr = ores.bf16_round(conv(x2.float().cpu().numpy().astype(np.float64), kp) * scp + shp) if proj else r.float().cpu().numpy().astype(np.float64)
+    w1 = ya + rr
+    want1 = ores.bf16_round(np.maximum(w1, 0) if act1 == 1 else w1)
+    g1 = y1.float().cpu().numpy().astype(np.float64)
+    tol1 = 2.0 ** -7 * np.abs(want1) + 2.0 ** -9 * np.abs(want1).max() + 2.0 ** -8 * (np.abs(ya) + np.abs(rr))
+    assert (np.abs(g1 - want1) <= tol1).all()
+    # the second product against the oracle FED WITH THE DEVICE'S y1 (one-ulp differences of y1 would otherwise be compared twice)
+    w2 = conv(g1, k2) * sc2 + sh2
+    want2 = ores.bf16_round(np.maximum(ores.bf16_round(w2), 0) if act2 == 1 else ores.bf16_round(w2))
+    ok, err = close_bf16(y2.float().cpu().numpy(), want2)
+    assert ok, "max rel err %.3e" % err
+
+
+def test_resnet50_plan_pairs_run_as_one_launch_and_change_no_bit(env):
+    """lowering.mark_pairs on the ResNet-50 plan: conv2_1 / conv2_2's increase layers carry HSEFR_OPF_PAIR_NEXT, the engine runs each
+    with the reduce layer behind it as one launch (the covered op's profiled interval is empty), and features AND every layer's
+    tensor equal the plan without pairs bit for bit."""
+    torch, ops, resnet50 = env
+    from hse_facerec_tf_amd import lowering
+    from hse_facerec_tf_amd.engine import Engine
+    w = resnet50.synthetic_weights(5)
+    paired = resnet50.build_plan(w, (224, 224), "caffe")
+    plain = resnet50.build_plan(w, (224, 224), "caffe", pair=False)
+    flagged = [L.name for L in paired.layers if L.flags & lowering.OPF_PAIR_NEXT]
+    assert flagged == ["conv2_1_1x1_increase", "conv2_2_1x1_increase"] and not any(L.flags for L in plain.layers)
+    x = torch.from_numpy(np.random.RandomState(2).uniform(-120, 130, (6, 224, 224, 3)).astype(np.float32)).cuda()
+    ea, eb = Engine(paired, max_batch=6), Engine(plain, max_batch=6)
+    fa, fb = ea.forward(x)["features"], eb.forward(x)["features"]
+    assert torch.equal(fa, fb)
+    ea.forward_all_layers(x)
+    eb.forward_all_layers(x)
+    for i, L in enumerate(paired.layers):
+        assert torch.equal(ea.layer_output(i, 6), eb.layer_output(i, 6)), L.name
+    ea.set_profiling(1)
+    ea.forward(x)
+    t = ea.op_times_ms(0)
+    for i, L in enumerate(paired.layers):
+        if L.flags & lowering.OPF_PAIR_NEXT:
+            assert t[i] > 0 and t[i + 1] < 0.002, (L.name, t[i], t[i + 1])     # (two event records back to back)
+    ea.close()
+    eb.close()

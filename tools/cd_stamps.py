@@ -40,18 +40,18 @@ for name in sys.argv[1:] or ["c4_3x3", "c4_red", "c4_inc"]:
     torch.cuda.synchronize()
     if C11:
         buf = np.zeros(512 * 4 * 8 - 2, np.uint64)
-        _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        _lib.check(_lib.lib().hsefr_debug_read_stamps(4, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
         b = np.concatenate([buf, [0, 0]]).astype(np.float64).reshape(512, 4, 8)
         roles = (("all four waves", slice(0, 4), ["loads issued + reads + MFMA", "wait for loads + LDS stage writes", "step barrier", "epilogue", "barrier behind it"]),)
     elif W2 or W4:
         buf = np.zeros(256 * 8 * 8 - (1 if W4 else 0), np.uint64)
-        _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        _lib.check(_lib.lib().hsefr_debug_read_stamps(5 if W4 else 6, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
         b = np.concatenate([buf, [0] * (1 if W4 else 0)]).astype(np.float64).reshape(256, 8, 8)
         roles = (("MFMA waves", slice(0, 4), ["ds_read + mfma issue", "step barrier", "epilogue"]),
                  ("loader waves", slice(4, 8), ["DMA issue", "vmcnt wait", "step barrier"]))
     else:
         buf = np.zeros(256 * 12 * 8 - (2 if WIN else 1), np.uint64)
-        _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        _lib.check(_lib.lib().hsefr_debug_read_stamps(7 if WIN else 3, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
         b = np.concatenate([buf, [0] * (2 if WIN else 1)]).astype(np.float64).reshape(256, 12, 8)
         roles = (("MFMA waves", slice(0, 8), ["ds_read + mfma issue", "step barrier", "epilogue", "tile barrier"]),
                  ("loader waves", slice(8, 12), ["DMA issue", "vmcnt wait", "step barrier", "tile barrier"]))

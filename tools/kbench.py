@@ -250,7 +250,7 @@ def bench_stamps():
             ops.pwconv1x1_f16split(x, None, sh, prepared=prep)
         torch.cuda.synchronize()
         buf = np.zeros((1024, 8, 8), np.uint64)
-        _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        _lib.check(_lib.lib().hsefr_debug_read_stamps(0, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
         used = buf[:, :, 7] > 0
         b = buf[used].astype(np.float64)
         names = ["gload issue", "ds_read+mfma issue", "wait+convert+ds_write", "barrier", "epilogue/loop", "step top"]
@@ -328,7 +328,7 @@ def bench_stemstamps():
             ops.stem2_fused(x, cw, csh, wd, dsc, dsh, w, sh, wd2, d2sc, d2sh)
     torch.cuda.synchronize()
     buf = np.zeros((512 * 4, 10), np.uint64)
-    _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+    _lib.check(_lib.lib().hsefr_debug_read_stamps(1, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
     b = buf[buf[:, 9] > 0].astype(np.float64)
     names = ["cursor + gather issue", "B conv1 mfma + region write", "barriers", "C depthwise 1 from LDS", "D pointwise mfma (+ patch write)",
              "E epilogue / depthwise 2 + stores", "scatter (wait gather)", "-"]
@@ -359,7 +359,7 @@ def bench_blkstamps():
             ops.dwpw_f16split(x, wd, dsc, dsh, None, sh, 1, prepared=prep)
         torch.cuda.synchronize()
         buf = np.zeros((512 * 4, 10), np.uint64)
-        _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+        _lib.check(_lib.lib().hsefr_debug_read_stamps(1, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
         names = ["wait vmcnt", "DMA issue", "depthwise (LDS -> A tile)", "barrier", "MFMA", "epilogue"]
         for role, rows in (("producers (v3) / all waves (v2)", buf[:1024]), ("consumers (v3)", buf[1024:])):
             b = rows[rows[:, 9] > 0].astype(np.float64)

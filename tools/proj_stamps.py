@@ -20,7 +20,7 @@ for (oh, c, cout, c2, s2) in ((56, 64, 256, 64, 1), (28, 128, 512, 256, 2), (14,
         ops.conv1x1_proj_bf16(x, w, sc, sh, x2, w2, sc, sh, s2, 1)
     torch.cuda.synchronize()
     buf = np.zeros(512 * 4 * 8 - 2, np.uint64)
-    _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+    _lib.check(_lib.lib().hsefr_debug_read_stamps(4, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
     b = np.concatenate([buf, [0, 0]]).astype(np.float64).reshape(512, 4, 8)
     rr = b.reshape(-1, 8); rr = rr[rr[:, 7] > 0]
     print("proj+inc %dx%d c%d+%d->%d: %d waves, lifetime %.0f cycles, %.1f steps -> %.0f cycles per step" % (oh, oh, c, c2, cout, len(rr), rr[:, 6].mean(), rr[:, 7].mean(), (rr[:, 6] / rr[:, 7]).mean()))

@@ -28,6 +28,6 @@ for hw, k, n in ((12, 512, 512),):
     ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(40))
     us = ts[20] * 1e3
     buf = np.zeros((256, 12, 8), np.uint64)
-    _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+    _lib.check(_lib.lib().hsefr_debug_read_stamps(2, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
     life = buf[:, :, 6].astype(np.float64)
     print(os.environ.get("HSEFR_LIB"), "median %.1f us, wave lifetime mean %.0f max %.0f ticks -> %.2f ticks/ns" % (us, life.mean(), life.max(), life.max() / us / 1e3))

@@ -24,7 +24,7 @@ eng.set_profiling(0)
 for _ in range(50): eng.forward(x)          # (unprofiled forwards: the stamps below are from a back-to-back pass)
 torch.cuda.synchronize()
 buf = np.zeros((256, 12, 8), np.uint64)
-_lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+_lib.check(_lib.lib().hsefr_debug_read_stamps(2, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
 life = buf[:, :, 6].astype(np.float64)
 last = len(eng.plan.layers) - 1
 print("last pwconv_ps launch of the pass (layer %d, %s): %.1f us with op events; wave lifetime max %.0f ticks -> %.2f ticks/ns" %

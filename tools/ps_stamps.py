@@ -40,7 +40,7 @@ for hw, k, n in ((12, 512, 512), (6, 1024, 1024), (24, 128, 256)):
             ops.pwconv1x1_presplit(xs, None, sh, prepared=prep)
     torch.cuda.synchronize()
     buf = np.zeros((256, 12, 8), np.uint64)
-    _lib.check(_lib.lib().hsefr_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
+    _lib.check(_lib.lib().hsefr_debug_read_stamps(2, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes))
     b = buf.astype(np.float64)
     for role, sl, names in (("MFMA waves", slice(0, 8), ["ds_read + mfma issue", "step barrier", "epilogue (DW: the depthwise)", "tile barrier", "DW: parking", "DW: barrier waits"]),
                             ("loader waves", slice(8, 12), ["DMA issue", "vmcnt wait", "step barrier", "tile barrier / epilogue set-up", "DW: barrier waits", "DW: the depthwise"])):
