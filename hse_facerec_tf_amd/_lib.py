@@ -25,6 +25,7 @@ SIGNATURES = {
     "hsefr_engine_graph_launches": (c_longlong, [c_void_p]),
     "hsefr_engine_create": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
     "hsefr_plan_validate": (c_int, [c_void_p, c_size_t]),
+    "hsefr_plan_describe": (c_int, [c_void_p, c_size_t, c_int, c_char_p, c_size_t]),
     "hsefr_engine_workspace_bytes": (c_size_t, [c_void_p]),
     "hsefr_engine_max_batch": (c_int, [c_void_p]),
     "hsefr_engine_forward": (c_int, [c_void_p, _fp, c_int, _fp, _fp, _fp, c_void_p]),

@@ -274,11 +274,11 @@ int launch_area_level(const unsigned char* src, float* dst, int sh, int sw, int 
         const size_t hoff = ((size_t)dw * sizeof(XCell) + 15) & ~(size_t)15;
         const size_t lds = hoff + ((size_t)fy + 3) * (size_t)dw * 3 * sizeof(float);
         if (!integer && lds <= 64 * 1024) {
-            hipLaunchKernelGGL(area_level_rows_kernel, dim3(dh), dim3(256), lds, s, src, dst, sh, sw, dh, dw, (int)hoff);
+            HSEFR_LAUNCH(area_level_rows_kernel, dim3(dh), dim3(256), lds, s, src, dst, sh, sw, dh, dw, (int)hoff);
             return launch_status("area_level_rows");
         }
     }
-    hipLaunchKernelGGL(area_level_kernel, dim3((dh * dw + 255) / 256), dim3(256), 0, s, src, dst, sh, sw, dh, dw);
+    HSEFR_LAUNCH(area_level_kernel, dim3((dh * dw + 255) / 256), dim3(256), 0, s, src, dst, sh, sw, dh, dw);
     return launch_status("area_level");
 }
 
@@ -286,7 +286,7 @@ int launch_area_crops(const unsigned char* src, const int* boxes, float* dst, in
     HSEFR_REQUIRE(sh > 0 && sw > 0 && n >= 0 && size > 0, HSEFR_ERR_INVALID, "area_crops: bad shape");
     if (n == 0) return HSEFR_OK;
     const long long total = (long long)n * size * size;
-    hipLaunchKernelGGL(area_crops_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, boxes, dst, sh, sw, n, size);
+    HSEFR_LAUNCH(area_crops_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, boxes, dst, sh, sw, n, size);
     return launch_status("area_crops");
 }
 

@@ -31,7 +31,19 @@ void set_error(const char* fmt, ...);
         }                                  \
     } while (0)
 
+// Route probe (hsefr_plan_describe): with the probe active on this host thread every launcher runs as usual up to the launch itself --
+// its shape checks, its choice of kernel family and template -- but HSEFR_LAUNCH records the kernel's name instead of launching it and no
+// HIP call is made: the plan's op -> kernel table comes from the SAME code that launches, on a machine with or without a GPU.
+bool route_probe();
+void route_record(const void* host_stub, const char* expr);      // the kernel's host-side stub (its symbol carries the template arguments)
+#define HSEFR_LAUNCH(kernel, grid, block, lds, stream, ...)                                                     \
+    do {                                                                                                        \
+        if (::hsefr::route_probe()) ::hsefr::route_record(reinterpret_cast<const void*>(&kernel), #kernel);     \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
+    } while (0)
+
 inline int launch_status(const char* what) {
+    if (route_probe()) return HSEFR_OK;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("launch of %s failed: %s", what, hipGetErrorString(e));
@@ -316,6 +328,8 @@ void set_w2_off(int v);
 void set_w4_off(int v);
 void set_w4_bres(int v);
 void set_pair_off(int v);
+void set_pair_ablate(int v);
+void set_pair_nt(int v);
 void set_nn1_y_mb(int v);
 int read_w4_stamps(void* host_out, size_t bytes);
 int read_w2_stamps(void* host_out, size_t bytes);

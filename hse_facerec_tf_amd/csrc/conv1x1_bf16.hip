@@ -346,7 +346,7 @@ int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shi
     // resident weight tiles: K <= 128 (at most two steps per tile) and a grid whose stride keeps a workgroup on one channel origin
     // (and BM >= 128: the epilogue's 16 KB of wave-private scratch must fit the stage's ACTIVATION rows, or it lands on the weights)
     nopj.b_resident = (BM >= 128 && total > g && K <= 128 && g % 8 == 0 && (g / 8) % tiles_n == 0 && g_c11_bres) ? 1 : 0;
-#define HSEFR_C11(R, A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, R, A>), grid, block, 0, s, x, wt, scale, shift, res, y, P, K, cout, tiles_n, (unsigned)total, rev, nopj)
+#define HSEFR_C11(R, A) HSEFR_LAUNCH((conv1x1_bf16_kernel<BM, BN, OCC, R, A>), grid, block, 0, s, x, wt, scale, shift, res, y, P, K, cout, tiles_n, (unsigned)total, rev, nopj)
     if (res) {
         if (act == HSEFR_ACT_RELU) HSEFR_C11(true, HSEFR_ACT_RELU);
         else if (act == HSEFR_ACT_RELU6) HSEFR_C11(true, HSEFR_ACT_RELU6);
@@ -373,7 +373,7 @@ int launch_proj_cfg(const u16* x, const u16* wt, const float* scale, const float
     const int rev = sweep_reverse();
     ProjParams pjr = pj;
     pjr.b_resident = (BM >= 128 && total > g && K + pj.K2 <= 128 && g % 8 == 0 && (g / 8) % tiles_n == 0 && g_c11_bres) ? 1 : 0;
-#define HSEFR_C11P(A) hipLaunchKernelGGL((conv1x1_bf16_kernel<BM, BN, OCC, false, A, true>), grid, block, 0, s, x, wt, scale, shift, nullptr, y, P, K, cout, tiles_n, (unsigned)total, rev, pjr)
+#define HSEFR_C11P(A) HSEFR_LAUNCH((conv1x1_bf16_kernel<BM, BN, OCC, false, A, true>), grid, block, 0, s, x, wt, scale, shift, nullptr, y, P, K, cout, tiles_n, (unsigned)total, rev, pjr)
     if (act == HSEFR_ACT_RELU) HSEFR_C11P(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_RELU6) HSEFR_C11P(HSEFR_ACT_RELU6);
     else HSEFR_C11P(HSEFR_ACT_NONE);

@@ -17,7 +17,8 @@
 //   * the walk is CHUNKED over Y1's channels: 32 channels at a time -- first product (K1 / 32 x 2 MFMAs per pixel block), epilogue,
 //     store, then that chunk's contribution to every channel of Y2 -- so only 2 x PB accumulator blocks of Y1 exist at any time;
 //   * all three weight matrices are RESIDENT in LDS (32 KB each at 64 -> 256 -> 64), loaded once per workgroup; the waves share nothing
-//     else: no barrier after the prologue, every wave streams its own 16 PB pixels (residual chunks requested two chunks ahead);
+//     else: no barrier after the prologue, every wave streams its own 16 PB pixels with the NEXT tile's operands in flight (a residual
+//     chunk is requested into the registers its predecessor was just read from: a whole tile of look-ahead per wave);
 //   * every vector-memory operation is a compiler-visible builtin (loads AND stores), so hipcc's own in-order vmcnt arithmetic is exact.
 // Every output element is accumulated over K in one fixed order by one wave: bit-identical run to run, independent of the grid; and K
 // is walked in the order the separate kernels walk it.
@@ -51,6 +52,8 @@ struct PairParams {
     unsigned ntiles;      // ceil(M / (16 PB))
     int reverse;
     float act1_lo, act1_hi, act2_lo, act2_hi;
+    int ablate;           // development builds, timing only (results WRONG): 1 = no residual loads, 2 = no y1 stores, 4 = no y2 stores, 8 = no second product
+    int nt;               // cache hints: 1 = y1 stores non-temporal, 2 = residual loads non-temporal, 4 = y2 stores non-temporal
 };
 
 // LDS row R of a weight image <-> output channel (conv1x1_w4_bf16.hip's permutation, per 32 channels): rows 16 b + i of a pair of
@@ -124,34 +127,65 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParam
     };
 
     const unsigned gw = blockIdx.x * WAVES + wave, nw = gridDim.x * WAVES;
-    for (unsigned t = gw; t < p.ntiles; t += nw) {
+#ifdef HSEFR_DEV
+    const int abl = p.ablate;
+#else
+    constexpr int abl = 0;
+#endif
+    constexpr unsigned OOR = 0x80000000u;        // beyond every resource (tensors < 2 GiB): loads return zeros, move no bytes
+    // the lane's pixel in pixel block 0 of wave tile t (tiles past the last: out of range)
+    auto tile_pix = [&](unsigned t) __attribute__((always_inline)) -> unsigned {
         const unsigned tt = p.reverse ? p.ntiles - 1u - t : t;
-        const unsigned pix0 = tt * (16u * PB) + (unsigned)l16;             // the lane's pixel in pixel block 0
-        // ---- the tile's activations, in B-operand layout straight from memory (rows past M: zeros) ----
-        bf16x8 xf[PB][H1];
-        bf16x8 x2f[PROJ ? PB : 1][PROJ ? HP : 1];
+        return tt * (16u * PB) + (unsigned)l16;
+    };
+    // ---- a tile's operands are requested ONE TILE AHEAD: the residual chunk j of the next tile goes into the registers chunk j of this tile
+    // has just been read from (CH chunks = a whole tile in flight per wave), the activations into a second set.  What the first version
+    // (residual two chunks ahead, activations at the top of their tile) measured at batch 128: residual loads + y1 stores + compute
+    // ADDED UP (157 us; 41 compute only, 89 without the loads, 78 without the stores) -- vmcnt retires in order, so every wait for a
+    // young load also waited for the stores just before it, and a tile began by draining the previous tile's stores.
+    bf16x8 xf[PB][H1], xn[PB][H1];
+    bf16x8 x2f[PROJ ? PB : 1][PROJ ? HP : 1], x2n[PROJ ? PB : 1][PROJ ? HP : 1];
+    f32x4 rr[PROJ ? 1 : CH][PB];
+    auto load_x = [&](bf16x8 (&dst)[PB][H1], bf16x8 (&dst2)[PROJ ? PB : 1][PROJ ? HP : 1], unsigned t) __attribute__((always_inline)) {
+        const bool live = t < p.ntiles;
+        const unsigned pix0 = tile_pix(t);
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
 #pragma unroll
             for (int hh = 0; hh < H1; ++hh)
-                xf[pb][hh] = __builtin_bit_cast(bf16x8, bload16(rx, (pix0 + 16u * pb) * (K1 * 2u) + (unsigned)(64 * hh + 16 * lq), 0));
+                dst[pb][hh] = __builtin_bit_cast(bf16x8, bload16(rx, live ? (pix0 + 16u * pb) * (K1 * 2u) + (unsigned)(64 * hh + 16 * lq) : OOR, 0));
             if (PROJ) {
 #pragma unroll
                 for (int hh = 0; hh < HP; ++hh)
-                    x2f[PROJ ? pb : 0][PROJ ? hh : 0] =
-                        __builtin_bit_cast(bf16x8, bload16(rx2, (pix0 + 16u * pb) * (K2 * 2u) + (unsigned)(64 * hh + 16 * lq), 0));
+                    dst2[PROJ ? pb : 0][PROJ ? hh : 0] =
+                        __builtin_bit_cast(bf16x8, bload16(rx2, live ? (pix0 + 16u * pb) * (K2 * 2u) + (unsigned)(64 * hh + 16 * lq) : OOR, 0));
             }
         }
-        const unsigned y1lane = pix0 * (N1 * 2u) + (unsigned)(16 * lq);      // + 16 pb rows, + 64 j bytes
-        f32x4 rr[3][PB];                                                    // residual chunks: a ring, two chunks ahead
-        auto load_res = [&](int j) __attribute__((always_inline)) {
+    };
+    auto load_res = [&](int j, unsigned t) __attribute__((always_inline)) {
+        const unsigned base = t < p.ntiles ? tile_pix(t) * (N1 * 2u) + (unsigned)(16 * lq + 64 * j) : OOR;
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) rr[j % 3][pb] = bload16(rres, y1lane + (unsigned)(16 * pb * N1 * 2 + 64 * j), 0);
-        };
-        if (!PROJ) {
-            load_res(0);
-            if (CH > 1) load_res(1);
+        for (int pb = 0; pb < PB; ++pb) {
+            const unsigned off = base == OOR ? OOR : base + (unsigned)(16 * pb * N1 * 2);
+            rr[PROJ ? 0 : j][pb] = (p.nt & 2) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off, 0, 2)) : bload16(rres, off, 0);
         }
+    };
+    auto store16 = [&](f32x4 v, const __amdgpu_buffer_rsrc_t& r, unsigned off, bool nt) __attribute__((always_inline)) {
+        if (nt) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(hsefr_u32x4, v), r, off, 0, 2);
+            hsefr_store_guard();
+        } else {
+            bstore16(v, r, off, 0);
+        }
+    };
+    load_x(xf, x2f, gw);
+    if (!PROJ && !(abl & 1)) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) load_res(j, gw);
+    }
+    for (unsigned t = gw; t < p.ntiles; t += nw) {
+        const unsigned pix0 = tile_pix(t);
+        const unsigned y1lane = pix0 * (N1 * 2u) + (unsigned)(16 * lq);      // + 16 pb rows, + 64 j bytes
         f32x4 acc2[MB2][PB];
 #pragma unroll
         for (int mb = 0; mb < MB2; ++mb)
@@ -160,7 +194,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParam
 
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            if (!PROJ && j + 2 < CH) load_res(j + 2);
+            if (j == 1) load_x(xn, x2n, t + nw);                              // the next tile's activations
             f32x4 acc[2][PB];
             if (PROJ) {
                 // the projected shortcut of these 32 channels: scaled, shifted, rounded to bf16 where its tensor used to be stored
@@ -214,6 +248,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParam
                 sh[b] = *(const f32x4*)(cst + N1 + 32 * j + 8 * lq + 4 * b);
             }
             bf16x8 yf[PB];
+            f32x4 o[PB];
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
                 float v[8];
@@ -221,23 +256,26 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParam
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 * b + e] = fmaf(acc[b][pb][e], sc[b][e], sh[b][e]);
-                const f32x4 r = rr[PROJ ? 0 : j % 3][pb];
+                const f32x4 r = rr[PROJ ? 0 : j][pb];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const unsigned rw = __float_as_uint(r[d]);
                     v[2 * d] = bfround(v[2 * d]) + __uint_as_float(rw << 16);
                     v[2 * d + 1] = bfround(v[2 * d + 1]) + __uint_as_float(rw & 0xFFFF0000u);
                 }
-                f32x4 o;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const float f0 = fminf(fmaxf(v[2 * d], p.act1_lo), p.act1_hi), f1 = fminf(fmaxf(v[2 * d + 1], p.act1_lo), p.act1_hi);
-                    o[d] = __uint_as_float(hsefr_pack_bf16x2(f0, f1));
+                    o[pb][d] = __uint_as_float(hsefr_pack_bf16x2(f0, f1));
                 }
-                bstore16(o, ry1, y1lane + (unsigned)(16 * pb * N1 * 2 + 64 * j), 0);
-                yf[pb] = __builtin_bit_cast(bf16x8, o);
+                yf[pb] = __builtin_bit_cast(bf16x8, o[pb]);
             }
+            if (!PROJ && !(abl & 1)) load_res(j, t + nw);                     // this chunk of the NEXT tile, into the registers just read
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+                if (!(abl & 2)) store16(o[pb], ry1, y1lane + (unsigned)(16 * pb * N1 * 2 + 64 * j), p.nt & 1);
             // ---- the chunk's contribution to every channel of Y2 ----
+            if (!(abl & 8))
 #pragma unroll
             for (int mb = 0; mb < MB2; ++mb) {
                 const bf16x8 a = wfrag(W2_OFF, N2, mb, j);
@@ -268,20 +306,34 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParam
                     const float f0 = fminf(fmaxf(v[2 * d], p.act2_lo), p.act2_hi), f1 = fminf(fmaxf(v[2 * d + 1], p.act2_lo), p.act2_hi);
                     o[d] = __uint_as_float(hsefr_pack_bf16x2(f0, f1));
                 }
-                bstore16(o, ry2, y2lane + (unsigned)(16 * pb * N2 * 2 + 64 * m2), 0);
+                if (!(abl & 4)) store16(o, ry2, y2lane + (unsigned)(16 * pb * N2 * 2 + 64 * m2), p.nt & 4);
+            }
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+#pragma unroll
+            for (int hh = 0; hh < H1; ++hh) xf[pb][hh] = xn[pb][hh];
+            if (PROJ) {
+#pragma unroll
+                for (int hh = 0; hh < HP; ++hh) x2f[PROJ ? pb : 0][PROJ ? hh : 0] = x2n[PROJ ? pb : 0][PROJ ? hh : 0];
             }
         }
     }
 }
 
 HSEFR_KNOB(g_pair_off, 0);     // dev builds: 1 = the engine never pairs (A/B timing against the two launches)
+HSEFR_KNOB(g_pair_ablate, 0);  // dev builds: PairParams::ablate
+HSEFR_KNOB(g_pair_nt, 1);      // PairParams::nt.  1 = y1 with the non-temporal hint: 410 MB of y1 + residual stream through a pair while the NEXT launch
+                               // (a 3x3) reads only the 51 MB of y2 -- measured in the network at batch 128, same box: the 3x3 behind a pair 47.3 -> 40.1 us,
+                               // the stage's last increase layer 90 -> 78, the pairs themselves +7 / +8 us; ResNet-50 1.745 -> 1.730 ms (hints on the
+                               // residual loads or on y2: slower)
 
 template <int K1, int K2, int N1, int N2, int PB, int WAVES, bool PROJ>
 int launch_pair(PairParams& p, hipStream_t s) {
     p.ntiles = (p.M + 16u * PB - 1u) / (16u * PB);
     const unsigned need = (p.ntiles + WAVES - 1) / WAVES;
     const unsigned g = need < 256u ? need : 256u;
-    hipLaunchKernelGGL((conv1x1_pair_bf16_kernel<K1, K2, N1, N2, PB, WAVES, PROJ>), dim3(g), dim3(WAVES * 64), 0, s, p);
+    HSEFR_LAUNCH((conv1x1_pair_bf16_kernel<K1, K2, N1, N2, PB, WAVES, PROJ>), dim3(g), dim3(WAVES * 64), 0, s, p);
     return launch_status("conv1x1_pair_bf16");
 }
 
@@ -289,6 +341,8 @@ int launch_pair(PairParams& p, hipStream_t s) {
 
 #ifdef HSEFR_DEV
 void set_pair_off(int v) { g_pair_off = v; }
+void set_pair_ablate(int v) { g_pair_ablate = v; }
+void set_pair_nt(int v) { g_pair_nt = v; }
 #endif
 
 // c -> cout1 (+ residual, or + the projection of x2 [.., c2]) -> cout2, all at the same pixels
@@ -314,12 +368,14 @@ int launch_conv1x1_pair_bf16(const void* x, const void* w1, const float* scale1,
     p.y1 = y1; p.w2 = w2; p.scale2 = scale2; p.shift2 = shift2; p.y2 = y2;
     p.M = (unsigned)pixels;
     p.reverse = sweep_reverse();
+    p.ablate = g_pair_ablate;
+    p.nt = g_pair_nt;
     p.act1_lo = act1 == HSEFR_ACT_NONE ? -INFINITY : 0.f;
     p.act1_hi = act1 == HSEFR_ACT_RELU6 ? 6.f : INFINITY;
     p.act2_lo = act2 == HSEFR_ACT_NONE ? -INFINITY : 0.f;
     p.act2_hi = act2 == HSEFR_ACT_RELU6 ? 6.f : INFINITY;
-    if (c2 > 0) return launch_pair<64, 64, 256, 64, 4, 8, true>(p, s);
-    return launch_pair<64, 64, 256, 64, 4, 8, false>(p, s);
+    if (c2 > 0) return launch_pair<64, 64, 256, 64, 2, 8, true>(p, s);
+    return launch_pair<64, 64, 256, 64, 2, 8, false>(p, s);
 }
 
 }  // namespace hsefr

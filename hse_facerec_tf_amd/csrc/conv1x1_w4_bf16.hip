@@ -455,7 +455,7 @@ int launch_w4(W4Params& p, hipStream_t s) {
     // resident weights: the steps of a tile divide the ring (K = 64 / 128 / 256) and the grid's stride keeps a workgroup on one channel origin
     // (xcd_remap_dir permutes inside blocks of eight: conv1x1_bf16.hip's rule)
     p.b_resident = (!PROJ && g_w4_bres && total > g && (p.K == 64 || p.K == 128 || p.K == 256) && g % 8 == 0 && (g / 8) % p.tiles_n == 0) ? 1 : 0;
-    hipLaunchKernelGGL((conv1x1_w4_bf16_kernel<RB, WAVES_M, PROJ>), dim3(g), dim3(512), 0, s, p);
+    HSEFR_LAUNCH((conv1x1_w4_bf16_kernel<RB, WAVES_M, PROJ>), dim3(g), dim3(512), 0, s, p);
     return launch_status("conv1x1_w4_bf16");
 }
 

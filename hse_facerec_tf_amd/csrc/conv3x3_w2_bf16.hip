@@ -449,7 +449,7 @@ int launch_w2(W2Params& p, hipStream_t s) {
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv3x3_w2: too many tiles");
     p.total_tiles = (unsigned)total;
     const unsigned g = (unsigned)(total < 256 ? total : 256);
-    hipLaunchKernelGGL((conv3x3_w2_bf16_kernel<RB, WAVES_M, WX, RBX, FLAT>), dim3(g), dim3(512), 0, s, p);
+    HSEFR_LAUNCH((conv3x3_w2_bf16_kernel<RB, WAVES_M, WX, RBX, FLAT>), dim3(g), dim3(512), 0, s, p);
     return launch_status("conv3x3_w2_bf16");
 }
 

@@ -431,7 +431,7 @@ int launch_w3(Win3Params& p, hipStream_t s) {
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv3x3_win: too many tiles");
     p.total_tiles = (unsigned)total;
     const unsigned g = (unsigned)(total < 256 ? total : 256);
-    hipLaunchKernelGGL((conv3x3_win_bf16_kernel<RBW, WAVES_M>), dim3(g), dim3(768), 0, s, p);
+    HSEFR_LAUNCH((conv3x3_win_bf16_kernel<RBW, WAVES_M>), dim3(g), dim3(768), 0, s, p);
     return launch_status("conv3x3_win_bf16");
 }
 

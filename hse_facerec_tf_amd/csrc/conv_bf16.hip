@@ -433,7 +433,7 @@ int launch_conv_cfg(ConvParams p, hipStream_t s) {
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv_bf16: too many tiles");
     p.total_tiles = (unsigned)total;
     p.reverse = sweep_reverse();
-    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, OCC>), dim3((unsigned)total), dim3(256), 0, s, p);
+    HSEFR_LAUNCH((conv_bf16_kernel<BM, BN, OCC>), dim3((unsigned)total), dim3(256), 0, s, p);
     return launch_status("conv_bf16");
 }
 
@@ -496,7 +496,7 @@ int launch_stem7x7_bf16(const float* x, const void* wt, const float* scale, cons
     p.x = x; p.wt = (const u16*)wt; p.scale = scale; p.shift = shift; p.y = (u16*)y;
     p.H = h; p.W = w; p.OH = oh; p.OW = ow; p.act = act; p.P = (unsigned)P; p.tiles = (unsigned)((P + 63) / 64);
     const unsigned g = p.tiles < 512u ? p.tiles : 512u;
-    hipLaunchKernelGGL(stem7x7_bf16_kernel, dim3(g), dim3(256), 0, s, p);
+    HSEFR_LAUNCH(stem7x7_bf16_kernel, dim3(g), dim3(256), 0, s, p);
     return launch_status("stem7x7_bf16");
 }
 
@@ -506,7 +506,7 @@ int launch_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c,
     if (n == 0) return HSEFR_OK;
     const long long total = (long long)n * oh * ow * (c / 8);
     HSEFR_REQUIRE(total < (1ll << 32), HSEFR_ERR_UNSUPPORTED, "maxpool: too large");
-    hipLaunchKernelGGL(maxpool3x3s2_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u16*)x,
+    HSEFR_LAUNCH(maxpool3x3s2_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u16*)x,
                        (u16*)y, h, w, c / 8, oh, ow, pad_t, pad_l, (unsigned)total);
     return launch_status("maxpool3x3s2_bf16");
 }
@@ -516,7 +516,7 @@ int launch_gap_bf16(const void* x, float* y, int n, int hw, int c, hipStream_t s
     if (n == 0) return HSEFR_OK;
     const int c8 = c / 8;
     const long long waves = (long long)n * ((c8 + 7) / 8);
-    hipLaunchKernelGGL(gap_bf16_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const u16*)x, y, n, hw, c8);
+    HSEFR_LAUNCH(gap_bf16_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, (const u16*)x, y, n, hw, c8);
     return launch_status("gap_bf16");
 }
 

@@ -382,7 +382,7 @@ int launch_cfg(ConvDmaParams& p, hipStream_t s) {
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv_dma_bf16: too many tiles");
     p.total_tiles = (unsigned)total;
     const unsigned g = (unsigned)(total < 256 ? total : 256);
-    hipLaunchKernelGGL((conv_dma_bf16_kernel<RB, WAVES_M>), dim3(g), dim3(768), 0, s, p);
+    HSEFR_LAUNCH((conv_dma_bf16_kernel<RB, WAVES_M>), dim3(g), dim3(768), 0, s, p);
     return launch_status("conv_dma_bf16");
 }
 

@@ -194,7 +194,7 @@ int launch_conv_f32_mfma(const float* x, const float* w, const float* scale, con
     p.tiles_n = cout / bn;
     const long long tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
     HSEFR_REQUIRE(tiles < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv_f32_mfma: grid too large");
-#define HSEFR_CF32(BN_, R_) hipLaunchKernelGGL((conv_f32_mfma_kernel<BN_, R_>), dim3((unsigned)tiles), dim3(256), 0, s, p)
+#define HSEFR_CF32(BN_, R_) HSEFR_LAUNCH((conv_f32_mfma_kernel<BN_, R_>), dim3((unsigned)tiles), dim3(256), 0, s, p)
     if (bn == 128) { if (runs) HSEFR_CF32(128, true); else HSEFR_CF32(128, false); }
     else { if (runs) HSEFR_CF32(64, true); else HSEFR_CF32(64, false); }
 #undef HSEFR_CF32

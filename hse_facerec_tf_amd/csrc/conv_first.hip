@@ -258,7 +258,7 @@ template <int STRIDE, int NI>
 int launch_mfma(const C3MParams& p, int act, hipStream_t s) {
     const unsigned g = p.tiles < 1024u ? p.tiles : 1024u;
     dim3 grid(g), block(256);
-#define HSEFR_C3M(A) hipLaunchKernelGGL((conv3x3_c3_mfma_kernel<STRIDE, NI, A>), grid, block, 0, s, p)
+#define HSEFR_C3M(A) HSEFR_LAUNCH((conv3x3_c3_mfma_kernel<STRIDE, NI, A>), grid, block, 0, s, p)
     if (act == HSEFR_ACT_RELU6) HSEFR_C3M(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_C3M(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_C3M(HSEFR_ACT_NONE);
@@ -307,7 +307,7 @@ int launch_conv_c3(const float* x, const float* wgt, const float* shift, float* 
     HSEFR_REQUIRE(nwg < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv_c3: grid too large");
     p.nwg = (unsigned)nwg;
     dim3 grid((unsigned)nwg), block(256);
-#define HSEFR_C3_LAUNCH(S, A) hipLaunchKernelGGL((conv3x3_c3_kernel<S, A>), grid, block, 0, s, p)
+#define HSEFR_C3_LAUNCH(S, A) HSEFR_LAUNCH((conv3x3_c3_kernel<S, A>), grid, block, 0, s, p)
     if (stride == 1) {
         if (act == HSEFR_ACT_RELU6) HSEFR_C3_LAUNCH(1, HSEFR_ACT_RELU6);
         else if (act == HSEFR_ACT_RELU) HSEFR_C3_LAUNCH(1, HSEFR_ACT_RELU);

@@ -129,7 +129,7 @@ int g_copy_variant = 0;  // unroll: (v & 3) -> {1, 2, 4, 8}; nt bits: (v >> 2) &
 
 template <int U, int NT>
 void launch_v(const f32x4* s, f32x4* d, size_t n, unsigned blocks, hipStream_t st) {
-    hipLaunchKernelGGL((copy_kernel<U, NT>), dim3(blocks), dim3(256), 0, st, s, d, n);
+    HSEFR_LAUNCH((copy_kernel<U, NT>), dim3(blocks), dim3(256), 0, st, s, d, n);
 }
 
 template <int U>
@@ -149,9 +149,9 @@ void set_clock_mode(int v) { g_clock_mode = v; }
 
 int launch_clock_probe(unsigned long long* out, int blocks, int iters, hipStream_t s) {
     HSEFR_REQUIRE(out && blocks > 0 && iters > 0, HSEFR_ERR_INVALID, "clock_probe: bad argument");
-    if (g_clock_mode == 1) hipLaunchKernelGGL(clock_probe_f16_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
-    else if (g_clock_mode == 2) hipLaunchKernelGGL(clock_probe_f16s_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
-    else hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
+    if (g_clock_mode == 1) HSEFR_LAUNCH(clock_probe_f16_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
+    else if (g_clock_mode == 2) HSEFR_LAUNCH(clock_probe_f16s_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
+    else HSEFR_LAUNCH(clock_probe_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
     return launch_status("clock_probe");
 }
 

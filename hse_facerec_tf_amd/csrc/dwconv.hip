@@ -241,25 +241,25 @@ static int launch_dwconv3x3_impl(const float* x, const float* wgt, const float* 
         const int look = S == 1 ? g_dw_look : g_dw_look2;                                            \
         if (a_log2) {   /* split rows for the GEMM behind (ReLU6 only: checked above) */           \
             if (A == HSEFR_ACT_RELU6) {                                                             \
-                if (S == 1) hipLaunchKernelGGL((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 0, 4, 1>), grid, block, 0, s, p); \
-                else if (g_dw_variant & 4) hipLaunchKernelGGL((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 2, 2, 1>), grid, block, 0, s, p); \
-                else hipLaunchKernelGGL((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 0, 2, 1>), grid, block, 0, s, p);      \
+                if (S == 1) HSEFR_LAUNCH((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 0, 4, 1>), grid, block, 0, s, p); \
+                else if (g_dw_variant & 4) HSEFR_LAUNCH((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 2, 2, 1>), grid, block, 0, s, p); \
+                else HSEFR_LAUNCH((dwconv3x3_kernel<S, HSEFR_ACT_RELU6, 0, 2, 1>), grid, block, 0, s, p);      \
             }                                                                                       \
             break;                                                                                  \
         }                                                                                           \
-        if (look == 3 && S == 1) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 3>), grid, block, 0, s, p); break; } \
-        if (look == 4) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 4>), grid, block, 0, s, p); break; } \
-        if (look == 5 && S == 1) { hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 5>), grid, block, 0, s, p); break; } \
+        if (look == 3 && S == 1) { HSEFR_LAUNCH((dwconv3x3_kernel<S, A, 0, 3>), grid, block, 0, s, p); break; } \
+        if (look == 4) { HSEFR_LAUNCH((dwconv3x3_kernel<S, A, 0, 4>), grid, block, 0, s, p); break; } \
+        if (look == 5 && S == 1) { HSEFR_LAUNCH((dwconv3x3_kernel<S, A, 0, 5>), grid, block, 0, s, p); break; } \
         switch (g_dw_variant & 3) {                                                                 \
             /* stride 2 (the layer in front of a pointwise GEMM): the output leaves with the non-temporal hint -- in the network the   \
                GEMM behind it runs 5 us faster (57.5 -> 52.3 at 24 x 24 x 128 -> 256) and the layer itself 1-3 us; non-temporal LOADS \
                (variants 1, 3) cost the layer 13 us, the hint on the split-row form (variant bit 2) nothing either way */        \
-            case 0: if (S == 2) hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 2, 2>), grid, block, 0, s, p);                          \
-                    else hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 0, 2>), grid, block, 0, s, p);                                  \
+            case 0: if (S == 2) HSEFR_LAUNCH((dwconv3x3_kernel<S, A, 2, 2>), grid, block, 0, s, p);                          \
+                    else HSEFR_LAUNCH((dwconv3x3_kernel<S, A, 0, 2>), grid, block, 0, s, p);                                  \
                     break;                                                                                                            \
-            case 1: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 1, 2>), grid, block, 0, s, p); break;   \
-            case 2: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 2, 2>), grid, block, 0, s, p); break;   \
-            default: hipLaunchKernelGGL((dwconv3x3_kernel<S, A, 3, 2>), grid, block, 0, s, p); break;  \
+            case 1: HSEFR_LAUNCH((dwconv3x3_kernel<S, A, 1, 2>), grid, block, 0, s, p); break;   \
+            case 2: HSEFR_LAUNCH((dwconv3x3_kernel<S, A, 2, 2>), grid, block, 0, s, p); break;   \
+            default: HSEFR_LAUNCH((dwconv3x3_kernel<S, A, 3, 2>), grid, block, 0, s, p); break;  \
         }                                                                                           \
     } while (0)
     if (stride == 1) {

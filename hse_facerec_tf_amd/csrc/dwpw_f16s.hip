@@ -595,7 +595,7 @@ int launch_t(DwPwSParams& p, int n, int act, hipStream_t s) {
     p.total = (unsigned)total;
     const unsigned cap = 256u * OCC;
     const unsigned g = p.total < cap ? p.total : cap;
-#define HSEFR_DWPWS(A) hipLaunchKernelGGL((dwpw_f16s_kernel<STRIDE, TW, BN, OCC, A>), dim3(g), dim3(256), 0, s, p)
+#define HSEFR_DWPWS(A) HSEFR_LAUNCH((dwpw_f16s_kernel<STRIDE, TW, BN, OCC, A>), dim3(g), dim3(256), 0, s, p)
     if (act == HSEFR_ACT_RELU6) HSEFR_DWPWS(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_DWPWS(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_DWPWS(HSEFR_ACT_NONE);
@@ -628,7 +628,7 @@ int launch_v3(DwPwSParams& p, int n, int act, hipStream_t s) {
     HSEFR_REQUIRE(total * (long long)(p.tiles_n > p.tiles_w ? (p.tiles_n > p.tiles_h ? p.tiles_n : p.tiles_h) : (p.tiles_w > p.tiles_h ? p.tiles_w : p.tiles_h)) < (1ll << 32),
                   HSEFR_ERR_UNSUPPORTED, "dwpw_f16split: grid too large for the quotient multipliers");
     const unsigned g = p.total < 256u ? p.total : 256u;
-#define HSEFR_DWPW3(A) hipLaunchKernelGGL((dwpw3_f16s_kernel<TW, BN, HS, A>), dim3(g), dim3(256 + 64 * (BN == 256 ? 8 : 4)), 0, s, p)
+#define HSEFR_DWPW3(A) HSEFR_LAUNCH((dwpw3_f16s_kernel<TW, BN, HS, A>), dim3(g), dim3(256 + 64 * (BN == 256 ? 8 : 4)), 0, s, p)
     if (act == HSEFR_ACT_RELU6) HSEFR_DWPW3(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_DWPW3(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_DWPW3(HSEFR_ACT_NONE);

@@ -213,7 +213,7 @@ int launch_t(const DwPwParams& p, hipStream_t s) {
     // alternating phases at 4 WG/CU and was retired in round 2; git history has it)
     const unsigned cap = 256u * OCC;
     const unsigned g = p.total < cap ? p.total : cap;
-    hipLaunchKernelGGL((dwpw_fused_kernel<STRIDE, C, BN, OCC>), dim3(g), dim3(256), 0, s, p);
+    HSEFR_LAUNCH((dwpw_fused_kernel<STRIDE, C, BN, OCC>), dim3(g), dim3(256), 0, s, p);
     return launch_status("dwpw_fused");
 }
 

@@ -8,7 +8,13 @@
 // a hipGraph by the caller.
 #include <string.h>
 
+#include <cxxabi.h>
+#include <dlfcn.h>
+#include <elf.h>
+
+#include <map>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -263,7 +269,7 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
         if (o.flags & HSEFR_OPF_HEADS) {
             HSEFR_REQUIRE(i + 3 < h.n_ops, HSEFR_ERR_INVALID, "plan op %u: HEADS needs three ops behind it", i);
             const hsefr_plan_op &a = ops[i + 1], &sm = ops[i + 2], &g = ops[i + 3];
-            HSEFR_REQUIRE(o.kind == HSEFR_OP_DENSE && o.act == HSEFR_ACT_RELU && o.cout == 256 && o.cin % 64 == 0 && o.cin <= 2048 &&
+            HSEFR_REQUIRE(o.kind == HSEFR_OP_DENSE && o.act == HSEFR_ACT_RELU && o.cout == 256 && o.cin > 0 && o.cin % 256 == 0 && o.cin <= 2048 &&
                               o.shift_off != HSEFR_NO_OFFSET && a.kind == HSEFR_OP_DENSE && a.act == HSEFR_ACT_NONE && a.cin == 256 && a.cout >= 1 &&
                               a.cout <= 128 && a.in_buf == o.out_buf && a.shift_off != HSEFR_NO_OFFSET && sm.kind == HSEFR_OP_SOFTMAX &&
                               sm.in_buf == a.out_buf && sm.cout == a.cout && g.kind == HSEFR_OP_DENSE && g.act == HSEFR_ACT_SIGMOID && g.cin == 256 &&
@@ -316,6 +322,68 @@ int read_stem_stamps(void* host_out, size_t bytes) {
     return HSEFR_ERR_UNSUPPORTED;
 }
 #endif
+// ---- route probe (common.h HSEFR_LAUNCH) ----
+static thread_local std::string* g_route_sink = nullptr;
+bool route_probe() { return g_route_sink != nullptr; }
+// kernel handle address -> demangled kernel name with its template arguments, from the library's OWN symbol table (the handles are local
+// symbols: hidden visibility, anonymous namespaces -- dladdr does not see them, .symtab does); built once, on the first describe
+static const std::map<uintptr_t, std::string>& stub_names() {
+    static const std::map<uintptr_t, std::string> table = [] {
+        std::map<uintptr_t, std::string> m;
+        Dl_info info;
+        if (!dladdr(reinterpret_cast<const void*>(&stub_names), &info) || !info.dli_fname) return m;
+        FILE* f = fopen(info.dli_fname, "rb");
+        if (!f) return m;
+        std::vector<unsigned char> img;
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (sz > 0) { img.resize((size_t)sz); if (fread(img.data(), 1, img.size(), f) != img.size()) img.clear(); }
+        fclose(f);
+        if (img.size() < sizeof(Elf64_Ehdr)) return m;
+        const Elf64_Ehdr* eh = reinterpret_cast<const Elf64_Ehdr*>(img.data());
+        if (memcmp(eh->e_ident, ELFMAG, SELFMAG) != 0 || eh->e_shentsize != sizeof(Elf64_Shdr) ||
+            eh->e_shoff + (uint64_t)eh->e_shnum * sizeof(Elf64_Shdr) > img.size()) return m;
+        const Elf64_Shdr* sh = reinterpret_cast<const Elf64_Shdr*>(img.data() + eh->e_shoff);
+        for (int i = 0; i < eh->e_shnum; ++i) {
+            if (sh[i].sh_type != SHT_SYMTAB || sh[i].sh_link >= eh->e_shnum) continue;
+            const Elf64_Shdr& st = sh[sh[i].sh_link];
+            if (sh[i].sh_offset + sh[i].sh_size > img.size() || st.sh_offset + st.sh_size > img.size()) continue;
+            const Elf64_Sym* sym = reinterpret_cast<const Elf64_Sym*>(img.data() + sh[i].sh_offset);
+            const char* str = reinterpret_cast<const char*>(img.data() + st.sh_offset);
+            for (size_t k = 0; k < sh[i].sh_size / sizeof(Elf64_Sym); ++k) {
+                // (a kernel's host-side HANDLE -- what `&kernel` evaluates to in host code -- is a data symbol with the kernel's own mangled name)
+                if (ELF64_ST_TYPE(sym[k].st_info) != STT_OBJECT || sym[k].st_name >= st.sh_size) continue;
+                const char* nm = str + sym[k].st_name;
+                if (strncmp(nm, "_ZN5hsefr", 9) != 0 || !strstr(nm, "_kernel")) continue;
+                int status = 0;
+                char* dm = abi::__cxa_demangle(nm, nullptr, nullptr, &status);
+                std::string t = (status == 0 && dm) ? dm : nm;
+                free(dm);
+                size_t cut = std::string::npos, depth = 0;
+                for (size_t q = 0; q < t.size(); ++q) {       // the '(' that opens the parameter list: the first one outside <...> after the name
+                    if (t[q] == '<') ++depth;
+                    else if (t[q] == '>') --depth;
+                    else if (t[q] == '(' && depth == 0 && q > 0 && t.compare(q, 21, "(anonymous namespace)") != 0) { cut = q; break; }
+                }
+                if (cut != std::string::npos) t.erase(cut);
+                for (const char* ns : {"void ", "hsefr::", "(anonymous namespace)::", "__device_stub__"})
+                    for (size_t q; (q = t.find(ns)) != std::string::npos;) t.erase(q, strlen(ns));
+                m[(uintptr_t)info.dli_fbase + sym[k].st_value] = t;
+            }
+        }
+        return m;
+    }();
+    return table;
+}
+void route_record(const void* host_stub, const char* expr) {
+    if (!g_route_sink) return;
+    const auto& tab = stub_names();
+    const auto it = tab.find((uintptr_t)host_stub);
+    std::string t = it != tab.end() ? it->second : std::string(expr ? expr : "?");
+    if (!g_route_sink->empty() && g_route_sink->back() != '\t') *g_route_sink += " + ";
+    *g_route_sink += t;
+}
 static thread_local int g_sweep_reverse = 0;    // set per op by the forward running on THIS host thread, read by its launchers
 int sweep_reverse() { return g_sweep_reverse; }
 void set_sweep_reverse(int v) { g_sweep_reverse = v; }
@@ -356,6 +424,8 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "stem5_grid")) { set_stem5_grid(value); return HSEFR_OK; }
     if (!strcmp(key, "stem5_segs")) { set_stem5_segs(value); return HSEFR_OK; }
     if (!strcmp(key, "pair_off")) { set_pair_off(value); return HSEFR_OK; }
+    if (!strcmp(key, "pair_ablate")) { set_pair_ablate(value); return HSEFR_OK; }
+    if (!strcmp(key, "pair_nt")) { set_pair_nt(value); return HSEFR_OK; }
     if (!strcmp(key, "heads_off")) { g_heads_off = value; return HSEFR_OK; }
     if (!strcmp(key, "dw_look")) { set_dw_look(value); return HSEFR_OK; }
     if (!strcmp(key, "dw_look2")) { set_dw_look2(value); return HSEFR_OK; }
@@ -523,6 +593,7 @@ int hsefr_engine_op_times_ms(hsefr_engine* e, int slot, float* ms, int n_ops) {
 static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d_input, int n, const std::vector<char>& needed,
                    hipStream_t s, hipEvent_t* pev, bool input_u8 = false) {
     const bool prof = pev != nullptr;
+    unsigned launches = 0;     // (a launch that covers several ops -- hsefr_op_flags -- counts once: the op behind it must still sweep the other way)
     if (prof) HSEFR_HIP_CHECK(hipEventRecord(pev[0], s));
     for (size_t i = 0; i < e->ops.size(); ++i) {
         const hsefr_plan_op& o = e->ops[i];
@@ -534,7 +605,7 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
         void* out = buf_ptr(tab, o.out_buf, d_input);
         int rc = HSEFR_OK;
         size_t covered = 0;       // ops behind this one that its launch computes as well (hsefr_op_flags)
-        set_sweep_reverse(g_sweep_alternate ? (int)(i & 1) : 0);   // consecutive layers sweep in opposite directions (common.h)
+        set_sweep_reverse(g_sweep_alternate ? (int)(launches++ & 1) : 0);   // consecutive LAUNCHES sweep in opposite directions (common.h)
         if ((o.flags & HSEFR_OPF_PAIR_NEXT) && needed[i + 1] && conv1x1_pair_bf16_supported((long long)n * o.oh * o.ow, o.cin, o.cout, e->ops[i + 1].cout,
                                                                                            o.w2_off != HSEFR_NO_OFFSET ? (o.reserved & 0xFFF) : 0)) {
             // increase (+ residual | + projected shortcut) -> the next block's reduce in one launch (csrc/conv1x1_pair_bf16.hip; the pattern
@@ -829,6 +900,44 @@ static int engine_forward(hsefr_engine* e, const void* d_input, bool input_u8, i
                                                hipMemcpyDeviceToDevice, s));
     }
     if (prof) e->prof_calls++;
+    return HSEFR_OK;
+}
+
+int hsefr_plan_describe(const void* plan, size_t plan_bytes, int n, char* out, size_t out_bytes) {
+    HSEFR_REQUIRE(out && out_bytes > 0 && n > 0, HSEFR_ERR_INVALID, "plan_describe: bad argument");
+    out[0] = 0;
+    hsefr_engine e;                      // tables only: no device memory, no HIP call (the probe keeps every launcher off the device)
+    const char* blob = nullptr;
+    int rc = check_plan_blob(plan, plan_bytes, e.hdr, e.bufs, e.ops, blob);
+    if (rc != HSEFR_OK) return rc;
+    e.max_batch = n;
+    // stand-in addresses (never dereferenced: nothing is launched): distinct, 16-byte aligned, non-null
+    e.d_blob = reinterpret_cast<char*>(uintptr_t(1) << 40);
+    e.d_overflow = reinterpret_cast<int*>(uintptr_t(1) << 39);
+    e.d_bufs.resize(e.hdr.n_buffers);
+    for (uint32_t i = 0; i < e.hdr.n_buffers; ++i) e.d_bufs[i] = reinterpret_cast<void*>((uintptr_t(2) << 40) + (uintptr_t(i) << 32));
+    std::string text;
+    std::vector<char> only(e.ops.size(), 0);
+    for (size_t i = 0; i < e.ops.size(); ++i) {
+        // op i alone, then with the ops its flags cover (a flagged op's launch needs them `needed`)
+        std::fill(only.begin(), only.end(), 0);
+        only[i] = 1;
+        const size_t span = (e.ops[i].flags & HSEFR_OPF_PAIR_NEXT) ? 1 : (e.ops[i].flags & HSEFR_OPF_HEADS) ? 3 : 0;
+        for (size_t k = 1; k <= span && i + k < e.ops.size(); ++k) only[i + k] = 1;
+        std::string line = std::to_string(i) + "\t" + std::to_string(e.ops[i].kind) + "\t";
+        g_route_sink = &line;
+        rc = run_ops(&e, e.d_bufs, reinterpret_cast<const void*>(uintptr_t(3) << 40), n, only, nullptr, nullptr,
+                     false);
+        g_route_sink = nullptr;
+        if (rc != HSEFR_OK) { e.d_blob = nullptr; e.d_overflow = nullptr; e.d_bufs.clear(); return rc; }
+        text += line + "\n";
+        for (size_t k = 1; k <= span && i + k < e.ops.size(); ++k)
+            text += std::to_string(i + k) + "\t" + std::to_string(e.ops[i + k].kind) + "\t(inside op " + std::to_string(i) + ")\n";
+        i += span;
+    }
+    e.d_blob = nullptr; e.d_overflow = nullptr; e.d_bufs.clear();     // (stand-ins: nothing to free)
+    HSEFR_REQUIRE(text.size() + 1 <= out_bytes, HSEFR_ERR_INVALID, "plan_describe: the table needs %zu bytes, the buffer holds %zu", text.size() + 1, out_bytes);
+    memcpy(out, text.c_str(), text.size() + 1);
     return HSEFR_OK;
 }
 

@@ -32,6 +32,11 @@ static void run_one(const void* blob, size_t bytes, const char* what) {
     int rc = hsefr_plan_validate(blob, bytes);
     if (rc == HSEFR_OK) {
         ++n_ok;
+        // the launch wrappers' host side (shape checks, tile choices, grid arithmetic) on the mutant's shapes: every launcher runs with the
+        // launch suppressed (hsefr_plan_describe) -- HSEFR_OK or a status with a message
+        static char table[1 << 18];
+        const int rd = hsefr_plan_describe(blob, bytes, 4, table, sizeof(table));
+        if (rd != HSEFR_OK && !hsefr_last_error_string()[0]) { ++n_silent; fprintf(stderr, "no message for status %d (%s, plan_describe)\n", rd, what); }
         hsefr_engine* e = nullptr;
         rc = hsefr_engine_create(blob, bytes, 4, &e);       // valid: goes on to the device (none here: HSEFR_ERR_HIP / NOMEM) or succeeds
         if (rc == HSEFR_OK) hsefr_engine_destroy(e);

@@ -300,13 +300,13 @@ int launch_mtcnn_stage1_level(const float* prob, const float* reg, int w, int h,
                               hipStream_t s) {
     HSEFR_REQUIRE(w > 0 && h > 0 && scale > 0 && (long long)w * h < (1ll << 31), HSEFR_ERR_INVALID, "mtcnn_stage1_level: bad map %dx%d", w, h);
     if (int rc = set_lds(stage1_level_kernel)) return rc;
-    hipLaunchKernelGGL(stage1_level_kernel, dim3(1), dim3(NT), sizeof(PostLds), s, prob, reg, w, h, scale, thr, found, counters);
+    HSEFR_LAUNCH(stage1_level_kernel, dim3(1), dim3(NT), sizeof(PostLds), s, prob, reg, w, h, scale, thr, found, counters);
     return launch_status("mtcnn_stage1_level");
 }
 
 int launch_mtcnn_stage1_finish(const double* found, int* counters, double* boxes, int* tab, int img_w, int img_h, hipStream_t s) {
     if (int rc = set_lds(stage1_finish_kernel)) return rc;
-    hipLaunchKernelGGL(stage1_finish_kernel, dim3(1), dim3(NT), sizeof(PostLds), s, found, counters, boxes, tab, img_w, img_h);
+    HSEFR_LAUNCH(stage1_finish_kernel, dim3(1), dim3(NT), sizeof(PostLds), s, found, counters, boxes, tab, img_w, img_h);
     return launch_status("mtcnn_stage1_finish");
 }
 
@@ -315,11 +315,11 @@ int launch_mtcnn_stage23_finish(int stage, const double* boxes_in, int n, const 
     HSEFR_REQUIRE((stage == 2 || stage == 3) && n >= 0, HSEFR_ERR_INVALID, "mtcnn_stage_finish: stage %d, n %d", stage, n);
     if (stage == 2) {
         if (int rc = set_lds(stage23_finish_kernel<2>)) return rc;
-        hipLaunchKernelGGL(stage23_finish_kernel<2>, dim3(1), dim3(NT), sizeof(PostLds), s, boxes_in, n, prob, reg, pts, thr, boxes_out, tab_out,
+        HSEFR_LAUNCH(stage23_finish_kernel<2>, dim3(1), dim3(NT), sizeof(PostLds), s, boxes_in, n, prob, reg, pts, thr, boxes_out, tab_out,
                            points_out, counters, img_w, img_h);
     } else {
         if (int rc = set_lds(stage23_finish_kernel<3>)) return rc;
-        hipLaunchKernelGGL(stage23_finish_kernel<3>, dim3(1), dim3(NT), sizeof(PostLds), s, boxes_in, n, prob, reg, pts, thr, boxes_out, tab_out,
+        HSEFR_LAUNCH(stage23_finish_kernel<3>, dim3(1), dim3(NT), sizeof(PostLds), s, boxes_in, n, prob, reg, pts, thr, boxes_out, tab_out,
                            points_out, counters, img_w, img_h);
     }
     return launch_status("mtcnn_stage_finish");
@@ -328,7 +328,7 @@ int launch_mtcnn_stage23_finish(int stage, const double* boxes_in, int n, const 
 int launch_mtcnn_nms(const double* boxes, int n, double thr, int use_min, int* keep, int* n_keep, hipStream_t s) {
     HSEFR_REQUIRE(n >= 0 && n <= CAP, HSEFR_ERR_UNSUPPORTED, "mtcnn_nms: %d boxes (capacity %d)", n, CAP);
     if (int rc = set_lds(nms_kernel)) return rc;
-    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(NT), sizeof(PostLds), s, boxes, n, thr, use_min, keep, n_keep);
+    HSEFR_LAUNCH(nms_kernel, dim3(1), dim3(NT), sizeof(PostLds), s, boxes, n, thr, use_min, keep, n_keep);
     return launch_status("mtcnn_nms");
 }
 

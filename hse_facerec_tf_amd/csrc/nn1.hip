@@ -267,7 +267,7 @@ int launch_pairwise_dist(const float* x, const float* y, int n, int m, int d, fl
     HSEFR_REQUIRE(n >= 0 && m >= 0, HSEFR_ERR_INVALID, "pairwise_dist: bad shape");
     if (n == 0 || m == 0) return HSEFR_OK;
     dim3 grid((m + 63) / 64, (n + 63) / 64), block(256);
-    hipLaunchKernelGGL(pairwise_dist_kernel, grid, block, 0, s, x, y, n, m, d, out, x == y ? 1 : 0);
+    HSEFR_LAUNCH(pairwise_dist_kernel, grid, block, 0, s, x, y, n, m, d, out, x == y ? 1 : 0);
     return launch_status("pairwise_dist");
 }
 
@@ -275,7 +275,7 @@ int launch_l2_normalize(const float* x, float* y, int n, int d, hipStream_t s) {
     HSEFR_REQUIRE(n >= 0 && d > 0, HSEFR_ERR_INVALID, "l2_normalize: bad shape");
     if (n == 0) return HSEFR_OK;
     dim3 grid((n + 3) / 4), block(256);
-    hipLaunchKernelGGL(l2_normalize_kernel, grid, block, 0, s, x, y, n, d);
+    HSEFR_LAUNCH(l2_normalize_kernel, grid, block, 0, s, x, y, n, d);
     return launch_status("l2_normalize");
 }
 
@@ -324,17 +324,17 @@ int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_in
             int rc = HSEFR_OK;
             if (hipMemsetAsync(qmax, 0, 4, s) != hipSuccess) rc = HSEFR_ERR_HIP;
             if (rc == HSEFR_OK) {
-                hipLaunchKernelGGL(nn1_prep_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, q, nq, d, qq, qmax);
-                hipLaunchKernelGGL(nn1_split_gallery_kernel, dim3((ng_pad + 3) / 4), dim3(256), 0, s, g, ng, ng_pad, d, w, descale, shift, qmax);
+                HSEFR_LAUNCH(nn1_prep_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, q, nq, d, qq, qmax);
+                HSEFR_LAUNCH(nn1_split_gallery_kernel, dim3((ng_pad + 3) / 4), dim3(256), 0, s, g, ng, ng_pad, d, w, descale, shift, qmax);
                 const long long n4 = (long long)nq * d / 4;
-                hipLaunchKernelGGL(nn1_scale_queries_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, q, qs, n4, qmax);
+                HSEFR_LAUNCH(nn1_scale_queries_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, q, qs, n4, qmax);
                 rc = launch_status("nn1 (split-f16 preparation)");
             }
             for (int q0 = 0; q0 < nq && rc == HSEFR_OK; q0 += qb) {
                 const int m = nq - q0 < qb ? nq - q0 : qb;
                 rc = launch_pwconv_f16s(qs + (size_t)q0 * d, w, descale, shift, y, m, d, ng_pad, 12, HSEFR_ACT_NONE, s);
                 if (rc == HSEFR_OK) {
-                    hipLaunchKernelGGL(nn1_row_argmin_kernel, dim3((m + 3) / 4), dim3(256), 0, s, y, m, ng, ng_pad, qq + q0, nn_index + q0,
+                    HSEFR_LAUNCH(nn1_row_argmin_kernel, dim3((m + 3) / 4), dim3(256), 0, s, y, m, ng, ng_pad, qq + q0, nn_index + q0,
                                        nn_dist2 ? nn_dist2 + q0 : nullptr);
                     rc = launch_status("nn1 (row arg-min)");
                 }
@@ -350,7 +350,7 @@ int launch_nn1(const float* q, const float* g, int nq, int ng, int d, int* nn_in
                   b_qs + b_w + b_y + b_small, nq, ng, d);
     }
     dim3 grid((nq + 31) / 32), block(256);
-    hipLaunchKernelGGL(nn1_kernel, grid, block, 0, s, q, g, nq, ng, d, nn_index, nn_dist2);
+    HSEFR_LAUNCH(nn1_kernel, grid, block, 0, s, q, g, nq, ng, d, nn_index, nn_dist2);
     return launch_status("nn1");
 }
 

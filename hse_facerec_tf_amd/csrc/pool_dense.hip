@@ -171,44 +171,24 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ 
 
 // ---- the age / gender heads in one launch (round 6) -------------------------------------------------------------------------------
 // feats (k -> 256, ReLU), age_pred (256 -> a) + softmax, gender_pred (256 -> 1) + sigmoid: four launches of 0.58 MFLOP per image -- 63 us
-// of the 3.2 ms batch-512 step (profiles/r05_agegender_layers.txt), most of it the LATENCY of dense_kernel's weight loads (sixteen in
-// flight, then 128 FMAs, then the next sixteen: 16 round trips per wave for k = 1024).  One workgroup = HR rows of x and ALL columns of
-// every head: sixteen waves = 4 column groups x 4 slices of k for the hidden layer (dense_kernel's own split: the partial sums meet in
-// LDS and are added in slice order, so `hidden` has dense_kernel's bits), the NEXT sixteen weights requested before the current
-// sixteen are used; then waves 0-7 run the age logits (2 column groups x 4 slices of 64) and waves 8-11 the gender logit from the
-// hidden rows in LDS, and waves 0..HR-1 softmax_kernel's row code.  hidden and logits are written too (per-layer tests read them).
-constexpr int HR = 4, HID = 256;
-__device__ __forceinline__ void dense_slice(const float* __restrict__ xs, int xpitch, const float* __restrict__ w, int cout, int col, int k0, int k1,
-                                            float (&acc)[HR]) {
-    // dense_kernel's inner loop for a slice whose length is a multiple of 16: the same fmaf nest in the same order
-    float wv[16], wn[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) wv[u] = w[(size_t)(k0 + u) * cout + col];
-    for (int kk = k0; kk < k1; kk += 16) {
-        const bool more = kk + 16 < k1;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) wn[u] = more ? w[(size_t)(kk + 16 + u) * cout + col] : 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int r = 0; r < HR; ++r) {
-                const float4 xv = *(const float4*)(xs + r * xpitch + kk + 4 * g);
-                acc[r] = fmaf(xv.w, wv[4 * g + 3], fmaf(xv.z, wv[4 * g + 2], fmaf(xv.y, wv[4 * g + 1], fmaf(xv.x, wv[4 * g], acc[r]))));
-            }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) wv[u] = wn[u];
-    }
-}
-
+// of the 3.2 ms batch-512 step (profiles/r05_agegender_layers.txt).  What they cost is the way dense_kernel reads its weights: a dword
+// per lane and k (256 bytes per wave instruction), 1 MB of w1 per 8 rows, 17 B/clk of the CU's vector-memory path.  (Measured first: the
+// same reads with all four heads in one workgroup and 16 or 64 weights in flight per lane -- 33 us either way, 49 with 8 rows per
+// workgroup: not latency, instruction count.)  Here a lane owns FOUR ADJACENT COLUMNS -- one 16-byte load per k, a wave instruction moves
+// a whole 1 KiB row of w1 -- and the sixteen waves of a workgroup split k sixteen ways for all 256 columns; the partial sums meet in LDS
+// and are added in slice order (fixed: bit-identical run to run and independent of the batch; another summation order than
+// dense_kernel's four slices, same fp32 grade).  hidden and logits are written too (per-layer tests read them).
+constexpr int HR = 4, HID = 256, HW = 16;        // rows per workgroup, hidden width, waves = slices of k
 __global__ __launch_bounds__(1024) void heads_kernel(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
                                                      const float* __restrict__ wa, const float* __restrict__ ba, const float* __restrict__ wg,
                                                      const float* __restrict__ bg, float* __restrict__ hidden, float* __restrict__ logits,
                                                      float* __restrict__ probs, float* __restrict__ gender, int n, int k, int a) {
-    extern __shared__ __attribute__((aligned(16))) float hs[];   // xs [HR][k] | part [4][HR][HID] | hid [HR][HID] | lg [HR][128]
+    extern __shared__ __attribute__((aligned(16))) float hs[];   // xs [HR][k] | part [HW][HR][HID] | hid [HR][HID] | lg [HR][128] | pg [HW][HR]
     float* xs = hs;
     float* part = xs + HR * k;
-    float* hid = part + 4 * HR * HID;
+    float* hid = part + HW * HR * HID;
     float* lg = hid + HR * HID;
+    float* pg = lg + HR * 128;
     const int r0 = blockIdx.x * HR;
     const int rows = min(HR, n - r0);
     {
@@ -218,50 +198,87 @@ __global__ __launch_bounds__(1024) void heads_kernel(const float* __restrict__ x
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    {   // hidden: column group cg (64 columns), slice ks of k (a quarter)
-        const int cg = wave & 3, ks = wave >> 2, kq = k >> 2;
-        float acc[HR];
+    {   // hidden: slice `wave` of k, columns 4 lane .. 4 lane + 3
+        const int ks = k / HW, k0 = wave * ks;
+        float4 acc[HR];
 #pragma unroll
-        for (int r = 0; r < HR; ++r) acc[r] = 0.f;
-        dense_slice(xs, k, w1, HID, cg * 64 + lane, ks * kq, ks * kq + kq, acc);
+        for (int r = 0; r < HR; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* wq = (const float4*)w1 + lane;              // row kk: wq[kk * 64]
+        for (int kk = k0; kk < k0 + ks; kk += 8) {              // eight 1-KiB rows of w1 in flight per wave, sixteen waves per CU
+            float4 wv[8];
 #pragma unroll
-        for (int r = 0; r < HR; ++r) part[(ks * HR + r) * HID + cg * 64 + lane] = acc[r];
+            for (int u = 0; u < 8; ++u) wv[u] = wq[(size_t)(kk + u) * 64];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < HR; ++r) {
+                    const float4 xv = *(const float4*)(xs + r * k + kk + 4 * g);
+                    const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 w = wv[4 * g + e];
+                        acc[r].x = fmaf(xe[e], w.x, acc[r].x);
+                        acc[r].y = fmaf(xe[e], w.y, acc[r].y);
+                        acc[r].z = fmaf(xe[e], w.z, acc[r].z);
+                        acc[r].w = fmaf(xe[e], w.w, acc[r].w);
+                    }
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < HR; ++r) *(float4*)(part + (wave * HR + r) * HID + 4 * lane) = acc[r];
     }
     __syncthreads();
     {
         const int r = threadIdx.x >> 8, c = threadIdx.x & 255;     // HR * HID = 1024 values, one per thread
-        const float sum = ((part[(0 * HR + r) * HID + c] + part[(1 * HR + r) * HID + c]) + part[(2 * HR + r) * HID + c]) + part[(3 * HR + r) * HID + c];
+        float sum = part[r * HID + c];
+#pragma unroll
+        for (int w = 1; w < HW; ++w) sum += part[(w * HR + r) * HID + c];
         const float v = fmaxf(sum + b1[c], 0.f);
         hid[r * HID + c] = v;
         if (r < rows) hidden[(size_t)(r0 + r) * HID + c] = v;
     }
     __syncthreads();
-    if (wave < 12) {
-        // age logits: waves 0-7 = 2 column groups x 4 slices of 64; gender logit: waves 8-11 = 4 slices, column 0
-        const bool age = wave < 8;
-        const int cg = age ? (wave & 1) : 0, ks = age ? (wave >> 1) : wave - 8;
-        const int cout = age ? a : 1, col = cg * 64 + lane;
-        float acc[HR];
+    {   // age logits (columns lane, lane + 64) and the gender logit: slice `wave` of the 256 hidden values (16 each)
+        const int k0 = wave * (HID / HW);
+        float acc0[HR], acc1[HR], accg[HR];
 #pragma unroll
-        for (int r = 0; r < HR; ++r) acc[r] = 0.f;
-        if (col < cout) dense_slice(hid, HID, age ? wa : wg, cout, col, ks * 64, ks * 64 + 64, acc);
-        float* pp = part + (age ? 0 : 4 * HR * 128);
+        for (int r = 0; r < HR; ++r) acc0[r] = acc1[r] = accg[r] = 0.f;
+        const int c0 = lane, c1 = lane + 64;
 #pragma unroll
-        for (int r = 0; r < HR; ++r) pp[(ks * HR + r) * 128 + col] = acc[r];
+        for (int u = 0; u < HID / HW; ++u) {
+            const float w0 = c0 < a ? wa[(size_t)(k0 + u) * a + c0] : 0.f, w1v = c1 < a ? wa[(size_t)(k0 + u) * a + c1] : 0.f;
+            const float wgv = wg[k0 + u];
+#pragma unroll
+            for (int r = 0; r < HR; ++r) {
+                const float h = hid[r * HID + k0 + u];
+                acc0[r] = fmaf(h, w0, acc0[r]);
+                acc1[r] = fmaf(h, w1v, acc1[r]);
+                accg[r] = fmaf(h, wgv, accg[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+            part[(wave * HR + r) * 128 + c0] = acc0[r];
+            part[(wave * HR + r) * 128 + c1] = acc1[r];
+            if (lane == 0) pg[wave * HR + r] = accg[r];
+        }
     }
     __syncthreads();
     if (threadIdx.x < HR * 128) {
         const int r = threadIdx.x >> 7, c = threadIdx.x & 127;
         if (c < a) {
-            const float sum = ((part[(0 * HR + r) * 128 + c] + part[(1 * HR + r) * 128 + c]) + part[(2 * HR + r) * 128 + c]) + part[(3 * HR + r) * 128 + c];
+            float sum = part[r * 128 + c];
+#pragma unroll
+            for (int w = 1; w < HW; ++w) sum += part[(w * HR + r) * 128 + c];
             const float v = sum + ba[c];
             lg[r * 128 + c] = v;
             if (r < rows) logits[(size_t)(r0 + r) * a + c] = v;
         }
     } else if (threadIdx.x < HR * 128 + HR) {
         const int r = threadIdx.x - HR * 128;
-        const float* pg = part + 4 * HR * 128;
-        const float sum = ((pg[(0 * HR + r) * 128] + pg[(1 * HR + r) * 128]) + pg[(2 * HR + r) * 128]) + pg[(3 * HR + r) * 128];
+        float sum = pg[r];
+#pragma unroll
+        for (int w = 1; w < HW; ++w) sum += pg[w * HR + r];
         if (r < rows) gender[r0 + r] = apply_act_rt(sum + bg[0], HSEFR_ACT_SIGMOID);
     }
     __syncthreads();
@@ -300,7 +317,7 @@ int launch_gap(const float* x, float* y, int n, int hw, int c, hipStream_t s) {
     const int c4 = c / 4;
     const long long waves = (long long)n * ((c4 + 15) / 16);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    hipLaunchKernelGGL(gap_kernel, grid, block, 0, s, (const float4*)x, (float4*)y, n, hw, c4);
+    HSEFR_LAUNCH(gap_kernel, grid, block, 0, s, (const float4*)x, (float4*)y, n, hw, c4);
     return launch_status("gap");
 }
 
@@ -311,7 +328,7 @@ int launch_dense(const float* x, const float* wgt, const float* bias, float* y, 
     if (n == 0) return HSEFR_OK;
     dim3 grid((n + DR - 1) / DR, (cout + DCOLS - 1) / DCOLS), block(256);
     const size_t lds = ((size_t)DR * k + 4 * DR * DCOLS) * sizeof(float);
-    hipLaunchKernelGGL(dense_kernel, grid, block, lds, s, x, wgt, bias, y, n, k, cout, act);
+    HSEFR_LAUNCH(dense_kernel, grid, block, lds, s, x, wgt, bias, y, n, k, cout, act);
     return launch_status("dense");
 }
 
@@ -320,17 +337,17 @@ int launch_softmax(const float* x, float* y, int n, int c, hipStream_t s) {
     HSEFR_REQUIRE(n >= 0, HSEFR_ERR_INVALID, "softmax: n=%d", n);
     if (n == 0) return HSEFR_OK;
     dim3 grid((n + 3) / 4), block(256);
-    hipLaunchKernelGGL(softmax_kernel, grid, block, 0, s, x, y, n, c);
+    HSEFR_LAUNCH(softmax_kernel, grid, block, 0, s, x, y, n, c);
     return launch_status("softmax");
 }
 
 int launch_heads_fused(const float* x, const float* w1, const float* b1, const float* wa, const float* ba, const float* wg, const float* bg,
                        float* hidden, float* logits, float* age_probs, float* gender, int n, int k, int a, hipStream_t s) {
-    HSEFR_REQUIRE(k > 0 && k % 64 == 0 && k <= 2048 && a >= 1 && a <= 128, HSEFR_ERR_UNSUPPORTED, "heads_fused: k=%d a=%d (k %% 64 == 0, k <= 2048, a <= 128)", k, a);
+    HSEFR_REQUIRE(k > 0 && k % 256 == 0 && k <= 2048 && a >= 1 && a <= 128, HSEFR_ERR_UNSUPPORTED, "heads_fused: k=%d a=%d (k %% 256 == 0, k <= 2048, a <= 128)", k, a);
     HSEFR_REQUIRE(n >= 0, HSEFR_ERR_INVALID, "heads_fused: n=%d", n);
     if (n == 0) return HSEFR_OK;
-    const size_t lds = ((size_t)HR * k + 4 * HR * HID + HR * HID + HR * 128) * sizeof(float);
-    hipLaunchKernelGGL(heads_kernel, dim3((n + HR - 1) / HR), dim3(1024), lds, s, x, w1, b1, wa, ba, wg, bg, hidden, logits, age_probs, gender, n, k, a);
+    const size_t lds = ((size_t)HR * k + HW * HR * HID + HR * HID + HR * 128 + HW * HR) * sizeof(float);
+    HSEFR_LAUNCH(heads_kernel, dim3((n + HR - 1) / HR), dim3(1024), lds, s, x, w1, b1, wa, ba, wg, bg, hidden, logits, age_probs, gender, n, k, a);
     return launch_status("heads_fused");
 }
 

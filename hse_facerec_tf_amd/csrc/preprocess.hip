@@ -292,7 +292,7 @@ int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, i
         const int bands = (oh + TB - 1) / TB;
         if (lds_bytes <= 64 * 1024 && (long long)n * bands < (1ll << 31)) {
 #define HSEFR_BAND(K)                                                                                                                 \
-    hipLaunchKernelGGL(pil_resize_u8_band_kernel<K>, dim3((unsigned)(n * bands)), dim3(256), lds_bytes, s, in, (unsigned*)out, xmin, \
+    HSEFR_LAUNCH(pil_resize_u8_band_kernel<K>, dim3((unsigned)(n * bands)), dim3(256), lds_bytes, s, in, (unsigned*)out, xmin, \
                        xcoef, xk, ymin, ycnt, ycoef, yk, H, W, oh, ow, TB, cap, bands, (long long)n * H * W * 3, (int)lin_bytes)
             if (kk <= 3) HSEFR_BAND(3);
             else if (kk <= 5) HSEFR_BAND(5);
@@ -301,8 +301,8 @@ int launch_pil_resize(const unsigned char* in, unsigned char* tmp, float* out, i
             return launch_status("pil_resize_fused");
         }
     }
-    hipLaunchKernelGGL(pil_resample_h_kernel, dim3(blocks_for(t1)), dim3(256), 0, s, in, tmp, xmin, xcnt, xcoef, xk, H, W, ow, t1);
-    hipLaunchKernelGGL(pil_resample_v_kernel, dim3(blocks_for(t2)), dim3(256), 0, s, tmp, out, ymin, ycnt, ycoef, yk, H, oh, ow, t2,
+    HSEFR_LAUNCH(pil_resample_h_kernel, dim3(blocks_for(t1)), dim3(256), 0, s, in, tmp, xmin, xcnt, xcoef, xk, H, W, ow, t1);
+    HSEFR_LAUNCH(pil_resample_v_kernel, dim3(blocks_for(t2)), dim3(256), 0, s, tmp, out, ymin, ycnt, ycoef, yk, H, oh, ow, t2,
                        mode, (float)mean[0], (float)mean[1], (float)mean[2], mean[0], mean[1], mean[2]);
     return launch_status("pil_resize");
 }
@@ -314,10 +314,10 @@ int launch_cv_resize(const unsigned char* in, float* out, int n, int H, int W, i
     if (n == 0) return HSEFR_OK;
     const long long t = (long long)n * oh * ow;
     if (H == oh && W == ow)
-        hipLaunchKernelGGL(u8_to_input_kernel, dim3(blocks_for(t)), dim3(256), 0, s, in, out, t, mode, (float)mean[0], (float)mean[1],
+        HSEFR_LAUNCH(u8_to_input_kernel, dim3(blocks_for(t)), dim3(256), 0, s, in, out, t, mode, (float)mean[0], (float)mean[1],
                            (float)mean[2], mean[0], mean[1], mean[2]);
     else
-        hipLaunchKernelGGL(cv_resize_linear_kernel, dim3(blocks_for(t)), dim3(256), 0, s, in, out, x0, x1, wx1, y0, y1, wy1, H, W, oh,
+        HSEFR_LAUNCH(cv_resize_linear_kernel, dim3(blocks_for(t)), dim3(256), 0, s, in, out, x0, x1, wx1, y0, y1, wy1, H, W, oh,
                            ow, t, mode, (float)mean[0], (float)mean[1], (float)mean[2], mean[0], mean[1], mean[2]);
     return launch_status("cv_resize");
 }

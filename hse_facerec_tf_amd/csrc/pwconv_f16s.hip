@@ -342,7 +342,7 @@ int launch_cfg(const float* x, const void* wsplit, const float* descale, const f
     const long long g = total < 256ll * OCC ? total : 256ll * OCC;
     dim3 grid((unsigned)g), block(128 * WAVES_N);
 #define HSEFR_PWS_LAUNCH(A)                                                                                         \
-    hipLaunchKernelGGL((pwconv_f16s_kernel<BM, BN, WAVES_N, OCC, A>), grid, block, 0, s, x, (const float*)wsplit, descale, shift, \
+    HSEFR_LAUNCH((pwconv_f16s_kernel<BM, BN, WAVES_N, OCC, A>), grid, block, 0, s, x, (const float*)wsplit, descale, shift, \
                        y, m, k, cout, a_scale, tiles_n, (unsigned)total, sweep_reverse())
     if (act == HSEFR_ACT_RELU6) HSEFR_PWS_LAUNCH(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_PWS_LAUNCH(HSEFR_ACT_RELU);

@@ -396,10 +396,10 @@ int launch_cfg(const float* x, const float* wt, const float* shift, float* y, lo
 #define HSEFR_PW_LAUNCH(A)                                                                                          \
     do {                                                                                                            \
         if (g_pw_dma && !g_pw_ablate)                                                                               \
-            hipLaunchKernelGGL((pwconv_f32_dma_kernel<BM, BN, OCC, A>), grid, block, 0, s, x, wt, shift, y, m, k, cout, \
+            HSEFR_LAUNCH((pwconv_f32_dma_kernel<BM, BN, OCC, A>), grid, block, 0, s, x, wt, shift, y, m, k, cout, \
                                tiles_n, (unsigned)total);                                                            \
         else                                                                                                        \
-            hipLaunchKernelGGL((pwconv_f32_kernel<BM, BN, OCC, A>), grid, block, 0, s, x, wt, shift, y, m, k, cout,  \
+            HSEFR_LAUNCH((pwconv_f32_kernel<BM, BN, OCC, A>), grid, block, 0, s, x, wt, shift, y, m, k, cout,  \
                                tiles_n, (unsigned)total, g_pw_ablate);                                               \
     } while (0)
     if (act == HSEFR_ACT_RELU6) HSEFR_PW_LAUNCH(HSEFR_ACT_RELU6);

@@ -698,7 +698,7 @@ int launch_mb(const void* xs, const void* wsplit, const float* descale, const fl
     if (g_ps_grid > 0 && (unsigned)g_ps_grid < g) g = (unsigned)g_ps_grid;
     const PsDwParams nodw{nullptr, nullptr, 0, 0, 0.f, 32 * MB};
 #define HSEFR_PS_LAUNCH(A)                                                                                                 \
-    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, 0>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, y, m, k, cout, tiles_n, \
+    HSEFR_LAUNCH((pwconv_ps_kernel<MB, A, 0>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, y, m, k, cout, tiles_n, \
                        (unsigned)total, sweep_reverse(), nodw)
     if (act == HSEFR_ACT_RELU6) HSEFR_PS_LAUNCH(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_PS_LAUNCH(HSEFR_ACT_RELU);
@@ -753,7 +753,7 @@ static int launch_psdw_relu6(const void* xs, const void* wsplit, const float* de
     const long long total = tiles_m * tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_dw: too many tiles");
     const unsigned g = (unsigned)(total < 256 ? total : 256);
-    hipLaunchKernelGGL((pwconv_ps_kernel<MB, HSEFR_ACT_RELU6, MODE, MW>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k,
+    HSEFR_LAUNCH((pwconv_ps_kernel<MB, HSEFR_ACT_RELU6, MODE, MW>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k,
                        cout, tiles_n, (unsigned)total, sweep_reverse(), dw);
     return launch_status("pwconv_presplit_dw");
 }
@@ -787,7 +787,7 @@ int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_dw: too many tiles");
     const unsigned g = (unsigned)(total < 256 ? total : 256);
 #define HSEFR_PSDW_LAUNCH(A, MODE)                                                                                               \
-    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, MODE>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
+    HSEFR_LAUNCH((pwconv_ps_kernel<MB, A, MODE>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
                        tiles_n, (unsigned)total, sweep_reverse(), dw)
     if (act == HSEFR_ACT_RELU) HSEFR_PSDW_LAUNCH(HSEFR_ACT_RELU, 1);
     else if (act == HSEFR_ACT_NONE) HSEFR_PSDW_LAUNCH(HSEFR_ACT_NONE, 1);
@@ -810,7 +810,7 @@ static int launch_psgap(const void* xs, const void* wsplit, const float* descale
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit_gap: too many tiles");
     const unsigned g = (unsigned)(total < 256 ? total : 256);
 #define HSEFR_PSGAP_LAUNCH(A)                                                                                                    \
-    hipLaunchKernelGGL((pwconv_ps_kernel<MB, A, 4>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
+    HSEFR_LAUNCH((pwconv_ps_kernel<MB, A, 4>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, (float*)nullptr, m, k, cout, \
                        tiles_n, (unsigned)total, sweep_reverse(), dw)
     if (act == HSEFR_ACT_RELU6) HSEFR_PSGAP_LAUNCH(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_PSGAP_LAUNCH(HSEFR_ACT_RELU);

@@ -168,7 +168,7 @@ int launch_conv2d_f32(const float* x, const float* w, const float* scale, const 
     if (n == 0) return HSEFR_OK;
     const long long total = (long long)n * oh * ow * (cout / 4);
     HSEFR_REQUIRE((total + 255) / 256 < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv2d_f32: grid too large");
-    hipLaunchKernelGGL(conv2d_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scale, shift, res, y, h, wd, c, oh, ow,
+    HSEFR_LAUNCH(conv2d_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, scale, shift, res, y, h, wd, c, oh, ow,
                        cout, kh, kw, stride, pad_t, pad_l, act, total);
     return launch_status("conv2d_f32");
 }
@@ -186,7 +186,7 @@ int launch_conv2d_direct(const float* x, const float* w, const float* bias, cons
     // nothing about x; a pixel row is c floats, so c % 4 == 0 keeps every pixel as aligned as the base)
     const int xvec = ((uintptr_t)x & 15) == 0 ? 4 : (((uintptr_t)x & 7) == 0 ? 2 : 1);
 #define HSEFR_CONV_DIRECT(CO)                                                                                                          \
-    hipLaunchKernelGGL(conv2d_direct_kernel<CO>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, alpha, y, h, wd, c, \
+    HSEFR_LAUNCH(conv2d_direct_kernel<CO>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, alpha, y, h, wd, c, \
                        oh, ow, cout, kh, kw, stride, pad_t, pad_l, total, xvec)
     if (co == 4) HSEFR_CONV_DIRECT(4);
     else if (co == 2) HSEFR_CONV_DIRECT(2);
@@ -201,7 +201,7 @@ int launch_maxpool_f32(const float* x, float* y, int n, int h, int w, int c, int
     if (n == 0) return HSEFR_OK;
     const long long total = (long long)n * oh * ow * c;
     HSEFR_REQUIRE(total < (1ll << 39), HSEFR_ERR_UNSUPPORTED, "maxpool: too large");
-    hipLaunchKernelGGL(maxpool_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, h, w, c, oh, ow, k, stride,
+    HSEFR_LAUNCH(maxpool_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, h, w, c, oh, ow, k, stride,
                        pad_t, pad_l, total);
     return launch_status("maxpool_f32");
 }

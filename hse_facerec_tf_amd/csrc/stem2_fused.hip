@@ -371,7 +371,7 @@ int launch_stem2_fused(const float* x, const float* cw, const float* cshift, con
     p.stamps = stamp_buffer(s);
 #endif
     const unsigned g = p.total < 512u ? p.total : 512u;      // 512 % 8 == 0: the kernel's incremental patch cursor relies on it
-#define HSEFR_STEM2(A) hipLaunchKernelGGL((stem2_fused_kernel<A>), dim3(g), dim3(256), 0, s, p)
+#define HSEFR_STEM2(A) HSEFR_LAUNCH((stem2_fused_kernel<A>), dim3(g), dim3(256), 0, s, p)
     if (act == HSEFR_ACT_RELU6) HSEFR_STEM2(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_STEM2(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_STEM2(HSEFR_ACT_NONE);

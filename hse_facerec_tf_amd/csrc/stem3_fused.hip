@@ -474,7 +474,7 @@ int launch_stem3_fused(const float* x, const void* cw_split, const float* cdesca
     p.stamps = stamp_buffer(s);
 #endif
     const unsigned g = p.total < 512u ? p.total : 512u;      // 512 % 8 == 0: the kernel's incremental patch cursor relies on it
-#define HSEFR_STEM3(A) hipLaunchKernelGGL((stem3_fused_kernel<A>), dim3(g), dim3(256), 0, s, p)
+#define HSEFR_STEM3(A) HSEFR_LAUNCH((stem3_fused_kernel<A>), dim3(g), dim3(256), 0, s, p)
     if (act == HSEFR_ACT_RELU6) HSEFR_STEM3(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_STEM3(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_STEM3(HSEFR_ACT_NONE);

@@ -514,8 +514,8 @@ int launch_stem4_fused(const void* x, int x_is_u8, const void* cw4, const float*
     const unsigned g = p.total < (unsigned)g_stem4_grid ? p.total : (unsigned)g_stem4_grid;      // % 8 == 0: the kernel's incremental patch cursor relies on it
 #define HSEFR_STEM4(A)                                                                                   \
     do {                                                                                                 \
-        if (x_is_u8) hipLaunchKernelGGL((stem4_fused_kernel<A, true>), dim3(g), dim3(256), 0, s, p);     \
-        else hipLaunchKernelGGL((stem4_fused_kernel<A, false>), dim3(g), dim3(256), 0, s, p);            \
+        if (x_is_u8) HSEFR_LAUNCH((stem4_fused_kernel<A, true>), dim3(g), dim3(256), 0, s, p);     \
+        else HSEFR_LAUNCH((stem4_fused_kernel<A, false>), dim3(g), dim3(256), 0, s, p);            \
     } while (0)
     if (act == HSEFR_ACT_RELU6) HSEFR_STEM4(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_STEM4(HSEFR_ACT_RELU);

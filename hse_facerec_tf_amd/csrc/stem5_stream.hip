@@ -560,8 +560,8 @@ int launch_stem5_stream(const void* x, int x_is_u8, const void* cw4, const float
     const unsigned g = (unsigned)(wgs < g_stem5_grid ? wgs : g_stem5_grid);
 #define HSEFR_STEM5(A)                                                                                            \
     do {                                                                                                          \
-        if (x_is_u8) hipLaunchKernelGGL((stem5_stream_kernel<A, true>), dim3(g), dim3(64 * WAVES), 0, s, p);      \
-        else hipLaunchKernelGGL((stem5_stream_kernel<A, false>), dim3(g), dim3(64 * WAVES), 0, s, p);             \
+        if (x_is_u8) HSEFR_LAUNCH((stem5_stream_kernel<A, true>), dim3(g), dim3(64 * WAVES), 0, s, p);      \
+        else HSEFR_LAUNCH((stem5_stream_kernel<A, false>), dim3(g), dim3(64 * WAVES), 0, s, p);             \
     } while (0)
     if (act == HSEFR_ACT_RELU6) HSEFR_STEM5(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_STEM5(HSEFR_ACT_RELU);

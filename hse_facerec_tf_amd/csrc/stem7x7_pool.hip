@@ -211,7 +211,7 @@ int launch_stem7x7_pool_bf16(const float* x, const void* wt, const float* scale,
     HSEFR_REQUIRE(tiles < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "stem7x7_pool: too many tiles");
     p.tiles = (unsigned)tiles;
     const unsigned g = p.tiles < 512u ? p.tiles : 512u;
-    hipLaunchKernelGGL(stem7x7_pool_bf16_kernel, dim3(g), dim3(256), 0, s, p);
+    HSEFR_LAUNCH(stem7x7_pool_bf16_kernel, dim3(g), dim3(256), 0, s, p);
     return launch_status("stem7x7_pool_bf16");
 }
 

@@ -363,7 +363,7 @@ int launch_stem_fused(const float* x, const float* cw, const float* cshift, cons
     p.stamps = stamp_buffer(s);
 #endif
     const unsigned g = p.total < 512u ? p.total : 512u;      // 512 % 8 == 0: the kernel's incremental patch cursor relies on it
-#define HSEFR_STEM(A) hipLaunchKernelGGL((stem_fused_kernel<A>), dim3(g), dim3(256), 0, s, p)
+#define HSEFR_STEM(A) HSEFR_LAUNCH((stem_fused_kernel<A>), dim3(g), dim3(256), 0, s, p)
     if (act == HSEFR_ACT_RELU6) HSEFR_STEM(HSEFR_ACT_RELU6);
     else if (act == HSEFR_ACT_RELU) HSEFR_STEM(HSEFR_ACT_RELU);
     else if (act == HSEFR_ACT_NONE) HSEFR_STEM(HSEFR_ACT_NONE);

@@ -51,6 +51,20 @@ _OP = struct.Struct("<II3i3i3i3i2iii5Q")         # hsefr_plan_op (112 bytes; `fl
 OPF_PAIR_NEXT, OPF_HEADS = 1, 2                   # hsefr_op_flags
 
 
+# Kernel families (csrc/*.hip) a plan may route to in the PRODUCT library, as Plan.describe() names them.  Development builds add
+# stem_fused_kernel (round 1's stem, lower_graph(stem_fusion="stem")) and conv3x3_win_bf16_kernel (the first window 3x3 kernel, forced by
+# the "w3_off" knob) for A/B timing; tests/test_lowering_cpu.py checks that the BASELINE plans stay inside this list.
+PRODUCT_KERNEL_FAMILIES = frozenset({
+    # MobileNet (fp32-grade): stems, depthwise, pointwise GEMMs, fused blocks, pool, heads
+    "stem5_stream_kernel", "stem4_fused_kernel", "stem3_fused_kernel", "stem2_fused_kernel", "conv3x3_c3_kernel", "conv3x3_c3_mfma_kernel",
+    "dwconv3x3_kernel", "pwconv_f32_dma_kernel", "pwconv_f32_kernel", "pwconv_f16s_kernel", "pwconv_ps_kernel", "dwpw_fused_kernel",
+    "dwpw_f16s_kernel", "dwpw2_f16s_kernel", "dwpw3_f16s_kernel", "gap_kernel", "dense_kernel", "softmax_kernel", "heads_kernel",
+    # ResNet (bf16, and the fp32-grade mode)
+    "stem7x7_pool_bf16_kernel", "stem7x7_bf16_kernel", "maxpool3x3s2_bf16_kernel", "conv_bf16_kernel", "conv1x1_bf16_kernel",
+    "conv1x1_w4_bf16_kernel", "conv1x1_pair_bf16_kernel", "conv3x3_w2_bf16_kernel", "conv_dma_bf16_kernel", "gap_bf16_kernel",
+    "conv_f32_mfma_kernel", "conv2d_f32_kernel", "maxpool_f32_kernel"})
+
+
 class LoweringError(NotImplementedError):
     """The graph uses a construct the engine has no kernel for (analogue of TF's
     'No OpKernel was registered' error)."""
@@ -321,6 +335,26 @@ class Plan:
                             self.in_hwc[2], *out_buf, *out_elems, len(blob))
         bufs = b"".join(_BUFFER.pack(e, 1, 0) for e in self.buffers)
         return head + bufs + b"".join(ops) + bytes(blob)
+
+    def describe(self, n: int = 1) -> List[Dict[str, object]]:
+        """Layer -> kernel (family<template arguments>) at batch `n`, from libhsefr's own launchers run with the launch suppressed
+        (hsefr_plan_describe: the routing code itself answers, on a machine with or without a GPU).  One dict per layer:
+        {"layer", "name", "kind", "kernels": [...], "family": [...], "inside": index of the flagged layer whose launch covers this one}."""
+        import ctypes
+        from . import _lib
+        blob = self.serialize()
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        out = ctypes.create_string_buffer(256 * max(1, len(self.layers)) + 1024)
+        _lib.check(_lib.lib().hsefr_plan_describe(ctypes.cast(buf, ctypes.c_void_p), len(blob), int(n), out, len(out)), "hsefr_plan_describe")
+        rows = []
+        for line in out.value.decode().splitlines():
+            idx, kind, what = line.split("\t")
+            i = int(idx)
+            inside = int(what[len("(inside op "):-1]) if what.startswith("(inside op ") else None
+            kernels = [] if inside is not None else [k for k in what.split(" + ") if k]
+            rows.append({"layer": i, "name": self.layers[i].name, "kind": int(kind), "kernels": kernels,
+                         "family": [k.split("<")[0] for k in kernels], "inside": inside})
+        return rows
 
     # algorithmic cost model (SURVEY 8d): every layer reads its input once, writes its output once
     def bytes_per_image(self, kinds: Optional[Sequence[int]] = None) -> int:
@@ -948,11 +982,11 @@ def mark_pairs(layers: List[Layer]) -> int:
 
 def mark_heads(layers: List[Layer]) -> int:
     """The age / gender heads (facial_analysis.py:109): DENSE k -> 256 + ReLU, DENSE 256 -> a + bias, SOFTMAX, DENSE 256 -> 1 + sigmoid, in
-    this order and adjacent, run as ONE launch (csrc/pool_dense.hip heads_kernel, same bits as the four): the first carries OPF_HEADS."""
+    this order and adjacent, run as ONE launch (csrc/pool_dense.hip heads_kernel; fp32 round-off apart from the four): the first carries OPF_HEADS."""
     n = 0
     for i in range(len(layers) - 3):
         F, A, S, G = layers[i:i + 4]
-        if (F.kind == OP_DENSE and F.act == ACT_RELU and F.out_shape[2] == 256 and F.in_shape[2] % 64 == 0 and F.in_shape[2] <= 2048 and F.flags == 0 and
+        if (F.kind == OP_DENSE and F.act == ACT_RELU and F.out_shape[2] == 256 and F.in_shape[2] % 256 == 0 and F.in_shape[2] <= 2048 and F.flags == 0 and
                 A.kind == OP_DENSE and A.act == ACT_NONE and A.src == i and 1 <= A.out_shape[2] <= 128 and
                 S.kind == OP_SOFTMAX and S.src == i + 1 and
                 G.kind == OP_DENSE and G.act == ACT_SIGMOID and G.src == i and G.out_shape[2] == 1 and

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define HSEFR_VERSION 140 /* 0.1.4: round-6 ABI (added: hsefr_plan_op.flags with HSEFR_OPF_PAIR_NEXT / HSEFR_OPF_HEADS, hsefr_conv1x1_pair_bf16, hsefr_heads_fused,
-                             hsefr_plan_validate, hsefr_nn1_fallbacks; removed from the product library: hsefr_stem_fused / HSEFR_OP_STEM_F16S (development builds only);
+                             hsefr_plan_validate, hsefr_plan_describe, hsefr_nn1_fallbacks; removed from the product library: hsefr_stem_fused / HSEFR_OP_STEM_F16S (development builds only);
                              130 = round 5, 120 = round 4, 110 = round 3, 100 = round 1-2) */
 
 typedef enum hsefr_status {
@@ -208,6 +208,12 @@ int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsef
  * message hsefr_engine_create would return for this blob.  The entry point the sanitizer / fuzz build drives
  * (csrc/build.sh with HSEFR_ASAN=1, tests/test_plan_blob_fuzz_cpu.py). */
 int hsefr_plan_validate(const void* plan, size_t plan_bytes);
+
+/* Which kernel runs each op of a plan at batch `n` (no GPU needed): one line per op, "index \t kind \t kernel<template arguments>" -- two
+ * kernels joined by " + " where an op is two launches, "(inside op i)" for an op a flagged op's launch covers (hsefr_op_flags).  The table
+ * is produced by the launchers themselves running with the launch suppressed: the same shape checks and routing decisions as a forward.
+ * `out` receives a NUL-terminated string; HSEFR_ERR_INVALID (with the size needed in the message) if it does not fit. */
+int hsefr_plan_describe(const void* plan, size_t plan_bytes, int n, char* out, size_t out_bytes);
 
 /* Batches of at most `max_n` images (default 0 = never) run as ONE hipGraph launch: the op sequence of a (batch size,
  * requested outputs) pair is captured once, reading an engine-owned copy of the input, and replayed.  For callers whose
@@ -397,8 +403,9 @@ int hsefr_softmax(const float* x, float* y, int n, int c, hsefr_stream_t stream)
  *   hidden = relu(x . w1 + b1)                      x [n,k], w1 [k,256], hidden [n,256]
  *   age_probs = softmax(hidden . wa + ba)           wa [256,a], a <= 128; logits [n,a], age_probs [n,a]
  *   gender = sigmoid(hidden . wg + bg)              wg [256,1]; gender [n,1]
- * Same contraction splits and summation order as hsefr_dense / hsefr_softmax: the four outputs equal the four launches' bit for bit.
- * k % 64 == 0, k <= 2048.  What the engine runs for a DENSE op flagged HSEFR_OPF_HEADS. */
+ * A lane owns four adjacent columns (16-byte weight loads), the workgroup's sixteen waves split k: fixed summation order (bit-identical
+ * run to run, independent of the batch), fp32 grade, round-off apart from hsefr_dense's four slices.
+ * k % 256 == 0, k <= 2048.  What the engine runs for a DENSE op flagged HSEFR_OPF_HEADS. */
 int hsefr_heads_fused(const float* x, const float* w1, const float* b1, const float* wa, const float* ba, const float* wg, const float* bg,
                       float* hidden, float* logits, float* age_probs, float* gender, int n, int k, int a, hsefr_stream_t stream);
 

@@ -358,7 +358,8 @@ def test_fused_stem2_vs_oracle(env, n, h, w):
     y = ops.stem2_fused(d(x), d(cw), d(csh), d(k1.reshape(3, 3, 32)), d(sc1), d(sh1), kp.T, d(psh), d(k2.reshape(3, 3, 64)), d(sc2), d(sh2))
     assert tuple(y.shape) == want.shape
     assert rel(y.cpu().numpy(), want) < 2 * TOL
-    y1 = ops.stem_fused(d(x), d(cw), d(csh), d(k1.reshape(3, 3, 32)), d(sc1), d(sh1), kp.T, d(psh))
+    # ... and against the unfused kernels (conv1, the fused first block, the stride-2 depthwise)
+    y1 = ops.dwpw_f16split(ops.conv3x3_c3(d(x), d(cw), d(csh), 2), d(k1.reshape(3, 3, 32)), d(sc1), d(sh1), kp.T, d(psh), 1)
     y2 = ops.dwconv3x3(y1, d(k2.reshape(3, 3, 64)), d(sc2), d(sh2), 2)
     assert rel(y.cpu().numpy(), y2.cpu().numpy()) < 2 * TOL
 
@@ -499,12 +500,12 @@ def test_dense_every_tiling_branch(env, n, k, cout, act):
     assert torch.equal(ops.dense(x, w, b, act), ops.dense(x, w, b, act))          # fixed summation order: bit-identical run to run
 
 
-@pytest.mark.parametrize("n,k,a", [(1, 1024, 100), (512, 1024, 100), (7, 1024, 100), (9, 256, 128), (3, 64, 1), (130, 2048, 37)])
-def test_fused_heads_equal_the_four_launches_bit_for_bit(env, n, k, a):
+@pytest.mark.parametrize("n,k,a", [(1, 1024, 100), (512, 1024, 100), (7, 1024, 100), (9, 256, 128), (3, 256, 1), (130, 2048, 37)])
+def test_fused_heads_vs_the_four_launches_and_float64(env, n, k, a):
     """hsefr_heads_fused (round 6): hidden = relu(x.w1 + b1), logits = hidden.wa + ba, softmax, gender = sigmoid(hidden.wg + bg) in one
-    launch -- every one of the four tensors bit-equal to hsefr_dense / hsefr_softmax (same slices of k, same fmaf nest, same order of
-    the partial sums), on the heads' own shape at batch 1 and 512, a ragged last row group, other k and class counts; and the
-    probabilities against a float64 evaluation."""
+    launch -- each of the four tensors against hsefr_dense / hsefr_softmax (another summation order: sixteen slices of k instead of four,
+    so round-off apart, at this suite's 2e-6) and against a float64 evaluation, on the heads' own shape at batch 1 and 512, a ragged last
+    row group, other k and class counts; bit-identical run to run and independent of a row's position in the batch."""
     torch, ops = env
     g = torch.Generator(device="cuda").manual_seed(n * 1000 + k + a)
     x = torch.rand((n, k), device="cuda", generator=g) * 2
@@ -517,17 +518,21 @@ def test_fused_heads_equal_the_four_launches_bit_for_bit(env, n, k, a):
     hid, lg, pr, gd = ops.heads_fused(x, w1, b1, wa, ba, wg, bg)
     h0 = ops.dense(x, w1, b1, 1)
     l0 = ops.dense(h0, wa, ba, 0)
-    assert torch.equal(hid, h0) and torch.equal(lg, l0)
-    assert torch.equal(pr, ops.softmax(l0)) and torch.equal(gd, ops.dense(h0, wg, bg, 3))
+    assert rel(hid.cpu().numpy(), h0.cpu().numpy()) < TOL and rel(lg.cpu().numpy(), l0.cpu().numpy()) < TOL
+    assert float((pr - ops.softmax(l0)).abs().max()) < TOL and float((gd - ops.dense(h0, wg, bg, 3)).abs().max()) < TOL
     h64 = np.maximum(x.cpu().numpy().astype(np.float64) @ w1.cpu().numpy().astype(np.float64) + b1.cpu().numpy(), 0)
+    assert rel(hid.cpu().numpy(), h64) < TOL
     l64 = h64 @ wa.cpu().numpy().astype(np.float64) + ba.cpu().numpy()
     p64 = np.exp(l64 - l64.max(axis=1, keepdims=True))
     p64 /= p64.sum(axis=1, keepdims=True)
-    assert np.abs(pr.cpu().numpy() - p64).max() < 2e-6
+    assert np.abs(pr.cpu().numpy() - p64).max() < TOL
     g64 = 1.0 / (1.0 + np.exp(-(h64 @ wg.cpu().numpy().astype(np.float64) + bg.cpu().numpy())))
-    assert np.abs(gd.cpu().numpy() - g64).max() < 2e-6
+    assert np.abs(gd.cpu().numpy() - g64).max() < TOL
     again = ops.heads_fused(x, w1, b1, wa, ba, wg, bg)
     assert all(torch.equal(p, q) for p, q in zip(again, (hid, lg, pr, gd)))
+    if n > 5:          # a row's results do not depend on its place in the batch (other row group, other slot in it)
+        sub = ops.heads_fused(x[3:n - 1].contiguous(), w1, b1, wa, ba, wg, bg)
+        assert all(torch.equal(p, q[3:n - 1]) for p, q in zip(sub, (hid, lg, pr, gd)))
 
 
 @pytest.mark.parametrize("c,cout,k,stride,padding", [(3, 10, 3, 1, "VALID"), (10, 16, 3, 1, "VALID"), (16, 32, 3, 1, "VALID"),

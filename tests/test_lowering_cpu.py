@@ -397,3 +397,43 @@ def test_pointwise_depthwise_epilogue_fusion(graph):
     want = plan_ref.run(lowering.lower_graph(graph, "input_1:0", ALL_OUTS, (96, 96), fuse=False).serialize(), x)
     for k in want:
         assert rel(got[k], want[k]) < 1e-5
+
+
+def test_plan_describe_routes_the_baseline_plans_to_product_kernels_only():
+    """Plan.describe() = layer -> kernel family<template arguments>, answered by libhsefr's own launchers with the
+    launch suppressed (no GPU needed).  The four BASELINE plans (MobileNet-192 batch 256, ResNet-50 bf16 batch 128, age / gender 224
+    batch 512 with three outputs, and the small-batch plan of the per-image calls) route only to families the product library lists,
+    every layer has a kernel or is covered by a flagged layer's launch, and the development-only families are not in the product."""
+    import subprocess
+    from conftest import MODEL_PB
+    from hse_facerec_tf_amd import _lib, graphdef, lowering, resnet50
+    g = graphdef.read_graph(MODEL_PB)
+    outs = {0: "global_pooling/Mean:0", 1: "age_pred/Softmax:0", 2: "gender_pred/Sigmoid:0"}
+    plans = {
+        "configs[1]": (lowering.lower_graph(g, "input_1:0", {0: outs[0]}, (192, 192), input_bound=256.0, u8_mean_bgr=(103.939, 116.779, 123.68)), 256),
+        "configs[2]": (resnet50.build_plan(resnet50.synthetic_weights(1), (224, 224), "caffe"), 128),
+        "configs[3]": (lowering.lower_graph(g, "input_1:0", outs, (224, 224), input_bound=256.0), 512),
+        "per-image": (lowering.lower_graph(g, "input_1:0", outs, (224, 224), input_bound=256.0, presplit="none"), 1),
+    }
+    seen = {}
+    for name, (plan, n) in plans.items():
+        rows = plan.describe(n)
+        assert [r["layer"] for r in rows] == list(range(len(plan.layers)))
+        for r in rows:
+            assert (r["inside"] is None) == bool(r["kernels"]), (name, r)
+            if r["inside"] is not None:
+                assert plan.layers[r["inside"]].flags != 0 and r["inside"] < r["layer"]
+            for fam in r["family"]:
+                assert fam in lowering.PRODUCT_KERNEL_FAMILIES, (name, r)
+        seen[name] = rows
+    fam = lambda name: [f for r in seen[name] for f in r["family"]]
+    assert fam("configs[1]")[0] == "stem5_stream_kernel" and fam("configs[1]").count("pwconv_ps_kernel") == 8
+    assert seen["configs[1]"][0]["kernels"] == ["stem5_stream_kernel<2, false>"]
+    assert fam("configs[2]").count("conv1x1_pair_bf16_kernel") == 2 and fam("configs[2]").count("conv3x3_w2_bf16_kernel") == 16
+    assert fam("configs[3]")[-1] == "heads_kernel" and [r["inside"] for r in seen["configs[3]"][-3:]] == [len(plans["configs[3]"][0].layers) - 4] * 3
+    assert "pwconv_ps_kernel" not in fam("per-image") and "heads_kernel" in fam("per-image")
+    L = _lib.lib()
+    if not hasattr(L, "hsefr_debug_set"):
+        syms = subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True).stdout
+        for dev_only in ("stem_fused_kernel", "conv3x3_win_bf16_kernel"):
+            assert dev_only not in syms, dev_only
