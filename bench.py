@@ -507,6 +507,89 @@ def profile_traffic_per_forward(tag, once_kernel=None):
         return None, None, None
 
 
+_BF16_STORE = None
+_SPLIT_F16 = ("pwconv_ps_kernel", "pwconv_f16s_kernel", "dwpw_f16s_kernel", "dwpw2_f16s_kernel", "dwpw3_f16s_kernel", "stem2_fused_kernel",
+              "stem3_fused_kernel", "stem4_fused_kernel", "stem5_stream_kernel")          # fp32 products as three f16 MFMA products
+_F32_MATRIX = ("pwconv_f32_dma_kernel", "pwconv_f32_kernel", "conv_f32_mfma_kernel", "conv3x3_c3_mfma_kernel")
+
+
+def side_kernel_table(plan, eng, x, want, B, steps, tag):
+    """The per-KERNEL view of a side config, in the shape of the headline's `kernels` / `roofline`: one row per kernel
+    instantiation as Plan.describe() names it (family<template arguments> -- the launchers' own routing), device time from the engine's
+    HIP-event ring over `steps` forwards on the forward's stream, algorithmic bytes and flops of the layers it runs (a launch that covers
+    several layers -- hsefr_op_flags -- counts them all; a tensor that never leaves the launch is not counted), the bound it is priced
+    against (the higher of its HBM floor and its matrix floor: bf16 at the dense 2.5 PF, split-f16 at a third of it, fp32 MFMA at 157 TF),
+    and the counter figures of the same kernel name in the newest committed profile of this config (profiles/rNN_<tag>_traffic.json).
+    -> (rows sorted by time, the dominant row as a `roofline` object)"""
+    import glob
+    from hse_facerec_tf_amd import lowering
+    eng.set_profiling(steps)
+    for _ in range(steps):
+        eng.forward(x, want)
+    per = np.mean([eng.op_times_ms(s) for s in range(steps)], axis=0)
+    eng.set_profiling(0)
+    rows = plan.describe(B)
+    prof, src, stale = {}, None, None
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_traffic.json" % tag)))
+    if cands:
+        pj = json.load(open(cands[-1]))
+        prof, src, stale = pj.get("kernels", {}), os.path.relpath(cands[-1], ROOT), pj.get("csrc_hash") != csrc_hash()
+    bf16_out = set(lowering._BF16_OUT)
+    bf16_in = {lowering.OP_CONV_BF16, lowering.OP_MAXPOOL_BF16, lowering.OP_GAP_BF16}
+
+    def lbytes(i, count_in=True):
+        L = plan.layers[i]
+        b = int(np.prod(L.out_shape)) * (2 if L.kind in bf16_out else 4) * B
+        if count_in:
+            b += int(np.prod(L.in_shape)) * (2 if L.kind in bf16_in else 4) * B
+        if L.res >= 0:      # the residual, or the block input a projected shortcut reads (strided: every stride-th pixel of it)
+            R = plan.layers[L.res]
+            px = int(np.prod(L.out_shape[:2])) if L.proj is not None else int(np.prod(R.out_shape[:2]))
+            b += px * (L.proj[0] if L.proj is not None else R.out_shape[2]) * 2 * B
+        for a in (L.w, L.scale, L.shift, L.w2, L.shift2, L.w0, L.shift0, L.w3, L.scale3, L.shift3):
+            if a is not None:
+                b += a.size * (2 if a.dtype == np.uint16 else 4)
+        return b
+    table = {}
+    for r in rows:
+        if r["inside"] is not None:
+            continue
+        i = r["layer"]
+        covered = [q["layer"] for q in rows if q["inside"] == i]
+        key = " + ".join(r["kernels"])
+        t = table.setdefault(key, {"kernel": key, "launches_per_step": 0, "ms": 0.0, "bytes": 0, "flops": 0, "layers": []})
+        t["launches_per_step"] += 1
+        t["ms"] += float(per[i])
+        t["bytes"] += lbytes(i) + sum(lbytes(j, count_in=plan.layers[j].src not in [i] + covered) for j in covered)
+        t["flops"] += sum(plan.layer_flops(plan.layers[j]) for j in [i] + covered) * B
+        t["layers"].append(plan.layers[i].name)
+    out = []
+    for key, t in table.items():
+        fam = key.split("<")[0]
+        peak_tf = MFMA_F16_PEAK_TF / 3 if fam in _SPLIT_F16 else MFMA_F32_PEAK_TF if fam in _F32_MATRIX else MFMA_F16_PEAK_TF if "bf16" in fam else None
+        ms = max(t["ms"], 1e-9)
+        t_hbm = t["bytes"] / (HBM_PEAK_GBS * 1e9)
+        t_mfma = t["flops"] / (peak_tf * 1e12) if peak_tf and t["flops"] else 0.0
+        if t_mfma > t_hbm:
+            bound, achieved, peak, unit = "mfma", t["flops"] / (ms * 1e-3) / 1e12, round(peak_tf, 1), "TFLOP/s"
+        else:
+            bound, achieved, peak, unit = "hbm", t["bytes"] / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        pk = prof.get(key.split(" + ")[0], {})
+        out.append({"kernel": key, "launches_per_step": t["launches_per_step"], "ms_per_step": round(t["ms"], 4),
+                    "avg_launch_us": round(t["ms"] / t["launches_per_step"] * 1e3, 2), "bound": bound, "achieved": round(achieved, 2), "peak": peak,
+                    "unit": unit, "frac": round(achieved / peak, 4), "algorithmic_bytes_per_launch": int(t["bytes"] / t["launches_per_step"]),
+                    "flops_per_step": int(t["flops"]), "floors_us": {"hbm": round(t_hbm * 1e6, 1), "mfma": round(t_mfma * 1e6, 1)},
+                    "traffic": None if "hbm_bytes_per_launch" not in pk else int(pk["hbm_bytes_per_launch"]),
+                    "traffic_unit": "HBM bytes per launch (PMC counters, this kernel name in the profile)", "traffic_source": src, "traffic_stale": stale,
+                    "mfma_util_pmc": pk.get("mfma_util"), "lds_conflict_share": pk.get("lds_conflict_share"),
+                    "layers": t["layers"] if len(t["layers"]) <= 6 else t["layers"][:5] + ["... %d more" % (len(t["layers"]) - 5)]})
+    out.sort(key=lambda k: -k["ms_per_step"])
+    dom = out[0] if out else None
+    roof = None if dom is None else {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "avg_launch_us",
+                                                         "launches_per_step", "mfma_util_pmc")}
+    return out, roof
+
+
 def run_other_configs(args, dev):
     import torch
     from hse_facerec_tf_amd import lowering, resnet50
@@ -527,7 +610,10 @@ def run_other_configs(args, dev):
         B = 128
         plan = resnet50.build_plan(resnet50.synthetic_weights(123), (224, 224), "caffe")
         eng = Engine(plan, max_batch=B, device=dev.index)
-        dt = time_engine(eng, gen(B, 224), (0,), steps, warm)
+        xr = gen(B, 224)
+        dt = time_engine(eng, xr, (0,), steps, warm)
+        rn_kernels, rn_roof = side_kernel_table(plan, eng, xr, (0,), B, steps, "resnet50")
+        del xr
         fl, by = resnet50.flops_per_image(plan), resnet50.activation_bytes_per_image(plan)
         wb = sum(int(np.asarray(L.w).size) * 2 for L in plan.layers if L.w is not None)
         t_hbm, t_mfma = (by * B + wb) / (HBM_PEAK_GBS * 1e9), fl * B / (MFMA_F16_PEAK_TF * 1e12)
@@ -542,7 +628,8 @@ def run_other_configs(args, dev):
                                  "frac": round(t_hbm / dt, 4), "traffic": rn_traffic, "traffic_unit": "HBM bytes per forward (batch %d)" % B,
                                  "traffic_source": rn_src, "traffic_stale": rn_stale, "algorithmic_bytes_per_forward": int(by * B + wb),
                                  "note": "layer-wise HBM floor %.3f ms vs bf16 MFMA floor %.3f ms per batch: the net is HBM-bound unless layers are fused"
-                                         % (t_hbm * 1e3, t_mfma * 1e3)}})
+                                         % (t_hbm * 1e3, t_mfma * 1e3)},
+                    "roofline_dominant_kernel": rn_roof, "kernels": rn_kernels})
         eng.close()
     except Exception as e:      # a failing side config must not take the headline line down
         out.append({"config": "BASELINE configs[2]: ResNet-50", "error": repr(e)})
@@ -556,7 +643,10 @@ def run_other_configs(args, dev):
         # products in exact fp32 and this config ran the older stem2 kernel: 0.91 instead of 0.78 ms of a 3.8 ms step)
         plan = lowering.lower_graph(g, "input_1:0", fetch, input_bound=256.0)
         eng = Engine(plan, max_batch=B, device=dev.index)
-        dt = time_engine(eng, gen(B, 224), (0, 1, 2), steps, warm)
+        xa = gen(B, 224)
+        dt = time_engine(eng, xa, (0, 1, 2), steps, warm)
+        ag_kernels, ag_roof = side_kernel_table(plan, eng, xa, (0, 1, 2), B, steps, "agegender")
+        del xa
         by = 40.948e6 * B + 12.74e6          # unfused layer-wise bytes per face @224 + weights per batch
         ag_traffic, ag_src, ag_stale = profile_traffic_per_forward("agegender", "stem5_stream")
         out.append({"config": "BASELINE configs[3]: age_gender_tf2 MobileNet-224 multi-head (features + age softmax + gender sigmoid), batch 512, fp32",
@@ -568,7 +658,8 @@ def run_other_configs(args, dev):
                                  "measured_hbm_gbs": None if not ag_traffic else round(ag_traffic / dt / 1e9, 1),
                                  "algorithmic_bytes_per_forward": int(by),
                                  "note": "achieved / frac: unfused layer-wise algorithmic bytes (40.948 MB/face, SURVEY 8d) / time; measured_hbm_gbs: "
-                                         "counter bytes (the fused plan moves fewer) / time"}})
+                                         "counter bytes (the fused plan moves fewer) / time"},
+                    "roofline_dominant_kernel": ag_roof, "kernels": ag_kernels})
         eng.close()
     except Exception as e:
         out.append({"config": "BASELINE configs[3]: age/gender MobileNet-224", "error": repr(e)})
@@ -598,11 +689,20 @@ def run_other_configs(args, dev):
         eng = Engine(plan, max_batch=B, device=dev.index)
         dt = time_engine(eng, gen(B, 224), (0,), max(3, steps // 4), 1)
         fl = resnet50.flops_per_image(plan)
+        rf_traffic, rf_src, rf_stale = profile_traffic_per_forward("resnet50_f32")
+        if rf_traffic is not None and rf_src:      # (profiled at the batch tools/bench_configs.py resnet50f32 runs: scale the activations' share to this one)
+            try:
+                pb = json.load(open(os.path.join(ROOT, rf_src))).get("batch")
+                rf_traffic = int(rf_traffic * B / pb) if pb else None
+            except Exception:
+                rf_traffic = None
         out.append({"config": "BASELINE configs[2] in the fp32-grade mode: ResNet-50 batch %d, every convolution an exact-fp32 implicit GEMM on the "
                               "fp32 matrix pipe (v_mfma_f32_32x32x2_f32; dtype='f32'; 1e-5 of the feature scale vs the fp64 oracle)" % B,
                     "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": max(3, steps // 4), "dtype": "f32",
                     "roofline": {"bound": "mfma", "achieved": round(fl * B / dt / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                 "frac": round(fl * B / dt / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                                 "frac": round(fl * B / dt / 1e12 / MFMA_F32_PEAK_TF, 4), "traffic": rf_traffic,
+                                 "traffic_unit": "HBM bytes per forward (batch %d), PMC counters scaled from the profiled batch" % B,
+                                 "traffic_source": rf_src, "traffic_stale": rf_stale,
                                  "note": "csrc/conv_f32_mfma.hip: the mode that meets the 1e-4 bar on a ResNet (the bf16 mode is at 5e-3)"}})
         eng.close()
     except Exception as e:
@@ -869,6 +969,25 @@ def main():
         allgather_ms = (time.perf_counter() - t1) / 10 * 1e3
         assert torch.equal(full[rank * B:(rank + 1) * B], out)
 
+    # who took part: the line certifies its own ranks -- the communicator's size as the backend reports it after the
+    # barriers above, the collective library's version, and every rank's device (name, PCI bus id, the GPU index it bound to) gathered
+    # through the group itself: an N > 1 line whose ranks shared a GPU, or that ran fewer ranks than it claims, shows it here
+    ranks_info, rccl_ranks, rccl_version = None, None, None
+    if grouped:
+        rccl_ranks = int(dist.get_world_size())
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": props.name,
+                "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+                "gcn_arch": getattr(props, "gcnArchName", None), "host": socket.gethostname(), "pid": os.getpid()}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
+        if args.backend == "nccl":
+            try:
+                v = torch.cuda.nccl.version()
+                rccl_version = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+            except Exception as e:
+                rccl_version = "unknown (%r)" % (e,)
+
     config5 = None
     if not args.no_config5:
         try:
@@ -1092,6 +1211,9 @@ def main():
                    "parallelism": "%d independent replicas, gallery sharded by image, one all-gather of embeddings" % world,
                    "backend": None if not grouped else ("RCCL (torch 'nccl')" if args.backend == "nccl" else "gloo"),
                    "process_group": bool(grouped),
+                   "rccl_ranks": rccl_ranks, "rccl_version": rccl_version, "ranks": ranks_info,
+                   "distinct_gpus": None if not ranks_info else len({(r["host"], r["pci_bus_id"]) for r in ranks_info}),
+                   "allgather_gbs": None if not allgather_ms else round(world * B * int(out.shape[1]) * 4 / (allgather_ms * 1e-3) / 1e9, 2),
                    # the knobs that change WHAT is benchmarked: effective values (keyword arguments only: the product reads
                    # no plan option from the environment)
                    "pw_math": "f16split" if any(L.a_log2 for L in plan.layers) else "f32",

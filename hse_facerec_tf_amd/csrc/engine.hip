@@ -96,6 +96,22 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                       "plan op %u: bad buffer ids (%d -> %d)", i, o.in_buf, o.out_buf);
         HSEFR_REQUIRE(o.res_buf == HSEFR_BUF_NONE || okbuf(o.res_buf, false), HSEFR_ERR_INVALID,
                       "plan op %u: bad residual buffer %d", i, o.res_buf);
+        // every dimension in a range the launch wrappers' 32-bit arithmetic is safe in (found by the sanitizer fuzz of round 6: an op with
+        // oh = INT_MAX and ow = 0 passed the byte checks below and overflowed a tile count), and the last output's first tap inside the
+        // image -- a kernel treats whatever lies beyond the image as padding, never as memory to read
+        HSEFR_REQUIRE(o.h >= 1 && o.h <= 32768 && o.w >= 1 && o.w <= 32768 && o.oh >= 1 && o.oh <= 32768 && o.ow >= 1 && o.ow <= 32768 && o.cin >= 1 &&
+                          o.cin <= 65536 && o.cout >= 1 && o.cout <= 65536 && o.kh >= 1 && o.kh <= 15 && o.kw >= 1 && o.kw <= 63 && o.stride >= 1 &&
+                          o.stride <= 8 && o.pad_t >= 0 && o.pad_t <= 15 && o.pad_l >= 0 && o.pad_l <= 15,
+                      HSEFR_ERR_INVALID, "plan op %u: a dimension is out of range (%dx%dx%d -> %dx%dx%d, kernel %dx%d / %d, pad %d %d)", i, o.h, o.w, o.cin,
+                      o.oh, o.ow, o.cout, o.kh, o.kw, o.stride, o.pad_t, o.pad_l);
+        {
+            const bool two_stages = o.kind == HSEFR_OP_STEM2_F16S || o.kind == HSEFR_OP_STEM3_F16S || o.kind == HSEFR_OP_STEM7X7_POOL_BF16;
+            const long long st = two_stages ? 4 : o.stride, slack = two_stages ? 3 : 0;
+            const bool spatial = !(o.kind == HSEFR_OP_DENSE || o.kind == HSEFR_OP_SOFTMAX || o.kind == HSEFR_OP_GAP || o.kind == HSEFR_OP_GAP_BF16 ||
+                                   o.kind == HSEFR_OP_PWCONV_PS_GAP);
+            HSEFR_REQUIRE(!spatial || ((long long)(o.oh - 1) * st - o.pad_t - slack < o.h && (long long)(o.ow - 1) * st - o.pad_l - slack < o.w),
+                          HSEFR_ERR_INVALID, "plan op %u: a %dx%d output does not fit a %dx%d input at stride %lld", i, o.oh, o.ow, o.h, o.w, st);
+        }
         for (uint64_t off : {o.w_off, o.scale_off, o.shift_off, o.w2_off, o.shift2_off})
             HSEFR_REQUIRE(off == HSEFR_NO_OFFSET || (off < h.blob_bytes && off % 16 == 0), HSEFR_ERR_INVALID,
                           "plan op %u: blob offset %llu out of range / unaligned", i, (unsigned long long)off);
@@ -408,6 +424,7 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "ps_mb")) { set_ps_mb(value); return HSEFR_OK; }
     if (!strcmp(key, "ps_grid")) { set_ps_grid(value); return HSEFR_OK; }
     if (!strcmp(key, "psdw_mode")) { set_psdw_mode(value); return HSEFR_OK; }
+    if (!strcmp(key, "ps_ablate")) { set_ps_ablate(value); return HSEFR_OK; }
     if (!strcmp(key, "cd_rb")) { set_cd_rb(value); return HSEFR_OK; }
     if (!strcmp(key, "cd_off")) { set_cd_off(value); return HSEFR_OK; }
     if (!strcmp(key, "w3_off")) { set_w3_off(value); return HSEFR_OK; }

@@ -69,6 +69,8 @@ def test_bench_two_self_launched_ranks_share_the_gpu_over_gloo():
                  "--config5-images", "701", "--config5-classes", "120"])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512
     assert len(line["per_rank_faces_per_s"]) == 2 and line["allgather_ms"] > 0
+    cfg = line["config"]          # two ranks over gloo on ONE GPU: the line says so itself
+    assert cfg["rccl_ranks"] == 2 and cfg["rccl_version"] is None and [r["rank"] for r in cfg["ranks"]] == [0, 1] and cfg["distinct_gpus"] == 1
     assert line["value"] == pytest.approx(2 * 256 * 1e3 / line["ms_per_step"], rel=1e-3)
     c5 = line["config5"]
     _check_config5(c5, 701, 2)
@@ -88,3 +90,28 @@ def test_bench_eight_ranks_lfw_shards_with_pad_rows_equal_the_single_rank_extrac
     assert c5["shard_rows"] == 1146 and c5["pad_rows"] == 4 and c5["allgather_bytes_per_rank"] == 1146 * 1024 * 4
     assert c5["gathered_rows"] == 9164 and c5["gathered_rows_differing_from_single_rank_extraction"] == 0
     assert c5["gathered_shard_equals_local"] is True and c5["num_classes"] == 1680
+
+
+def test_side_configs_carry_a_per_kernel_view():
+    """other_configs[ResNet-50 bf16] and other_configs[age / gender] carry `kernels` (one row per kernel instantiation,
+    named by the launchers' own routing) and the dominant kernel as a roofline object of the headline's shape; the strict-fp32 ResNet
+    carries `traffic` once a profile of it is committed."""
+    line = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipeline", "--no-latency", "--no-config5", "--no-sustained", "--no-op-events"])
+    oc = {o["config"].split(":")[0]: o for o in line["other_configs"]}
+    for key, fam in (("BASELINE configs[2]", "conv"), ("BASELINE configs[3]", "pwconv_ps_kernel")):
+        o = oc[key]
+        assert "error" not in o, o
+        ks, rf = o["kernels"], o["roofline_dominant_kernel"]
+        assert len(ks) >= 5 and ks == sorted(ks, key=lambda k: -k["ms_per_step"]) and rf["kernel"] == ks[0]["kernel"]
+        assert any(k["kernel"].startswith(fam) for k in ks)
+        for k in ks:
+            assert k["bound"] in ("hbm", "mfma") and k["frac"] == pytest.approx(k["achieved"] / k["peak"], rel=2e-3, abs=2e-4) and k["launches_per_step"] >= 1
+            for f in ("avg_launch_us", "algorithmic_bytes_per_launch", "traffic", "traffic_stale", "mfma_util_pmc", "floors_us"):
+                assert f in k
+        assert abs(sum(k["ms_per_step"] for k in ks) - o["ms_per_step"]) < 0.35 * o["ms_per_step"]          # (event packets cost a few percent)
+        for f in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_per_step"):
+            assert f in rf
+    assert any("conv1x1_pair_bf16_kernel" in k["kernel"] for k in oc["BASELINE configs[2]"]["kernels"])
+    assert any(k["kernel"] == "heads_kernel" for k in oc["BASELINE configs[3]"]["kernels"])
+    f32 = next(o for o in line["other_configs"] if o["config"].startswith("BASELINE configs[2] in the fp32-grade mode"))
+    assert "traffic" in f32["roofline"] and "traffic_source" in f32["roofline"]

@@ -2,7 +2,7 @@
 
 hsefr_engine_create parses a caller-supplied plan blob (offsets, sizes, buffer ids, kinds: everything the reference hands to
 tf.import_graph_def at facerec_test.py:41-48 arrives here as bytes).  csrc/build.sh with HSEFR_ASAN=1 compiles the HOST half of the
-product's sources with -fsanitize=address,undefined (no device code is compiled and none runs: GPU sanitizers are not available on
+product's sources under both sanitizers (flags: csrc/build_asan_flags.sh; no device code is compiled and none runs: GPU sanitizers are not available on
 this pool) into csrc/build_asan/libhsefr_asan.so + the driver csrc/fuzz_plan.cc.  The driver pushes >= 12 000 truncated, bit-flipped and
 field-mutated copies of six real plans through hsefr_plan_validate and hsefr_engine_create: every one must come back as HSEFR_OK or as a
 negative hsefr_status with a message; a crash or a sanitizer report aborts the driver and fails this test."""

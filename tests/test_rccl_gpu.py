@@ -104,6 +104,11 @@ def test_bench_force_group_runs_every_collective_on_rccl(launcher):
                        "--no-other-configs", "--no-pipeline", "--no-latency", "--config5-images", "700", "--config5-classes", "120"], launcher)
     assert line["n_gpus"] == 1 and line["config"]["backend"].startswith("RCCL") and line["config"]["process_group"] is True
     assert line["allgather_ms"] is not None and line["allgather_ms"] > 0
+    # the line certifies its own ranks: communicator size, RCCL version, every rank's device through the group itself
+    cfg = line["config"]
+    assert cfg["rccl_ranks"] == 1 and cfg["rccl_version"] and cfg["rccl_version"][0].isdigit() and cfg["distinct_gpus"] == 1
+    assert len(cfg["ranks"]) == 1 and cfg["ranks"][0]["rank"] == 0 and cfg["ranks"][0]["device_name"] and ":" in cfg["ranks"][0]["pci_bus_id"]
+    assert cfg["allgather_gbs"] == pytest.approx(256 * 1024 * 4 / (line["allgather_ms"] * 1e-3) / 1e9, rel=0.02)
     c5 = line["config5"]
     assert "error" not in c5, c5
     assert c5["gathered_shard_equals_local"] is True and c5["allgather_ms"] > 0

@@ -13,7 +13,8 @@ import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
-forwards = int(sys.argv[3]) if len(sys.argv) > 3 else None      # forwards of the profiled command (tools/bench_configs.py prints it): bench.py divides by it
+forwards = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] else None      # forwards of the profiled command (tools/bench_configs.py prints it): bench.py divides by it
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else None         # images per forward of the profiled command, where bench.py runs the config at another batch
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -84,7 +85,7 @@ import bench  # noqa: E402  (csrc_hash: bench.py marks the traffic figures stale
 # file predates that and gets the hash of the sources at collect time, as before
 hf = os.path.join(src, "csrc_hash.txt")
 profiled_hash = open(hf).read().strip() if os.path.exists(hf) else bench.csrc_hash()
-json.dump({"csrc_hash": profiled_hash, "forwards": forwards, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); "
+json.dump({"csrc_hash": profiled_hash, "forwards": forwards, "batch": batch, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); "
                      "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
            "kernels": traffic}, open(os.path.join(out, "%s_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(traffic, indent=1))

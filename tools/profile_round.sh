@@ -14,10 +14,12 @@ if [ "${2:-}" = "collect" ]; then
   python3 tools/make_profile_summary.py gpurun_out/prof_${TAG}_resnet ${TAG}_resnet50 "$(fw _resnet)"
   python3 tools/make_profile_summary.py gpurun_out/prof_${TAG}_agegender ${TAG}_agegender "$(fw _agegender)"
   python3 tools/make_profile_summary.py gpurun_out/prof_${TAG}_f32 ${TAG}_mobilenet_f32 "$(fw _f32)"
+  [ -d gpurun_out/prof_${TAG}_rnf32 ] && python3 tools/make_profile_summary.py gpurun_out/prof_${TAG}_rnf32 ${TAG}_resnet50_f32 "$(fw _rnf32)" 32
   cp gpurun_out/prof_${TAG}/layers.txt profiles/${TAG}_layers.txt
   cp gpurun_out/prof_${TAG}_resnet/layers.txt profiles/${TAG}_resnet50_layers.txt
   cp gpurun_out/prof_${TAG}_agegender/layers.txt profiles/${TAG}_agegender_layers.txt
   cp gpurun_out/prof_${TAG}_f32/layers.txt profiles/${TAG}_mobilenet_f32_layers.txt
+  [ -s gpurun_out/prof_${TAG}_rnf32/layers.txt ] && cp gpurun_out/prof_${TAG}_rnf32/layers.txt profiles/${TAG}_resnet50_f32_layers.txt
   [ -s gpurun_out/prof_${TAG}/bench_line.json ] && cp gpurun_out/prof_${TAG}/bench_line.json profiles/${TAG}_bench_line.json
   exit 0
 fi
@@ -27,9 +29,11 @@ bash tools/gpu_pmc.sh gpurun_out/prof_${TAG} python3 $R/bench.py $HEAD
 bash tools/gpu_pmc.sh gpurun_out/prof_${TAG}_resnet python3 $R/tools/bench_configs.py resnet50
 bash tools/gpu_pmc.sh gpurun_out/prof_${TAG}_agegender python3 $R/tools/bench_configs.py agegender
 bash tools/gpu_pmc.sh gpurun_out/prof_${TAG}_f32 python3 $R/tools/bench_configs.py mobilenet_f32
+BC_STEPS=5 bash tools/gpu_pmc.sh gpurun_out/prof_${TAG}_rnf32 python3 $R/tools/bench_configs.py resnet50f32      # the fp32-grade ResNet mode, batch 32
 cd "$R"
 python3 tools/bench_configs.py mobilenet192 > gpurun_out/prof_${TAG}/layers.txt 2>&1
 python3 tools/bench_configs.py resnet50 > gpurun_out/prof_${TAG}_resnet/layers.txt 2>&1
 python3 tools/bench_configs.py agegender > gpurun_out/prof_${TAG}_agegender/layers.txt 2>&1
 python3 tools/bench_configs.py mobilenet_f32 > gpurun_out/prof_${TAG}_f32/layers.txt 2>&1
-for d in "" _resnet _agegender _f32; do python3 -c "import bench; print(bench.csrc_hash())" > gpurun_out/prof_${TAG}$d/csrc_hash.txt; done      # the sources these counters belong to
+BC_STEPS=5 python3 tools/bench_configs.py resnet50f32 > gpurun_out/prof_${TAG}_rnf32/layers.txt 2>&1
+for d in "" _resnet _agegender _f32 _rnf32; do python3 -c "import bench; print(bench.csrc_hash())" > gpurun_out/prof_${TAG}$d/csrc_hash.txt; done      # the sources these counters belong to
