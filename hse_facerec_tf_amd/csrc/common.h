@@ -314,6 +314,7 @@ void set_stem5_segs(int v);
 void set_c11(int v);
 void set_c11_tile(int v);
 void set_c11_bres(int v);
+void set_c11_adv(int v);
 int read_c11_stamps(void* host_out, size_t bytes);
 void set_dwpws_tw(int v);
 void set_dwpws_bn(int v);

@@ -67,6 +67,11 @@ struct ProjParams {        // the projected shortcut of PROJ kernels
     const float* shift2;   // [Cout]
     int K2, stride, H2, W2, OH, OW;
     long long x2_bytes;
+    int adv;               // (both kernel forms; round 6) rows a tile ADVANCES by, <= BM: the tile computes BM rows but owns -- loads, adds the
+                           // residual of, stores -- only the first `adv` (every resource ends with the tile's last own row: what lies beyond
+                           // reads as zeros and moves no bytes).  Chosen by the launcher so that the tiles fill whole rounds of the grid's
+                           // slots: 14 x 14 x 1024 at batch 128 is 1568 tiles of 128 rows = 3.06 rounds that cost 4; as 2048 tiles of 98 rows
+                           // it is 4.0 rounds of 0.77 of the memory work each (these layers are bound by what a CU's memory path moves)
     int b_resident;        // (both kernel forms) 1: a tile's K loop is at most two steps AND every tile of a workgroup has the same channel
                            // origin -- each LDS stage then always holds the SAME weight tile: it is loaded with the first two steps and
                            // never again (a quarter to a half of the kernel's load instructions on the K <= 128 layers, which are bound
@@ -106,9 +111,10 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
 
     auto tile_origin = [&](unsigned i, long long& mm0, int& nn0) {
         const unsigned lt = xcd_remap_dir(blockIdx.x + (i < ntile ? i : ntile - 1) * gridDim.x, total_tiles, reverse);
-        mm0 = (long long)(lt / tiles_n) * BM;
+        mm0 = (long long)(lt / tiles_n) * pj.adv;
         nn0 = (lt % tiles_n) * BN;
     };
+    auto own_end = [&](long long mm0) { return mm0 + pj.adv < P ? mm0 + pj.adv : P; };      // one past the tile's last own row
     __amdgpu_buffer_rsrc_t ra_rsrc, rb_rsrc, rb2_rsrc;
     const __amdgpu_buffer_rsrc_t ra2_rsrc = make_rsrc(PROJ ? pj.x2 : nullptr, PROJ ? pj.x2_bytes : 0);
     unsigned pf_i = 0;
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
         long long mm0;
         int nn0;
         tile_origin(i, mm0, nn0);
-        ra_rsrc = make_rsrc(x + mm0 * K, (P - mm0) * (long long)rowbytes);
+        ra_rsrc = make_rsrc(x + mm0 * K, (own_end(mm0) - mm0) * (long long)rowbytes);
         rb_rsrc = make_rsrc(wt + (long long)nn0 * K, (long long)(Cout - nn0) * rowbytes);
         if (PROJ) {
             rb2_rsrc = make_rsrc(pj.wt2 + (long long)nn0 * pj.K2, (long long)(Cout - nn0) * rowbytes2);
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
                 const unsigned n = mu / ohow, rem = mu - n * ohow;
                 const unsigned oh = rem / (unsigned)pj.OW, ow = rem - oh * (unsigned)pj.OW;
                 const unsigned pix = (n * (unsigned)pj.H2 + oh * (unsigned)pj.stride) * (unsigned)pj.W2 + ow * (unsigned)pj.stride;
-                avoff2[PROJ ? p : 0] = m < P ? pix * rowbytes2 + 16u * sch : 0x80000000u;
+                avoff2[PROJ ? p : 0] = m < own_end(mm0) ? pix * rowbytes2 + 16u * sch : 0x80000000u;
             }
         }
     };
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
             ec = *(const f32x4*)(src + n0 + 4 * ej);
         }
         if (RES && first) {      // this tile's residual chunks, in the layout the epilogue stores in (uniform branch)
-            const __amdgpu_buffer_rsrc_t rr = make_rsrc(res + m0 * Cout + n0, ((P - m0) * Cout - n0) * 2ll);
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(res + m0 * Cout + n0, ((own_end(m0) - m0) * Cout - n0) * 2ll);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
         }
         if (ckt == KT) {
             const float* et = &Et[ci & 1][0][0];
-            const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + m0 * Cout + n0, ((P - m0) * Cout - n0) * 2ll);
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(y + m0 * Cout + n0, ((own_end(m0) - m0) * Cout - n0) * 2ll);
             unsigned char* scr = &smem[PB][wave * 4096];       // stage PB: every wave is past its last read (barrier above)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
@@ -330,19 +336,46 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
 }
 
 HSEFR_KNOB(g_c11_bres, 1);   // dev builds: 0 = reload the weight tile every step also where it could stay resident (A/B timing)
+HSEFR_KNOB(g_c11_adv, 1);    // 1 = always BM: the product's tiling; dev builds: 0 = choose_adv's estimate, other = that many rows.
+                             // MEASURED AND LOST (round 6, ResNet-50 batch 128 in the network, same box): the 14 x 14 x 1024 increase layers as
+                             // 2048 tiles of 98 own rows (4.0 rounds of 512 slots) 35.5 us against 32.5 us as 1568 tiles of 128 (3.06 rounds);
+                             // 112 and 120 rows: 32.3-33.7; the 28 x 28 x 512 layers 45-47 against 43-44.  The "3.06 rounds cost 4" reading of
+                             // round 5 was wrong: persistent workgroups, two per CU, do not run in rounds -- the partial last round overlaps
+                             // the one before it, and a shorter tile only adds tiles (weight tile, constants, barriers per tile)
+
+// rows per tile (ProjParams::adv): the candidate in [BM / 2, BM] with the lowest estimated cost = rounds of the grid's slots x the
+// share of a full tile's time a tile of that many own rows takes (FIXED of it does not shrink with the rows: the MFMAs run on all BM
+// rows, the weight tile is loaded whole); ties go to the taller tile
+template <int BM>
+int choose_adv(long long P, unsigned tiles_n, long long slots) {
+    if (g_c11_adv == 1) return BM;
+    if (g_c11_adv > 1) return g_c11_adv < BM ? g_c11_adv : BM;
+    constexpr double FIXED = 0.3;
+    int best = BM;
+    double best_cost = 1e300;
+    for (int adv = BM; adv >= BM / 2; --adv) {
+        const long long tiles = ((P + adv - 1) / adv) * tiles_n;
+        if (tiles <= slots) return best_cost < 1e300 ? best : BM;          // a single (partial) round: the tallest tile that still is one
+        const double cost = (double)((tiles + slots - 1) / slots) * (FIXED + (1.0 - FIXED) * adv / BM);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = adv; }
+    }
+    return best;
+}
 
 template <int BM, int BN, int OCC>
 int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shift, const u16* res, u16* y, long long P, int K,
                int cout, int act, hipStream_t s) {
-    const long long tiles_m = (P + BM - 1) / BM;
     const unsigned tiles_n = cout / BN;
+    const long long slots = 256ll * OCC;
+    const int adv = choose_adv<BM>(P, tiles_n, slots);
+    const long long tiles_m = (P + adv - 1) / adv;
     const long long total = tiles_m * tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv1x1_bf16: too many tiles");
-    const long long slots = 256ll * OCC;
     const long long g = total < slots ? total : slots;
     dim3 grid((unsigned)g), block(256);
     const int rev = sweep_reverse();
     ProjParams nopj{};
+    nopj.adv = adv;
     // resident weight tiles: K <= 128 (at most two steps per tile) and a grid whose stride keeps a workgroup on one channel origin
     // (and BM >= 128: the epilogue's 16 KB of wave-private scratch must fit the stage's ACTIVATION rows, or it lands on the weights)
     nopj.b_resident = (BM >= 128 && total > g && K <= 128 && g % 8 == 0 && (g / 8) % tiles_n == 0 && g_c11_bres) ? 1 : 0;
@@ -363,15 +396,17 @@ int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shi
 template <int BM, int BN, int OCC>
 int launch_proj_cfg(const u16* x, const u16* wt, const float* scale, const float* shift, u16* y, long long P, int K, int cout, int act,
                     const ProjParams& pj, hipStream_t s) {
-    const long long tiles_m = (P + BM - 1) / BM;
     const unsigned tiles_n = cout / BN;
+    const long long slots = 256ll * OCC;
+    const int adv = choose_adv<BM>(P, tiles_n, slots);
+    const long long tiles_m = (P + adv - 1) / adv;
     const long long total = tiles_m * tiles_n;
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "conv1x1_proj_bf16: too many tiles");
-    const long long slots = 256ll * OCC;
     const long long g = total < slots ? total : slots;
     dim3 grid((unsigned)g), block(256);
     const int rev = sweep_reverse();
     ProjParams pjr = pj;
+    pjr.adv = adv;
     pjr.b_resident = (BM >= 128 && total > g && K + pj.K2 <= 128 && g % 8 == 0 && (g / 8) % tiles_n == 0 && g_c11_bres) ? 1 : 0;
 #define HSEFR_C11P(A) HSEFR_LAUNCH((conv1x1_bf16_kernel<BM, BN, OCC, false, A, true>), grid, block, 0, s, x, wt, scale, shift, nullptr, y, P, K, cout, tiles_n, (unsigned)total, rev, pjr)
     if (act == HSEFR_ACT_RELU) HSEFR_C11P(HSEFR_ACT_RELU);
@@ -401,6 +436,7 @@ int read_c11_stamps(void* host_out, size_t bytes) {
 void set_c11(int v) { g_c11 = v; }
 void set_c11_tile(int v) { g_c11_tile = v; }
 void set_c11_bres(int v) { g_c11_bres = v; }
+void set_c11_adv(int v) { g_c11_adv = v; }
 #endif
 bool conv1x1_bf16_enabled(bool has_res, int k, int cout) {
     switch (g_c11) {      // values > 1: bisection aids

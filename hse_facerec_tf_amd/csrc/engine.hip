@@ -435,6 +435,7 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "c11")) { set_c11(value); return HSEFR_OK; }
     if (!strcmp(key, "c11_tile")) { set_c11_tile(value); return HSEFR_OK; }
     if (!strcmp(key, "c11_bres")) { set_c11_bres(value); return HSEFR_OK; }
+    if (!strcmp(key, "c11_adv")) { set_c11_adv(value); return HSEFR_OK; }
     if (!strcmp(key, "stem4_grid")) { set_stem4_grid(value); return HSEFR_OK; }
     if (!strcmp(key, "stem4")) { g_stem4 = value; return HSEFR_OK; }
     if (!strcmp(key, "stem5")) { g_stem5 = value; return HSEFR_OK; }
