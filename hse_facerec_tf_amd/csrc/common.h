@@ -323,7 +323,6 @@ void set_pws_tile(int v);
 void set_ps_mb(int v);
 void set_ps_grid(int v);
 void set_psdw_mode(int v);
-void set_ps_ablate(int v);
 void set_cd_rb(int v);
 void set_w3_off(int v);
 void set_w2_off(int v);

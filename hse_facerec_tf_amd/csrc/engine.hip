@@ -424,7 +424,6 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "ps_mb")) { set_ps_mb(value); return HSEFR_OK; }
     if (!strcmp(key, "ps_grid")) { set_ps_grid(value); return HSEFR_OK; }
     if (!strcmp(key, "psdw_mode")) { set_psdw_mode(value); return HSEFR_OK; }
-    if (!strcmp(key, "ps_ablate")) { set_ps_ablate(value); return HSEFR_OK; }
     if (!strcmp(key, "cd_rb")) { set_cd_rb(value); return HSEFR_OK; }
     if (!strcmp(key, "cd_off")) { set_cd_off(value); return HSEFR_OK; }
     if (!strcmp(key, "w3_off")) { set_w3_off(value); return HSEFR_OK; }

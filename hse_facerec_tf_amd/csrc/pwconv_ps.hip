@@ -69,8 +69,10 @@ __device__ unsigned long long g_ps_stamps[256 * 12 * 8];
 #define PS_STAMP_FLUSH do { } while (0)
 #endif
 
-#ifdef HSEFR_DEV
-#define PS_EPI_STORE(v, r, off) do { if (!(dw.ablate & 4)) bstore16_welded_nt(v, r, off, 0u); } while (0)
+#if defined(HSEFR_PS_KO) && ((HSEFR_PS_KO) & 4)
+// (the value stays "used": with nothing behind it hipcc removes the depthwise arithmetic that produced it, and the build measures the
+// whole epilogue -- bit 8 asks for exactly that)
+#define PS_EPI_STORE(v, r, off) do { if (!((HSEFR_PS_KO) & 8)) { f32x4 v_ = (v); asm volatile("" ::"v"(v_)); } } while (0)
 #else
 #define PS_EPI_STORE(v, r, off) bstore16_welded_nt(v, r, off, 0u)
 #endif
@@ -89,9 +91,6 @@ struct PsDwParams {
     float clamp_hi;       // 6 * out_scale (pool mode: 1 / HW)
     int tile_rows;        // rows of the matrix a tile ADVANCES by = whole maps per tile x HW (<= 32 MB; the tile's remaining rows are
                           // computed but belong to the next tile: 14 x 14 maps ride in 224-row tiles, five 7 x 7 maps in 256-row ones)
-    int ablate;           // development builds, timing only (results WRONG): 1 = the activation pieces of every tile whose channel origin is
-                          // not 0 move no bytes (out-of-range source: the piece is still issued) -- what "A streamed once per M tile" could save;
-                          // 2 = the same for the weight pieces of every step; 4 = no split-row / output stores in the epilogue
 };
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -370,8 +369,11 @@ __global__ __launch_bounds__(768, 1) void pwconv_ps_kernel(const void* __restric
 #pragma unroll
             for (int j = 0; j < PPW; ++j) {
                 const int p = lw * PPW + j;       // wave-uniform: the resource is picked with scalar selects
-#ifdef HSEFR_DEV
-                const bool dead = p < BM / 8 ? ((dw.ablate & 1) && pf_n0 != 0) : (dw.ablate & 2) != 0;
+#ifdef HSEFR_PS_KO      // knock-out builds (timing only, results WRONG; HSEFR_EXTRA_FLAGS=-DHSEFR_PS_KO=<bits>): 1 = the activation pieces of every
+                        // tile whose channel origin is not 0 move no bytes (out-of-range source; the piece is still issued), 2 = the weight
+                        // pieces likewise, 4 = no epilogue stores.  Compile-time on purpose: the same switch as a run-time flag made the
+                        // loaders' issue loop 45 % slower (58 -> 85 us per layer) -- it must stay branch-free (lesson 19)
+                const bool dead = p < BM / 8 ? (((HSEFR_PS_KO) & 1) && pf_n0 != 0) : ((HSEFR_PS_KO) & 2) != 0;
                 piece(p < BM / 8 ? ra_rsrc : rb_rsrc, base + p * 1024, dead ? 0x80000000u : pv[j], dead ? 0u : so);
 #else
                 piece(p < BM / 8 ? ra_rsrc : rb_rsrc, base + p * 1024, pv[j], so);
@@ -699,7 +701,6 @@ int choose_mb(long long m, int cout, int forced) {
 HSEFR_KNOB(g_ps_mb, 0);   // dev builds: 8 | 9 = forced tile height / 32
 HSEFR_KNOB(g_ps_grid, 0); // dev builds: > 0 = forced number of persistent workgroups (contention experiments)
 HSEFR_KNOB(g_psdw_mode, 0); // dev builds: 1 = the masked depthwise epilogue on 12 x 12 maps too (A/B against the bordered one)
-HSEFR_KNOB(g_ps_ablate, 0); // dev builds: PsDwParams::ablate
 
 template <int MB>
 int launch_mb(const void* xs, const void* wsplit, const float* descale, const float* shift, float* y, long long m, int k, int cout,
@@ -710,7 +711,7 @@ int launch_mb(const void* xs, const void* wsplit, const float* descale, const fl
     HSEFR_REQUIRE(total < (1ll << 31), HSEFR_ERR_UNSUPPORTED, "pwconv_presplit: too many tiles");
     unsigned g = (unsigned)(total < 256 ? total : 256);
     if (g_ps_grid > 0 && (unsigned)g_ps_grid < g) g = (unsigned)g_ps_grid;
-    const PsDwParams nodw{nullptr, nullptr, 0, 0, 0.f, 32 * MB, g_ps_ablate};
+    const PsDwParams nodw{nullptr, nullptr, 0, 0, 0.f, 32 * MB};
 #define HSEFR_PS_LAUNCH(A)                                                                                                 \
     HSEFR_LAUNCH((pwconv_ps_kernel<MB, A, 0>), dim3(g), dim3(768), 0, s, xs, wsplit, descale, shift, y, m, k, cout, tiles_n, \
                        (unsigned)total, sweep_reverse(), nodw)
@@ -728,7 +729,6 @@ int launch_mb(const void* xs, const void* wsplit, const float* descale, const fl
 void set_ps_mb(int v) { g_ps_mb = v; }
 void set_ps_grid(int v) { g_ps_grid = v; }
 void set_psdw_mode(int v) { g_psdw_mode = v; }
-void set_ps_ablate(int v) { g_ps_ablate = v; }
 int read_ps_stamps(void* host_out, size_t bytes) {
 #ifdef HSEFR_PS_STAMPS
     HSEFR_REQUIRE(bytes <= sizeof(unsigned long long) * 256 * 12 * 8, HSEFR_ERR_INVALID, "read_ps_stamps: too many bytes");
@@ -782,7 +782,7 @@ int launch_pwconv_ps_dw(const void* xs, const void* wsplit, const float* descale
     HSEFR_REQUIRE(out_log2 >= 1 && out_log2 <= 12, HSEFR_ERR_INVALID, "pwconv_presplit_dw: out_log2=%d", out_log2);
     if (m == 0) return HSEFR_OK;
     const int mb = (map_w == 12 && map_hw == 144) || act != HSEFR_ACT_RELU6 ? 9 : dw_tile_mb(map_hw);      // (14 x 14 -> 7, 7 x 7 -> 8)
-    PsDwParams dw{dwc, ys, map_w, map_hw, 6.f * (float)(1 << out_log2), (32 * mb / map_hw) * map_hw, g_ps_ablate};
+    PsDwParams dw{dwc, ys, map_w, map_hw, 6.f * (float)(1 << out_log2), (32 * mb / map_hw) * map_hw};
     if (act == HSEFR_ACT_RELU6) {
         const bool square = map_hw == map_w * map_w && g_psdw_mode != 1;      // the zero-bordered chunk buffer: 12 x 12, 14 x 14, 7 x 7 maps
         if (dw_stride == 2 && map_w == 14) return launch_psdw_relu6<7, 3, 14>(xs, wsplit, descale, shift, m, k, cout, dw, s);
@@ -841,7 +841,7 @@ int launch_pwconv_ps_gap(const void* xs, const void* wsplit, const float* descal
                   "pwconv_presplit_gap: m=%lld k=%d cout=%d map %d not covered (33 <= map <= 288 pixels)", m, k, cout, map_hw);
     if (m == 0) return HSEFR_OK;
     const int mb = act == HSEFR_ACT_RELU6 ? dw_tile_mb(map_hw) : 9;
-    const PsDwParams dw{nullptr, y, 0, map_hw, 1.0f / (float)map_hw, (32 * mb / map_hw) * map_hw, g_ps_ablate};
+    const PsDwParams dw{nullptr, y, 0, map_hw, 1.0f / (float)map_hw, (32 * mb / map_hw) * map_hw};
     if (act == HSEFR_ACT_RELU6 && mb == 7) return launch_psgap<7>(xs, wsplit, descale, shift, m, k, cout, act, dw, s);
     if (act == HSEFR_ACT_RELU6 && mb == 8) return launch_psgap<8>(xs, wsplit, descale, shift, m, k, cout, act, dw, s);
     return launch_psgap<9>(xs, wsplit, descale, shift, m, k, cout, act, dw, s);

@@ -146,6 +146,33 @@ def test_increase_layer_with_projected_shortcut_vs_oracle_and_vs_the_two_launch_
     assert torch.equal(ops.conv1x1_proj_bf16(d(x), pk(k1), f(sc), f(sh), d(x2), pk(k2), f(sc2), f(sh2), s2, act), got)     # run to run
 
 
+@pytest.mark.parametrize("n,hw,c,cout,c2", [(128, 56, 64, 256, 64), (100, 56, 64, 128, 64), (70, 28, 64, 256, 64)])
+def test_register_staged_kernels_with_resident_weight_tiles_bit_for_bit(env, n, hw, c, cout, c2):
+    """the register-staged 1x1 kernel keeps its weight tile RESIDENT in LDS when a tile's K loop is at most two steps and the
+    grid's stride keeps a workgroup on one channel origin (more tiles than slots).  Nothing small reaches that state: here the plain kernel
+    with a residual (K = 64) and the PROJ kernel (K + K2 = 128) at shapes with more than 512 tiles of 128 x 128, both outputs bit for bit
+    against the general implicit-GEMM kernel (the same convolution written as a 3 x 3 whose outer taps are zero) resp. the two-launch form."""
+    torch, ops, resnet50 = env
+    g = torch.Generator(device="cuda").manual_seed(hw * 31 + n + cout)
+    x = torch.randn((n, hw, hw, c), device="cuda", generator=g).to(torch.bfloat16)
+    x2 = torch.randn((n, hw, hw, c2), device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn((cout, c), device="cuda", generator=g) / c ** 0.5).to(torch.bfloat16)
+    w2 = (torch.randn((cout, c2), device="cuda", generator=g) / c2 ** 0.5).to(torch.bfloat16)
+    sc, sh = torch.rand((cout,), device="cuda", generator=g) + 0.5, torch.randn((cout,), device="cuda", generator=g)
+    sc2, sh2 = torch.rand((cout,), device="cuda", generator=g) + 0.5, torch.randn((cout,), device="cuda", generator=g)
+    assert ((n * hw * hw + 127) // 128) * (cout // 128) > 512
+    r = torch.randn((n, hw, hw, cout), device="cuda", generator=g).to(torch.bfloat16)
+    w3 = torch.zeros((cout, 3, 3, c), device="cuda", dtype=torch.bfloat16)
+    w3[:, 1, 1, :] = w
+    ref = ops.conv_bf16(x, w3.reshape(cout, 9 * c).contiguous(), sc, sh, 3, 3, 1, 1, r, 1)
+    for _ in range(2):
+        assert torch.equal(ops.conv_bf16(x, w, sc, sh, 1, 1, 1, 0, r, 1), ref)
+    pr = ops.conv_bf16(x2, w2, sc2, sh2, 1, 1, 1, 0, None, 0)
+    two = ops.conv_bf16(x, w, sc, sh, 1, 1, 1, 0, pr, 1)
+    for _ in range(2):
+        assert torch.equal(ops.conv1x1_proj_bf16(x, w, sc, sh, x2, w2, sc2, sh2, 1, 1), two)
+
+
 def test_conv_bf16_exact_integers(env):
     """Small integers are exact in bf16 and fp32: any im2col / fragment-map / swizzle mix-up shows as an exact mismatch."""
     torch, ops, resnet50 = env

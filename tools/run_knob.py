@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run another tool with development knobs set first (libhsefr_dev.so):   KNOBS=w4_off=2,c11_bres=0 python tools/run_knob.py tools/bench_configs.py resnet50"""
 import os, sys, runpy
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("HSEFR_LIB", "libhsefr_dev.so")
 from hse_facerec_tf_amd import _lib
 for kv in os.environ.get("KNOBS", "").split(","):
