@@ -6,7 +6,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 # product sources.  Development builds add round 1's stem (reachable only through lower_graph(stem_fusion="stem")) and the first window 3x3
 # convolution (conv3x3_w2_bf16.hip took its layers in round 5), each kept for A/B timing, plus the calibration kernels of devtools.hip.
-SRCS="engine.hip conv_first.hip dwconv.hip pwconv_f32.hip pwconv_f16s.hip pwconv_ps.hip pool_dense.hip nn1.hip conv_bf16.hip conv1x1_bf16.hip preprocess.hip dwpw_fused.hip dwpw_f16s.hip stem2_fused.hip stem3_fused.hip stem4_fused.hip stem5_stream.hip conv_f32_mfma.hip smallnet.hip area_resize.hip stem7x7_pool.hip conv_dma_bf16.hip conv3x3_w2_bf16.hip conv1x1_w4_bf16.hip conv1x1_pair_bf16.hip mtcnn_post.hip"
+SRCS="engine.hip conv_first.hip dwconv.hip pwconv_f32.hip pwconv_f16s.hip pwconv_ps.hip pool_dense.hip nn1.hip conv_bf16.hip conv1x1_bf16.hip preprocess.hip dwpw_fused.hip dwpw_f16s.hip stem2_fused.hip stem3_fused.hip stem4_fused.hip stem5_stream.hip conv_f32_mfma.hip smallnet.hip area_resize.hip stem7x7_pool.hip stem7s_stream.hip conv_dma_bf16.hip conv3x3_w2_bf16.hip conv1x1_w4_bf16.hip conv1x1_pair_bf16.hip mtcnn_post.hip"
 # -Wno-inline-asm: the LDS-DMA statements write M0 and say so in their clobber lists; clang warns that M0 is a
 # reserved register for every instantiation -- the declaration is the point (the compiler must not assume M0 survives)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-result -Wno-inline-asm"

@@ -232,6 +232,9 @@ int launch_conv_dma_bf16(const void* x, const void* wt, const float* scale, cons
                          int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act, hipStream_t s);
 int launch_stem7x7_pool_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h, int w,
                              int ph, int pw, int pool_pad_t, int pool_pad_l, hipStream_t s);
+bool stem7s_stream_supported(long long n, int h, int w, int ph, int pw);
+int launch_stem7s_stream(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h, int w, int ph, int pw,
+                         int pool_pad_t, int pool_pad_l, hipStream_t s);
 int launch_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int pad_t, int pad_l,
                              hipStream_t s);
 int launch_gap_bf16(const void* x, float* y, int n, int hw, int c, hipStream_t s);
@@ -329,10 +332,12 @@ void set_w2_off(int v);
 void set_w4_off(int v);
 void set_w4_bres(int v);
 void set_pair_off(int v);
+void set_stem7s(int v);
 void set_pair_ablate(int v);
 void set_pair_nt(int v);
 void set_nn1_y_mb(int v);
 int read_w4_stamps(void* host_out, size_t bytes);
+int read_s7_stamps(void* host_out, size_t bytes);
 int read_w2_stamps(void* host_out, size_t bytes);
 int read_w3_stamps(void* host_out, size_t bytes);
 int read_cd_stamps(void* host_out, size_t bytes);

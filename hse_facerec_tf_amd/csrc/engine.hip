@@ -441,6 +441,7 @@ int hsefr_debug_set(const char* key, int value) {
     if (!strcmp(key, "stem5_grid")) { set_stem5_grid(value); return HSEFR_OK; }
     if (!strcmp(key, "stem5_segs")) { set_stem5_segs(value); return HSEFR_OK; }
     if (!strcmp(key, "pair_off")) { set_pair_off(value); return HSEFR_OK; }
+    if (!strcmp(key, "stem7s")) { set_stem7s(value); return HSEFR_OK; }
     if (!strcmp(key, "pair_ablate")) { set_pair_ablate(value); return HSEFR_OK; }
     if (!strcmp(key, "pair_nt")) { set_pair_nt(value); return HSEFR_OK; }
     if (!strcmp(key, "heads_off")) { g_heads_off = value; return HSEFR_OK; }
@@ -475,6 +476,7 @@ int hsefr_debug_read_stamps(int kernel, void* host_out, size_t bytes) {
         case HSEFR_STAMPS_W4: return read_w4_stamps(host_out, bytes);
         case HSEFR_STAMPS_W2: return read_w2_stamps(host_out, bytes);
         case HSEFR_STAMPS_W3: return read_w3_stamps(host_out, bytes);
+        case HSEFR_STAMPS_S7: return read_s7_stamps(host_out, bytes);
         default: set_error("debug_read_stamps: unknown kernel id %d", kernel); return HSEFR_ERR_INVALID;
     }
 }

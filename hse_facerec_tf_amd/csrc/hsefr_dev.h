@@ -29,7 +29,8 @@ typedef enum hsefr_stamp_kernel {
     HSEFR_STAMPS_C11 = 4,  /* conv1x1_bf16.hip: the register-staged 1x1 GEMM [512 * 4][8]      */
     HSEFR_STAMPS_W4 = 5,   /* conv1x1_w4_bf16.hip: the four-wave 1x1 GEMM    [256][8][8]       */
     HSEFR_STAMPS_W2 = 6,   /* conv3x3_w2_bf16.hip: the four-wave window 3x3  [256][8][8]       */
-    HSEFR_STAMPS_W3 = 7    /* conv3x3_win_bf16.hip: the window 3x3           [256][12][8]      */
+    HSEFR_STAMPS_W3 = 7,   /* conv3x3_win_bf16.hip: the window 3x3           [256][12][8]      */
+    HSEFR_STAMPS_S7 = 8    /* stem7s_stream.hip: ResNet's streaming stem     [512][4][10] (-DHSEFR_S7_STAMPS) */
 } hsefr_stamp_kernel;
 int hsefr_debug_read_stamps(int kernel, void* host_out, size_t bytes);
 int hsefr_debug_clock_probe(unsigned long long* d_out, int blocks, int iters, hsefr_stream_t stream);

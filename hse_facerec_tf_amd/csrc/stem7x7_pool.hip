@@ -202,6 +202,8 @@ int launch_stem7x7_pool_bf16(const float* x, const void* wt, const float* scale,
     HSEFR_REQUIRE(2 * (ph - 1) - pool_pad_t < oh && 2 * (pw - 1) - pool_pad_l < ow, HSEFR_ERR_INVALID,
                   "stem7x7_pool: pooled size %dx%d does not fit a %dx%d conv map", ph, pw, oh, ow);
     if (n == 0) return HSEFR_OK;
+    // the streaming form (stem7s_stream.hip, round 6) wherever it covers the shape; this patch kernel otherwise
+    if (stem7s_stream_supported(n, h, w, ph, pw)) return launch_stem7s_stream(x, wt, scale, shift, y, n, h, w, ph, pw, pool_pad_t, pool_pad_l, s);
     StemPoolParams p;
     p.x = x; p.wt = (const u16*)wt; p.scale = scale; p.shift = shift; p.y = (u16*)y;
     p.H = h; p.W = w; p.OH = oh; p.OW = ow; p.PH = ph; p.PW = pw; p.ppt = pool_pad_t; p.ppl = pool_pad_l;

@@ -60,7 +60,7 @@ PRODUCT_KERNEL_FAMILIES = frozenset({
     "dwconv3x3_kernel", "pwconv_f32_dma_kernel", "pwconv_f32_kernel", "pwconv_f16s_kernel", "pwconv_ps_kernel", "dwpw_fused_kernel",
     "dwpw_f16s_kernel", "dwpw2_f16s_kernel", "dwpw3_f16s_kernel", "gap_kernel", "dense_kernel", "softmax_kernel", "heads_kernel",
     # ResNet (bf16, and the fp32-grade mode)
-    "stem7x7_pool_bf16_kernel", "stem7x7_bf16_kernel", "maxpool3x3s2_bf16_kernel", "conv_bf16_kernel", "conv1x1_bf16_kernel",
+    "stem7s_stream_kernel", "stem7x7_pool_bf16_kernel", "stem7x7_bf16_kernel", "maxpool3x3s2_bf16_kernel", "conv_bf16_kernel", "conv1x1_bf16_kernel",
     "conv1x1_w4_bf16_kernel", "conv1x1_pair_bf16_kernel", "conv3x3_w2_bf16_kernel", "conv_dma_bf16_kernel", "gap_bf16_kernel",
     "conv_f32_mfma_kernel", "conv2d_f32_kernel", "maxpool_f32_kernel"})
 
