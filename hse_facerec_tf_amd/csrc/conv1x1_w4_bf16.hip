@@ -31,6 +31,9 @@
 
 #include "common.h"
 
+#ifndef W4_RESAUX
+#define W4_RESAUX 0     // cache policy of the residual loads (buffer aux bits: 1 glc, 2 slc), as conv1x1_bf16.hip's C11_RESAUX
+#endif
 namespace hsefr {
 
 namespace {
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(512) void conv1x1_w4_bf16_kernel(W4Params p) {
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    rres[rb][j] = bload16(rr, ylane + 64u * (unsigned)j, __builtin_amdgcn_readfirstlane((unsigned)(16 * rb) * (unsigned)p.Cout * 2u));
+                    rres[rb][j] = __builtin_bit_cast(hsefr_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ylane + 64u * (unsigned)j, __builtin_amdgcn_readfirstlane((unsigned)(16 * rb) * (unsigned)p.Cout * 2u), W4_RESAUX));
         }
 #pragma unroll
         for (int blk = 0; blk < 2 && blk < RB; ++blk) { ar[blk][0] = lda(acur, blk, 0); ar[blk][1] = lda(acur, blk, 1); }

@@ -32,6 +32,9 @@
 
 #include "common.h"
 
+#ifndef PWS_AAUX
+#define PWS_AAUX 0     // cache policy of the activation loads (buffer aux bits: 1 glc, 2 slc)
+#endif
 namespace hsefr {
 
 namespace {
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(128 * WAVES_N, OCC) void pwconv_f16s_kernel(const f
         constexpr int S = decltype(SET)::value;
         const unsigned so = (unsigned)pf_kt * (BK * 4u);
 #pragma unroll
-        for (int p = 0; p < AP; ++p) ra[S][p] = bload16(ra_rsrc, voff, so + (unsigned)(SR * p) * rowbytes);
+        for (int p = 0; p < AP; ++p) ra[S][p] = __builtin_bit_cast(hsefr_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, voff, so + (unsigned)(SR * p) * rowbytes, PWS_AAUX));
 #pragma unroll
         for (int p = 0; p < BP; ++p) rb[S][p] = bload16(rb_rsrc, voff, so + (unsigned)(SR * p) * rowbytes);
     };

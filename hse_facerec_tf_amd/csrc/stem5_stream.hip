@@ -62,6 +62,9 @@ struct Stem5Params {
     long long x_bytes;
 };
 
+#ifndef S5_LDAUX
+#define S5_LDAUX 0     // cache policy of the image loads (buffer aux bits: 1 glc, 2 slc); slc measured in the network: +6 us at 192 x 192 x 256, +-0 at 224 x 224 x 512 (ResNet stem: a gain, stem7s_stream.hip)
+#endif
 #ifndef S5_KS
 #define S5_KS 6
 #endif
@@ -257,8 +260,8 @@ __global__ __launch_bounds__(64 * WAVES, S5_WGS) void stem5_stream_kernel(Stem5P
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const unsigned voff = (rok && wok[k]) ? (unsigned)((rowpart + wcol[k]) * VB) : 0x80000000u;
-                if constexpr (U8) rawv[k] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff, 0, 0);
-                else rawv[k] = bload16(rx, voff, 0);
+                if constexpr (U8) rawv[k] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff, 0, S5_LDAUX);
+                else rawv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, S5_LDAUX));
             }
         };
 

@@ -32,6 +32,9 @@
 
 #include "common.h"
 
+#ifndef S7_LDAUX
+#define S7_LDAUX 2   // cache policy of the image loads (buffer aux bits: 1 glc, 2 slc): streamed once -- with slc the pooled map survives for its two readers (the projection pair behind the stem 98 -> 90 us, the stem itself + 1.5)
+#endif
 #ifndef S7_KO
 #define S7_KO 0      // knock-out builds (timing only, results WRONG): 1 = no MFMAs, 2 = no scale / ReLU / horizontal maxima, 4 = the window loads move no bytes, 8 = no output stores
 #endif
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void stem7s_stream_kernel(Stem7sPara
             for (int r = 0; r < 3; ++r) {
                 const int iy = Rb + 4 * s + 5 + wrow[r];
                 const bool ok = wcol[r] && iy >= 0 && iy < p.H;
-                raw[r] = __builtin_amdgcn_raw_buffer_load_b96(rx, (ok && !(S7_KO & 4)) ? woff[r] + (unsigned)s * rowstep : 0x80000000u, 0, 0);
+                raw[r] = __builtin_amdgcn_raw_buffer_load_b96(rx, (ok && !(S7_KO & 4)) ? woff[r] + (unsigned)s * rowstep : 0x80000000u, 0, S7_LDAUX);
             }
         };
         auto to_px = [](u32x3 v) __attribute__((always_inline)) -> u32x2 {
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void stem7s_stream_kernel(Stem7sPara
                 const int rr = i / WPX, pp = i - WPX * rr;
                 const int iy = Rb + rr, ix = ix0 + pp;
                 const bool ok = rr < 5 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rx, ok ? (unsigned)(((n * p.H + iy) * p.W + ix) * 12) : 0x80000000u, 0, 0);
+                const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rx, ok ? (unsigned)(((n * p.H + iy) * p.W + ix) * 12) : 0x80000000u, 0, S7_LDAUX);
                 if (rr < 5) *(u32x2*)(L + rr * WROWB + pp * 8) = to_px(v);
             }
         }
@@ -220,10 +223,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void stem7s_stream_kernel(Stem7sPara
             const int py = py_a + s - 1;
             const bool edge = cA < 0 || cA + 1 >= p.OH || cx0 < 0 || cx0 + 16 > p.OW;      // (uniform) some conv row / column of the step lies outside the map
             const bool rval[2] = {cA >= 0 && cA < p.OH, cA + 1 >= 0 && cA + 1 < p.OH};
-            auto xfrag = [&](int it) __attribute__((always_inline)) -> bf16x8 {
-                const int slot = (4 * PH3 + 2 * (it / 7) + it % 7) % RING;
-                return *(const bf16x8*)(L + slot * WROWB + fr0);
-            };
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 f32x4 acc[2][2];
@@ -231,30 +230,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void stem7s_stream_kernel(Stem7sPara
                 for (int cr = 0; cr < 2; ++cr)
 #pragma unroll
                     for (int k = 0; k < 2; ++k) acc[cr][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifndef S7_DEPTH
-#define S7_DEPTH 7
-#endif
-                // fragment reads S7_DEPTH ahead of the MFMAs that use them: the reads of a conv row go out together (a read one ahead left
-                // every MFMA pair waiting for an LDS round trip: 90 us; hipcc's own choice, six ahead with the full accumulator set, spilled)
-                bf16x8 xb[14];
+                // the step's NINE window rows at the lane's column: conv row cr, kernel row dy is window row 2 cr + dy -- rows 2 .. 6 serve both
+                // conv rows (9 ds_read_b128 per half where "7 per conv row" was 14; kept across both channel halves they spill)
+                bf16x8 xr[9];
 #pragma unroll
-                for (int it = 0; it < S7_DEPTH; ++it) xb[it] = xfrag(it);
+                for (int r = 0; r < 9; ++r) xr[r] = *(const bf16x8*)(L + ((4 * PH3 + r) % RING) * WROWB + fr0);
 #pragma unroll
-                for (int it = 0; it < 14; ++it) {
-                    if (it + S7_DEPTH < 14 && (it % S7_DEPTH) == 0) {
+                for (int dy = 0; dy < 7; ++dy)
 #pragma unroll
-                        for (int j2 = 0; j2 < S7_DEPTH; ++j2)
-                            if (it + S7_DEPTH + j2 < 14) xb[it + S7_DEPTH + j2] = xfrag(it + S7_DEPTH + j2);
-                    }
-                    wave_order();
+                    for (int cr = 0; cr < 2; ++cr) {
 #if !(S7_KO & 1)
 #pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        acc[it / 7][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb[it], wf[2 * hb + k][it % 7], acc[it / 7][k], 0, 0, 0);
+                        for (int k = 0; k < 2; ++k)
+                            acc[cr][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xr[2 * cr + dy], wf[2 * hb + k][dy], acc[cr][k], 0, 0, 0);
 #else
-                    acc[it / 7][0][0] += (float)xb[it][0];       // (knock-out build: the fragment stays "used")
+                        acc[cr][0][0] += (float)xr[2 * cr + dy][0];       // (knock-out build: the fragment stays "used")
 #endif
-                }
+                    }
                 S7_STAMP(2 + 2 * hb);      // fragment reads + MFMAs of the half
                 // ---- scale, shift, ReLU and the pool's three ROWS, in the lane (pixels are the MFMA's rows here: the lane holds conv columns
                 // 4 q4 + e of ONE channel per block, so scale and shift are two registers per block -- with the channels as rows they were

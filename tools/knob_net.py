@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-network A/B of development-library knobs on one box, one process: the same engine, the knob flipped between timed blocks.
-usage: HSEFR_LIB=libhsefr_dev.so python tools/knob_net.py <resnet50|agegender|mobilenet192> <knob> <v0,v1,...> [first_op last_op]
+usage: HSEFR_LIB=libhsefr_dev.so [KN_BATCH=n (resnet50)] python tools/knob_net.py <resnet50|agegender|mobilenet192> <knob> <v0,v1,...> [first_op last_op]
 prints ms / step per value (three alternating rounds, best of each) and the per-op times of ops first..last."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,7 @@ vals = [int(v) for v in sys.argv[3].split(",")]
 lo, hi = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (0, -1)
 rs = np.random.RandomState(123)
 if what == "resnet50":
-    B, want = 128, (0,)
+    B, want = int(os.environ.get("KN_BATCH", "128")), (0,)
     plan = resnet50.build_plan(resnet50.synthetic_weights(123), (224, 224), "caffe")
     x = torch.from_numpy(rs.uniform(-128, 128, (B, 224, 224, 3)).astype(np.float32)).cuda()
 elif what == "agegender":
