@@ -620,7 +620,7 @@ def run_other_configs(args, dev):
         # measured HBM bytes per forward from the committed PMC profile of this config (tools/gpu_pmc.sh over
         # tools/bench_configs.py resnet50: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled): sum over its kernels
         # of launches x bytes per launch, divided by the number of forwards (= launches of the once-per-forward stem kernel)
-        rn_traffic, rn_src, rn_stale = profile_traffic_per_forward("resnet50", "stem7x7_pool")
+        rn_traffic, rn_src, rn_stale = profile_traffic_per_forward("resnet50", "stem7")
         out.append({"config": "BASELINE configs[2]: ResNet-50 embeddings (2048-D), batch 128, 224x224x3, bf16 storage + bf16 MFMA, fp32 accumulate",
                     "value": round(B / dt, 1), "unit": "faces/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "dtype": "bf16",
                     "weights": "synthetic (seed 123)", "tflops": round(fl * B / dt / 1e12, 1),
