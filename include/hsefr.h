@@ -106,7 +106,7 @@ typedef enum hsefr_op_kind {
                                   ResNet-style graphs (csrc/smallnet.hip).  w_off = TF HWIO kernel fp32, cout % 4 == 0  */
     HSEFR_OP_MAXPOOL_F32 = 19, /* k x k / stride max-pool with windows clipped to the image, fp32 (kh = kw = k)          */
     HSEFR_OP_STEM7X7_POOL_BF16 = 20, /* STEM7X7_BF16 (act must be ReLU) + the 3x3 / 2 max-pool behind it in one kernel
-                                  (csrc/stem7x7_pool.hip): fp32 image in, POOLED bf16 map out (oh, ow = pooled size);
+                                  (csrc/stem7s_stream.hip; csrc/stem7x7_pool.hip beyond 32-bit offsets): fp32 image in, POOLED bf16 map out (oh, ow = pooled size);
                                   reserved = pool_pad_t | pool_pad_l << 4, each 0 or 1; blob operands as STEM7X7_BF16    */
     HSEFR_OP_PWCONV_PS_DW = 21, /* PWCONV_PS + the NEXT block's depthwise 3x3 (stride 1, SAME) + scale + shift + ReLU6 in the GEMM's epilogue,
                                   output = that depthwise layer's split rows (csrc/pwconv_ps.hip): h * w <= 288; stride = the depthwise's
@@ -552,7 +552,9 @@ int hsefr_conv2d_f32(const float* x, const float* wgt, const float* scale, const
 
 /* conv1 7x7/2 pad 3 (3 -> 64) + scale + shift + ReLU + max-pool 3x3/2 in one kernel: x fp32 [n,h,w,3], wgt_t as
  * hsefr_stem7x7_bf16, y bf16 [n,ph,pw,64].  Pool windows start at 2 * p - pool_pad and are clipped to the conv map
- * (pool_pad 0 with ph = ceil((oh - 3) / 2) + 1 is Caffe's ceil mode; TF SAME / an explicit Pad pass 0 or 1). */
+ * (pool_pad 0 with ph = ceil((oh - 3) / 2) + 1 is Caffe's ceil mode; TF SAME / an explicit Pad pass 0 or 1).  Runs the streaming kernel
+ * (csrc/stem7s_stream.hip) where the launch fits 32-bit byte offsets, the patch kernel (csrc/stem7x7_pool.hip) otherwise: same rounding
+ * points, fp32 accumulation order differs (rare one-ulp bf16 differences between the two). */
 int hsefr_stem7x7_pool_bf16(const float* x, const void* wgt_t, const float* scale, const float* shift, void* y, int n, int h, int w,
                             int ph, int pw, int pool_pad_t, int pool_pad_l, hsefr_stream_t stream);
 

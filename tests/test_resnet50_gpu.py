@@ -376,9 +376,10 @@ def test_resnet_style_frozen_graph_in_the_fp32_grade_mode(env, tmp_path, pool, b
 
 
 @pytest.mark.parametrize("n,h,w,ceil,ppad", [(2, 64, 64, True, 0), (1, 224, 224, True, 0), (1, 224, 224, False, 0), (3, 37, 51, True, 0),
-                                              (2, 38, 38, False, 1), (1, 70, 45, False, 0), (2, 30, 29, True, 1)])
+                                              (2, 38, 38, False, 1), (1, 70, 45, False, 0), (2, 30, 29, True, 1), (2, 7, 9, True, 0)])
 def test_fused_stem_pool_vs_oracle(env, n, h, w, ceil, ppad):
-    """conv1 + ReLU + pool1 in one kernel (csrc/stem7x7_pool.hip) against the oracle's conv -> bf16 -> clipped max-pool, and
+    """conv1 + ReLU + pool1 in one kernel (csrc/stem7s_stream.hip; the 7 x 9 image is below its minimum and runs the patch kernel,
+    csrc/stem7x7_pool.hip) against the oracle's conv -> bf16 -> clipped max-pool, and
     against the two-kernel path (same rounding points; fp32 accumulation order differs: rare one-ulp bf16 differences)."""
     torch, ops, resnet50 = env
     rs = np.random.RandomState(h * 3 + w)
