@@ -230,11 +230,15 @@ bool conv_dma_forced();
 bool conv_dma_bf16_supported(long long n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw);
 int launch_conv_dma_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,
                          int w, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act, hipStream_t s);
+// wfrag: the weight image in the streaming kernel's fragment order (stem7s_reorder_weights; STEM7S_WFRAG_BYTES), or null -- then the kernel
+// re-orders wt itself, in every workgroup's prologue.  The engine makes the image once per plan.
 int launch_stem7x7_pool_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h, int w,
-                             int ph, int pw, int pool_pad_t, int pool_pad_l, hipStream_t s);
+                             int ph, int pw, int pool_pad_t, int pool_pad_l, hipStream_t s, const void* wfrag = nullptr);
 bool stem7s_stream_supported(long long n, int h, int w, int ph, int pw);
 int launch_stem7s_stream(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h, int w, int ph, int pw,
-                         int pool_pad_t, int pool_pad_l, hipStream_t s);
+                         int pool_pad_t, int pool_pad_l, hipStream_t s, const void* wfrag = nullptr);
+constexpr size_t STEM7S_WFRAG_BYTES = 4 * 7 * 64 * 16;
+int stem7s_reorder_weights(const void* wt, void* wfrag, hipStream_t s);
 int launch_maxpool3x3s2_bf16(const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int pad_t, int pad_l,
                              hipStream_t s);
 int launch_gap_bf16(const void* x, float* y, int n, int hw, int c, hipStream_t s);

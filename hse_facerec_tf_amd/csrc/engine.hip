@@ -45,6 +45,8 @@ struct hsefr_engine {
     std::vector<void*> d_bufs;
     char* d_blob = nullptr;
     int* d_overflow = nullptr;        // input-bound flag of STEM3 ops (hsefr_engine_input_overflow)
+    std::vector<void*> d_derived;     // per op: an operand the engine derives from the blob once (STEM7X7_POOL_BF16: the weight image in the
+                                      // streaming kernel's fragment order), or null
     size_t device_bytes = 0;
     int max_batch = 0;
     int device = 0;
@@ -551,6 +553,18 @@ int hsefr_engine_create(const void* plan, size_t plan_bytes, int max_batch, hsef
         set_error("engine_create: hipMalloc for the overflow flag failed");
         return fail(HSEFR_ERR_NOMEM);
     }
+    e->d_derived.assign(e->ops.size(), nullptr);
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        const hsefr_plan_op& o = e->ops[i];
+        if (o.kind != HSEFR_OP_STEM7X7_POOL_BF16) continue;
+        if (hipMalloc(&e->d_derived[i], STEM7S_WFRAG_BYTES) != hipSuccess) {
+            set_error("engine_create: hipMalloc for the stem's fragment-ordered weights failed");
+            return fail(HSEFR_ERR_NOMEM);
+        }
+        e->device_bytes += STEM7S_WFRAG_BYTES;
+        if (int rc = stem7s_reorder_weights(blob_ptr(e, o.w_off), e->d_derived[i], nullptr)) return fail(rc);
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { set_error("engine_create: re-ordering the stem's weights failed"); return fail(HSEFR_ERR_HIP); }
+    }
     e->d_bufs.assign(h.n_buffers, nullptr);
     for (uint32_t i = 0; i < h.n_buffers; ++i) {
         const size_t bytes = (size_t)e->bufs[i].elems_per_image * e->bufs[i].elem_bytes * max_batch;
@@ -732,7 +746,7 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
             case HSEFR_OP_STEM7X7_POOL_BF16:
                 rc = launch_stem7x7_pool_bf16((const float*)in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
                                               (const float*)blob_ptr(e, o.shift_off), out, n, o.h, o.w, o.oh, o.ow, o.reserved & 15,
-                                              (o.reserved >> 4) & 15, s);
+                                              (o.reserved >> 4) & 15, s, i < e->d_derived.size() ? e->d_derived[i] : nullptr);
                 break;
             case HSEFR_OP_MAXPOOL_BF16:
                 rc = launch_maxpool3x3s2_bf16(in, out, n, o.h, o.w, o.cin, o.oh, o.ow, o.pad_t, o.pad_l, s);
@@ -1000,6 +1014,8 @@ int hsefr_engine_destroy(hsefr_engine* e) {
         if (b) (void)hipFree(b);
     if (e->d_blob) (void)hipFree(e->d_blob);
     if (e->d_overflow) (void)hipFree(e->d_overflow);
+    for (void* b : e->d_derived)
+        if (b) (void)hipFree(b);
     for (auto ev : e->events) (void)hipEventDestroy(ev);
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);

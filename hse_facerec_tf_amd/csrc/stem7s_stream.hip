@@ -51,6 +51,7 @@ typedef unsigned short u16;
 struct Stem7sParams {
     const float* x;      // [N,H,W,3] fp32
     const u16* wt;       // [64][8][32] bf16, k = dy*32 + dx*3 + ci, zero padded (resnet50.pack_stem_weight)
+    const bf16x8* wfrag; // the same weights in fragment order (stem7s_reorder_kernel), or null: the kernel re-orders wt itself
     const float* scale;  // [64]
     const float* shift;  // [64]
     u16* y;              // [N,PH,PW,64] bf16
@@ -88,43 +89,56 @@ __device__ unsigned long long g_s7_stamps[512 * 4 * 10];
 #define S7_STAMP_RESET do { } while (0)
 #define S7_STAMP_FLUSH do { } while (0)
 #endif
+// fragment f = (nb * 7 + dy) * 64 + lane of the weight image: channel 16 nb + lane % 16, kernel row dy, pixels 2 (lane / 16) and + 1 as
+// [R, G, B, 0] each, from the blob's [64][8][32] image (k = dy * 32 + dx * 3 + ci)
+template <typename P> __device__ __forceinline__ bf16x8 wfrag_of(P img, int f) {
+    const int fl = f & 63, fdy = (f >> 6) % 7, fnb = f / (64 * 7);
+    const auto row = img + (16 * fnb + (fl & 15)) * 256 + fdy * 32;
+    unsigned short v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int dx = 2 * (fl >> 4) + (i >> 2), ci = i & 3;
+        v[i] = (dx < 7 && ci < 3) ? row[dx * 3 + ci] : (unsigned short)0;
+    }
+    return __builtin_bit_cast(bf16x8, *(const __attribute__((ext_vector_type(8))) unsigned short*)v);
+}
+
+// the engine's one-off: the whole image in fragment order (STEM7S_WFRAG_BYTES)
+__global__ __launch_bounds__(256) void stem7s_reorder_kernel(const u16* wt, bf16x8* out) {
+    for (int f = threadIdx.x; f < 4 * 7 * 64; f += 256) out[f] = wfrag_of(wt, f);
+}
+
 __global__ __launch_bounds__(64 * WAVES, 2) void stem7s_stream_kernel(Stem7sParams p) {
     __shared__ __attribute__((aligned(128))) unsigned char smem[64 * 512 + 4 * 7 * 64 * 16];       // the weight image (32 KB) + its fragment-ordered copy (28 KB) during the prologue, then WAVES x WAVE_LDS
-    __shared__ __attribute__((aligned(16))) float Es[128];                       // scale | shift
     static_assert(WAVES * WAVE_LDS <= 64 * 512, "the wave regions fit where the weight image was");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, q4 = lane >> 4;
     S7_STAMP_DECL;
 
-    // ---- prologue: the weight image through LDS into fragment registers, re-ordered to four values per pixel ----
-    for (int i = tid; i < 64 * 512 / 16; i += 64 * WAVES) ((f32x4*)smem)[i] = ((const f32x4*)p.wt)[i];
-    if (tid < 64) Es[tid] = p.scale[tid];
-    else if (tid < 128) Es[tid] = p.shift[tid - 64];
-    __syncthreads();
-    // the workgroup re-orders the image ONCE into fragment order -- [nb][dy][lane] x 16 bytes, behind the image -- and every lane reads its 28
-    // fragments as ds_read_b128 (each wave gathering its own registers was 224 ds_read_u16 per lane: a quarter of a wave's lifetime)
-    for (int f = tid; f < 4 * 7 * 64; f += 64 * WAVES) {
-        const int fl = f & 63, fdy = (f >> 6) % 7, fnb = f / (64 * 7);
-        const u16* row = (const u16*)smem + (16 * fnb + (fl & 15)) * 256 + fdy * 32;
-        unsigned short v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int dx = 2 * (fl >> 4) + (i >> 2), ci = i & 3;
-            v[i] = (dx < 7 && ci < 3) ? row[dx * 3 + ci] : (unsigned short)0;
-        }
-        *(bf16x8*)(smem + 64 * 512 + f * 16) = __builtin_bit_cast(bf16x8, *(const __attribute__((ext_vector_type(8))) unsigned short*)v);
-    }
-    __syncthreads();
+    // ---- prologue: the weight image into fragment registers, re-ordered to four values per pixel.  With the engine's fragment-ordered copy
+    // (p.wfrag: made once per plan) that is 28 16-byte loads per lane; without it (direct calls) the workgroup re-orders the blob's image
+    // through LDS -- [nb][dy][lane] x 16 bytes behind the image, every lane then reads 28 ds_read_b128 (each wave gathering its own
+    // registers was 224 ds_read_u16 per lane: a quarter of a wave's lifetime; the workgroup's pass is still a tenth) ----
     bf16x8 wf[4][7];     // [channel block nb][kernel row dy]: lane (channel 16 nb + l16, k slice q4) holds k = 32 dy + 8 q4 .. + 7 = pixels 2 q4, 2 q4 + 1
+    float scl[4], shf[4];      // the lane's channel of every block (16 nb + l16): scale and shift stay in registers
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < 4; ++nb) { scl[nb] = p.scale[16 * nb + l16]; shf[nb] = p.shift[16 * nb + l16]; }
+    if (p.wfrag) {       // (uniform)
 #pragma unroll
-        for (int dy = 0; dy < 7; ++dy) wf[nb][dy] = *(const bf16x8*)(smem + 64 * 512 + ((nb * 7 + dy) * 64 + lane) * 16);
-    // the lane's channel of every block (16 nb + l16): scale and shift stay in registers
-    float scl[4], shf[4];
+        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) { scl[nb] = Es[16 * nb + l16]; shf[nb] = Es[64 + 16 * nb + l16]; }
-    __syncthreads();     // the image's bytes become the waves' regions
+            for (int dy = 0; dy < 7; ++dy) wf[nb][dy] = p.wfrag[(nb * 7 + dy) * 64 + lane];
+    } else {
+        for (int i = tid; i < 64 * 512 / 16; i += 64 * WAVES) ((f32x4*)smem)[i] = ((const f32x4*)p.wt)[i];
+        __syncthreads();
+        for (int f = tid; f < 4 * 7 * 64; f += 64 * WAVES) *(bf16x8*)(smem + 64 * 512 + f * 16) = wfrag_of((const u16*)smem, f);
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int dy = 0; dy < 7; ++dy) wf[nb][dy] = *(const bf16x8*)(smem + 64 * 512 + ((nb * 7 + dy) * 64 + lane) * 16);
+        __syncthreads();     // the image's bytes become the waves' regions
+    }
     unsigned char* const L = smem + wave * WAVE_LDS;
     S7_STAMP(7);         // the prologue: weights into fragment registers
     // the eighth pixel of a row's last fragment (pixel 35) is written by no load: zero once (finite under its zero weights)
@@ -343,10 +357,10 @@ bool stem7s_stream_supported(long long n, int h, int w, int ph, int pw) {
 }
 
 int launch_stem7s_stream(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h, int w, int ph, int pw,
-                         int pool_pad_t, int pool_pad_l, hipStream_t s) {
+                         int pool_pad_t, int pool_pad_l, hipStream_t s, const void* wfrag) {
     HSEFR_REQUIRE(stem7s_stream_supported(n, h, w, ph, pw), HSEFR_ERR_UNSUPPORTED, "stem7s_stream: shape not covered");
     Stem7sParams p;
-    p.x = x; p.wt = (const u16*)wt; p.scale = scale; p.shift = shift; p.y = (u16*)y;
+    p.x = x; p.wt = (const u16*)wt; p.wfrag = (const bf16x8*)wfrag; p.scale = scale; p.shift = shift; p.y = (u16*)y;
     p.H = h; p.W = w; p.OH = (h - 1) / 2 + 1; p.OW = (w - 1) / 2 + 1; p.PH = ph; p.PW = pw; p.ppt = pool_pad_t; p.ppl = pool_pad_l;
     p.strips = (pw + KS - 1) / KS;
     // vertical segments: enough units for the 2048 resident waves (a segment costs one start-up step)
@@ -363,6 +377,11 @@ int launch_stem7s_stream(const float* x, const void* wt, const float* scale, con
     const unsigned need = (p.total + WAVES - 1) / WAVES;
     HSEFR_LAUNCH(stem7s_stream_kernel, dim3(need < 512u ? need : 512u), dim3(64 * WAVES), 0, s, p);
     return launch_status("stem7s_stream");
+}
+
+int stem7s_reorder_weights(const void* wt, void* wfrag, hipStream_t s) {
+    HSEFR_LAUNCH(stem7s_reorder_kernel, dim3(1), dim3(256), 0, s, (const u16*)wt, (bf16x8*)wfrag);
+    return launch_status("stem7s_reorder");
 }
 
 }  // namespace hsefr

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7_pool_bf16_kernel(StemPoolParam
 }  // namespace
 
 int launch_stem7x7_pool_bf16(const float* x, const void* wt, const float* scale, const float* shift, void* y, int n, int h, int w,
-                             int ph, int pw, int pool_pad_t, int pool_pad_l, hipStream_t s) {
+                             int ph, int pw, int pool_pad_t, int pool_pad_l, hipStream_t s, const void* wfrag) {
     HSEFR_REQUIRE(n >= 0 && h > 0 && w > 0 && ph > 0 && pw > 0, HSEFR_ERR_INVALID, "stem7x7_pool: bad shape");
     HSEFR_REQUIRE((pool_pad_t == 0 || pool_pad_t == 1) && (pool_pad_l == 0 || pool_pad_l == 1), HSEFR_ERR_UNSUPPORTED,
                   "stem7x7_pool: pool padding (%d, %d) not in {0, 1}", pool_pad_t, pool_pad_l);
@@ -203,7 +203,7 @@ int launch_stem7x7_pool_bf16(const float* x, const void* wt, const float* scale,
                   "stem7x7_pool: pooled size %dx%d does not fit a %dx%d conv map", ph, pw, oh, ow);
     if (n == 0) return HSEFR_OK;
     // the streaming form (stem7s_stream.hip, round 6) wherever it covers the shape; this patch kernel otherwise
-    if (stem7s_stream_supported(n, h, w, ph, pw)) return launch_stem7s_stream(x, wt, scale, shift, y, n, h, w, ph, pw, pool_pad_t, pool_pad_l, s);
+    if (stem7s_stream_supported(n, h, w, ph, pw)) return launch_stem7s_stream(x, wt, scale, shift, y, n, h, w, ph, pw, pool_pad_t, pool_pad_l, s, wfrag);
     StemPoolParams p;
     p.x = x; p.wt = (const u16*)wt; p.scale = scale; p.shift = shift; p.y = (u16*)y;
     p.H = h; p.W = w; p.OH = oh; p.OW = ow; p.PH = ph; p.PW = pw; p.ppt = pool_pad_t; p.ppl = pool_pad_l;
