@@ -24,6 +24,11 @@
 // is walked in the order the separate kernels walk it.
 #include "common.h"
 
+#ifndef PAIR_XAUX
+#define PAIR_XAUX 0     // cache policy of the activation loads: bits 0-1 x (the 3x3 layer's output: this launch is its only reader), bits 2-3 x2 (the
+                        // block input of the PROJ form: its last reader); buffer aux bits: 1 glc, 2 slc.  Measured in the network (2, 8, 10 against 0, two
+                        // rounds): the pairs + 2..6 us, nothing gained behind them -- left at 0
+#endif
 namespace hsefr {
 
 namespace {
@@ -153,12 +158,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParam
         for (int pb = 0; pb < PB; ++pb) {
 #pragma unroll
             for (int hh = 0; hh < H1; ++hh)
-                dst[pb][hh] = __builtin_bit_cast(bf16x8, bload16(rx, live ? (pix0 + 16u * pb) * (K1 * 2u) + (unsigned)(64 * hh + 16 * lq) : OOR, 0));
+                dst[pb][hh] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, live ? (pix0 + 16u * pb) * (K1 * 2u) + (unsigned)(64 * hh + 16 * lq) : OOR, 0, PAIR_XAUX & 3));
             if (PROJ) {
 #pragma unroll
                 for (int hh = 0; hh < HP; ++hh)
                     dst2[PROJ ? pb : 0][PROJ ? hh : 0] =
-                        __builtin_bit_cast(bf16x8, bload16(rx2, live ? (pix0 + 16u * pb) * (K2 * 2u) + (unsigned)(64 * hh + 16 * lq) : OOR, 0));
+                        __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx2, live ? (pix0 + 16u * pb) * (K2 * 2u) + (unsigned)(64 * hh + 16 * lq) : OOR, 0, (PAIR_XAUX >> 2) & 3));
             }
         }
     };
