@@ -409,6 +409,22 @@ def test_fused_stem_pool_vs_oracle(env, n, h, w, ceil, ppad):
         assert float((d > 0).float().mean()) < 2e-3 and bool((d <= 0.0079 * two.float().abs() + 1e-6).all())      # <= one bf16 ulp, rarely
 
 
+def test_fused_stem_pool_many_units_per_wave(env):
+    """More strip units than resident waves (300 images x 3 strips x 3 segments = 2700 > 2048): a wave of the streaming stem walks several
+    units -- fresh carried rows, fresh window ring -- and the sweep direction flips between launches.  Reference: the two-kernel path
+    (conv1 map + max-pool), same rounding points (rare one-ulp bf16 differences: another fp32 accumulation order)."""
+    torch, ops, resnet50 = env
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.uniform(-130, 150, (300, 64, 64, 3)).astype(np.float32)).cuda()
+    wd = ops.bf16_from_bits(resnet50.pack_stem_weight((rs.randn(7, 7, 3, 64) * 0.02).astype(np.float32)))
+    sc, sh = torch.from_numpy(rs.uniform(0.5, 1.5, 64).astype(np.float32)).cuda(), torch.from_numpy(rs.randn(64).astype(np.float32)).cuda()
+    two = ops.maxpool3x3s2_bf16(ops.stem7x7_bf16(x, wd, sc, sh), True).float()
+    for _ in range(2):
+        got = ops.stem7x7_pool_bf16(x, wd, sc, sh).float()
+        d = (got - two).abs()
+        assert float((d > 0).float().mean()) < 2e-3 and bool((d <= 0.0079 * two.abs() + 1e-6).all())
+
+
 def test_resnet50_fused_stem_equals_unfused_network(env):
     """The whole network with and without the fused stem: same features to bf16-pipeline accuracy (the only difference is the
     accumulation order inside conv1), and the fused plan is what ResNet50Extractor runs by default."""
