@@ -510,6 +510,7 @@ def profile_traffic_per_forward(tag, once_kernel=None):
 _BF16_STORE = None
 _SPLIT_F16 = ("pwconv_ps_kernel", "pwconv_f16s_kernel", "dwpw_f16s_kernel", "dwpw2_f16s_kernel", "dwpw3_f16s_kernel", "stem2_fused_kernel",
               "stem3_fused_kernel", "stem4_fused_kernel", "stem5_stream_kernel")          # fp32 products as three f16 MFMA products
+_BF16_MATRIX = ("stem7s_stream_kernel",)          # bf16 MFMA kernels whose name does not say so
 _F32_MATRIX = ("pwconv_f32_dma_kernel", "pwconv_f32_kernel", "conv_f32_mfma_kernel", "conv3x3_c3_mfma_kernel")
 
 
@@ -566,7 +567,7 @@ def side_kernel_table(plan, eng, x, want, B, steps, tag):
     out = []
     for key, t in table.items():
         fam = key.split("<")[0]
-        peak_tf = MFMA_F16_PEAK_TF / 3 if fam in _SPLIT_F16 else MFMA_F32_PEAK_TF if fam in _F32_MATRIX else MFMA_F16_PEAK_TF if "bf16" in fam else None
+        peak_tf = MFMA_F16_PEAK_TF / 3 if fam in _SPLIT_F16 else MFMA_F32_PEAK_TF if fam in _F32_MATRIX else MFMA_F16_PEAK_TF if "bf16" in fam or fam in _BF16_MATRIX else None
         ms = max(t["ms"], 1e-9)
         t_hbm = t["bytes"] / (HBM_PEAK_GBS * 1e9)
         t_mfma = t["flops"] / (peak_tf * 1e12) if peak_tf and t["flops"] else 0.0
@@ -574,7 +575,8 @@ def side_kernel_table(plan, eng, x, want, B, steps, tag):
             bound, achieved, peak, unit = "mfma", t["flops"] / (ms * 1e-3) / 1e12, round(peak_tf, 1), "TFLOP/s"
         else:
             bound, achieved, peak, unit = "hbm", t["bytes"] / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-        pk = prof.get(key.split(" + ")[0], {})
+        k0 = key.split(" + ")[0]
+        pk = prof.get(k0) or prof.get("hsefr::" + k0) or {}      # (the profile keeps the namespace on names without template arguments)
         out.append({"kernel": key, "launches_per_step": t["launches_per_step"], "ms_per_step": round(t["ms"], 4),
                     "avg_launch_us": round(t["ms"] / t["launches_per_step"] * 1e3, 2), "bound": bound, "achieved": round(achieved, 2), "peak": peak,
                     "unit": unit, "frac": round(achieved / peak, 4), "algorithmic_bytes_per_launch": int(t["bytes"] / t["launches_per_step"]),
