@@ -106,7 +106,7 @@ static_assert(4 + 12 * (CXW - 1) + 32 <= WRP, "the second K step of a row's last
 static_assert(S5_WGS * (WAVES * WAVE_LDS + 14 * 1024) <= 160 * 1024, "S5_WGS workgroups per CU");
 
 __device__ __forceinline__ int swzb(int row, int chunk) { return row * 128 + 16 * (chunk ^ ((row >> 1) & 7) ^ ((row & 1) << 2)); }
-__device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+[[maybe_unused]] __device__ __forceinline__ float relu6(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
 __device__ __forceinline__ f32x4 vfma(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x4 as_v(float4 a) { return (f32x4){a.x, a.y, a.z, a.w}; }
 // the waves of a workgroup do not synchronise: what one lane wrote to LDS another lane of the SAME wave reads back, in
