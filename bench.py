@@ -545,7 +545,7 @@ def side_kernel_table(plan, eng, x, want, B, steps, tag):
             b += int(np.prod(L.in_shape)) * (2 if L.kind in bf16_in else 4) * B
         if L.res >= 0:      # the residual, or the block input a projected shortcut reads (strided: every stride-th pixel of it)
             R = plan.layers[L.res]
-            px = int(np.prod(L.out_shape[:2])) if L.proj is not None else int(np.prod(R.out_shape[:2]))
+            px = int(np.prod(L.out_shape[:2])) if (L.proj is not None or L.res_geom is not None) else int(np.prod(R.out_shape[:2]))
             b += px * (L.proj[0] if L.proj is not None else R.out_shape[2]) * 2 * B
         for a in (L.w, L.scale, L.shift, L.w2, L.shift2, L.w0, L.shift0, L.w3, L.scale3, L.shift3):
             if a is not None:

@@ -189,6 +189,8 @@ int launch_conv_bf16(const void* x, const void* wt, const float* scale, const fl
                      int pad_l, int act, hipStream_t s);
 int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
                         long long P, int K, int cout, int act, hipStream_t s);
+int launch_conv1x1_sres_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int oh,
+                             int ow, int K, int cout, int stride, int h2, int w2, int act, hipStream_t s);
 bool conv1x1_bf16_enabled(bool has_res, int k, int cout);
 int launch_conv1x1_proj_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* x2, const void* wt2,
                              const float* scale2, const float* shift2, void* y, int n, int oh, int ow, int K, int cout, int k2, int stride,

@@ -70,6 +70,10 @@ struct ProjParams {        // the projected shortcut of PROJ kernels
     const float* shift2;   // [Cout]
     int K2, stride, H2, W2, OH, OW;
     long long x2_bytes;
+    int rs_stride;         // (plain RES kernels; round 6) > 0: the residual is read from a LARGER map -- row p = (img, oy, ox) of the output adds
+    unsigned m_ohow, m_ow; // res[img, oy * rs_stride, ox * rs_stride, :] of a [N, H2, W2, Cout] tensor of x2_bytes bytes (H2, W2, OH, OW above;
+                           // m_* = ceil(2^32 / d) for d = OH * OW, OW: exact quotients while p * d < 2^32).  The last block of a ResNet stage
+                           // computed only at the pixels the next stage's stride-2 layers read (lowering.subsample_stage_tails)
     int adv;               // (both kernel forms; round 6) rows a tile ADVANCES by, <= BM: the tile computes BM rows but owns -- loads, adds the
                            // residual of, stores -- only the first `adv` (every resource ends with the tile's last own row: what lies beyond
                            // reads as zeros and moves no bytes).  Chosen by the launcher so that the tiles fill whole rounds of the grid's
@@ -226,7 +230,22 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
             const float* src = etab == 0 ? scale : etab == 1 ? shift : etab == 2 ? pj.scale2 : pj.shift2;
             ec = *(const f32x4*)(src + n0 + 4 * ej);
         }
-        if (RES && first) {      // this tile's residual chunks, in the layout the epilogue stores in (uniform branch)
+        if (RES && first && pj.rs_stride > 0) {      // the residual's pixels are every rs_stride-th of a larger map: one address per row (uniform branch)
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(res, pj.x2_bytes);
+            const unsigned ohow = (unsigned)(pj.OH * pj.OW), pend = (unsigned)own_end(m0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int i = 0; i < 32 / RPI; ++i) {
+                    const unsigned pr = (unsigned)m0 + (unsigned)(wm * WM + mi * 32 + erow + RPI * i);
+                    const unsigned img = __umulhi(pr, pj.m_ohow), rem = pr - img * ohow;
+                    const unsigned oy = __umulhi(rem, pj.m_ow), ox = rem - oy * (unsigned)pj.OW;
+                    const unsigned pix = (img * (unsigned)pj.H2 + oy * (unsigned)pj.rs_stride) * (unsigned)pj.W2 + ox * (unsigned)pj.rs_stride;
+                    const unsigned off = (pix * (unsigned)Cout + (unsigned)(n0 + wn * WN + 8 * ech)) * 2u;
+                    rres[RES ? mi * (32 / RPI) + i : 0] =
+                        __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rr, pr < pend ? off : 0x80000000u, 0, C11_RESAUX));
+                }
+        } else if (RES && first) {      // this tile's residual chunks, in the layout the epilogue stores in (uniform branch)
             const __amdgpu_buffer_rsrc_t rr = make_rsrc(res + m0 * Cout + n0, ((own_end(m0) - m0) * Cout - n0) * 2ll);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -367,7 +386,7 @@ int choose_adv(long long P, unsigned tiles_n, long long slots) {
 
 template <int BM, int BN, int OCC>
 int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shift, const u16* res, u16* y, long long P, int K,
-               int cout, int act, hipStream_t s) {
+               int cout, int act, hipStream_t s, const ProjParams* sres) {
     const unsigned tiles_n = cout / BN;
     const long long slots = 256ll * OCC;
     const int adv = choose_adv<BM>(P, tiles_n, slots);
@@ -378,6 +397,7 @@ int launch_cfg(const u16* x, const u16* wt, const float* scale, const float* shi
     dim3 grid((unsigned)g), block(256);
     const int rev = sweep_reverse();
     ProjParams nopj{};
+    if (sres) nopj = *sres;      // (strided residual: rs_stride, H2, W2, OH, OW, m_*, x2_bytes)
     nopj.adv = adv;
     // resident weight tiles: K <= 128 (at most two steps per tile) and a grid whose stride keeps a workgroup on one channel origin
     // (and BM >= 128: the epilogue's 16 KB of wave-private scratch must fit the stage's ACTIVATION rows, or it lands on the weights)
@@ -454,8 +474,8 @@ bool conv1x1_bf16_enabled(bool has_res, int k, int cout) {
 }
 
 // x [P][K] bf16, wt [cout][K] bf16, y [P][cout] bf16; K % 64 == 0, cout % 64 == 0 (checked by the caller, launch_conv_bf16)
-int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
-                        long long P, int K, int cout, int act, hipStream_t s) {
+static int launch_c11(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
+                      long long P, int K, int cout, int act, hipStream_t s, const ProjParams* sres) {
     const u16* xx = (const u16*)x;
     const u16* ww = (const u16*)wt;
     const u16* rr = (const u16*)res;
@@ -464,9 +484,36 @@ int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const
     const long long t128 = ((P + 127) / 128) * (cout / 128);
     // (dev builds: 64 x 128 tiles, three workgroups per CU.  Measured on the short-K increase layers: 3-7 % SLOWER than 128 x 128 -- its 16 KB
     // of epilogue scratch does not fit beside resident weights in a 64-row stage, and with the weights re-loaded every step it loses)
-    if (cout % 128 == 0 && g_c11_tile == 3) return launch_cfg<64, 128, 3>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
-    if (cout % 128 == 0 && (g_c11_tile == 2 || (t128 >= 768 && g_c11_tile != 1))) return launch_cfg<128, 128, 2>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
-    return launch_cfg<128, 64, 3>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s);
+    if (cout % 128 == 0 && g_c11_tile == 3) return launch_cfg<64, 128, 3>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s, sres);
+    if (cout % 128 == 0 && (g_c11_tile == 2 || (t128 >= 768 && g_c11_tile != 1))) return launch_cfg<128, 128, 2>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s, sres);
+    return launch_cfg<128, 64, 3>(xx, ww, scale, shift, rr, yy, P, K, cout, act, s, sres);
+}
+
+int launch_conv1x1_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y,
+                        long long P, int K, int cout, int act, hipStream_t s) {
+    return launch_c11(x, wt, scale, shift, res, y, P, K, cout, act, s, nullptr);
+}
+
+// The same layer with the residual read from a LARGER map at every `stride`-th pixel (round 6):
+//   y[(i, oy, ox), :] = act( bf16( scale * (x[(i, oy, ox), :] . wt) + shift ) + res[i, oy * stride, ox * stride, :] )
+// x [n][oh][ow][K], res [n][h2][w2][cout]: the last block of a ResNet stage computed only at the pixels the next stage's stride-2 layers
+// read (lowering.subsample_stage_tails) -- its shortcut is still the full-size map of the block before it.
+int launch_conv1x1_sres_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int oh,
+                             int ow, int K, int cout, int stride, int h2, int w2, int act, hipStream_t s) {
+    HSEFR_REQUIRE(K > 0 && K % 64 == 0 && cout > 0 && cout % 64 == 0, HSEFR_ERR_UNSUPPORTED, "conv1x1_sres_bf16: channels %d -> %d must be multiples of 64", K, cout);
+    HSEFR_REQUIRE(res && n >= 0 && oh > 0 && ow > 0 && stride >= 1 && stride <= 3 && (oh - 1) * stride < h2 && (ow - 1) * stride < w2, HSEFR_ERR_INVALID,
+                  "conv1x1_sres_bf16: a %dx%d output is not a stride-%d view of a %dx%d residual", oh, ow, stride, h2, w2);
+    HSEFR_REQUIRE(act == HSEFR_ACT_NONE || act == HSEFR_ACT_RELU || act == HSEFR_ACT_RELU6, HSEFR_ERR_UNSUPPORTED, "conv1x1_sres_bf16: act %d", act);
+    if (n == 0) return HSEFR_OK;
+    const long long P = (long long)n * oh * ow;
+    ProjParams g{};
+    g.rs_stride = stride; g.H2 = h2; g.W2 = w2; g.OH = oh; g.OW = ow;
+    g.x2_bytes = (long long)n * h2 * w2 * cout * 2;
+    HSEFR_REQUIRE(P * oh * ow < (1ll << 32) && g.x2_bytes < (1ll << 32), HSEFR_ERR_UNSUPPORTED, "conv1x1_sres_bf16: tensors beyond the 32-bit offsets");
+    g.m_ohow = (unsigned)(((1ull << 32) + (unsigned)(oh * ow) - 1) / (unsigned)(oh * ow));
+    g.m_ow = (unsigned)(((1ull << 32) + (unsigned)ow - 1) / (unsigned)ow);
+    HSEFR_REQUIRE(oh * ow > 1 && ow > 1, HSEFR_ERR_UNSUPPORTED, "conv1x1_sres_bf16: maps of one pixel / one column");
+    return launch_c11(x, wt, scale, shift, res, y, P, K, cout, act, s, &g);
 }
 
 // The increase layer of a stage's first block with its projected shortcut in the same launch (PROJ, see the header):
@@ -486,7 +533,7 @@ int launch_conv1x1_proj_bf16(const void* x, const void* wt, const float* scale, 
     if (conv1x1_w4_proj_preferred(P, K, k2, cout) && conv1x1_w4_bf16_supported(n, oh, ow, K, oh, ow, cout, 1) &&
         conv1x1_w4_bf16_supported(n, h2, w2, k2, oh, ow, cout, stride))      // the matrix-bound pairs: four wide MFMA waves + loaders (csrc/conv1x1_w4_bf16.hip)
         return launch_conv1x1_w4_proj_bf16(x, wt, scale, shift, x2, wt2, scale2, shift2, y, n, oh, ow, K, cout, k2, stride, h2, w2, act, s);
-    ProjParams pj;
+    ProjParams pj{};
     pj.x2 = (const u16*)x2; pj.wt2 = (const u16*)wt2; pj.scale2 = scale2; pj.shift2 = shift2;
     pj.K2 = k2; pj.stride = stride; pj.H2 = h2; pj.W2 = w2; pj.OH = oh; pj.OW = ow;
     pj.x2_bytes = (long long)n * h2 * w2 * k2 * 2;

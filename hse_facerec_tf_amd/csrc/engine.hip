@@ -178,6 +178,14 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                         return HSEFR_ERR_INVALID;
                     HSEFR_REQUIRE((uint64_t)h2 * w2 * k2 * 2 <= bufs[o.res_buf].elems_per_image * bufs[o.res_buf].elem_bytes, HSEFR_ERR_INVALID,
                                   "plan op %u: projected shortcut input exceeds buffer %d", i, o.res_buf);
+                } else if (o.reserved != 0) {
+                    // strided residual (round 6): res_buf is a LARGER map [h2, w2, cout] read at every stride-th pixel; reserved = stride << 12 | h2 << 14 | w2 << 23
+                    const int k2 = o.reserved & 0xFFF, st2 = (o.reserved >> 12) & 3, h2 = (o.reserved >> 14) & 0x1FF, w2 = (o.reserved >> 23) & 0x1FF;
+                    HSEFR_REQUIRE(k2 == 0 && o.kh == 1 && o.kw == 1 && o.stride == 1 && o.pad_t == 0 && o.pad_l == 0 && o.res_buf >= 0 && st2 >= 1 &&
+                                      o.oh == o.h && o.ow == o.w && o.oh * o.ow > 1 && o.ow > 1 && (o.oh - 1) * st2 < h2 && (o.ow - 1) * st2 < w2,
+                                  HSEFR_ERR_INVALID, "plan op %u: bad strided residual (stride %d, %dx%d)", i, st2, h2, w2);
+                    HSEFR_REQUIRE((uint64_t)h2 * w2 * co * 2 <= bufs[o.res_buf].elems_per_image * bufs[o.res_buf].elem_bytes, HSEFR_ERR_INVALID,
+                                  "plan op %u: strided residual exceeds buffer %d", i, o.res_buf);
                 }
                 break;
             case HSEFR_OP_STEM7X7_POOL_BF16:
@@ -720,6 +728,12 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                                   (o.reserved >> 14) & 0x1FF, (o.reserved >> 23) & 0x1FF, o.act, s);
                     break;
                 }
+                if (o.res_buf >= 0 && o.reserved != 0) {      // the residual is a stride view of a larger map (csrc/conv1x1_bf16.hip, rs_stride)
+                    rc = launch_conv1x1_sres_bf16(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off), (const float*)blob_ptr(e, o.shift_off),
+                                                  tab[o.res_buf], out, n, o.oh, o.ow, o.cin, o.cout, (o.reserved >> 12) & 3, (o.reserved >> 14) & 0x1FF,
+                                                  (o.reserved >> 23) & 0x1FF, o.act, s);
+                    break;
+                }
                 rc = launch_conv_bf16(in, blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
                                       (const float*)blob_ptr(e, o.shift_off),
                                       o.res_buf >= 0 ? tab[o.res_buf] : nullptr, out, n, o.h, o.w, o.cin, o.oh,
@@ -1184,6 +1198,12 @@ int hsefr_conv1x1_proj_bf16(const void* x, const void* wgt_t, const float* scale
     HSEFR_REQUIRE(n == 0 || (x && wgt_t && scale && shift && x2 && wgt2_t && scale2 && shift2 && y), HSEFR_ERR_INVALID, "conv1x1_proj_bf16: null pointer");
     return launch_conv1x1_proj_bf16(x, wgt_t, scale, shift, x2, wgt2_t, scale2, shift2, y, n, oh, ow, c, cout, c2, stride2, h2, w2, act,
                                     (hipStream_t)stream);
+}
+
+int hsefr_conv1x1_sres_bf16(const void* x, const void* wgt_t, const float* scale, const float* shift, const void* res, void* y, int n, int oh,
+                            int ow, int c, int cout, int res_stride, int h2, int w2, int act, hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n == 0 || (x && wgt_t && scale && shift && res && y), HSEFR_ERR_INVALID, "conv1x1_sres_bf16: null pointer");
+    return launch_conv1x1_sres_bf16(x, wgt_t, scale, shift, res, y, n, oh, ow, c, cout, res_stride, h2, w2, act, (hipStream_t)stream);
 }
 
 int hsefr_conv1x1_pair_bf16(const void* x, const void* w1_t, const float* scale1, const float* shift1, const void* res, const void* x2,

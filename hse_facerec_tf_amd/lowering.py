@@ -204,6 +204,8 @@ class Layer:
     u8_mean_bgr: Optional[Tuple[float, float, float]] = None   # STEM3_F16S: BGR mean folded into the uint8-input constants (None: no uint8 entry)
     proj: Optional[Tuple[int, int, int, int]] = None   # CONV_BF16 + projected shortcut (fuse_proj): (cin2, stride2, h2, w2) of the 1x1 projection
                                                        # of layer `res`'s output; w2 = its packed kernel [cout][cin2], shift2 = [scale2 | shift2]
+    res_geom: Optional[Tuple[int, int, int]] = None    # CONV_BF16 1x1 + residual read from a LARGER map (subsample_stage_tails): (stride, h2, w2) of layer `res`'s output
+    graph_hw: Optional[Tuple[int, int]] = None         # subsample_stage_tails: the output height / width this layer has in the GRAPH (it computes every s-th pixel of it)
     out_split: int = 0                                 # DWCONV3X3: > 0 = output stored as split rows scaled by 2^out_split
     in_split: bool = False                             # PWCONV: the input buffer holds split rows (wire kind OP_PWCONV_PS)
     flags: int = 0                                     # hsefr_op_flags: launch-level fusion with the op(s) BEHIND this one (mark_pairs, mark_heads)
@@ -260,6 +262,13 @@ class Plan:
                 w2 = L.w2
                 aux = c2 | (s2 << 12) | (h2 << 14) | (wd2 << 23)
                 if aux >= 1 << 31:              # w2 >= 256 reaches bit 31 of the signed wire field; the C side masks after >> 23
+                    aux -= 1 << 32
+            if L.res_geom is not None:          # the residual is a stride view of a larger map (hsefr.h: hsefr_conv1x1_sres_bf16)
+                assert L.kind == OP_CONV_BF16 and L.res >= 0 and L.proj is None and L.kh == 1 and L.kw == 1 and L.stride == 1
+                s2, h2, wd2 = L.res_geom
+                assert 1 <= s2 <= 3 and 0 < h2 < 512 and 0 < wd2 < 512 and tuple(self.layers[L.res].out_shape) == (h2, wd2, L.out_shape[2])
+                aux = (s2 << 12) | (h2 << 14) | (wd2 << 23)
+                if aux >= 1 << 31:
                     aux -= 1 << 32
             if L.kind in (OP_STEM2_F16S, OP_STEM3_F16S):
                 w = np.concatenate([L.w0.reshape(-1), L.shift0.reshape(-1), L.w.reshape(-1), L.scale.reshape(-1), L.shift.reshape(-1),
@@ -953,13 +962,72 @@ def fuse_proj(layers: List[Layer], keep: Sequence[int]) -> Tuple[List[Layer], Di
     return new_layers, remap
 
 
+def subsample_stage_tails(layers: List[Layer], keep: Sequence[int]) -> int:
+    """ResNet (Caffe-style: a stage's stride sits on the first block's 1x1 layers): the LAST bottleneck of a stage feeds only stride-2 1x1
+    layers -- the next stage's reduce layer and its projected shortcut -- which read every other pixel of its output: three quarters of that
+    block's 3x3 and increase layers are computed, written and never read.  Where a tensor T's consumers are ALL 1x1 stride-s layers without
+    padding (as `src`, or as the block input of a projected shortcut), T is not requested, its producer I is a 1x1 stride-1 layer with a
+    residual and I's own input X comes from a 3x3 / stride 1 / pad 1 layer that nothing else reads, then
+        X's layer runs at stride s (same kernel, same taps: output pixel (oy, ox) is the old (s oy, s ox)),
+        I runs on that compact map and reads its residual at every s-th pixel of the full-size map (`res_geom`; csrc/conv1x1_bf16.hip),
+        the consumers read the compact T at stride 1.
+    The values at the pixels that are kept are the values the full-size layers had there (same products, same K order per pixel, same
+    rounding points): the features are unchanged, the plan's tensors for X and T are `[::s, ::s]` of the graph's.  At batch 128 this takes a
+    quarter of conv2_3 / conv3_4 / conv4_6's 3x3 and increase layers: 0.12 ms of ResNet-50's 1.65.  Call after fuse_proj, before mark_pairs /
+    assign_buffers.  Returns the number of stage tails rewritten."""
+    consumers: Dict[int, List[Tuple[int, str]]] = {}
+    for i, L in enumerate(layers):
+        if L.src >= 0:
+            consumers.setdefault(L.src, []).append((i, "src"))
+        if L.res >= 0:
+            consumers.setdefault(L.res, []).append((i, "res"))
+    done = 0
+    for t, I in enumerate(layers):
+        cons = consumers.get(t, [])
+        if not cons or t in keep or not (I.kind == OP_CONV_BF16 and I.kh == 1 and I.kw == 1 and I.stride == 1 and I.pad_t == 0 and I.pad_l == 0 and
+                                         I.res >= 0 and I.proj is None and I.res_geom is None and I.src >= 0 and I.flags == 0):
+            continue
+        h, w, c = I.out_shape
+        strides = set()
+        for j, how in cons:
+            C = layers[j]
+            if how == "src" and C.kind == OP_CONV_BF16 and C.kh == 1 and C.kw == 1 and C.pad_t == 0 and C.pad_l == 0 and C.stride > 1 and C.proj is None:
+                strides.add(C.stride)
+            elif how == "res" and C.kind == OP_CONV_BF16 and C.proj is not None and C.proj[1] > 1 and C.proj[2:] == (h, w):
+                strides.add(C.proj[1])
+            else:
+                strides.add(0)
+        if len(strides) != 1 or 0 in strides:
+            continue
+        s = strides.pop()
+        X = layers[I.src]
+        if not (X.kind == OP_CONV_BF16 and X.kh == 3 and X.kw == 3 and X.stride == 1 and X.pad_t == 1 and X.pad_l == 1 and X.res < 0 and X.proj is None and
+                I.src not in keep and [q for q, _ in consumers.get(I.src, [])] == [t] and X.flags == 0 and tuple(X.out_shape[:2]) == (h, w) and
+                tuple(layers[I.res].out_shape) == (h, w, c) and h < 512 and w < 512):
+            continue
+        oh, ow = (h - 1) // s + 1, (w - 1) // s + 1
+        if oh * ow <= 1 or ow <= 1:
+            continue
+        X.stride, X.out_shape, X.graph_hw = s, (oh, ow, X.out_shape[2]), (h, w)
+        I.in_shape, I.out_shape, I.res_geom, I.graph_hw = X.out_shape, (oh, ow, c), (s, h, w), (h, w)
+        for j, how in cons:
+            C = layers[j]
+            if how == "src":
+                C.stride, C.in_shape = 1, I.out_shape
+                assert tuple(C.out_shape[:2]) == (oh, ow), (C.name, C.out_shape, oh, ow)
+            else:
+                C.proj = (C.proj[0], 1, oh, ow)
+        done += 1
+    return done
+
+
 def pair_fusable(A: Layer, B: Layer, a_index: int) -> bool:
     """csrc/conv1x1_pair_bf16.hip (conv1x1_pair_bf16_shape_supported): a 1x1 stride-1 bf16 convolution 64 -> 256 with a residual or a
     same-pixel projected shortcut from 64 channels, read by the 1x1 stride-1 convolution 256 -> 64 right behind it."""
     def plain_1x1(L):
         return (L.kind == OP_CONV_BF16 and L.kh == 1 and L.kw == 1 and L.stride == 1 and L.pad_t == 0 and L.pad_l == 0 and
                 tuple(L.in_shape[:2]) == tuple(L.out_shape[:2]) and L.flags == 0)
-    if not (plain_1x1(A) and plain_1x1(B) and B.src == a_index and B.res < 0 and B.proj is None and A.res >= 0):
+    if not (plain_1x1(A) and plain_1x1(B) and B.src == a_index and B.res < 0 and B.proj is None and A.res >= 0 and A.res_geom is None):
         return False
     if A.proj is not None and not (A.proj[0] == 64 and A.proj[1] == 1 and tuple(A.proj[2:]) == tuple(A.out_shape[:2])):
         return False
@@ -1373,6 +1441,7 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
             layers, remap = fuse_pass(layers, [li for li, _ in out_layers.values()])
             out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}
             tensor_layer = {name: remap[li] for name, li in tensor_layer.items() if remap[li] >= 0}
+        subsample_stage_tails(layers, [li for li, _ in out_layers.values()])      # a stage's last block at the pixels the next stage reads
     if fuse:   # early MobileNet blocks: depthwise result stays on the CU (csrc/dwpw_fused.hip)
         layers, remap = fuse_dwpw(layers, [li for li, _ in out_layers.values()])
         out_layers = {slot: (remap[li], e) for slot, (li, e) in out_layers.items()}

@@ -582,6 +582,21 @@ def conv1x1_proj_bf16(x, w_packed, scale, shift, x2, w2_packed, scale2, shift2, 
 
 
 @_device_guarded
+def conv1x1_sres_bf16(x, w_packed, scale, shift, res, res_stride: int = 2, act: int = ACT_RELU):
+    """A 1x1 convolution whose residual is a stride view of a larger map (hsefr_conv1x1_sres_bf16):
+    act(bf16(scale * x.w + shift) + res[:, ::res_stride, ::res_stride, :][:, :oh, :ow]).  x [n,oh,ow,c], res [n,h2,w2,cout] bf16."""
+    torch = _lib.require_gpu()
+    _bf16c(x, "x"), _bf16c(w_packed, "w"), _f32c(scale, "scale"), _f32c(shift, "shift"), _bf16c(res, "res")
+    n, oh, ow, c = x.shape
+    n2, h2, w2, cout = res.shape
+    if n2 != n or tuple(w_packed.shape) != (cout, c):
+        raise ValueError("conv1x1_sres_bf16: inconsistent shapes")
+    y = torch.empty((n, oh, ow, cout), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().hsefr_conv1x1_sres_bf16(x.data_ptr(), w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr(), y.data_ptr(),
+                                                  n, oh, ow, c, cout, res_stride, h2, w2, act, _lib.current_stream_ptr()), "hsefr_conv1x1_sres_bf16")
+    return y
+
+
 def conv1x1_pair_bf16(x, w1_packed, scale1, shift1, w2_packed, scale2, shift2, res=None, x2=None, wp_packed=None, scale_p=None, shift_p=None,
                       act1: int = ACT_RELU, act2: int = ACT_RELU):
     """A bottleneck's increase layer and the next bottleneck's reduce layer in one launch (hsefr_conv1x1_pair_bf16):

@@ -84,13 +84,15 @@ def pack_stem_weight(kernel_hwio: np.ndarray) -> np.ndarray:
 
 
 def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224, 224), pool: str = "caffe", dtype: str = "bf16",
-               fuse: bool = True, pair: bool = True) -> Plan:
+               fuse: bool = True, pair: bool = True, subsample: bool = True) -> Plan:
     """pool='caffe': pad-0 ceil-mode max-pool (112 -> 56); pool='valid': keras_vggface's valid pool (112 -> 55).
     dtype='bf16': the bf16-MFMA kernels (BASELINE config 3's throughput mode); dtype='f32': the same layers on the exact-fp32
     general kernels (OP_CONV_F32 / OP_MAXPOOL_F32 / OP_GAP) -- the fp32-grade mode, 1e-4 against the fp64 oracle.
     fuse (bf16 only): conv1 + pool1 run as one kernel (lowering.fuse_stem_pool) and the four projected shortcuts run inside their
     block's increase layer (lowering.fuse_proj); False keeps every layer's tensor.
-    pair (with fuse): the 56-pixel stage's increase layers run in one launch with the next block's reduce layer (lowering.mark_pairs)."""
+    pair (with fuse): the 56-pixel stage's increase layers run in one launch with the next block's reduce layer (lowering.mark_pairs).
+    subsample (with fuse): the last block of the 56-, 28- and 14-pixel stages computes its 3x3 and increase layers only at the pixels the
+    next stage's stride-2 layers read (lowering.subsample_stage_tails): same features, three layers' tensors become [::2, ::2] of the graph's."""
     if dtype not in ("bf16", "f32"):
         raise ValueError("dtype must be 'bf16' or 'f32', not %r" % (dtype,))
     f32 = dtype == "f32"
@@ -145,11 +147,21 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
         gap = remap[gap]
         layers, remap = lowering.fuse_proj(layers, [gap])
         gap = remap[gap]
+        if subsample:
+            lowering.subsample_stage_tails(layers, [gap])
         if pair:
             lowering.mark_pairs(layers)
     buffers = assign_buffers(layers, {gap})
     names = {L.name: i for i, L in enumerate(layers)}
     return Plan(layers, (H, W, 3), buffers, {OUT_FEATURES: (gap, cin)}, names)
+
+
+def _graph_scale(L) -> float:
+    """Layers of a stage's last block compute every s-th pixel of their graph tensor (lowering.subsample_stage_tails): the ALGORITHMIC figures
+    below stay the graph's -- the work the reference does -- whatever the plan skips."""
+    if L.graph_hw is None:
+        return 1.0
+    return (L.graph_hw[0] * L.graph_hw[1]) / float(L.out_shape[0] * L.out_shape[1])
 
 
 def flops_per_image(plan: Plan) -> int:
@@ -158,21 +170,35 @@ def flops_per_image(plan: Plan) -> int:
         if L.kind == lowering.OP_STEM7X7_POOL_BF16:
             tot += Plan.layer_flops(L)
         if L.kind in (OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32):
-            tot += Plan.layer_flops(L)          # (a projected shortcut folded into its increase layer counts there)
+            tot += int(round(Plan.layer_flops(L) * _graph_scale(L)))          # (a projected shortcut folded into its increase layer counts there)
     return tot
 
 
+def executed_flops_per_image(plan: Plan) -> int:
+    """What the plan's kernels compute (flops_per_image minus the pixels subsample_stage_tails skips)."""
+    return sum(Plan.layer_flops(L) for L in plan.layers if L.kind in (lowering.OP_STEM7X7_POOL_BF16, OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32))
+
+
 def activation_bytes_per_image(plan: Plan) -> int:
+    """The layer-wise minimum traffic of the GRAPH: every layer reads its input once and writes its output once, whatever the plan
+    fuses or skips."""
     tot = 0
     for L in plan.layers:
         in_b = 4 if L.kind in (OP_STEM7X7_BF16, lowering.OP_STEM7X7_POOL_BF16) else 2
-        tot += int(np.prod(L.in_shape)) * in_b + L.out_bytes
+        src = plan.layers[L.src] if L.src >= 0 else None
+        in_elems = int(np.prod(L.in_shape))
+        if src is not None and src.graph_hw is not None:      # in the graph this layer read the full-size tensor
+            in_elems = src.graph_hw[0] * src.graph_hw[1] * src.out_shape[2]
+        tot += in_elems * in_b + int(round(L.out_bytes * _graph_scale(L)))
         if L.res >= 0 and L.proj is None:
-            tot += plan.layers[L.res].out_bytes
+            tot += int(round(L.out_bytes * _graph_scale(L))) if L.res_geom is not None else plan.layers[L.res].out_bytes
         elif L.res >= 0:
             # the UNFUSED pair's traffic (the layer-wise figure SURVEY 8d prices the network with, unchanged by the fusion): the
             # projection reads the block input and writes its tensor, the increase layer reads it back
             c2, s2, h2, w2 = L.proj
+            R = plan.layers[L.res]
+            if R.graph_hw is not None:
+                h2, w2 = R.graph_hw
             oh, ow, cout = L.out_shape
             tot += h2 * w2 * c2 * 2 + 2 * oh * ow * cout * 2
     return tot

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define HSEFR_VERSION 140 /* 0.1.4: round-6 ABI (added: hsefr_plan_op.flags with HSEFR_OPF_PAIR_NEXT / HSEFR_OPF_HEADS, hsefr_conv1x1_pair_bf16, hsefr_heads_fused,
+#define HSEFR_VERSION 141 /* 0.1.4: round-6 ABI (added: hsefr_plan_op.flags with HSEFR_OPF_PAIR_NEXT / HSEFR_OPF_HEADS, hsefr_conv1x1_pair_bf16, hsefr_heads_fused,
                              hsefr_plan_validate, hsefr_plan_describe, hsefr_nn1_fallbacks; removed from the product library: hsefr_stem_fused / HSEFR_OP_STEM_F16S (development builds only);
                              130 = round 5, 120 = round 4, 110 = round 3, 100 = round 1-2) */
 
@@ -82,7 +82,9 @@ typedef enum hsefr_op_kind {
     HSEFR_OP_DENSE = 5,        /* x[N,K] . W[K,Cout] + b, act                                             */
     HSEFR_OP_SOFTMAX = 6,      /* row softmax                                                             */
     HSEFR_OP_CONV_BF16 = 7,    /* KxK conv (1x1/3x3, stride 1|2) as bf16-MFMA implicit GEMM, fp32 acc,
-                                  + shift (+ residual) + act; bf16 activations                            */
+                                  + shift (+ residual) + act; bf16 activations.  w2_off set: + projected shortcut
+                                  (hsefr_conv1x1_proj_bf16); residual, no w2_off, reserved != 0: the residual is a stride view
+                                  of a larger map (hsefr_conv1x1_sres_bf16: reserved = stride << 12 | h2 << 14 | w2 << 23)  */
     HSEFR_OP_MAXPOOL_BF16 = 8, /* 3x3/2 max-pool, bf16                                                    */
     HSEFR_OP_GAP_BF16 = 9,     /* mean over H,W of bf16 activations -> fp32                               */
     HSEFR_OP_STEM7X7_BF16 = 10,/* 7x7/2 pad-3 conv over the fp32 3-channel image -> 64 ch bf16 (+scale+shift+ReLU) */
@@ -427,6 +429,15 @@ int hsefr_conv_bf16(const void* x, const void* wgt_t, const float* scale, const 
 int hsefr_conv1x1_proj_bf16(const void* x, const void* wgt_t, const float* scale, const float* shift, const void* x2, const void* wgt2_t,
                             const float* scale2, const float* shift2, void* y, int n, int oh, int ow, int c, int cout, int c2, int stride2,
                             int h2, int w2, int act, hsefr_stream_t stream);
+
+/* A 1x1 convolution whose RESIDUAL is a stride view of a larger map (round 6):
+ *   y[(i, oy, ox), :] = act( bf16( scale * (x[(i, oy, ox), :] . wgt_t) + shift ) + res[i, oy * res_stride, ox * res_stride, :] )
+ * x [n,oh,ow,c], wgt_t [cout][c], res [n,h2,w2,cout], y [n,oh,ow,cout], all bf16; c, cout multiples of 64; (oh - 1) * res_stride < h2.  The last
+ * bottleneck of a ResNet stage feeds only stride-2 1x1 layers: its 3x3 and increase layers run at the pixels those layers read
+ * (lowering.subsample_stage_tails; results identical at those pixels), and the block's shortcut is still the full-size map of the block
+ * before it.  What the engine runs for an HSEFR_OP_CONV_BF16 with a residual, no w2_off and reserved = res_stride << 12 | h2 << 14 | w2 << 23. */
+int hsefr_conv1x1_sres_bf16(const void* x, const void* wgt_t, const float* scale, const float* shift, const void* res, void* y, int n, int oh,
+                            int ow, int c, int cout, int res_stride, int h2, int w2, int act, hsefr_stream_t stream);
 
 /* Two chained 1x1 convolutions at the same pixels in ONE launch (round 6; csrc/conv1x1_pair_bf16.hip): a bottleneck's increase layer
  * and the next bottleneck's reduce layer,

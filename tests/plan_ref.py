@@ -207,6 +207,11 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
                 ss2 = arr(sh2_off, 2 * cout)
                 pr_ = tfo.conv2d(res.reshape(n, h2, wd2, c2), k2, (s2, s2), "", explicit_pads=(0, 0, 0, 0))
                 y = y + bf16_round(pr_ * ss2[:cout] + ss2[cout:]).reshape(y.shape)
+            elif res is not None and _r != 0:
+                # strided residual (lowering.subsample_stage_tails): res_buf is a LARGER map [h2, w2, cout] read at every s2-th pixel
+                s2, h2, wd2 = (_r >> 12) & 3, (_r >> 14) & 0x1FF, (_r >> 23) & 0x1FF
+                assert (_r & 0xFFF) == 0 and kh == 1 and kw == 1 and stride == 1
+                y = y + res.reshape(n, h2, wd2, cout)[:, ::s2, ::s2, :][:, :oh, :ow, :]
             elif res is not None:
                 y = y + res.reshape(y.shape)
             y = bf16_round(_act(y, act))

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libhsefr.so does not export %s" % name
     # and the binding table covers the header one-to-one
     assert sorted(_lib.SIGNATURES) == declared_functions()
-    assert L.hsefr_version() == 140
+    assert L.hsefr_version() == 141
 
 
 def test_code_object_targets_gfx950_only():

@@ -409,6 +409,48 @@ def test_fused_stem_pool_vs_oracle(env, n, h, w, ceil, ppad):
         assert float((d > 0).float().mean()) < 2e-3 and bool((d <= 0.0079 * two.float().abs() + 1e-6).all())      # <= one bf16 ulp, rarely
 
 
+@pytest.mark.parametrize("n,oh,ow,c,cout,st,h2,w2", [(2, 28, 28, 64, 256, 2, 56, 56), (3, 14, 14, 128, 512, 2, 28, 28), (5, 7, 7, 256, 1024, 2, 14, 14),
+                                                       (2, 13, 9, 64, 128, 2, 25, 17), (1, 5, 6, 64, 64, 3, 13, 16), (37, 14, 14, 64, 256, 2, 28, 27),
+                                                       (128, 28, 28, 64, 256, 2, 56, 56)])
+def test_conv1x1_with_a_strided_residual_equals_the_gathered_form(env, n, oh, ow, c, cout, st, h2, w2):
+    """hsefr_conv1x1_sres_bf16 (the increase layer of a stage's last block on the compact map, lowering.subsample_stage_tails): the residual
+    read at every st-th pixel of a larger map -- BIT FOR BIT the plain layer on the gathered residual (same kernel, same K order; only the
+    residual's addresses differ), ragged last tiles and odd maps included."""
+    torch, ops, resnet50 = env
+    g = torch.Generator(device="cuda").manual_seed(n * 131 + oh)
+    x = (torch.rand((n, oh, ow, c), device="cuda", generator=g) * 2 - 0.5).to(torch.bfloat16)
+    r = (torch.randn((n, h2, w2, cout), device="cuda", generator=g)).to(torch.bfloat16)
+    w = (torch.randn((cout, c), device="cuda", generator=g) / c ** 0.5).to(torch.bfloat16)
+    sc = torch.rand(cout, device="cuda", generator=g) + 0.5
+    sh = torch.randn(cout, device="cuda", generator=g)
+    rg = r[:, ::st, ::st, :][:, :oh, :ow, :].contiguous()
+    for act in (1, 0):
+        got = ops.conv1x1_sres_bf16(x, w, sc, sh, r, st, act)
+        want = ops.conv_bf16(x, w, sc, sh, 1, 1, res=rg, act=act)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    with pytest.raises(Exception):
+        ops.conv1x1_sres_bf16(x, w, sc, sh, r[:, :(oh - 1) * st, :, :].contiguous(), st)      # the map does not reach the last output row
+
+
+def test_resnet50_with_and_without_subsampled_stage_tails(env):
+    """The whole network with the last block of the 56-, 28- and 14-pixel stages computed only where the next stage reads it
+    (lowering.subsample_stage_tails, the default) against the plan that computes every pixel: the same features to bf16-pipeline accuracy
+    (the stride-2 3x3 layers run on another kernel: another fp32 accumulation order), both within the oracle's tolerance elsewhere."""
+    torch, ops, resnet50 = env
+    from hse_facerec_tf_amd.engine import Engine
+    w = resnet50.synthetic_weights(11)
+    x = torch.from_numpy(np.random.RandomState(2).uniform(-120, 130, (6, 224, 224, 3)).astype(np.float32)).cuda()
+    outs = []
+    for sub in (True, False):
+        plan = resnet50.build_plan(w, (224, 224), "caffe", subsample=sub)
+        assert sum(L.res_geom is not None for L in plan.layers) == (3 if sub else 0)
+        eng = Engine(plan, max_batch=6)
+        outs.append(list(eng.forward(x, (0,)).values())[0].float().cpu().numpy())
+        eng.close()
+    a, b = outs
+    assert np.isfinite(a).all() and np.abs(a - b).max() <= 0.02 * np.abs(b).max() and np.abs(a - b).mean() <= 2e-3 * np.abs(b).mean()
+
+
 def test_fused_stem_pool_many_units_per_wave(env):
     """More strip units than resident waves (300 images x 3 strips x 3 segments = 2700 > 2048): a wave of the streaming stem walks several
     units -- fresh carried rows, fresh window ring -- and the sweep direction flips between launches.  Reference: the two-kernel path
