@@ -470,7 +470,8 @@ int launch_conv_bf16(const void* x, const void* wt, const float* scale, const fl
     // 1x1 layers from 256+ channels (a strided gather costs the DMA nothing: 57 vs 84 us on 56x56x256 -> 28x28x512), the 1x1 reductions from 1024+ channels.  The other 1x1 layers and the 64-channel stage stay
     // on the register-staged kernels (few K-steps per tile: the DMA pipeline's per-tile costs are not amortised, and the
     // residual is prefetched there).
-    const bool deep = (kh * kw > 1 && P <= 150000) || (kh * kw == 1 && stride == 2 && c >= 256) || (kh * kw == 1 && c >= 1024 && !res);
+    // (round 6: the stride-2 3x3 of the 56-pixel stage's last block -- 64 channels: one K-step per tap -- 34 us there, 27 on the general kernel)
+    const bool deep = (kh * kw > 1 && P <= 150000 && !(stride == 2 && c <= 64)) || (kh * kw == 1 && stride == 2 && c >= 256) || (kh * kw == 1 && c >= 1024 && !res);
     if ((deep || conv_dma_forced()) && conv_dma_bf16_supported(n, h, w, c, oh, ow, cout, kh, kw))
         return launch_conv_dma_bf16(x, wt, scale, shift, res, y, n, h, w, c, oh, ow, cout, kh, kw, stride, pad_t, pad_l, act, s);
     ConvParams p;

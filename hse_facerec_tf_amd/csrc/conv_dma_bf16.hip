@@ -353,19 +353,22 @@ __global__ __launch_bounds__(768, 1) void conv_dma_bf16_kernel(ConvDmaParams p) 
 
 struct DmaCfg { int waves_m, rb; };
 
-// Tile height per layer: fewest (rounds of 256 workgroups) x (rows per tile + a fixed per-tile cost)
+// Tile shape per layer: fewest (rounds of 256 workgroups) x (rows per tile + a fixed per-tile cost) x (the tile's width).  Layers whose
+// channel count allows the 128-wide tiles may still take the 64-wide ones: a stride-2 3x3 on a 14 x 14 map at batch 128 is 6272 rows --
+// 98 tiles of 128 x 128 on 256 CUs; as 196 tiles of 128 x 64 it is one round of tiles that cost 0.6 of a wide one (32 -> 20 us)
 DmaCfg choose_cfg(long long m, int cout, int forced_rb) {
     DmaCfg best{0, 0};
     double best_cost = -1;
-    const bool wide = cout % 128 == 0;
-    const int wavesm = wide ? 2 : 4, bn = wide ? 128 : 64;
-    const int rb_lo = wide ? 4 : 2, rb_hi = wide ? 9 : 5;
-    for (int rb = rb_hi; rb >= rb_lo; --rb) {
-        if (forced_rb > 0 && rb != forced_rb) continue;
-        const long long bm = (long long)wavesm * 16 * rb;
-        const long long tiles = ((m + bm - 1) / bm) * (cout / bn);
-        const double cost = (double)((tiles + 255) / 256) * ((double)bm + 48.0);
-        if (best_cost < 0 || cost < best_cost) { best = DmaCfg{wavesm, rb}; best_cost = cost; }
+    for (int wide = cout % 128 == 0 ? 1 : 0; wide >= 0; --wide) {
+        const int wavesm = wide ? 2 : 4, bn = wide ? 128 : 64;
+        const int rb_lo = wide ? 4 : 2, rb_hi = wide ? 9 : 5;
+        for (int rb = rb_hi; rb >= rb_lo; --rb) {
+            if (forced_rb > 0 && rb != forced_rb) continue;
+            const long long bm = (long long)wavesm * 16 * rb;
+            const long long tiles = ((m + bm - 1) / bm) * (cout / bn);
+            const double cost = (double)((tiles + 255) / 256) * ((double)bm + 48.0) * (wide ? 1.0 : 0.6);
+            if (best_cost < 0 || cost < best_cost - 1e-9) { best = DmaCfg{wavesm, rb}; best_cost = cost; }
+        }
     }
     return best;
 }
