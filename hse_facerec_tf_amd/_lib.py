@@ -61,6 +61,7 @@ SIGNATURES = {
     "hsefr_conv1x1_proj_bf16": (c_int, [_fp] * 9 + [c_int] * 10 + [c_void_p]),
     "hsefr_conv1x1_sres_bf16": (c_int, [_fp] * 6 + [c_int] * 9 + [c_void_p]),
     "hsefr_conv1x1_pair_bf16": (c_int, [_fp] * 14 + [c_longlong] + [c_int] * 6 + [c_void_p]),
+    "hsefr_conv1x1_pair_sub2_bf16": (c_int, [_fp] * 14 + [c_int] * 9 + [c_void_p]),
     "hsefr_stem7x7_bf16": (c_int, [_fp, _fp, _fp, _fp, _fp] + [c_int] * 6 + [c_void_p]),
     "hsefr_stem7x7_pool_bf16": (c_int, [_fp, c_void_p, _fp, _fp, c_void_p] + [c_int] * 7 + [c_void_p]),
     "hsefr_maxpool3x3s2_bf16": (c_int, [_fp, _fp] + [c_int] * 8 + [c_void_p]),

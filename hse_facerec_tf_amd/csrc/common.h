@@ -227,7 +227,7 @@ bool conv1x1_pair_bf16_supported(long long pixels, int c, int cout1, int cout2, 
 int launch_conv1x1_pair_bf16(const void* x, const void* w1, const float* scale1, const float* shift1, const void* res, const void* x2,
                              const void* wp, const float* scale_p, const float* shift_p, void* y1, const void* w2, const float* scale2,
                              const float* shift2, void* y2, long long pixels, int c, int cout1, int cout2, int c2, int act1, int act2,
-                             hipStream_t s);
+                             hipStream_t s, int y1_stride = 1, int h = 0, int w = 0);
 bool conv_dma_forced();
 bool conv_dma_bf16_supported(long long n, int h, int w, int c, int oh, int ow, int cout, int kh, int kw);
 int launch_conv_dma_bf16(const void* x, const void* wt, const float* scale, const float* shift, const void* res, void* y, int n, int h,

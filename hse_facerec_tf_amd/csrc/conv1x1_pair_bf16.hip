@@ -59,6 +59,11 @@ struct PairParams {
     float act1_lo, act1_hi, act2_lo, act2_hi;
     int ablate;           // development builds, timing only (results WRONG): 1 = no residual loads, 2 = no y1 stores, 4 = no y2 stores, 8 = no second product
     int nt;               // cache hints: 1 = y1 stores non-temporal, 2 = residual loads non-temporal, 4 = y2 stores non-temporal
+    int y1_stride;        // 1: y1 [M][N1].  2: y1 is stored at the pixels with even row AND column only, as a compact [n][(H+1)/2][(W+1)/2][N1] map
+                          // (the second product still reads every pixel, from registers): the tensor's only other reader takes every second pixel of
+                          // it (the residual of a stage's last block, lowering.compact_pair_outputs) -- three quarters of the pair's largest store gone
+    unsigned W, HW, m_hw, m_w, OW2, OHW2;      // y1_stride 2: the map (W, H W), ceil(2^32 / d) for d = H W, W, the compact map's width and pixels
+    long long y1_bytes;
 };
 
 // LDS row R of a weight image <-> output channel (conv1x1_w4_bf16.hip's permutation, per 32 channels): rows 16 b + i of a pair of
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParam
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (long long)p.M * K1 * 2);
     const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(PROJ ? p.x2 : nullptr, PROJ ? (long long)p.M * K2 * 2 : 0);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(PROJ ? nullptr : p.res, PROJ ? 0 : (long long)p.M * N1 * 2);
-    const __amdgpu_buffer_rsrc_t ry1 = make_rsrc(p.y1, (long long)p.M * N1 * 2);
+    const __amdgpu_buffer_rsrc_t ry1 = make_rsrc(p.y1, p.y1_bytes);
     const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(p.y2, (long long)p.M * N2 * 2);
 
     // fragment address of a weight image: row (16 blk + l16), K half hh (32 channels), swizzled like the four-wave GEMM's stages
@@ -190,7 +195,19 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParam
     }
     for (unsigned t = gw; t < p.ntiles; t += nw) {
         const unsigned pix0 = tile_pix(t);
-        const unsigned y1lane = pix0 * (N1 * 2u) + (unsigned)(16 * lq);      // + 16 pb rows, + 64 j bytes
+        unsigned y1off[PB];      // byte offset of the lane's pixel of block pb in y1 (+ 64 j per chunk); out of range where the pixel is not stored
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const unsigned pix = pix0 + 16u * pb;
+            if (p.y1_stride == 2) {      // (uniform)
+                const unsigned img = __umulhi(pix, p.m_hw), rem = pix - img * p.HW;
+                const unsigned oy = __umulhi(rem, p.m_w), ox = rem - oy * p.W;
+                const bool keep = pix < p.M && ((oy | ox) & 1u) == 0u;
+                y1off[pb] = keep ? (img * p.OHW2 + (oy >> 1) * p.OW2 + (ox >> 1)) * (N1 * 2u) + (unsigned)(16 * lq) : OOR;
+            } else {
+                y1off[pb] = pix * (N1 * 2u) + (unsigned)(16 * lq);
+            }
+        }
         f32x4 acc2[MB2][PB];
 #pragma unroll
         for (int mb = 0; mb < MB2; ++mb)
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParam
             if (!PROJ && !(abl & 1)) load_res(j, t + nw);                     // this chunk of the NEXT tile, into the registers just read
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb)
-                if (!(abl & 2)) store16(o[pb], ry1, y1lane + (unsigned)(16 * pb * N1 * 2 + 64 * j), p.nt & 1);
+                if (!(abl & 2)) store16(o[pb], ry1, y1off[pb] + (unsigned)(64 * j), p.nt & 1);
             // ---- the chunk's contribution to every channel of Y2 ----
             if (!(abl & 8))
 #pragma unroll
@@ -362,7 +379,7 @@ bool conv1x1_pair_bf16_supported(long long pixels, int c, int cout1, int cout2, 
 int launch_conv1x1_pair_bf16(const void* x, const void* w1, const float* scale1, const float* shift1, const void* res, const void* x2,
                              const void* wp, const float* scale_p, const float* shift_p, void* y1, const void* w2, const float* scale2,
                              const float* shift2, void* y2, long long pixels, int c, int cout1, int cout2, int c2, int act1, int act2,
-                             hipStream_t s) {
+                             hipStream_t s, int y1_stride, int h, int w) {
     HSEFR_REQUIRE(conv1x1_pair_bf16_supported(pixels, c, cout1, cout2, c2), HSEFR_ERR_UNSUPPORTED,
                   "conv1x1_pair_bf16: %d -> %d -> %d (projection from %d) over %lld pixels not covered", c, cout1, cout2, c2, pixels);
     HSEFR_REQUIRE((c2 > 0) != (res != nullptr), HSEFR_ERR_INVALID, "conv1x1_pair_bf16: exactly one of residual / projected shortcut");
@@ -372,6 +389,16 @@ int launch_conv1x1_pair_bf16(const void* x, const void* w1, const float* scale1,
     p.x = x; p.w1 = w1; p.scale1 = scale1; p.shift1 = shift1; p.res = res; p.x2 = x2; p.wp = wp; p.scale_p = scale_p; p.shift_p = shift_p;
     p.y1 = y1; p.w2 = w2; p.scale2 = scale2; p.shift2 = shift2; p.y2 = y2;
     p.M = (unsigned)pixels;
+    p.y1_stride = y1_stride; p.y1_bytes = pixels * cout1 * 2;
+    p.W = p.HW = p.m_hw = p.m_w = p.OW2 = p.OHW2 = 0;
+    if (y1_stride != 1) {
+        HSEFR_REQUIRE(y1_stride == 2 && h > 1 && w > 1 && pixels % ((long long)h * w) == 0 && pixels * h * w < (1ll << 32), HSEFR_ERR_INVALID,
+                      "conv1x1_pair_bf16: y1 at stride %d of a %dx%d map over %lld pixels", y1_stride, h, w, pixels);
+        p.W = (unsigned)w; p.HW = (unsigned)(h * w);
+        p.m_hw = (unsigned)(((1ull << 32) + p.HW - 1) / p.HW); p.m_w = (unsigned)(((1ull << 32) + p.W - 1) / p.W);
+        p.OW2 = (unsigned)((w + 1) / 2); p.OHW2 = (unsigned)(((h + 1) / 2) * ((w + 1) / 2));
+        p.y1_bytes = pixels / ((long long)h * w) * p.OHW2 * cout1 * 2;
+    }
     p.reverse = sweep_reverse();
     p.ablate = g_pair_ablate;
     p.nt = g_pair_nt;

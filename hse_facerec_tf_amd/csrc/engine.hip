@@ -124,7 +124,8 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
         const uint64_t out_cap = bufs[o.out_buf].elems_per_image * bufs[o.out_buf].elem_bytes;
         HSEFR_REQUIRE(out_bytes <= out_cap, HSEFR_ERR_INVALID, "plan op %u: output %llu bytes/image exceeds buffer %d (%llu)", i,
                       (unsigned long long)out_bytes, o.out_buf, (unsigned long long)out_cap);
-        if (o.in_buf >= 0) {
+        const bool from_registers = i > 0 && (ops[i - 1].flags & HSEFR_OPF_OUT_SUB2) && o.in_buf == ops[i - 1].out_buf;      // (checked with the flag below)
+        if (o.in_buf >= 0 && !from_registers) {
             const uint64_t in_bytes = (uint64_t)o.h * o.w * o.cin * (in_bf16 ? 2 : 4);
             HSEFR_REQUIRE(in_bytes <= bufs[o.in_buf].elems_per_image * bufs[o.in_buf].elem_bytes, HSEFR_ERR_INVALID,
                           "plan op %u: input exceeds buffer %d", i, o.in_buf);
@@ -274,17 +275,20 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
     // launch-level fusions (hsefr_op_flags): the pattern behind a flagged op must be exactly the one its fused launch computes
     for (uint32_t i = 0; i < h.n_ops; ++i) {
         const hsefr_plan_op& o = ops[i];
-        HSEFR_REQUIRE((o.flags & ~(HSEFR_OPF_PAIR_NEXT | HSEFR_OPF_HEADS)) == 0, HSEFR_ERR_INVALID, "plan op %u: unknown flags 0x%x", i, o.flags);
+        HSEFR_REQUIRE((o.flags & ~(HSEFR_OPF_PAIR_NEXT | HSEFR_OPF_HEADS | HSEFR_OPF_OUT_SUB2)) == 0, HSEFR_ERR_INVALID, "plan op %u: unknown flags 0x%x", i, o.flags);
+        HSEFR_REQUIRE(!(o.flags & HSEFR_OPF_OUT_SUB2) || (o.flags & HSEFR_OPF_PAIR_NEXT), HSEFR_ERR_INVALID, "plan op %u: OUT_SUB2 without PAIR_NEXT", i);
         if (o.flags & HSEFR_OPF_PAIR_NEXT) {
             HSEFR_REQUIRE(i + 1 < h.n_ops, HSEFR_ERR_INVALID, "plan op %u: PAIR_NEXT on the last op", i);
             const hsefr_plan_op& b = ops[i + 1];
             const bool proj = o.w2_off != HSEFR_NO_OFFSET;
             const int c2 = proj ? (o.reserved & 0xFFF) : 0, st2 = (o.reserved >> 12) & 3, h2 = (o.reserved >> 14) & 0x1FF, w2 = (o.reserved >> 23) & 0x1FF;
+            const bool sub2 = (o.flags & HSEFR_OPF_OUT_SUB2) != 0;      // the first output is stored at even rows / columns only; the second op reads all of it
             HSEFR_REQUIRE(o.kind == HSEFR_OP_CONV_BF16 && b.kind == HSEFR_OP_CONV_BF16 && o.kh == 1 && o.kw == 1 && o.stride == 1 && o.pad_t == 0 &&
-                              o.pad_l == 0 && o.oh == o.h && o.ow == o.w && b.kh == 1 && b.kw == 1 && b.stride == 1 && b.pad_t == 0 && b.pad_l == 0 &&
-                              b.h == o.oh && b.w == o.ow && b.oh == b.h && b.ow == b.w && b.cin == o.cout && b.in_buf == o.out_buf &&
+                              o.pad_l == 0 && (sub2 ? (o.oh == (o.h + 1) / 2 && o.ow == (o.w + 1) / 2 && o.h > 1 && o.w > 1) : (o.oh == o.h && o.ow == o.w)) &&
+                              b.kh == 1 && b.kw == 1 && b.stride == 1 && b.pad_t == 0 && b.pad_l == 0 &&
+                              b.h == o.h && b.w == o.w && b.oh == b.h && b.ow == b.w && b.cin == o.cout && b.in_buf == o.out_buf &&
                               b.res_buf == HSEFR_BUF_NONE && b.w2_off == HSEFR_NO_OFFSET && b.flags == 0 && o.res_buf >= 0 &&
-                              (!proj || (st2 == 1 && h2 == o.oh && w2 == o.ow)),
+                              (!proj || (st2 == 1 && h2 == o.h && w2 == o.w)),
                           HSEFR_ERR_INVALID, "plan op %u: PAIR_NEXT needs two 1x1 stride-1 bf16 convolutions at the same pixels, the first with a residual "
                           "or a same-pixel projected shortcut, the second reading the first", i);
             HSEFR_REQUIRE(b.out_buf != o.in_buf && b.out_buf != o.res_buf && b.out_buf != o.out_buf, HSEFR_ERR_INVALID,
@@ -647,8 +651,11 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
         int rc = HSEFR_OK;
         size_t covered = 0;       // ops behind this one that its launch computes as well (hsefr_op_flags)
         set_sweep_reverse(g_sweep_alternate ? (int)(launches++ & 1) : 0);   // consecutive LAUNCHES sweep in opposite directions (common.h)
-        if ((o.flags & HSEFR_OPF_PAIR_NEXT) && needed[i + 1] && conv1x1_pair_bf16_supported((long long)n * o.oh * o.ow, o.cin, o.cout, e->ops[i + 1].cout,
-                                                                                           o.w2_off != HSEFR_NO_OFFSET ? (o.reserved & 0xFFF) : 0)) {
+        const bool sub2 = (o.flags & HSEFR_OPF_OUT_SUB2) != 0;
+        const bool pair_ok = (o.flags & HSEFR_OPF_PAIR_NEXT) && needed[i + 1] &&
+                             conv1x1_pair_bf16_supported((long long)n * o.h * o.w, o.cin, o.cout, e->ops[i + 1].cout, o.w2_off != HSEFR_NO_OFFSET ? (o.reserved & 0xFFF) : 0);
+        HSEFR_REQUIRE(!sub2 || pair_ok, HSEFR_ERR_UNSUPPORTED, "forward: op %zu stores its output at every second pixel (OUT_SUB2) and cannot run without the pair launch", i);
+        if (pair_ok) {
             // increase (+ residual | + projected shortcut) -> the next block's reduce in one launch (csrc/conv1x1_pair_bf16.hip; the pattern
             // was checked by validate_plan): both tensors are written, the second product reads the first from registers
             const hsefr_plan_op& b = e->ops[i + 1];
@@ -658,7 +665,7 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                                           proj ? nullptr : tab[o.res_buf], proj ? tab[o.res_buf] : nullptr, proj ? blob_ptr(e, o.w2_off) : nullptr,
                                           proj ? ssp : nullptr, proj ? ssp + o.cout : nullptr, out, blob_ptr(e, b.w_off),
                                           (const float*)blob_ptr(e, b.scale_off), (const float*)blob_ptr(e, b.shift_off), tab[b.out_buf],
-                                          (long long)n * o.oh * o.ow, o.cin, o.cout, b.cout, proj ? (o.reserved & 0xFFF) : 0, o.act, b.act, s);
+                                          (long long)n * o.h * o.w, o.cin, o.cout, b.cout, proj ? (o.reserved & 0xFFF) : 0, o.act, b.act, s, sub2 ? 2 : 1, o.h, o.w);
             covered = 1;
         } else if ((o.flags & HSEFR_OPF_HEADS) && !g_heads_off && needed[i + 1] && needed[i + 2] && needed[i + 3]) {
             // the age / gender heads in one launch (csrc/pool_dense.hip): hidden, logits, probabilities and the gender sigmoid are all written
@@ -1216,6 +1223,18 @@ int hsefr_conv1x1_pair_bf16(const void* x, const void* w1_t, const float* scale1
                   HSEFR_ERR_INVALID, "conv1x1_pair_bf16: null pointer");
     return launch_conv1x1_pair_bf16(x, w1_t, scale1, shift1, c2 == 0 ? res : nullptr, x2, wp_t, scale_p, shift_p, y1, w2_t, scale2, shift2, y2, pixels,
                                     c, cout1, cout2, c2, act1, act2, (hipStream_t)stream);
+}
+
+int hsefr_conv1x1_pair_sub2_bf16(const void* x, const void* w1_t, const float* scale1, const float* shift1, const void* res, const void* x2,
+                                 const void* wp_t, const float* scale_p, const float* shift_p, void* y1, const void* w2_t, const float* scale2,
+                                 const float* shift2, void* y2, int n, int h, int w, int c, int cout1, int cout2, int c2, int act1, int act2,
+                                 hsefr_stream_t stream) {
+    HSEFR_REQUIRE(n >= 0 && h > 1 && w > 1, HSEFR_ERR_INVALID, "conv1x1_pair_sub2_bf16: %d maps of %dx%d", n, h, w);
+    if (n == 0) return HSEFR_OK;
+    HSEFR_REQUIRE(x && w1_t && scale1 && shift1 && y1 && w2_t && scale2 && shift2 && y2 && (c2 == 0 ? res != nullptr : (x2 && wp_t && scale_p && shift_p)),
+                  HSEFR_ERR_INVALID, "conv1x1_pair_sub2_bf16: null pointer");
+    return launch_conv1x1_pair_bf16(x, w1_t, scale1, shift1, c2 == 0 ? res : nullptr, x2, wp_t, scale_p, shift_p, y1, w2_t, scale2, shift2, y2,
+                                    (long long)n * h * w, c, cout1, cout2, c2, act1, act2, (hipStream_t)stream, 2, h, w);
 }
 
 int hsefr_stem7x7_bf16(const float* x, const void* wgt_t, const float* scale, const float* shift, void* y, int n, int h,

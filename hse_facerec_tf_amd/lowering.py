@@ -48,7 +48,7 @@ NO_OFFSET = 0xFFFFFFFFFFFFFFFF
 _HEADER = struct.Struct("<QIIIIII3i3IQ")          # hsefr_plan_header
 _BUFFER = struct.Struct("<QII")                   # hsefr_plan_buffer
 _OP = struct.Struct("<II3i3i3i3i2iii5Q")         # hsefr_plan_op (112 bytes; `flags` sits where the struct's padding was until round 6)
-OPF_PAIR_NEXT, OPF_HEADS = 1, 2                   # hsefr_op_flags
+OPF_PAIR_NEXT, OPF_HEADS, OPF_OUT_SUB2 = 1, 2, 4  # hsefr_op_flags
 
 
 # Kernel families (csrc/*.hip) a plan may route to in the PRODUCT library, as Plan.describe() names them.  Development builds add
@@ -386,6 +386,8 @@ class Plan:
     def layer_flops(L: "Layer") -> int:
         """Algorithmic multiply-add flops of ONE layer per image (fused layers: the sum of what they replace)."""
         oh, ow, cout = L.out_shape
+        if L.flags & OPF_OUT_SUB2 and L.graph_hw is not None:      # computed at every pixel, stored at every second one (compact_pair_outputs)
+            oh, ow = L.graph_hw
         if L.kind in (OP_CONV_C3, OP_PWCONV_F32, OP_DENSE, OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32):
             return 2 * oh * ow * cout * (L.kh * L.kw * L.in_shape[2] + (L.proj[0] if L.proj is not None else 0))
         if L.kind == OP_DWCONV3X3:
@@ -1048,6 +1050,30 @@ def mark_pairs(layers: List[Layer]) -> int:
     return n
 
 
+def compact_pair_outputs(layers: List[Layer], keep: Sequence[int]) -> int:
+    """After mark_pairs and subsample_stage_tails: a paired increase layer A (flags PAIR_NEXT: the next op reads its output from registers)
+    whose tensor has ONE other reader -- the strided residual of a stage's last block (res_geom stride 2 over A's whole map) -- stores only
+    the pixels that reader takes (OPF_OUT_SUB2: even rows and columns, a compact map), and the reader's residual becomes an ordinary one.
+    At batch 128 the 56-pixel stage's second pair writes 51 MB of its 205 MB tensor.  Returns the number of pairs rewritten."""
+    done = 0
+    for a, A in enumerate(layers):
+        if not (A.flags & OPF_PAIR_NEXT) or A.flags & OPF_OUT_SUB2 or a in keep or a + 1 >= len(layers) or layers[a + 1].src != a:
+            continue
+        h, w, c = A.out_shape
+        others = [(j, L) for j, L in enumerate(layers) if j != a + 1 and (L.src == a or L.res == a)]
+        if not others or h < 2 or w < 2 or tuple(A.in_shape[:2]) != (h, w):
+            continue
+        if not all(L.res == a and L.src != a and L.proj is None and L.res_geom == (2, h, w) for _, L in others):
+            continue
+        A.flags |= OPF_OUT_SUB2
+        A.graph_hw, A.out_shape = (h, w), ((h + 1) // 2, (w + 1) // 2, c)
+        for _, L in others:
+            assert tuple(L.out_shape) == tuple(A.out_shape), (L.name, L.out_shape, A.out_shape)
+            L.res_geom = None
+        done += 1
+    return done
+
+
 def mark_heads(layers: List[Layer]) -> int:
     """The age / gender heads (facial_analysis.py:109): DENSE k -> 256 + ReLU, DENSE 256 -> a + bias, SOFTMAX, DENSE 256 -> 1 + sigmoid, in
     this order and adjacent, run as ONE launch (csrc/pool_dense.hip heads_kernel; fp32 round-off apart from the four): the first carries OPF_HEADS."""
@@ -1478,6 +1504,7 @@ def lower_graph(g: Graph, input_tensor: str, outputs: Dict[int, str], input_hw: 
     if fuse and launch_fusion:        # launch-level fusions: the ops stay, the engine runs flagged groups as one launch (hsefr_op_flags)
         if dtype == "bf16":
             mark_pairs(layers)
+            compact_pair_outputs(layers, [li for li, _ in out_layers.values()])
         if dtype == "f32":
             mark_heads(layers)
     buffers = assign_buffers(layers, {li for li, _ in out_layers.values()})

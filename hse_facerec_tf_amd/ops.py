@@ -598,11 +598,12 @@ def conv1x1_sres_bf16(x, w_packed, scale, shift, res, res_stride: int = 2, act: 
 
 
 def conv1x1_pair_bf16(x, w1_packed, scale1, shift1, w2_packed, scale2, shift2, res=None, x2=None, wp_packed=None, scale_p=None, shift_p=None,
-                      act1: int = ACT_RELU, act2: int = ACT_RELU):
+                      act1: int = ACT_RELU, act2: int = ACT_RELU, y1_sub2: bool = False):
     """A bottleneck's increase layer and the next bottleneck's reduce layer in one launch (hsefr_conv1x1_pair_bf16):
     y1 = act1(bf16(scale1 * x.w1 + shift1) + R), R = res or bf16(scale_p * x2.wp + shift_p);  y2 = act2(bf16(scale2 * y1.w2 + shift2)).
     x [n,h,w,c] bf16, w1_packed [cout1,c], res [n,h,w,cout1] | x2 [n,h,w,c2] with wp_packed [cout1,c2], w2_packed [cout2,cout1]
-    -> (y1 [n,h,w,cout1], y2 [n,h,w,cout2]) bf16."""
+    -> (y1 [n,h,w,cout1], y2 [n,h,w,cout2]) bf16.  y1_sub2: y1 is stored at even rows / columns only, [n,(h+1)//2,(w+1)//2,cout1]
+    (hsefr_conv1x1_pair_sub2_bf16)."""
     torch = _lib.require_gpu()
     _bf16c(x, "x"), _bf16c(w1_packed, "w1"), _f32c(scale1, "scale1"), _f32c(shift1, "shift1")
     _bf16c(w2_packed, "w2"), _f32c(scale2, "scale2"), _f32c(shift2, "shift2")
@@ -620,9 +621,15 @@ def conv1x1_pair_bf16(x, w1_packed, scale1, shift1, w2_packed, scale2, shift2, r
         c2 = x2.shape[3]
         if tuple(x2.shape[:3]) != (n, h, w) or tuple(wp_packed.shape) != (cout1, c2):
             raise ValueError("conv1x1_pair_bf16: the projected shortcut reads the same pixels")
-    y1 = torch.empty((n, h, w, cout1), dtype=torch.bfloat16, device=x.device)
+    y1 = torch.empty((n, (h + 1) // 2, (w + 1) // 2, cout1) if y1_sub2 else (n, h, w, cout1), dtype=torch.bfloat16, device=x.device)
     y2 = torch.empty((n, h, w, cout2), dtype=torch.bfloat16, device=x.device)
     ptr = lambda t: 0 if t is None else t.data_ptr()
+    if y1_sub2:
+        _lib.check(_lib.lib().hsefr_conv1x1_pair_sub2_bf16(x.data_ptr(), w1_packed.data_ptr(), scale1.data_ptr(), shift1.data_ptr(), ptr(res), ptr(x2),
+                                                           ptr(wp_packed), ptr(scale_p), ptr(shift_p), y1.data_ptr(), w2_packed.data_ptr(),
+                                                           scale2.data_ptr(), shift2.data_ptr(), y2.data_ptr(), n, h, w, c, cout1, cout2, c2, act1, act2,
+                                                           _lib.current_stream_ptr()), "hsefr_conv1x1_pair_sub2_bf16")
+        return y1, y2
     _lib.check(_lib.lib().hsefr_conv1x1_pair_bf16(x.data_ptr(), w1_packed.data_ptr(), scale1.data_ptr(), shift1.data_ptr(), ptr(res), ptr(x2),
                                                   ptr(wp_packed), ptr(scale_p), ptr(shift_p), y1.data_ptr(), w2_packed.data_ptr(),
                                                   scale2.data_ptr(), shift2.data_ptr(), y2.data_ptr(), n * h * w, c, cout1, cout2, c2, act1, act2,

@@ -151,6 +151,8 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
             lowering.subsample_stage_tails(layers, [gap])
         if pair:
             lowering.mark_pairs(layers)
+            if subsample:
+                lowering.compact_pair_outputs(layers, [gap])
     buffers = assign_buffers(layers, {gap})
     names = {L.name: i for i, L in enumerate(layers)}
     return Plan(layers, (H, W, 3), buffers, {OUT_FEATURES: (gap, cin)}, names)
@@ -170,7 +172,8 @@ def flops_per_image(plan: Plan) -> int:
         if L.kind == lowering.OP_STEM7X7_POOL_BF16:
             tot += Plan.layer_flops(L)
         if L.kind in (OP_CONV_BF16, OP_STEM7X7_BF16, OP_CONV_F32):
-            tot += int(round(Plan.layer_flops(L) * _graph_scale(L)))          # (a projected shortcut folded into its increase layer counts there)
+            # (a projected shortcut folded into its increase layer counts there; an OUT_SUB2 layer computes -- and counts -- every pixel already)
+            tot += int(round(Plan.layer_flops(L) * (1.0 if L.flags & lowering.OPF_OUT_SUB2 else _graph_scale(L))))
     return tot
 
 
@@ -191,7 +194,7 @@ def activation_bytes_per_image(plan: Plan) -> int:
             in_elems = src.graph_hw[0] * src.graph_hw[1] * src.out_shape[2]
         tot += in_elems * in_b + int(round(L.out_bytes * _graph_scale(L)))
         if L.res >= 0 and L.proj is None:
-            tot += int(round(L.out_bytes * _graph_scale(L))) if L.res_geom is not None else plan.layers[L.res].out_bytes
+            tot += int(round(L.out_bytes * _graph_scale(L)))      # (the residual has the layer's own shape in the graph)
         elif L.res >= 0:
             # the UNFUSED pair's traffic (the layer-wise figure SURVEY 8d prices the network with, unchanged by the fusion): the
             # projection reads the block input and writes its tensor, the increase layer reads it back

@@ -170,8 +170,13 @@ typedef enum hsefr_op_flags {
     HSEFR_OPF_PAIR_NEXT = 1, /* CONV_BF16 1x1 (+ residual | + projected shortcut) whose output the NEXT op, a CONV_BF16 1x1 at the same
                                 pixels, reads: both in one launch, the first output stored and chained through registers into the second
                                 product (csrc/conv1x1_pair_bf16.hip): ResNet-50's increase -> next reduce in the 56-pixel stage          */
-    HSEFR_OPF_HEADS = 2      /* DENSE k -> 256 + ReLU followed by DENSE 256 -> A (<= 128) + bias, SOFTMAX over it, and DENSE 256 -> 1 +
+    HSEFR_OPF_HEADS = 2,     /* DENSE k -> 256 + ReLU followed by DENSE 256 -> A (<= 128) + bias, SOFTMAX over it, and DENSE 256 -> 1 +
                                 sigmoid: the age / gender heads of facial_analysis.py:109 in one launch (csrc/pool_dense.hip)         */
+    HSEFR_OPF_OUT_SUB2 = 4   /* with PAIR_NEXT only: the flagged op's OWN output is stored at the pixels with even row and column only --
+                                oh = (h + 1) / 2, ow = (w + 1) / 2 describe the stored map -- while the covered op reads all h x w pixels
+                                from registers: the tensor's only other reader takes every second pixel of it (the shortcut of a ResNet
+                                stage's last block, lowering.compact_pair_outputs).  Such a pair has no two-launch form: a forward that
+                                cannot run it as one launch fails                                                                      */
 } hsefr_op_flags;
 
 typedef struct hsefr_plan_op {
@@ -452,6 +457,14 @@ int hsefr_conv1x1_pair_bf16(const void* x, const void* w1_t, const float* scale1
                             const void* wp_t, const float* scale_p, const float* shift_p, void* y1, const void* w2_t, const float* scale2,
                             const float* shift2, void* y2, long long pixels, int c, int cout1, int cout2, int c2, int act1, int act2,
                             hsefr_stream_t stream);
+
+/* The same launch with y1 STORED at the pixels with even row and column only (a compact [n,(h+1)/2,(w+1)/2,cout1] map; y2 unchanged, from
+ * every pixel): for a y1 whose only other reader takes every second pixel of it.  x [n,h,w,c].  What the engine runs for a PAIR_NEXT op that
+ * also carries HSEFR_OPF_OUT_SUB2. */
+int hsefr_conv1x1_pair_sub2_bf16(const void* x, const void* w1_t, const float* scale1, const float* shift1, const void* res, const void* x2,
+                                 const void* wp_t, const float* scale_p, const float* shift_p, void* y1, const void* w2_t, const float* scale2,
+                                 const float* shift2, void* y2, int n, int h, int w, int c, int cout1, int cout2, int c2, int act1, int act2,
+                                 hsefr_stream_t stream);
 
 /* ResNet stem: 7x7 / stride 2 / pad 3 conv over the fp32 image [n,h,w,3] -> [n,oh,ow,64] bf16, + scale + shift + act.
  * wgt_t [64][256] bf16 with k = dy*32 + dx*3 + ci, zero padded. */

@@ -13,7 +13,7 @@ from oracle import tf_graph as tfo
 
 HEADER = struct.Struct("<QIIIIII3i3IQ")
 BUFFER = struct.Struct("<QII")
-OP = struct.Struct("<II3i3i3i3i2ii4x5Q")
+OP = struct.Struct("<II3i3i3i3i2iii5Q")
 NO_OFFSET = 0xFFFFFFFFFFFFFFFF
 
 
@@ -68,15 +68,21 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
     split_fmt = {}          # buffer -> a_log2 of the split rows it holds (0 = plain fp32): the storage-format contract
     x = x.astype(dtype)
     for i, o in enumerate(p["ops"]):
-        (kind, act, in_buf, out_buf, res_buf, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l, _r,
+        (kind, act, in_buf, out_buf, res_buf, h, w, cin, oh, ow, cout, kh, kw, stride, pad_t, pad_l, _r, flags,
          w_off, sc_off, sh_off, w2_off, sh2_off) = o
         src = x if in_buf == -1 else mem[in_buf]
+        if i > 0 and p["ops"][i - 1][17] & 4 and in_buf == p["ops"][i - 1][3]:
+            src = in_registers      # the op behind an OUT_SUB2 pair reads the full map (from registers), not the stored compact one
         src = src.reshape(n, h, w, cin)
+        sub2 = bool(flags & 4)
         res = None if res_buf < 0 else mem[res_buf]
         assert in_buf != out_buf, "op %d writes the buffer it reads" % i
         assert res_buf != out_buf
         if check_buffers:
             assert p["bufs"][out_buf][0] * p["bufs"][out_buf][1] >= oh * ow * cout * (2 if kind in (7, 8, 10, 20) else 4)
+        if sub2:                    # hsefr_op_flags OUT_SUB2: computed at every pixel, stored at even rows / columns
+            assert flags & 1 and kind == 7 and kh == 1 and kw == 1 and (oh, ow) == ((h + 1) // 2, (w + 1) // 2)
+            oh, ow = h, w
         if kind == 1:
             k = arr(w_off, kh * kw * cin * cout).reshape(kh, kw, cin, cout)
             pb = (oh - 1) * stride + kh - h - pad_t
@@ -276,6 +282,8 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
         assert y.shape[1:] == (oh, ow, cout), (i, y.shape, (oh, ow, cout))
         if kind not in (12, 16, 21, 22):
             assert split_fmt.get(in_buf, 0) == 0 or in_buf == -1, "op %d (kind %d) reads split rows it cannot decode" % (i, kind)
+        if sub2:
+            in_registers, y = y, y.reshape(n, h, w, cout)[:, ::2, ::2, :]
         mem[out_buf] = y
         split_fmt[out_buf] = _r if kind == 2 else (_r >> 8 if kind == 21 else 0)
     outs = {}

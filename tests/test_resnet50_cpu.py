@@ -96,7 +96,13 @@ def test_generic_lowering_of_a_resnet_style_graph(pool, bn, head, hw):
     fl = {L.name: L for L in fused.layers}
     # the stride-2 projection of the second stage reads the first stage's last block, which runs at the pixels it reads (round 6)
     assert fl["conv3_1_1x1_increase"].proj[1] == 1 and fl["conv3_1_1x1_reduce"].stride == 1 and fl["conv2_2_3x3"].stride == 2
-    assert fl["conv2_2_1x1_increase"].res_geom == (2,) + fl["conv2_1_1x1_increase"].out_shape[:2] and sum(L.res_geom is not None for L in fused.layers) == 1
+    # ... and its shortcut -- the output of the pair in front of it -- is stored at the pixels it reads (lowering.compact_pair_outputs)
+    assert fl["conv2_1_1x1_increase"].flags == lowering.OPF_PAIR_NEXT | lowering.OPF_OUT_SUB2 and fl["conv2_1_1x1_increase"].out_shape == fl["conv2_2_1x1_increase"].out_shape
+    assert fl["conv2_2_1x1_increase"].res_geom is None and fl["conv2_2_1x1_reduce"].in_shape[:2] == fl["conv2_1_1x1_increase"].graph_hw
+    nolaunch = lowering.lower_graph(g, "input:0", {0: "pool5_7x7_s1:0"}, dtype="bf16", launch_fusion=False)
+    nl = {L.name: L for L in nolaunch.layers}
+    assert nl["conv2_2_1x1_increase"].res_geom == (2,) + nl["conv2_1_1x1_increase"].out_shape[:2] and nl["conv2_1_1x1_increase"].flags == 0
+    assert np.array_equal(plan_ref.run(nolaunch.serialize(), x)["features"], plan_ref.run(fused.serialize(), x)["features"])
     assert fused.layers[0].pad3 == (plan.layers[1].pad_t, plan.layers[1].pad_l) == ((1, 1) if (pool, hw) == ("SAME", 38) else (0, 0))
     assert np.array_equal(plan_ref.run(fused.serialize(), x)["features"], plan_ref.run(plan.serialize(), x)["features"])
     # conv1's tensor requested as an output keeps the stem unfused
@@ -181,7 +187,7 @@ def test_projected_shortcut_geometry_of_a_256_pixel_block_input_serializes():
         return seen
     assert words(plan, True) == [tuple(L.proj) for L in pj]
     # the strided residual's word (round 6: stride << 12 | h2 << 14 | w2 << 23, no channel count) has the same top bit
-    sub = resnet50.build_plan(resnet50.synthetic_weights(1), (1024, 1024), "caffe")
+    sub = resnet50.build_plan(resnet50.synthetic_weights(1), (1024, 1024), "caffe", pair=False)      # (with pairs the 256-pixel stage's shortcut is stored compact)
     sg = [L for L in sub.layers if L.res_geom is not None]
     assert sg[0].res_geom == (2, 256, 256) and words(sub, False) == [(0,) + tuple(L.res_geom) for L in sg]
 
@@ -199,12 +205,17 @@ def test_stage_tails_run_at_the_pixels_the_next_stage_reads():
         ii, I = by[blk + "_1x1_increase"]
         c = I.out_shape[2]
         assert X.stride == 2 and (X.kh, X.pad_t, X.pad_l) == (3, 1, 1) and X.out_shape[:2] == (hw // 2, hw // 2) and X.graph_hw == (hw, hw)
-        assert I.src == ix and I.in_shape == X.out_shape and I.out_shape == (hw // 2, hw // 2, c) and I.res_geom == (2, hw, hw) and I.graph_hw == (hw, hw)
-        assert plan.layers[I.res].out_shape == (hw, hw, c) and plan.layers[I.res].graph_hw is None      # the shortcut: the full-size map of the block before
+        assert I.src == ix and I.in_shape == X.out_shape and I.out_shape == (hw // 2, hw // 2, c) and I.graph_hw == (hw, hw)
+        R = plan.layers[I.res]
+        if hw == 56:     # the shortcut comes out of a pair launch: stored at the pixels this block reads (lowering.compact_pair_outputs)
+            assert I.res_geom is None and R.flags == lowering.OPF_PAIR_NEXT | lowering.OPF_OUT_SUB2 and R.out_shape == I.out_shape and R.graph_hw == (hw, hw)
+            assert plan.layers[I.res + 1].src == I.res and plan.layers[I.res + 1].in_shape == (hw, hw, c)      # ... while the pair's second product reads all of it
+        else:            # the shortcut: the full-size map of the block before, read at every second pixel
+            assert I.res_geom == (2, hw, hw) and R.out_shape == (hw, hw, c) and R.graph_hw is None
         _, R = by[nxt + "_1x1_reduce"]
         _, P = by[nxt + "_1x1_increase"]
         assert R.src == ii and R.stride == 1 and R.in_shape == I.out_shape and P.res == ii and P.proj[1:] == (1, hw // 2, hw // 2)
-    assert sum(L.res_geom is not None for L in plan.layers) == 3 and sum(L.flags != 0 for L in plan.layers) == 2      # the two stage-2 pairs are still pairs
+    assert sum(L.flags != 0 for L in plan.layers) == 2      # the two stage-2 pairs are still pairs
     assert abs(resnet50.executed_flops_per_image(plan) / resnet50.flops_per_image(plan) - 0.9026) < 1e-3
     blob = plan.serialize()
     L = _lib.lib()

@@ -432,6 +432,23 @@ def test_conv1x1_with_a_strided_residual_equals_the_gathered_form(env, n, oh, ow
         ops.conv1x1_sres_bf16(x, w, sc, sh, r[:, :(oh - 1) * st, :, :].contiguous(), st)      # the map does not reach the last output row
 
 
+@pytest.mark.parametrize("n,h,w,proj", [(2, 56, 56, False), (3, 28, 20, True), (1, 13, 9, False), (128, 56, 56, False), (5, 7, 31, True)])
+def test_pair_with_its_first_output_stored_at_even_pixels(env, n, h, w, proj):
+    """hsefr_conv1x1_pair_sub2_bf16 (HSEFR_OPF_OUT_SUB2): y1 stored at even rows / columns only -- bit for bit y1[:, ::2, ::2] of the plain pair,
+    y2 (computed from every pixel, in registers) unchanged; odd maps, ragged tiles, both shortcut forms."""
+    torch, ops, resnet50 = env
+    g = torch.Generator(device="cuda").manual_seed(h * 7 + w)
+    bf = lambda *sh: (torch.randn(sh, device="cuda", generator=g)).to(torch.bfloat16)
+    x, w1, w2 = bf(n, h, w, 64), (bf(256, 64).float() / 8).to(torch.bfloat16), (bf(64, 256).float() / 16).to(torch.bfloat16)
+    s1, b1, s2, b2 = (torch.rand(256, device="cuda", generator=g) + 0.5, torch.randn(256, device="cuda", generator=g),
+                      torch.rand(64, device="cuda", generator=g) + 0.5, torch.randn(64, device="cuda", generator=g))
+    kw = dict(x2=bf(n, h, w, 64), wp_packed=(bf(256, 64).float() / 8).to(torch.bfloat16), scale_p=s1.clone(), shift_p=b1.clone()) if proj else dict(res=bf(n, h, w, 256))
+    y1, y2 = ops.conv1x1_pair_bf16(x, w1, s1, b1, w2, s2, b2, **kw)
+    c1, c2 = ops.conv1x1_pair_bf16(x, w1, s1, b1, w2, s2, b2, y1_sub2=True, **kw)
+    assert tuple(c1.shape) == (n, (h + 1) // 2, (w + 1) // 2, 256)
+    assert torch.equal(c1.view(torch.int16), y1[:, ::2, ::2, :].contiguous().view(torch.int16)) and torch.equal(c2.view(torch.int16), y2.view(torch.int16))
+
+
 def test_resnet50_with_and_without_subsampled_stage_tails(env):
     """The whole network with the last block of the 56-, 28- and 14-pixel stages computed only where the next stage reads it
     (lowering.subsample_stage_tails, the default) against the plan that computes every pixel: the same features to bf16-pipeline accuracy
@@ -443,7 +460,7 @@ def test_resnet50_with_and_without_subsampled_stage_tails(env):
     outs = []
     for sub in (True, False):
         plan = resnet50.build_plan(w, (224, 224), "caffe", subsample=sub)
-        assert sum(L.res_geom is not None for L in plan.layers) == (3 if sub else 0)
+        assert sum(L.graph_hw is not None for L in plan.layers) == (7 if sub else 0)      # three 3x3 + three increase layers + the pair output stored compact
         eng = Engine(plan, max_batch=6)
         outs.append(list(eng.forward(x, (0,)).values())[0].float().cpu().numpy())
         eng.close()
