@@ -36,7 +36,8 @@ extern "C" {
 #endif
 
 #define HSEFR_VERSION 141 /* 0.1.4: round-6 ABI (added: hsefr_plan_op.flags with HSEFR_OPF_PAIR_NEXT / HSEFR_OPF_HEADS, hsefr_conv1x1_pair_bf16, hsefr_heads_fused,
-                             hsefr_plan_validate, hsefr_plan_describe, hsefr_nn1_fallbacks; removed from the product library: hsefr_stem_fused / HSEFR_OP_STEM_F16S (development builds only);
+                             hsefr_plan_validate, hsefr_plan_describe, hsefr_nn1_fallbacks; 141: HSEFR_OPF_OUT_SUB2, hsefr_conv1x1_sres_bf16, hsefr_conv1x1_pair_sub2_bf16, the
+                             strided-residual word of HSEFR_OP_CONV_BF16; removed from the product library: hsefr_stem_fused / HSEFR_OP_STEM_F16S (development builds only);
                              130 = round 5, 120 = round 4, 110 = round 3, 100 = round 1-2) */
 
 typedef enum hsefr_status {
