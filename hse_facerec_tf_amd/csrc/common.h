@@ -129,6 +129,23 @@ __device__ __forceinline__ unsigned hsefr_pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(hsefr_f32x2{lo, hi}, hsefr_bf16x2));
 }
 
+// Exact unsigned division by a launch-invariant divisor d >= 2, for EVERY 32-bit numerator (the "add" form of division by multiplication:
+// q0 = mulhi(x, m), q = (((x - q0) >> 1) + q0) >> sh with m = floor(2^32 (2^s - d) / d) + 1, s = ceil(log2 d), sh = s - 1).  Four vector
+// instructions; the plain mulhi-by-ceil(2^32 / d) shortcut is exact only while x d < 2^32, which a large batch of large maps exceeds.
+struct hsefr_udiv { unsigned m, sh; };
+inline hsefr_udiv hsefr_udiv_make(unsigned d) {       // d >= 2
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    hsefr_udiv r;
+    r.m = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+    r.sh = s - 1;
+    return r;
+}
+__device__ __forceinline__ unsigned hsefr_udiv_do(unsigned x, hsefr_udiv k) {
+    const unsigned q0 = __umulhi(x, k.m);
+    return (((x - q0) >> 1) + q0) >> k.sh;
+}
+
 // Sweep direction.  Every kernel walks its output (and so its input) in one address order; consecutive layers sweep in
 // OPPOSITE orders, so that a layer starts on the bytes its producer wrote last -- the ones still in the 256 MiB
 // Infinity Cache -- instead of chasing an LRU that evicts every line just before it is needed (a 302 MB activation

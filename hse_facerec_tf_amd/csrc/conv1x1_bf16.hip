@@ -71,9 +71,9 @@ struct ProjParams {        // the projected shortcut of PROJ kernels
     int K2, stride, H2, W2, OH, OW;
     long long x2_bytes;
     int rs_stride;         // (plain RES kernels; round 6) > 0: the residual is read from a LARGER map -- row p = (img, oy, ox) of the output adds
-    unsigned m_ohow, m_ow; // res[img, oy * rs_stride, ox * rs_stride, :] of a [N, H2, W2, Cout] tensor of x2_bytes bytes (H2, W2, OH, OW above;
-                           // m_* = ceil(2^32 / d) for d = OH * OW, OW: exact quotients while p * d < 2^32).  The last block of a ResNet stage
-                           // computed only at the pixels the next stage's stride-2 layers read (lowering.subsample_stage_tails)
+    hsefr_udiv d_ohow, d_ow; // res[img, oy * rs_stride, ox * rs_stride, :] of a [N, H2, W2, Cout] tensor of x2_bytes bytes (H2, W2, OH, OW above;
+                           // d_*: exact division by OH * OW and by OW, common.h).  The last block of a ResNet stage computed only at the
+                           // pixels the next stage's stride-2 layers read (lowering.subsample_stage_tails)
     int adv;               // (both kernel forms; round 6) rows a tile ADVANCES by, <= BM: the tile computes BM rows but owns -- loads, adds the
                            // residual of, stores -- only the first `adv` (every resource ends with the tile's last own row: what lies beyond
                            // reads as zeros and moves no bytes).  Chosen by the launcher so that the tiles fill whole rounds of the grid's
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bf16_kernel(const u16* __res
 #pragma unroll
                 for (int i = 0; i < 32 / RPI; ++i) {
                     const unsigned pr = (unsigned)m0 + (unsigned)(wm * WM + mi * 32 + erow + RPI * i);
-                    const unsigned img = __umulhi(pr, pj.m_ohow), rem = pr - img * ohow;
-                    const unsigned oy = __umulhi(rem, pj.m_ow), ox = rem - oy * (unsigned)pj.OW;
+                    const unsigned img = hsefr_udiv_do(pr, pj.d_ohow), rem = pr - img * ohow;
+                    const unsigned oy = hsefr_udiv_do(rem, pj.d_ow), ox = rem - oy * (unsigned)pj.OW;
                     const unsigned pix = (img * (unsigned)pj.H2 + oy * (unsigned)pj.rs_stride) * (unsigned)pj.W2 + ox * (unsigned)pj.rs_stride;
                     const unsigned off = (pix * (unsigned)Cout + (unsigned)(n0 + wn * WN + 8 * ech)) * 2u;
                     rres[RES ? mi * (32 / RPI) + i : 0] =
@@ -509,10 +509,10 @@ int launch_conv1x1_sres_bf16(const void* x, const void* wt, const float* scale, 
     ProjParams g{};
     g.rs_stride = stride; g.H2 = h2; g.W2 = w2; g.OH = oh; g.OW = ow;
     g.x2_bytes = (long long)n * h2 * w2 * cout * 2;
-    HSEFR_REQUIRE(P * oh * ow < (1ll << 32) && g.x2_bytes < (1ll << 32), HSEFR_ERR_UNSUPPORTED, "conv1x1_sres_bf16: tensors beyond the 32-bit offsets");
-    g.m_ohow = (unsigned)(((1ull << 32) + (unsigned)(oh * ow) - 1) / (unsigned)(oh * ow));
-    g.m_ow = (unsigned)(((1ull << 32) + (unsigned)ow - 1) / (unsigned)ow);
+    HSEFR_REQUIRE(P < (1ll << 31) && g.x2_bytes < (1ll << 32), HSEFR_ERR_UNSUPPORTED, "conv1x1_sres_bf16: tensors beyond the 32-bit offsets");
     HSEFR_REQUIRE(oh * ow > 1 && ow > 1, HSEFR_ERR_UNSUPPORTED, "conv1x1_sres_bf16: maps of one pixel / one column");
+    g.d_ohow = hsefr_udiv_make((unsigned)(oh * ow));
+    g.d_ow = hsefr_udiv_make((unsigned)ow);
     return launch_c11(x, wt, scale, shift, res, y, P, K, cout, act, s, &g);
 }
 

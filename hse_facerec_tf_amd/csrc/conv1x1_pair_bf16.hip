@@ -62,7 +62,8 @@ struct PairParams {
     int y1_stride;        // 1: y1 [M][N1].  2: y1 is stored at the pixels with even row AND column only, as a compact [n][(H+1)/2][(W+1)/2][N1] map
                           // (the second product still reads every pixel, from registers): the tensor's only other reader takes every second pixel of
                           // it (the residual of a stage's last block, lowering.compact_pair_outputs) -- three quarters of the pair's largest store gone
-    unsigned W, HW, m_hw, m_w, OW2, OHW2;      // y1_stride 2: the map (W, H W), ceil(2^32 / d) for d = H W, W, the compact map's width and pixels
+    unsigned W, HW, OW2, OHW2;      // y1_stride 2: the map (W, H W), the compact map's width and pixels
+    hsefr_udiv d_hw, d_w;           // ... exact division by H W and by W (common.h)
     long long y1_bytes;
 };
 
@@ -200,8 +201,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_pair_bf16_kernel(PairParam
         for (int pb = 0; pb < PB; ++pb) {
             const unsigned pix = pix0 + 16u * pb;
             if (p.y1_stride == 2) {      // (uniform)
-                const unsigned img = __umulhi(pix, p.m_hw), rem = pix - img * p.HW;
-                const unsigned oy = __umulhi(rem, p.m_w), ox = rem - oy * p.W;
+                const unsigned img = hsefr_udiv_do(pix, p.d_hw), rem = pix - img * p.HW;
+                const unsigned oy = hsefr_udiv_do(rem, p.d_w), ox = rem - oy * p.W;
                 const bool keep = pix < p.M && ((oy | ox) & 1u) == 0u;
                 y1off[pb] = keep ? (img * p.OHW2 + (oy >> 1) * p.OW2 + (ox >> 1)) * (N1 * 2u) + (unsigned)(16 * lq) : OOR;
             } else {
@@ -390,12 +391,13 @@ int launch_conv1x1_pair_bf16(const void* x, const void* w1, const float* scale1,
     p.y1 = y1; p.w2 = w2; p.scale2 = scale2; p.shift2 = shift2; p.y2 = y2;
     p.M = (unsigned)pixels;
     p.y1_stride = y1_stride; p.y1_bytes = pixels * cout1 * 2;
-    p.W = p.HW = p.m_hw = p.m_w = p.OW2 = p.OHW2 = 0;
+    p.W = p.HW = p.OW2 = p.OHW2 = 0;
+    p.d_hw = p.d_w = hsefr_udiv{0u, 0u};
     if (y1_stride != 1) {
-        HSEFR_REQUIRE(y1_stride == 2 && h > 1 && w > 1 && pixels % ((long long)h * w) == 0 && pixels * h * w < (1ll << 32), HSEFR_ERR_INVALID,
+        HSEFR_REQUIRE(y1_stride == 2 && h > 1 && w > 1 && pixels % ((long long)h * w) == 0, HSEFR_ERR_INVALID,
                       "conv1x1_pair_bf16: y1 at stride %d of a %dx%d map over %lld pixels", y1_stride, h, w, pixels);
         p.W = (unsigned)w; p.HW = (unsigned)(h * w);
-        p.m_hw = (unsigned)(((1ull << 32) + p.HW - 1) / p.HW); p.m_w = (unsigned)(((1ull << 32) + p.W - 1) / p.W);
+        p.d_hw = hsefr_udiv_make(p.HW); p.d_w = hsefr_udiv_make(p.W);
         p.OW2 = (unsigned)((w + 1) / 2); p.OHW2 = (unsigned)(((h + 1) / 2) * ((w + 1) / 2));
         p.y1_bytes = pixels / ((long long)h * w) * p.OHW2 * cout1 * 2;
     }

@@ -411,11 +411,12 @@ def test_fused_stem_pool_vs_oracle(env, n, h, w, ceil, ppad):
 
 @pytest.mark.parametrize("n,oh,ow,c,cout,st,h2,w2", [(2, 28, 28, 64, 256, 2, 56, 56), (3, 14, 14, 128, 512, 2, 28, 28), (5, 7, 7, 256, 1024, 2, 14, 14),
                                                        (2, 13, 9, 64, 128, 2, 25, 17), (1, 5, 6, 64, 64, 3, 13, 16), (37, 14, 14, 64, 256, 2, 28, 27),
-                                                       (128, 28, 28, 64, 256, 2, 56, 56)])
+                                                       (128, 28, 28, 64, 256, 2, 56, 56), (17, 128, 128, 64, 64, 2, 256, 255)])
 def test_conv1x1_with_a_strided_residual_equals_the_gathered_form(env, n, oh, ow, c, cout, st, h2, w2):
     """hsefr_conv1x1_sres_bf16 (the increase layer of a stage's last block on the compact map, lowering.subsample_stage_tails): the residual
     read at every st-th pixel of a larger map -- BIT FOR BIT the plain layer on the gathered residual (same kernel, same K order; only the
-    residual's addresses differ), ragged last tiles and odd maps included."""
+    residual's addresses differ), ragged last tiles and odd maps included; the last case has rows x pixels-per-map beyond 2^32 (the row ->
+    (image, y, x) quotients must be exact for every 32-bit row, csrc/common.h hsefr_udiv)."""
     torch, ops, resnet50 = env
     g = torch.Generator(device="cuda").manual_seed(n * 131 + oh)
     x = (torch.rand((n, oh, ow, c), device="cuda", generator=g) * 2 - 0.5).to(torch.bfloat16)
@@ -432,7 +433,7 @@ def test_conv1x1_with_a_strided_residual_equals_the_gathered_form(env, n, oh, ow
         ops.conv1x1_sres_bf16(x, w, sc, sh, r[:, :(oh - 1) * st, :, :].contiguous(), st)      # the map does not reach the last output row
 
 
-@pytest.mark.parametrize("n,h,w,proj", [(2, 56, 56, False), (3, 28, 20, True), (1, 13, 9, False), (128, 56, 56, False), (5, 7, 31, True)])
+@pytest.mark.parametrize("n,h,w,proj", [(2, 56, 56, False), (3, 28, 20, True), (1, 13, 9, False), (128, 56, 56, False), (5, 7, 31, True), (3, 256, 250, False)])
 def test_pair_with_its_first_output_stored_at_even_pixels(env, n, h, w, proj):
     """hsefr_conv1x1_pair_sub2_bf16 (HSEFR_OPF_OUT_SUB2): y1 stored at even rows / columns only -- bit for bit y1[:, ::2, ::2] of the plain pair,
     y2 (computed from every pixel, in registers) unchanged; odd maps, ragged tiles, both shortcut forms."""
