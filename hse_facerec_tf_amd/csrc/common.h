@@ -280,7 +280,8 @@ int launch_dwpw_fused(const float* x, const float* wd, const float* dscale, cons
 int launch_conv2d_direct(const float* x, const float* w, const float* bias, const float* alpha, float* y, int n, int h, int wd, int c,
                          int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, hipStream_t s);
 int launch_conv_f32_mfma(const float* x, const float* w, const float* scale, const float* shift, const float* res, float* y, int n, int h,
-                         int wd, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act, hipStream_t s);
+                         int wd, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act, hipStream_t s,
+                         int res_stride = 0, int res_h = 0, int res_w = 0);
 bool conv_f32_mfma_supported(int c, int cout);
 int launch_conv2d_f32(const float* x, const float* w, const float* scale, const float* shift, const float* res, float* y, int n, int h,
                       int wd, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act, hipStream_t s);

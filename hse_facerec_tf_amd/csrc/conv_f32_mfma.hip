@@ -37,6 +37,8 @@ struct ConvF32Params {
     long long M;         // N*OH*OW
     int K, KT;           // KH*KW*C, ceil(K / 16)
     unsigned tiles_n;
+    int rs_stride, rs_h, rs_w;      // > 0: res is a LARGER map [N, rs_h, rs_w, Cout] read at every rs_stride-th pixel (lowering.subsample_stage_tails)
+    hsefr_udiv d_ohow, d_ow;        // ... exact division by OH * OW and OW (common.h)
 };
 
 constexpr int BM = 128, BK = 16;
@@ -150,6 +152,12 @@ __global__ __launch_bounds__(256, 2) void conv_f32_mfma_kernel(ConvF32Params p) 
     for (int i = 0; i < 2; ++i) {
         const long long pix = m0 + wm * 64 + 32 * i + l32;
         if (pix >= p.M) continue;
+        long long rpix = pix;                 // the residual's pixel: the output's own, or (img, oy * s, ox * s) of the larger map
+        if (p.rs_stride > 0) {
+            const unsigned img = hsefr_udiv_do((unsigned)pix, p.d_ohow), rem = (unsigned)pix - img * (unsigned)(p.OH * p.OW);
+            const unsigned oy = hsefr_udiv_do(rem, p.d_ow), ox = rem - oy * (unsigned)p.OW;
+            rpix = ((long long)img * p.rs_h + oy * (unsigned)p.rs_stride) * p.rs_w + ox * (unsigned)p.rs_stride;
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_mfma_kernel(ConvF32Params p) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[i][j][4 * g + e], sc[e], sh[e]);
                 if (p.res) {
-                    const f32x4 r = *(const f32x4*)(p.res + pix * p.Cout + ch);
+                    const f32x4 r = *(const f32x4*)(p.res + rpix * p.Cout + ch);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += r[e];
                 }
@@ -177,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void conv_f32_mfma_kernel(ConvF32Params p) 
 bool conv_f32_mfma_supported(int c, int cout) { return cout % 64 == 0 && c > 0; }
 
 int launch_conv_f32_mfma(const float* x, const float* w, const float* scale, const float* shift, const float* res, float* y, int n, int h,
-                         int wd, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act, hipStream_t s) {
+                         int wd, int c, int oh, int ow, int cout, int kh, int kw, int stride, int pad_t, int pad_l, int act, hipStream_t s,
+                         int res_stride, int res_h, int res_w) {
     HSEFR_REQUIRE(n >= 0 && h > 0 && wd > 0 && c > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && oh > 0 && ow > 0, HSEFR_ERR_INVALID,
                   "conv_f32_mfma: bad shape");
     HSEFR_REQUIRE(cout % 64 == 0, HSEFR_ERR_UNSUPPORTED, "conv_f32_mfma: cout=%d must be a multiple of 64", cout);
@@ -187,6 +196,13 @@ int launch_conv_f32_mfma(const float* x, const float* w, const float* scale, con
     p.H = h; p.W = wd; p.C = c; p.OH = oh; p.OW = ow; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
     p.act = act;
     p.M = (long long)n * oh * ow;
+    p.rs_stride = 0; p.rs_h = p.rs_w = 0; p.d_ohow = p.d_ow = hsefr_udiv{0u, 0u};
+    if (res_stride > 0) {
+        HSEFR_REQUIRE(res && oh * ow > 1 && ow > 1 && (oh - 1) * res_stride < res_h && (ow - 1) * res_stride < res_w && p.M < (1ll << 32), HSEFR_ERR_INVALID,
+                      "conv_f32_mfma: a %dx%d output is not a stride-%d view of a %dx%d residual", oh, ow, res_stride, res_h, res_w);
+        p.rs_stride = res_stride; p.rs_h = res_h; p.rs_w = res_w;
+        p.d_ohow = hsefr_udiv_make((unsigned)(oh * ow)); p.d_ow = hsefr_udiv_make((unsigned)ow);
+    }
     p.K = kh * kw * c;
     p.KT = (p.K + BK - 1) / BK;
     const bool runs = c % 16 == 0;

@@ -148,6 +148,15 @@ static int validate_plan(const hsefr_plan_header& h, const hsefr_plan_buffer* bu
                 if (o.scale_off != HSEFR_NO_OFFSET && !need(o.scale_off, co * 4, "scale")) return HSEFR_ERR_INVALID;
                 if (o.shift_off != HSEFR_NO_OFFSET && !need(o.shift_off, co * 4, "shift")) return HSEFR_ERR_INVALID;
                 HSEFR_REQUIRE(o.cout % 4 == 0, HSEFR_ERR_UNSUPPORTED, "plan op %u: fp32 convolution with cout=%d (must be a multiple of 4)", i, o.cout);
+                if (o.reserved != 0) {      // strided residual, as HSEFR_OP_CONV_BF16's (round 6): only the fp32-MFMA kernel reads one
+                    const int k2 = o.reserved & 0xFFF, st2 = (o.reserved >> 12) & 3, h2 = (o.reserved >> 14) & 0x1FF, w2 = (o.reserved >> 23) & 0x1FF;
+                    HSEFR_REQUIRE(k2 == 0 && o.kh == 1 && o.kw == 1 && o.stride == 1 && o.pad_t == 0 && o.pad_l == 0 && o.res_buf >= 0 && st2 >= 1 &&
+                                      o.oh == o.h && o.ow == o.w && o.oh * o.ow > 1 && o.ow > 1 && (o.oh - 1) * st2 < h2 && (o.ow - 1) * st2 < w2 &&
+                                      conv_f32_mfma_supported(o.cin, o.cout),
+                                  HSEFR_ERR_INVALID, "plan op %u: bad strided residual (stride %d, %dx%d)", i, st2, h2, w2);
+                    HSEFR_REQUIRE((uint64_t)h2 * w2 * co * 4 <= bufs[o.res_buf].elems_per_image * bufs[o.res_buf].elem_bytes, HSEFR_ERR_INVALID,
+                                  "plan op %u: strided residual exceeds buffer %d", i, o.res_buf);
+                }
                 break;
             case HSEFR_OP_CONV_C3:
                 if (!need(o.w_off, kk * ci * co * 4, "kernel") || !need(o.shift_off, co * 4, "shift")) return HSEFR_ERR_INVALID;
@@ -750,7 +759,8 @@ static int run_ops(hsefr_engine* e, const std::vector<void*>& tab, const void* d
                 if (conv_f32_mfma_supported(o.cin, o.cout)) {       // exact fp32 on the fp32 matrix pipe (csrc/conv_f32_mfma.hip)
                     rc = launch_conv_f32_mfma((const float*)in, (const float*)blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),
                                               (const float*)blob_ptr(e, o.shift_off), o.res_buf >= 0 ? (const float*)tab[o.res_buf] : nullptr,
-                                              (float*)out, n, o.h, o.w, o.cin, o.oh, o.ow, o.cout, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.act, s);
+                                              (float*)out, n, o.h, o.w, o.cin, o.oh, o.ow, o.cout, o.kh, o.kw, o.stride, o.pad_t, o.pad_l, o.act, s,
+                                              o.res_buf >= 0 ? (o.reserved >> 12) & 3 : 0, (o.reserved >> 14) & 0x1FF, (o.reserved >> 23) & 0x1FF);
                     break;
                 }
                 rc = launch_conv2d_f32((const float*)in, (const float*)blob_ptr(e, o.w_off), (const float*)blob_ptr(e, o.scale_off),

@@ -264,7 +264,7 @@ class Plan:
                 if aux >= 1 << 31:              # w2 >= 256 reaches bit 31 of the signed wire field; the C side masks after >> 23
                     aux -= 1 << 32
             if L.res_geom is not None:          # the residual is a stride view of a larger map (hsefr.h: hsefr_conv1x1_sres_bf16)
-                assert L.kind == OP_CONV_BF16 and L.res >= 0 and L.proj is None and L.kh == 1 and L.kw == 1 and L.stride == 1
+                assert L.kind in (OP_CONV_BF16, OP_CONV_F32) and L.res >= 0 and L.proj is None and L.kh == 1 and L.kw == 1 and L.stride == 1
                 s2, h2, wd2 = L.res_geom
                 assert 1 <= s2 <= 3 and 0 < h2 < 512 and 0 < wd2 < 512 and tuple(self.layers[L.res].out_shape) == (h2, wd2, L.out_shape[2])
                 aux = (s2 << 12) | (h2 << 14) | (wd2 << 23)
@@ -986,16 +986,19 @@ def subsample_stage_tails(layers: List[Layer], keep: Sequence[int]) -> int:
     done = 0
     for t, I in enumerate(layers):
         cons = consumers.get(t, [])
-        if not cons or t in keep or not (I.kind == OP_CONV_BF16 and I.kh == 1 and I.kw == 1 and I.stride == 1 and I.pad_t == 0 and I.pad_l == 0 and
+        conv = I.kind      # bf16 plans, and the fp32-grade plans of the same graphs (OP_CONV_F32: its MFMA kernel reads the strided residual too)
+        if conv == OP_CONV_F32 and I.out_shape[2] % 64 != 0:
+            continue
+        if not cons or t in keep or not (I.kind in (OP_CONV_BF16, OP_CONV_F32) and I.kh == 1 and I.kw == 1 and I.stride == 1 and I.pad_t == 0 and I.pad_l == 0 and
                                          I.res >= 0 and I.proj is None and I.res_geom is None and I.src >= 0 and I.flags == 0):
             continue
         h, w, c = I.out_shape
         strides = set()
         for j, how in cons:
             C = layers[j]
-            if how == "src" and C.kind == OP_CONV_BF16 and C.kh == 1 and C.kw == 1 and C.pad_t == 0 and C.pad_l == 0 and C.stride > 1 and C.proj is None:
+            if how == "src" and C.kind == conv and C.kh == 1 and C.kw == 1 and C.pad_t == 0 and C.pad_l == 0 and C.stride > 1 and C.proj is None:
                 strides.add(C.stride)
-            elif how == "res" and C.kind == OP_CONV_BF16 and C.proj is not None and C.proj[1] > 1 and C.proj[2:] == (h, w):
+            elif how == "res" and C.kind == conv and C.proj is not None and C.proj[1] > 1 and C.proj[2:] == (h, w):
                 strides.add(C.proj[1])
             else:
                 strides.add(0)
@@ -1003,7 +1006,7 @@ def subsample_stage_tails(layers: List[Layer], keep: Sequence[int]) -> int:
             continue
         s = strides.pop()
         X = layers[I.src]
-        if not (X.kind == OP_CONV_BF16 and X.kh == 3 and X.kw == 3 and X.stride == 1 and X.pad_t == 1 and X.pad_l == 1 and X.res < 0 and X.proj is None and
+        if not (X.kind == conv and X.kh == 3 and X.kw == 3 and X.stride == 1 and X.pad_t == 1 and X.pad_l == 1 and X.res < 0 and X.proj is None and
                 I.src not in keep and [q for q, _ in consumers.get(I.src, [])] == [t] and X.flags == 0 and tuple(X.out_shape[:2]) == (h, w) and
                 tuple(layers[I.res].out_shape) == (h, w, c) and h < 512 and w < 512):
             continue

@@ -142,6 +142,8 @@ def build_plan(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (224,
     gap = add(Layer(OP_GAP if f32 else OP_GAP_BF16, "pool5_7x7_s1", cur, (h, w_, cin), (1, 1, cin)))
     for L in layers:
         L.sealed = True
+    if fuse and f32 and subsample:
+        lowering.subsample_stage_tails(layers, [gap])
     if fuse and not f32:
         layers, remap = lowering.fuse_stem_pool(layers, [gap])
         gap = remap[gap]

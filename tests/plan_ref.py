@@ -265,7 +265,11 @@ def run(blob: bytes, x: np.ndarray, dtype=np.float64, check_buffers=True):
                 y = y * arr(sc_off, cout)
             if sh_off != NO_OFFSET:
                 y = y + arr(sh_off, cout)
-            if res is not None:
+            if res is not None and _r != 0:      # strided residual, as kind 7's
+                s2, h2, wd2 = (_r >> 12) & 3, (_r >> 14) & 0x1FF, (_r >> 23) & 0x1FF
+                assert (_r & 0xFFF) == 0 and kh == 1 and kw == 1 and stride == 1 and cout % 64 == 0
+                y = y + res.reshape(n, h2, wd2, cout)[:, ::s2, ::s2, :][:, :oh, :ow, :]
+            elif res is not None:
                 y = y + res.reshape(y.shape)
             y = _act(y, act)
         elif kind == 19:     # k x k / stride max-pool with clipped windows, fp32
